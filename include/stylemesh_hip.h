@@ -1,0 +1,178 @@
+/*
+ * libstylemesh_hip.so - C ABI of the MI355X-native StyleMesh texture-optimisation hot path.
+ *
+ * The reference (lukasHoel/stylemesh) has no FFI: its hot path is Python calling PyTorch ATen operators.
+ * Each entry point below replaces the ATen operator sequence reached from the cited reference lines
+ * (paths relative to the reference repository). INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types. All pointers are DEVICE pointers unless a
+ *    parameter is documented as host. fp32 everywhere (the reference computes in fp32).
+ *  - Every call is asynchronous on the caller's hipStream_t (passed as void*), allocates nothing and
+ *    keeps no state: the caller owns every buffer. Return value: 0 (hipSuccess) or a hipError_t.
+ *  - Feature maps use the "padded planar" layout: [C][plane] floats; a plane holds (H+2) rows of Wp
+ *    floats, Wp = sm_fmap_row_stride(W) (a multiple of 4); pixel (y,x) lives at q = (y+1)*Wp + (x+1);
+ *    row 0, row H+1, column 0 and columns > W are zero and MUST stay zero (kernels that write a plane
+ *    write zeros there). Buffers need SM_FMAP_GUARD floats of readable slack before and after.
+ *  - Textures / gradients / Adam moments keep the reference layout [3][H][W] per layer
+ *    (model/texture/texture.py:29-32); the layers of a hierarchical texture sit back to back in one arena.
+ */
+#ifndef STYLEMESH_HIP_H
+#define STYLEMESH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_MAX_TEX_LAYERS 8
+#define SM_FMAP_GUARD 4096 /* floats of slack required before and after every feature-map buffer */
+
+/* epilogue flags of sm_conv3x3 */
+#define SM_EPI_BIAS_RELU 1 /* out = relu(acc + bias[co])                                  (forward)  */
+#define SM_EPI_RELU_MASK 2 /* out = gate[co][q] > 0 ? v : 0                               (dgrad)    */
+#define SM_EPI_ADD 4       /* v += out[co][q] (value already in the output buffer) before the gate   */
+
+/* ---- layout helpers (host, pure functions) -------------------------------------------------------- */
+int sm_fmap_row_stride(int W);        /* Wp */
+int sm_fmap_plane(int H, int W);      /* floats per channel plane (multiple of 64) */
+int sm_abi_version(void);
+
+/* ---- texture: model/texture/texture.py ------------------------------------------------------------ */
+
+/* K1. HierarchicalNeuralTexture.forward / NeuralTexture.forward (texture.py:46-54,96-100):
+ * out[c][q] = sum_l bilinear_border_sample(layer_l, grid), align_corners=True, for a [h][w][2] grid in
+ * [-1,1]. Layers must already be clamped (normalize(), texture.py:41-44; sm_adam_fused keeps them so).
+ * out: padded planar fmap with out_channels >= 3 planes (planes >= 3 are left untouched = zero). */
+int sm_tex_sample_fwd(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
+                      const float* grid, int h, int w, float* out, void* stream);
+
+/* K2. Backward of K1 (ATen grid_sampler_2d_backward + RepeatBackward + the zero-filled dense gradient,
+ * texture.py:49-53) fused with the two tensor hooks of model/model.py:195-202,245-251:
+ * grad_layer_l[c][tap] += pixel_weight[y][x] * grad_img[c][q] * bilinear_weight(tap)  (atomic).
+ * pixel_weight: dense [h][w] or NULL (= 1). Gradients ACCUMULATE into grad_layers. */
+int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
+                      const float* grid, int h, int w, const float* grad_img, const float* pixel_weight,
+                      void* stream);
+
+/* K7. torch.optim.Adam.step (model/model.py:387-395) fused with the analytic gradient of
+ * HierarchicalNeuralTexture.regularizer (texture.py:102-108: g += reg_coef[seg] * p), the next forward's
+ * normalize() clamp (texture.py:41-44), zeroing of the gradient for the next step, and the reduction
+ * sum(p_new^2) per segment that the next step's tex_reg loss value needs (sumsq_out[seg], pre-zeroed).
+ * The arena holds n_seg layers back to back: seg_end[i] = end offset (floats) of layer i.
+ * grad_scale multiplies the data-term gradient first (1/R after an all-reduce over R ranks).
+ * bias_corr1 = 1-beta1^t and bias_corr2 = 1-beta2^t are computed by the caller in double; the betas are
+ * doubles because torch derives the fp32 constants 1-beta from Python doubles. */
+int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end,
+                  const float* reg_coef, int n_seg, float lr, double beta1, double beta2, float eps,
+                  double bias_corr1, double bias_corr2, float grad_scale, float clamp_lo, float clamp_hi,
+                  int zero_grad, float* sumsq_out, void* stream);
+
+/* normalize() alone (texture.py:41-44) + per-segment sum of squares (for the first step's tex_reg). */
+int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float clamp_lo, float clamp_hi,
+                   float* sumsq_out, void* stream);
+
+/* ---- VGG feature stack: model/losses/content_and_style_losses.py:7-70 ------------------------------ */
+
+/* K3/K4. 3x3, pad 1, stride 1 convolution as an implicit-im2col GEMM on fp32 MFMA.
+ * in [Cin_pad][plane], wt [9][Cin_pad][Cout] (tap-major, Cout fastest; see sm_pack_* in the Python host),
+ * out [Cout][plane]. Forward (nn.Conv2d + F.relu, :49-68): flags = SM_EPI_BIAS_RELU.
+ * Data gradient (ATen convolution_backward + threshold_backward): call with the flipped / transposed
+ * weights and flags = SM_EPI_RELU_MASK [| SM_EPI_ADD]; gate = the conv INPUT's forward activation.
+ * Cin_pad must be a multiple of 4 (8 when > 4), Cout a multiple of 64. */
+int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate,
+               int Cin_pad, int Cout, int H, int W, int flags, void* stream);
+
+/* Data gradient of the first conv (64 -> 3 channels; conv1_1, :11,49): out [3][plane] from
+ * dz [64][plane], wd [9][64][4] (tap-major, 3 real output channels + 1 zero). */
+int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream);
+
+/* nn.MaxPool2d(2,2) (:27-32,51,54,59,64), floor output size: in [C][plane(H,W)] -> out [C][plane(H/2,W/2)]. */
+int sm_maxpool2x2_fwd(const float* in, float* out, int C, int H, int W, void* stream);
+
+/* max_pool2d backward fused with the ReLU gate of the layer below: for each 2x2 window the gradient goes
+ * to the first maximum (row-major, ATen order) if that activation is > 0.
+ * act [C][plane(H,W)] forward activation, pooled [C][plane(H/2,W/2)], dpooled likewise, dact out. */
+int sm_maxpool2x2_bwd_relu(const float* act, const float* pooled, const float* dpooled, float* dact, int C,
+                           int H, int W, void* stream);
+
+/* ---- Gram / style / content losses: content_and_style_losses.py:74-80,136-143,288-350 --------------- */
+
+/* K5a. Masked Gram sums S_k = (m_k F)(m_k F)^T for up to two 0/1 masks (GramMatrix :74-80 on
+ * masked_features :136-143, without the 1/N). feat [C][plane]; mask0/mask1 one plane each (mask1 may be
+ * NULL); S0/S1 [C][C], pre-zeroed, upper-triangular 64x64 tiles are accumulated atomically. */
+int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
+                   int H, int W, void* stream);
+
+/* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
+ * For each mask k: G_k = S_k / max(N_k,1) (N from counts[k]; N_k == 0 -> G_k = 0, and with
+ * skip_if_empty[k] the term is dropped, :332). Terms: for t in 0..n_terms-1: mask k = term_mask[t],
+ * target Y = targets[t] ([C][C]), loss += coef * mean((Y - G_k)^2), D_k += coef' * (G_k - Y).
+ * coef = style_weight * loss_weight * (*factor) [/ avg_n for gram_mode 'average'].
+ * Writes D0/D1 [C][C] (full symmetric) such that dL/dF = m_0 * (D0 F) + m_1 * (D1 F), and atomically adds
+ * the loss value to *loss_out. history (may be NULL): [9][C][C] ring of past normalised mask-0 Grams for
+ * gram_mode 'average' (:319-323): the first hist_len entries are averaged with the current Gram, which is
+ * then stored in entry hist_slot. targets / term_mask / skip_if_empty are HOST arrays (<= 4 terms). */
+int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
+                  const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty,
+                  float weight, int C, float* D0, float* D1, float* loss_out, float* history, int hist_len,
+                  int hist_slot, void* stream);
+
+/* K5c. dF[c][q] = m0[q] * (D0 F)[c][q] + m1[q] * (D1 F)[c][q], optionally gated by feat > 0
+ * (for the top layer r51, whose ReLU gate no later dgrad applies). OVERWRITES dfeat. */
+int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, const float* D0,
+                     const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* stream);
+
+/* K6. Masked content MSE (:343-348): loss += coef * sum m (P-T)^2 / (C N); dP = coef * 2 m (P-T)/(C N),
+ * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred. */
+int sm_mse_masked(const float* pred, const float* target, const float* mask, const float* count,
+                  const float* factor, float weight, float* dpred, float* loss_out, int C, int H, int W,
+                  void* stream);
+
+/* ---- per-view constants: model/model.py:188-254, content_and_style_losses.py:146-217 ---------------- */
+
+/* Level masks and depth-interpolation weights at the view resolution (mask_depth, mask_interpolation_weight,
+ * erode: model/model.py:204-239). For level i: E[i] = erode(((rounded==i)|(other==i)) & mask),
+ * Wt[i] = erode((rounded==i)&mask)*w + erode((other==i)&mask)*(1-w). E, Wt: [n_levels][h][w]. */
+int sm_level_masks(const int64_t* rounded, const int64_t* other, const float* interp_w, const uint8_t* mask,
+                   int h, int w, int n_levels, float* E, float* Wt, void* stream);
+
+/* Per-level maps at the level's resolution (model/model.py:199,219,238; losses :161):
+ * M = nearest(E) > 0; pixel_weight = [bilinear(angle_guidance)] * [nearest(Wt)]; passed = bilinear(angle_deg) < thr.
+ * Any of Wt, angle_guidance, angle_deg, pixel_weight, passed may be NULL (factor 1 / passed = 1 / not written).
+ * Also accumulates sum(M) into *m_sum (pre-zeroed). */
+int sm_level_maps(const float* E, const float* Wt, const float* angle_guidance, const float* angle_deg,
+                  float angle_threshold, int h, int w, int H, int W, float* M, float* pixel_weight,
+                  uint8_t* passed, float* m_sum, void* stream);
+
+/* Layer-resolution masks (calculate_pyramid :172-174,181): nearest-down of M, M*passed, M*!passed into
+ * padded planes m_all / m_pass / m_fail (hl x wl), and their sums into counts[0..2] (pre-zeroed). */
+int sm_layer_masks(const float* M, const uint8_t* passed, int H, int W, int hl, int wl, float* m_all,
+                   float* m_pass, float* m_fail, float* counts, void* stream);
+
+/* factor[i] = (counts_all[i]/size[i]) / sum_j (counts_all[j]/size[j]) over n levels (:181,200-204).
+ * counts_all[i] points at the level's N_all; all device pointers given as a device array. */
+int sm_level_factors(const float* const* counts_all, const float* sizes, int n, float* const* factors,
+                     void* stream);
+
+/* F.interpolate(..., mode='bilinear') between padded planar fmaps (:176, content target). */
+int sm_fmap_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
+
+/* F.interpolate(..., mode='bilinear') dense [C][h][w] -> padded planar [C][plane(H,W)] (style pyramid :94,120;
+ * also the plain dense->padded copy when sizes match). */
+int sm_image_to_fmap(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
+int sm_fmap_to_image(const float* in, int C, int H, int W, float* out, void* stream);
+
+/* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
+
+/* Thin RCCL wrapper: in-place sum all-reduce of the texture-gradient arena (ncclAllReduce, fp32).
+ * comm is an ncclComm_t owned by the caller. Returns a ncclResult_t (0 = success). */
+int sm_allreduce_grad(void* comm, float* g, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,343 @@
+// K5 / K6: masked Gram matrices on the fp32 matrix cores, the style-loss value and its derivative matrices,
+// the Gram backward GEMM, and the masked content MSE.
+//
+// Reference operators replaced (lukasHoel/stylemesh, model/losses/content_and_style_losses.py):
+// masked_features (:136-143, bool-mask gather -> here: multiply by the 0/1 mask, same sums), GramMatrix
+// (:74-80, torch.bmm), nn.MSELoss (:265) and the loss loops of ContentAndStyleLoss.forward (:301-348),
+// plus their autograd backward (bmm backward, index_put_, mse backward).
+#include "common.h"
+
+namespace sm {
+
+// ---------------------------------------------------------------------------------------------------
+// K5a: S_k[i][j] = sum_q m_k[q] F[i][q] F[j][q]   (split over q, upper-triangular 64x64 tiles, atomics)
+// ---------------------------------------------------------------------------------------------------
+constexpr int GRAM_QC = 32;     // positions per LDS chunk
+constexpr int GRAM_LD = 33;     // padded row length: conflict-free column reads
+constexpr int GRAM_QB = 2048;   // positions per block
+
+template <int NMASK>
+__global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restrict__ feat, const float* __restrict__ mask0,
+                                                          const float* __restrict__ mask1, float* S0, float* S1, int C,
+                                                          int plane, int q_begin, int q_end) {
+    __shared__ float FsA[64 * GRAM_LD];
+    __shared__ float FsB[64 * GRAM_LD];
+    __shared__ float Ms[2][GRAM_QC];
+    // tile pair (tm <= tn) from blockIdx.y
+    const int T = C / 64;
+    int tm = 0, rem = blockIdx.y;
+    while (rem >= T - tm) { rem -= T - tm; ++tm; }
+    const int tn = tm + rem;
+    const bool diag = tm == tn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc[NMASK];
+#pragma unroll
+    for (int k = 0; k < NMASK; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    const int qs = q_begin + blockIdx.x * GRAM_QB;
+    const int qe = min(qs + GRAM_QB, q_end);
+    for (int q0 = qs; q0 < qe; q0 += GRAM_QC) {
+        // stage 64 rows x 32 positions of each operand: 512 float4 per operand, 2 per thread
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * 256;
+            const int row = i >> 3, c4 = (i & 7) * 4;
+            const int q = q0 + c4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (q < qe) {  // q_end and chunk starts are multiples of 4
+                va = *reinterpret_cast<const float4*>(feat + (size_t)(tm * 64 + row) * plane + q);
+                if (!diag) vb = *reinterpret_cast<const float4*>(feat + (size_t)(tn * 64 + row) * plane + q);
+            }
+            float* da = FsA + row * GRAM_LD + c4;
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            if (!diag) {
+                float* db = FsB + row * GRAM_LD + c4;
+                db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+            }
+        }
+        if (tid < GRAM_QC) {
+            const int q = q0 + tid;
+            Ms[0][tid] = (q < qe) ? mask0[q] : 0.f;
+            if (NMASK > 1) Ms[1][tid] = (q < qe) ? mask1[q] : 0.f;
+        }
+        __syncthreads();
+        const float* Bsrc = diag ? FsA : FsB;
+#pragma unroll
+        for (int kk = 0; kk < GRAM_QC / 2; ++kk) {
+            const int k = kk * 2 + lhi;
+            const float a = FsA[(wm + l31) * GRAM_LD + k];
+            const float b = Bsrc[(wn + l31) * GRAM_LD + k];
+#pragma unroll
+            for (int mk = 0; mk < NMASK; ++mk)
+                acc[mk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a * Ms[mk][k], b, acc[mk], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mk = 0; mk < NMASK; ++mk) {
+        float* S = mk == 0 ? S0 : S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int col = tn * 64 + wn + l31;
+            const float v = acc[mk][r];
+            if (v != 0.f) atomicAdd(S + (size_t)row * C + col, v);
+        }
+    }
+}
+
+// upper-triangular tile storage: element (i,j) lives at [i][j] when tile(i) <= tile(j), else at [j][i]
+__device__ __forceinline__ float sym_read(const float* S, int C, int i, int j) {
+    return ((i >> 6) <= (j >> 6)) ? S[(size_t)i * C + j] : S[(size_t)j * C + i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5b: loss value + derivative matrices D_k for one (level, layer)
+// ---------------------------------------------------------------------------------------------------
+struct StyleTerms {
+    const float* target[4];
+    int mask[4];
+    int n;
+    int skip_if_empty[2];
+};
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
+                                                         const float* __restrict__ counts,
+                                                         const float* __restrict__ factor, StyleTerms terms,
+                                                         float weight, int C, float* __restrict__ D0,
+                                                         float* __restrict__ D1, float* loss_out, float* history,
+                                                         int hist_len, int hist_slot) {
+    __shared__ float red[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int i = idx / C, j = idx - i * C;
+    const float f = *factor;
+    const float inv_c2 = 1.f / ((float)C * (float)C);
+    float G[2], invN[2], d[2] = {0.f, 0.f};
+    bool empty[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* S = k == 0 ? S0 : S1;
+        const float N = (S != nullptr) ? counts[k] : 0.f;
+        empty[k] = !(N > 0.f);
+        invN[k] = empty[k] ? 0.f : 1.f / N;
+        G[k] = (S != nullptr && !empty[k]) ? sym_read(S, C, i, j) / N : 0.f;  // N == 0: masked_features -> zeros
+    }
+    float navg = 1.f;
+    float Gavg0 = G[0];
+    if (history) {  // gram_mode 'average': mean over the current and up to 9 detached previous Grams (:319-323)
+        const size_t cc = (size_t)C * C;
+        for (int h = 0; h < hist_len; ++h) Gavg0 += history[h * cc + idx];
+        navg = (float)(hist_len + 1);
+        Gavg0 /= navg;
+        history[(size_t)hist_slot * cc + idx] = G[0];
+    }
+    float loss = 0.f;
+    for (int t = 0; t < terms.n; ++t) {
+        const int k = terms.mask[t];
+        if (empty[k] && terms.skip_if_empty[k]) continue;
+        const float g = (k == 0) ? Gavg0 : G[k];
+        const float diff = g - terms.target[t][idx];
+        loss += diff * diff;
+        // dL/dF = 2 dL/dS F (S symmetric), dL/dS = dL/dG / N, dL/dG = weight f (2/C^2) (G - Y) [/ navg]
+        d[k] += diff * (4.f * weight * f * inv_c2 * invN[k] / ((k == 0) ? navg : 1.f));
+    }
+    D0[idx] = d[0];
+    if (D1) D1[idx] = d[1];
+    const float tot = block_sum256(loss, red);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * weight * f * inv_c2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5c: dF[c][q] = m0[q] (D0 F)[c][q] + m1[q] (D1 F)[c][q]   -  GEMM M = C, N = positions, K = C
+// Block tile 64 (channels) x 256 (positions), 4 waves side by side, K-chunk 16 channels.
+// ---------------------------------------------------------------------------------------------------
+template <int NMASK, bool RELU_GATE>
+__global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restrict__ feat,
+                                                            const float* __restrict__ mask0,
+                                                            const float* __restrict__ mask1, const float* __restrict__ D0,
+                                                            const float* __restrict__ D1, float* __restrict__ dfeat, int C,
+                                                            int plane, int q_begin, int q_end) {
+    constexpr int KC = 16, BN = 256;
+    __shared__ __attribute__((aligned(16))) float As[NMASK][KC * 64];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int m0 = blockIdx.y * 64;
+    const int q0 = q_begin + blockIdx.x * BN;
+    const int wn = wave * 64;
+    f32x16 acc[NMASK][2][2];
+#pragma unroll
+    for (int k = 0; k < NMASK; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < C; k0 += KC) {
+        // D rows k0..k0+15, columns m0..m0+63 (D symmetric: D[k][m] == D[m][k]); 256 float4 per matrix
+        {
+            const int row = tid >> 4, c4 = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&As[0][row * 64 + c4]) =
+                *reinterpret_cast<const float4*>(D0 + (size_t)(k0 + row) * C + m0 + c4);
+            if (NMASK > 1)
+                *reinterpret_cast<float4*>(&As[NMASK - 1][row * 64 + c4]) =
+                    *reinterpret_cast<const float4*>(D1 + (size_t)(k0 + row) * C + m0 + c4);
+        }
+        // F rows k0..k0+15, positions q0..q0+255: 1024 float4, 4 per thread
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * 256;
+            const int row = i >> 6, c4 = (i & 63) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + c4 < q_end) v = *reinterpret_cast<const float4*>(feat + (size_t)(k0 + row) * plane + q0 + c4);
+            *reinterpret_cast<float4*>(&Bs[row * BN + c4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            const int k = kp * 2 + lhi;
+            const float b0 = Bs[k * BN + wn + l31], b1 = Bs[k * BN + wn + 32 + l31];
+#pragma unroll
+            for (int mk = 0; mk < NMASK; ++mk) {
+                const float a0 = As[mk][k * 64 + l31], a1 = As[mk][k * 64 + 32 + l31];
+                acc[mk][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[mk][0][0], 0, 0, 0);
+                acc[mk][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[mk][0][1], 0, 0, 0);
+                acc[mk][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[mk][1][0], 0, 0, 0);
+                acc[mk][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[mk][1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int q = q0 + wn + nj * 32 + l31;
+        if (q >= q_end) continue;
+        const float w0 = mask0[q];
+        const float w1 = (NMASK > 1) ? mask1[q] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const size_t o = (size_t)c * plane + q;
+                float v = w0 * acc[0][mi][nj][r];
+                if (NMASK > 1) v += w1 * acc[NMASK - 1][mi][nj][r];
+                if (RELU_GATE) v = (feat[o] > 0.f) ? v : 0.f;
+                dfeat[o] = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K6: masked content MSE + gradient
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         const float* __restrict__ mask, const float* __restrict__ count,
+                                                         const float* __restrict__ factor, float weight,
+                                                         float* __restrict__ dpred, float* loss_out, int C, int plane,
+                                                         int q_begin, int q_end) {
+    __shared__ float red[4];
+    const int c = blockIdx.y;
+    const int q = q_begin + (blockIdx.x * 256 + threadIdx.x) * 4;
+    const float N = *count;
+    const float coef = (N > 0.f) ? weight * (*factor) / ((float)C * N) : 0.f;
+    float part = 0.f;
+    if (q < q_end) {
+        const size_t o = (size_t)c * plane + q;
+        const float4 p = *reinterpret_cast<const float4*>(pred + o);
+        const float4 t = *reinterpret_cast<const float4*>(target + o);
+        const float4 m = *reinterpret_cast<const float4*>(mask + q);
+        float4 d = make_float4(m.x * (p.x - t.x), m.y * (p.y - t.y), m.z * (p.z - t.z), m.w * (p.w - t.w));
+        part = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;  // m in {0,1}: m^2 = m
+        const float c2 = 2.f * coef;
+        *reinterpret_cast<float4*>(dpred + o) = make_float4(c2 * d.x, c2 * d.y, c2 * d.z, c2 * d.w);
+    }
+    const float tot = block_sum256(part, red);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * coef);
+}
+
+}  // namespace sm
+
+extern "C" {
+
+int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H, int W,
+                   void* stream) {
+    if (C % 64 != 0) return (int)hipErrorInvalidValue;
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
+    const int q_begin = Wp, q_end = (H + 1) * Wp;
+    const int T = C / 64;
+    dim3 grid((q_end - q_begin + sm::GRAM_QB - 1) / sm::GRAM_QB, T * (T + 1) / 2);
+    if (mask1)
+        hipLaunchKernelGGL(sm::gram_masked_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
+                           C, plane, q_begin, q_end);
+    else
+        hipLaunchKernelGGL(sm::gram_masked_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
+                           C, plane, q_begin, q_end);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
+                  const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty, float weight,
+                  int C, float* D0, float* D1, float* loss_out, float* history, int hist_len, int hist_slot,
+                  void* stream) {
+    if (n_terms < 1 || n_terms > 4 || (C * C) % 256 != 0) return (int)hipErrorInvalidValue;
+    sm::StyleTerms t;
+    t.n = n_terms;
+    for (int i = 0; i < n_terms; ++i) {
+        t.target[i] = targets[i];
+        t.mask[i] = term_mask[i];
+        if (term_mask[i] == 1 && (S1 == nullptr || D1 == nullptr)) return (int)hipErrorInvalidValue;
+    }
+    t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
+    t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
+    hipLaunchKernelGGL(sm::style_loss_kernel, dim3(C * C / 256), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
+                       t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, const float* D0, const float* D1,
+                     float* dfeat, int C, int H, int W, int relu_gate, void* stream) {
+    if (C % 64 != 0) return (int)hipErrorInvalidValue;
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
+    const int q_begin = Wp, q_end = (H + 1) * Wp;
+    dim3 grid((q_end - q_begin + 255) / 256, C / 64);
+    hipStream_t s = (hipStream_t)stream;
+#define SM_GB(NM, RG)                                                                                                  \
+    hipLaunchKernelGGL((sm::gram_backward_kernel<NM, RG>), grid, dim3(256), 0, s, feat, mask0, mask1, D0, D1, dfeat, C, \
+                       plane, q_begin, q_end)
+    if (mask1 && D1) {
+        if (relu_gate) SM_GB(2, true); else SM_GB(2, false);
+    } else {
+        if (relu_gate) SM_GB(1, true); else SM_GB(1, false);
+    }
+#undef SM_GB
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_mse_masked(const float* pred, const float* target, const float* mask, const float* count, const float* factor,
+                  float weight, float* dpred, float* loss_out, int C, int H, int W, void* stream) {
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
+    const int q_begin = Wp, q_end = (H + 1) * Wp;
+    dim3 grid(((q_end - q_begin) / 4 + 255) / 256, C);
+    hipLaunchKernelGGL(sm::mse_masked_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, target, mask, count, factor,
+                       weight, dpred, loss_out, C, plane, q_begin, q_end);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// K1 / K2 / K7: texture sampling, its scatter-add backward, and the fused regulariser + Adam + clamp update.
+//
+// Reference operators replaced (lukasHoel/stylemesh): F.grid_sample(bilinear, border, align_corners=True) and
+// its backward (model/texture/texture.py:46-54,96-100), the angle / depth gradient hooks
+// (model/model.py:195-202,245-251), HierarchicalNeuralTexture.regularizer (texture.py:102-108),
+// NeuralTexture.normalize (texture.py:41-44) and torch.optim.Adam.step (model/model.py:387-395).
+// All HBM-bound: one pass over the view's pixels (K1, K2) or over the texture arena (K7).
+#include "common.h"
+
+namespace sm {
+
+struct TexLayers {
+    float* p[SM_MAX_TEX_LAYERS];
+    int w[SM_MAX_TEX_LAYERS];
+    int h[SM_MAX_TEX_LAYERS];
+    int n;
+};
+
+// ATen grid_sampler source index (align_corners=True) + border clip; returns the 4 tap weights in ATen's
+// order nw, ne, sw, se and the integer corner.
+struct Taps {
+    int x0, y0;
+    float nw, ne, sw, se;
+    bool x1_in, y1_in;
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int W, int H) {
+    float ix = ((gx + 1.f) / 2.f) * (float)(W - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+    const float fx = floorf(ix), fy = floorf(iy);
+    Taps t;
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    const float ex = fx + 1.f, ey = fy + 1.f;  // south-east corner
+    t.nw = (ex - ix) * (ey - iy);
+    t.ne = (ix - fx) * (ey - iy);
+    t.sw = (ex - ix) * (iy - fy);
+    t.se = (ix - fx) * (iy - fy);
+    t.x1_in = t.x0 + 1 <= W - 1;
+    t.y1_in = t.y0 + 1 <= H - 1;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
+                                                             float* __restrict__ out, int Wp, int plane) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const float2 g = grid[i];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int l = 0; l < L.n; ++l) {
+        const int W = L.w[l], H = L.h[l];
+        const Taps t = make_taps(g.x, g.y, W, H);
+        const float* p = L.p[l] + (size_t)t.y0 * W + t.x0;
+        const size_t cs = (size_t)W * H;
+        float v0, v1, v2;
+        v0 = p[0] * t.nw;
+        v1 = p[cs] * t.nw;
+        v2 = p[2 * cs] * t.nw;
+        if (t.x1_in) {
+            v0 += p[1] * t.ne;
+            v1 += p[cs + 1] * t.ne;
+            v2 += p[2 * cs + 1] * t.ne;
+        }
+        if (t.y1_in) {
+            v0 += p[W] * t.sw;
+            v1 += p[cs + W] * t.sw;
+            v2 += p[2 * cs + W] * t.sw;
+            if (t.x1_in) {
+                v0 += p[W + 1] * t.se;
+                v1 += p[cs + W + 1] * t.se;
+                v2 += p[2 * cs + W + 1] * t.se;
+            }
+        }
+        acc0 += v0;
+        acc1 += v1;
+        acc2 += v2;
+    }
+    const size_t q = (size_t)(y + 1) * Wp + x + 1;
+    out[q] = acc0;
+    out[plane + q] = acc1;
+    out[2 * (size_t)plane + q] = acc2;
+}
+
+__global__ __launch_bounds__(256) void tex_sample_bwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
+                                                             const float* __restrict__ gimg,
+                                                             const float* __restrict__ pixel_weight, int Wp, int plane) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const size_t q = (size_t)(y + 1) * Wp + x + 1;
+    float g0 = gimg[q], g1 = gimg[plane + q], g2 = gimg[2 * (size_t)plane + q];
+    if (pixel_weight) {
+        const float pw = pixel_weight[i];
+        g0 *= pw;
+        g1 *= pw;
+        g2 *= pw;
+    }
+    if (g0 == 0.f && g1 == 0.f && g2 == 0.f) return;  // adding zero is a no-op: skip the atomics
+    const float2 g = grid[i];
+    for (int l = 0; l < L.n; ++l) {
+        const int W = L.w[l], H = L.h[l];
+        const Taps t = make_taps(g.x, g.y, W, H);
+        float* p = L.p[l] + (size_t)t.y0 * W + t.x0;
+        const size_t cs = (size_t)W * H;
+        atomicAdd(p, g0 * t.nw);
+        atomicAdd(p + cs, g1 * t.nw);
+        atomicAdd(p + 2 * cs, g2 * t.nw);
+        if (t.x1_in) {
+            atomicAdd(p + 1, g0 * t.ne);
+            atomicAdd(p + cs + 1, g1 * t.ne);
+            atomicAdd(p + 2 * cs + 1, g2 * t.ne);
+        }
+        if (t.y1_in) {
+            atomicAdd(p + W, g0 * t.sw);
+            atomicAdd(p + cs + W, g1 * t.sw);
+            atomicAdd(p + 2 * cs + W, g2 * t.sw);
+            if (t.x1_in) {
+                atomicAdd(p + W + 1, g0 * t.se);
+                atomicAdd(p + cs + W + 1, g1 * t.se);
+                atomicAdd(p + 2 * cs + W + 1, g2 * t.se);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K7 fused update over the whole texture arena (all layers back to back), float4 per thread.
+// ---------------------------------------------------------------------------------------------------
+struct Segs {
+    size_t end[SM_MAX_TEX_LAYERS];
+    float reg[SM_MAX_TEX_LAYERS];
+    int n;
+};
+
+__device__ __forceinline__ int seg_of(const Segs& s, size_t i) {
+    int k = 0;
+    while (k < s.n - 1 && i >= s.end[k]) ++k;
+    return k;
+}
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, Segs segs, float lr_over_bc1,
+                                                   float one_minus_beta1, float beta2, float one_minus_beta2,
+                                                   float eps, float inv_sqrt_bc2,
+                                                   float grad_scale, float lo, float hi, int zero_grad,
+                                                   float* __restrict__ sumsq) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // sum(p^2) per segment: a block almost always lies inside one segment (k_blk); elements of a block that
+    // straddles a boundary and belong to another segment are added one by one.
+    const int k_blk = seg_of(segs, (size_t)blockIdx.x * 1024);
+    float sq = 0.f;
+    if (i0 < n) {
+        const bool full = i0 + 4 <= n;
+        float pv[4], gv[4], mv[4], vv[4];
+        if (full) {
+            *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
+            if (ADAM) {
+                *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
+                *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
+                *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
+            }
+        } else {
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = i0 + j < n;
+                pv[j] = ok ? p[i0 + j] : 0.f;
+                if (ADAM) {
+                    gv[j] = ok ? g[i0 + j] : 0.f;
+                    mv[j] = ok ? m[i0 + j] : 0.f;
+                    vv[j] = ok ? v[i0 + j] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = seg_of(segs, i0 + j);
+            float x = pv[j];
+            if (ADAM) {
+                const float gr = fmaf(gv[j], grad_scale, segs.reg[k] * x);  // data term (+ mean over ranks) + reg
+                mv[j] = mv[j] + (gr - mv[j]) * one_minus_beta1;             // exp_avg.lerp_(grad, 1 - beta1)
+                vv[j] = vv[j] * beta2 + (gr * gr) * one_minus_beta2;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+                const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+                x = x - lr_over_bc1 * (mv[j] / denom);
+            }
+            x = fminf(hi, fmaxf(x, lo));  // the clamp the next forward would start with
+            pv[j] = x;
+            if (sumsq && i0 + j < n) {
+                if (k == k_blk) sq += x * x;
+                else atomicAdd(sumsq + k, x * x);
+            }
+        }
+        if (full) {
+            *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
+            if (ADAM) {
+                *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
+                *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vv);
+                if (zero_grad) *reinterpret_cast<float4*>(g + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int j = 0; j < 4 && i0 + j < n; ++j) {
+                p[i0 + j] = pv[j];
+                if (ADAM) {
+                    m[i0 + j] = mv[j];
+                    v[i0 + j] = vv[j];
+                    if (zero_grad) g[i0 + j] = 0.f;
+                }
+            }
+        }
+    }
+    if (sumsq) {
+        const float s = block_sum(sq);
+        if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_blk, s);
+    }
+}
+
+static TexLayers make_layers(float* const* layers, const int* lw, const int* lh, int n) {
+    TexLayers L;
+    L.n = n;
+    for (int i = 0; i < n; ++i) {
+        L.p[i] = layers[i];
+        L.w[i] = lw[i];
+        L.h[i] = lh[i];
+    }
+    return L;
+}
+
+}  // namespace sm
+
+extern "C" {
+
+int sm_tex_sample_fwd(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
+                      const float* grid, int h, int w, float* out, void* stream) {
+    if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS) return (int)hipErrorInvalidValue;
+    sm::TexLayers L = sm::make_layers(const_cast<float* const*>(layers), layer_w, layer_h, n_layers);
+    const int n = h * w;
+    hipLaunchKernelGGL(sm::tex_sample_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L,
+                       reinterpret_cast<const float2*>(grid), h, w, out, sm::row_stride(w), sm::plane_size(h, w));
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
+                      const float* grid, int h, int w, const float* grad_img, const float* pixel_weight,
+                      void* stream) {
+    if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS) return (int)hipErrorInvalidValue;
+    sm::TexLayers L = sm::make_layers(grad_layers, layer_w, layer_h, n_layers);
+    const int n = h * w;
+    hipLaunchKernelGGL(sm::tex_sample_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L,
+                       reinterpret_cast<const float2*>(grid), h, w, grad_img, pixel_weight, sm::row_stride(w),
+                       sm::plane_size(h, w));
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int make_segs(sm::Segs& s, size_t n, const size_t* seg_end, const float* reg_coef, int n_seg) {
+    if (n_seg < 1 || n_seg > SM_MAX_TEX_LAYERS || seg_end[n_seg - 1] != n) return (int)hipErrorInvalidValue;
+    s.n = n_seg;
+    for (int i = 0; i < n_seg; ++i) {
+        s.end[i] = seg_end[i];
+        s.reg[i] = reg_coef ? reg_coef[i] : 0.f;
+    }
+    return 0;
+}
+
+int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end, const float* reg_coef,
+                  int n_seg, float lr, double beta1, double beta2, float eps, double bias_corr1, double bias_corr2,
+                  float grad_scale, float clamp_lo, float clamp_hi, int zero_grad, float* sumsq_out, void* stream) {
+    sm::Segs s;
+    if (int e = make_segs(s, n, seg_end, reg_coef, n_seg)) return e;
+    const size_t blocks = (n + 1023) / 1024;
+    // step_size = lr / bias_correction1 and 1 / sqrt(bias_correction2) in double, as torch computes them
+    const float lr_over_bc1 = (float)((double)lr / bias_corr1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_corr2));
+    hipLaunchKernelGGL(sm::adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       s, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, inv_sqrt_bc2,
+                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float clamp_lo, float clamp_hi,
+                   float* sumsq_out, void* stream) {
+    sm::Segs s;
+    if (int e = make_segs(s, n, seg_end, nullptr, n_seg)) return e;
+    const size_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(sm::adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, n, s, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, clamp_lo,
+                       clamp_hi, 0, sumsq_out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""ctypes binding of ``libstylemesh_hip.so`` (the C ABI declared in ``include/stylemesh_hip.h``).
+
+PyTorch supplies device memory and streams only: every call passes raw ``tensor.data_ptr()`` device pointers
+and the current HIP stream. There is NO fallback: if the library is missing the import of any product
+module raises, and every non-zero return code raises ``RuntimeError`` (the reference surface reports
+errors as Python exceptions, SURVEY.md section 8 b).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
+
+SM_MAX_TEX_LAYERS = 8
+SM_FMAP_GUARD = 4096
+EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD = 1, 2, 4
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> argtypes; must list every symbol include/stylemesh_hip.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "sm_fmap_row_stride": [_i],
+    "sm_fmap_plane": [_i, _i],
+    "sm_abi_version": [],
+    "sm_tex_sample_fwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "sm_tex_sample_bwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp],
+    "sm_clamp_sumsq": [_vp, _sz, _vp, _i, _f, _f, _vp, _vp],
+    "sm_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
+    "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "sm_level_masks": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "sm_level_maps": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sm_layer_masks": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sm_level_factors": [_vp, _vp, _i, _vp, _vp],
+    "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
+    "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
+    "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
+    "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or stylemesh_amd/csrc/build.sh")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        raise RuntimeError(f"libstylemesh_hip: {what} failed with HIP error code {code}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor / FMap (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    if hasattr(t, "ptr"):
+        return t.ptr
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+    return t.data_ptr()
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*[ptr(p) for p in ptrs])
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def float_array(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def size_array(vals):
+    return (C.c_size_t * len(vals))(*[int(v) for v in vals])
+
+
+def row_stride(W: int) -> int:
+    return lib.sm_fmap_row_stride(W)
+
+
+def plane(H: int, W: int) -> int:
+    return lib.sm_fmap_plane(H, W)

@@ -1,0 +1,152 @@
+"""One thin Python function per C-ABI entry point (argument marshalling only, no arithmetic)."""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+from .fmap import FMap
+from .hip import lib, ptr
+
+CLAMP_LO, CLAMP_HI = -123.6800, 151.0610  # reference model/texture/texture.py:43
+
+
+# ---- weight packing (one-time setup; layout transforms only) ------------------------------------------------
+def pack_conv_fwd(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [9][Cin_pad][Cout] (tap-major, Cout fastest), Cin padded with zeros to 4 / 8k."""
+    cout, cin = weight.shape[:2]
+    cin_pad = 4 if cin <= 4 else (cin + 7) // 8 * 8
+    w = weight.permute(2, 3, 1, 0).reshape(9, cin, cout)
+    out = torch.zeros(9, cin_pad, cout, dtype=torch.float32, device=weight.device)
+    out[:, :cin] = w
+    return out.contiguous()
+
+
+def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
+    """Weights of the data-gradient conv: dx[ci][p] = sum W[co][ci][2-ky][2-kx] dy[co][p + (ky-1,kx-1)]
+    -> [9][Cout][Cin_pad4] (the roles of the channel dimensions swap)."""
+    cout, cin = weight.shape[:2]
+    cin_pad = (cin + 3) // 4 * 4
+    w = weight.flip(2, 3).permute(2, 3, 0, 1).reshape(9, cout, cin)
+    out = torch.zeros(9, cout, cin_pad, dtype=torch.float32, device=weight.device)
+    out[:, :, :cin] = w
+    return out.contiguous()
+
+
+# ---- texture -------------------------------------------------------------------------------------------------
+def tex_sample_fwd(layers, grid: torch.Tensor, out: FMap):
+    h, w = grid.shape[-3], grid.shape[-2]
+    assert out.H == h and out.W == w and out.C >= 3 and grid.shape[-1] == 2
+    hip.check(lib.sm_tex_sample_fwd(hip.ptr_array(layers), hip.int_array([l.shape[2] for l in layers]),
+                                    hip.int_array([l.shape[1] for l in layers]), len(layers), ptr(grid), h, w,
+                                    out.ptr, hip.stream()), "sm_tex_sample_fwd")
+
+
+def tex_sample_bwd(grad_layers, grid: torch.Tensor, grad_img: FMap, pixel_weight=None):
+    h, w = grid.shape[-3], grid.shape[-2]
+    assert grad_img.H == h and grad_img.W == w
+    hip.check(lib.sm_tex_sample_bwd(hip.ptr_array(grad_layers), hip.int_array([l.shape[2] for l in grad_layers]),
+                                    hip.int_array([l.shape[1] for l in grad_layers]), len(grad_layers), ptr(grid),
+                                    h, w, grad_img.ptr, ptr(pixel_weight), hip.stream()), "sm_tex_sample_bwd")
+
+
+def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
+               zero_grad=True, sumsq_out=None):
+    n = p.numel()
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    hip.check(lib.sm_adam_fused(ptr(p), ptr(g), ptr(m), ptr(v), n, hip.size_array(seg_end),
+                                hip.float_array(reg_coef), len(seg_end), lr, beta1, beta2, eps, bc1, bc2,
+                                grad_scale, CLAMP_LO, CLAMP_HI, int(zero_grad), ptr(sumsq_out), hip.stream()),
+              "sm_adam_fused")
+
+
+def clamp_sumsq(p, seg_end, sumsq_out=None):
+    hip.check(lib.sm_clamp_sumsq(ptr(p), p.numel(), hip.size_array(seg_end), len(seg_end), CLAMP_LO, CLAMP_HI,
+                                 ptr(sumsq_out), hip.stream()), "sm_clamp_sumsq")
+
+
+# ---- VGG -----------------------------------------------------------------------------------------------------
+def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None):
+    cin_pad, cout = wt.shape[1], wt.shape[2]
+    assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
+    hip.check(lib.sm_conv3x3(inp.ptr, ptr(wt), ptr(bias), out.ptr, ptr(gate), cin_pad, cout, inp.H, inp.W, flags,
+                             hip.stream()), "sm_conv3x3")
+
+
+def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):
+    assert wd.shape[2] == 4 and wd.shape[1] == dz.C and out.C >= 3
+    hip.check(lib.sm_conv3x3_dgrad_c3(dz.ptr, ptr(wd), out.ptr, dz.C, dz.H, dz.W, hip.stream()), "sm_conv3x3_dgrad_c3")
+
+
+def maxpool_fwd(inp: FMap, out: FMap):
+    assert (out.H, out.W, out.C) == (inp.H // 2, inp.W // 2, inp.C)
+    hip.check(lib.sm_maxpool2x2_fwd(inp.ptr, out.ptr, inp.C, inp.H, inp.W, hip.stream()), "sm_maxpool2x2_fwd")
+
+
+def maxpool_bwd_relu(act: FMap, pooled: FMap, dpooled: FMap, dact: FMap):
+    hip.check(lib.sm_maxpool2x2_bwd_relu(act.ptr, pooled.ptr, dpooled.ptr, dact.ptr, act.C, act.H, act.W,
+                                         hip.stream()), "sm_maxpool2x2_bwd_relu")
+
+
+# ---- losses --------------------------------------------------------------------------------------------------
+def gram_masked(feat: FMap, mask0, mask1, S0, S1):
+    hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
+                                 hip.stream()), "sm_gram_masked")
+
+
+def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight, C, D0, D1, loss_out,
+               history=None, hist_len=0, hist_slot=0):
+    hip.check(lib.sm_style_loss(ptr(S0), ptr(S1), ptr(counts), ptr(factor), hip.ptr_array(targets),
+                                hip.int_array(term_mask), len(targets), hip.int_array(skip_if_empty), weight, C,
+                                ptr(D0), ptr(D1), ptr(loss_out), ptr(history), hist_len, hist_slot, hip.stream()),
+              "sm_style_loss")
+
+
+def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool):
+    hip.check(lib.sm_gram_backward(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C, feat.H,
+                                   feat.W, int(relu_gate), hip.stream()), "sm_gram_backward")
+
+
+def mse_masked(pred: FMap, target: FMap, mask, count, factor, weight, dpred: FMap, loss_out):
+    hip.check(lib.sm_mse_masked(pred.ptr, target.ptr, ptr(mask), ptr(count), ptr(factor), weight, dpred.ptr,
+                                ptr(loss_out), pred.C, pred.H, pred.W, hip.stream()), "sm_mse_masked")
+
+
+# ---- per-view constants ----------------------------------------------------------------------------------------
+def level_masks(rounded, other, interp_w, mask_u8, n_levels, E, Wt):
+    h, w = mask_u8.shape[-2:]
+    hip.check(lib.sm_level_masks(ptr(rounded), ptr(other), ptr(interp_w), ptr(mask_u8), h, w, n_levels, ptr(E),
+                                 ptr(Wt), hip.stream()), "sm_level_masks")
+
+
+def level_maps(E, Wt, angle_guidance, angle_deg, thr, h, w, H, W, M, pixel_weight, passed, m_sum):
+    hip.check(lib.sm_level_maps(ptr(E), ptr(Wt), ptr(angle_guidance), ptr(angle_deg), thr, h, w, H, W, ptr(M),
+                                ptr(pixel_weight), ptr(passed), ptr(m_sum), hip.stream()), "sm_level_maps")
+
+
+def layer_masks(M, passed, H, W, hl, wl, m_all, m_pass, m_fail, counts):
+    hip.check(lib.sm_layer_masks(ptr(M), ptr(passed), H, W, hl, wl, ptr(m_all), ptr(m_pass), ptr(m_fail),
+                                 ptr(counts), hip.stream()), "sm_layer_masks")
+
+
+def level_factors(counts_all, sizes, factors):
+    hip.check(lib.sm_level_factors(hip.ptr_array(counts_all), hip.float_array(sizes), len(sizes),
+                                   hip.ptr_array(factors), hip.stream()), "sm_level_factors")
+
+
+def fmap_resize_bilinear(inp: FMap, out: FMap):
+    hip.check(lib.sm_fmap_resize_bilinear(inp.ptr, inp.C, inp.H, inp.W, out.ptr, out.H, out.W, hip.stream()),
+              "sm_fmap_resize_bilinear")
+
+
+def image_to_fmap(img: torch.Tensor, out: FMap):
+    c, h, w = img.shape[-3:]
+    assert out.C >= c
+    hip.check(lib.sm_image_to_fmap(ptr(img), c, h, w, out.ptr, out.H, out.W, hip.stream()), "sm_image_to_fmap")
+
+
+def fmap_to_image(inp: FMap, channels=None) -> torch.Tensor:
+    c = inp.C if channels is None else channels
+    out = torch.empty(c, inp.H, inp.W, dtype=torch.float32, device=inp.buf.device)
+    hip.check(lib.sm_fmap_to_image(inp.ptr, c, inp.H, inp.W, ptr(out), hip.stream()), "sm_fmap_to_image")
+    return out

@@ -1,0 +1,349 @@
+"""Per-kernel parity: each C-ABI entry point on the GPU against the oracle (torch CPU fp32) on seeded inputs.
+fp32 tolerances are stated per test; summation order differs (MFMA k-order, atomics) so nothing is bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import stylemesh_oracle as O
+from conftest import load_golden
+from gpu_util import assert_close, rel_err, require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    require_gpu()
+    from stylemesh_amd.runtime import fmap, hip, ops
+    return type("RT", (), dict(FMap=fmap.FMap, hip=hip, ops=ops))
+
+
+def dev(x):
+    return x.contiguous().cuda()
+
+
+# ------------------------------------------------------------------ K1 / K2
+def test_tex_sample_forward_backward_golden(rt):
+    d = load_golden("g1_texture")
+    grid, up = torch.from_numpy(d["grid"]), torch.from_numpy(d["upstream"])
+    layers = [torch.from_numpy(d[f"layer{i}"]).clamp(O.CLAMP_LO, O.CLAMP_HI) for i in range(4)]
+    dl = [dev(l) for l in layers]
+    h, w = grid.shape[1:3]
+    for n_layers, key_out, key_grad in ((1, "flat_out", "flat_grad"), (4, "hier_out", "hier_grad")):
+        out = rt.FMap(4, h, w)
+        rt.ops.tex_sample_fwd(dl[:n_layers], dev(grid), out)
+        assert_close(out.to_dense(3), d[key_out][0], 1e-5, 2e-4, key_out)
+        assert out.border_is_zero()
+        gimg = rt.FMap(3, h, w).from_dense(up[0])
+        grads = [torch.zeros_like(l) for l in dl[:n_layers]]
+        rt.ops.tex_sample_bwd(grads, dev(grid), gimg)
+        for i, g in enumerate(grads):
+            ref = d[key_grad] if n_layers == 1 else d[f"{key_grad}{i}"]
+            assert_close(g, ref, 1e-5, 1e-5 * float(np.abs(ref).max()), f"{key_grad}{i}")
+    # known answers of SURVEY.md 8 a3
+    tex = dev(torch.arange(12.).view(1, 3, 4).repeat(3, 1, 1))
+    pg = dev(torch.tensor([[[[-1., -1.], [1., 1.], [0., 0.], [1.2, -3.]]]]))
+    out = rt.FMap(3, 1, 4)
+    rt.ops.tex_sample_fwd([tex], pg, out)
+    assert_close(out.to_dense()[0, 0], [0, 11, 5.5, 3], 1e-6, 1e-6)
+
+
+def test_tex_sample_backward_pixel_weight_and_accumulate(rt):
+    torch.manual_seed(0)
+    H, W, h, w = 33, 47, 40, 56
+    grid = torch.rand(1, h, w, 2) * 2.2 - 1.1
+    up = torch.randn(1, 3, h, w)
+    pw = torch.rand(h, w)
+    pw[:5] = 0
+    ref = O.grid_sample_border_backward_explicit((3, H, W), grid, up * pw)
+    g = torch.full((3, H, W), 0.5).cuda()
+    rt.ops.tex_sample_bwd([g], dev(grid), rt.FMap(3, h, w).from_dense(up[0]), dev(pw))
+    assert_close(g - 0.5, ref, 1e-4, 1e-5 * float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------ K3 / K4
+CONV_CASES = [
+    # (Cin, Cout, H, W)
+    (3, 64, 17, 21),      # first layer, KC = 4
+    (64, 64, 40, 56),     # BM = 64 tile
+    (64, 128, 20, 28),    # BM = 128 tile
+    (128, 128, 13, 131),  # wide & short, several N tiles per row
+    (256, 256, 9, 11),    # tiny plane: one partially filled N tile
+    (512, 512, 5, 7),
+    (64, 64, 3, 300),
+]
+
+
+@pytest.mark.parametrize("cin,cout,H,W", CONV_CASES)
+def test_conv3x3_forward(rt, cin, cout, H, W):
+    torch.manual_seed(cin + cout + H)
+    x = torch.randn(1, cin, H, W) * 3
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout) * 0.3
+    ref = F.relu(F.conv2d(x, wgt, b, padding=1))[0]
+    xin = rt.FMap(max(cin, 4), H, W).from_dense(x[0])
+    out = rt.FMap(cout, H, W)
+    out.planes.fill_(7.0)  # the kernel must (re)write every position of rows 1..H, zeros on the border columns
+    out.planes[:, :out.Wp] = 0
+    out.planes[:, (H + 1) * out.Wp:] = 0
+    rt.ops.conv3x3(xin, dev(rt.ops.pack_conv_fwd(wgt)), dev(b), out, rt.hip.EPI_BIAS_RELU)
+    assert_close(out.to_dense(), ref, 1e-4, 1e-4 * float(ref.abs().max()))
+    assert out.border_is_zero()
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 17, 21), (64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131)])
+def test_conv3x3_dgrad_with_gate_and_add(rt, cin, cout, H, W):
+    torch.manual_seed(cin * 3 + W)
+    x = torch.randn(1, cin, H, W)          # forward activation of the conv's input (post-ReLU values incl. zeros)
+    x = F.relu(x).requires_grad_(True)
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    dy = torch.randn(1, cout, H, W)
+    addend = torch.randn(cin, H, W)
+    F.conv2d(x, wgt, None, padding=1).backward(dy)
+    gate = (x.detach()[0] > 0).float()
+    wd = dev(rt.ops.pack_conv_dgrad(wgt))
+    dyf = rt.FMap(cout, H, W).from_dense(dy[0])
+    act = rt.FMap(cin, H, W).from_dense(x.detach()[0])
+    scale = float(x.grad.abs().max())
+    out = rt.FMap(cin, H, W)
+    rt.ops.conv3x3(dyf, wd, None, out, 0)
+    assert_close(out.to_dense(), x.grad[0], 1e-4, 1e-4 * scale, "plain dgrad")
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK, gate=act)
+    assert_close(out.to_dense(), x.grad[0] * gate, 1e-4, 1e-4 * scale, "gated dgrad")
+    out.from_dense(addend)
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK | rt.hip.EPI_ADD, gate=act)
+    assert_close(out.to_dense(), (x.grad[0] + addend) * gate, 1e-4, 1e-4 * scale, "gated dgrad + add")
+    assert out.border_is_zero()
+
+
+def test_conv3x3_first_layer_dgrad(rt):
+    torch.manual_seed(5)
+    H, W = 23, 37
+    x = torch.randn(1, 3, H, W, requires_grad=True)
+    wgt = torch.randn(64, 3, 3, 3) * 0.3
+    dy = torch.randn(1, 64, H, W)
+    F.conv2d(x, wgt, None, padding=1).backward(dy)
+    out = rt.FMap(3, H, W)
+    rt.ops.conv3x3_dgrad_c3(rt.FMap(64, H, W).from_dense(dy[0]), dev(rt.ops.pack_conv_dgrad(wgt)), out)
+    assert_close(out.to_dense(), x.grad[0], 1e-4, 1e-5 * float(x.grad.abs().max()))
+    assert out.border_is_zero()
+
+
+@pytest.mark.parametrize("H,W", [(8, 12), (9, 13), (17, 21), (2, 2)])
+def test_maxpool_forward_backward(rt, H, W):
+    torch.manual_seed(H * W)
+    C = 5
+    x = F.relu(torch.randn(1, C, H, W))
+    x[0, 0, :2, :2] = 1.5   # a tie inside one window: first element (row-major) wins
+    x = x.requires_grad_(True)
+    y = F.max_pool2d(x, 2, 2)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    ref_dx = x.grad[0] * (x.detach()[0] > 0)
+    act = rt.FMap(C, H, W).from_dense(x.detach()[0])
+    pooled = rt.FMap(C, H // 2, W // 2)
+    rt.ops.maxpool_fwd(act, pooled)
+    assert_close(pooled.to_dense(), y[0], 0, 0)
+    assert pooled.border_is_zero()
+    dact = rt.FMap(C, H, W)
+    rt.ops.maxpool_bwd_relu(act, pooled, rt.FMap(C, H // 2, W // 2).from_dense(dy[0]), dact)
+    assert_close(dact.to_dense(), ref_dx, 0, 0)
+    assert dact.border_is_zero()
+
+
+# ------------------------------------------------------------------ K5 / K6
+@pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False)])
+def test_gram_style_loss_and_backward(rt, C, H, W, multi):
+    torch.manual_seed(C + H)
+    feat = F.relu(torch.randn(1, C, H, W)).requires_grad_(True)
+    m_all = (torch.rand(1, 1, H, W) > 0.3).float()
+    passed = torch.rand(1, 1, H, W) > 0.5
+    m_pass, m_fail = m_all * passed, m_all * (~passed)
+    Y2 = torch.randn(C, C); Y2 = (Y2 + Y2.T) / 2
+    Y0 = torch.randn(C, C); Y0 = (Y0 + Y0.T) / 2
+    weight, factor = 1e-4 * 1000.0, 0.37
+    mse = torch.nn.MSELoss()
+    if multi:
+        gp = O.gram_matrix(O.masked_features(feat, m_pass))
+        gf = O.gram_matrix(O.masked_features(feat, m_fail))
+        loss = weight * factor * (mse(Y2[None], gp) + mse(Y2[None], gf) + mse(Y0[None], gp))
+        masks, targets, term_mask, skip = (m_pass, m_fail), [Y2, Y2, Y0], [0, 1, 0], [0, 1]
+    else:
+        gp = O.gram_matrix(O.masked_features(feat, m_all))
+        loss = weight * factor * mse(Y0[None], gp)
+        masks, targets, term_mask, skip = (m_all, None), [Y0], [0], [0, 0]
+    loss.backward()
+    f = rt.FMap(C, H, W).from_dense(feat.detach()[0])
+    mk = [rt.FMap(1, H, W).from_dense(m[0]) if m is not None else None for m in masks]
+    S = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda() if multi else None]
+    rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1])
+    n0 = float(masks[0].sum())
+    ref_S0 = gp[0] * n0
+    T = C // 64
+    tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
+    assert_close(S[0].cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
+    counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
+    D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
+    loss_out = torch.zeros(1).cuda()
+    rt.ops.style_loss(S[0], S[1], counts, dev(torch.tensor([factor])), [dev(t) for t in targets], term_mask, skip,
+                      weight, C, D[0], D[1], loss_out)
+    assert_close(loss_out, loss.detach().reshape(1), 1e-4, 0)
+    df = rt.FMap(C, H, W)
+    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=False)
+    assert_close(df.to_dense(), feat.grad[0], 1e-4, 2e-5 * float(feat.grad.abs().max()))
+    assert df.border_is_zero()
+    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=True)
+    assert_close(df.to_dense(), feat.grad[0] * (feat.detach()[0] > 0), 1e-4, 2e-5 * float(feat.grad.abs().max()))
+
+
+def test_style_loss_empty_masks(rt):
+    """N_pass == 0 -> Gram of zeros still compared with the target; N_fail == 0 -> term dropped (:332)."""
+    C, H, W = 64, 6, 6
+    feat = torch.rand(1, C, H, W)
+    Y = torch.randn(C, C); Y = (Y + Y.T) / 2
+    f = rt.FMap(C, H, W).from_dense(feat[0])
+    zero = rt.FMap(1, H, W)
+    S = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda()]
+    rt.ops.gram_masked(f, zero, zero, S[0], S[1])
+    D = [torch.ones(C, C).cuda(), torch.ones(C, C).cuda()]
+    loss_out = torch.zeros(1).cuda()
+    rt.ops.style_loss(S[0], S[1], dev(torch.zeros(2)), dev(torch.tensor([0.5])), [dev(Y), dev(Y)], [0, 1], [0, 1],
+                      2.0, C, D[0], D[1], loss_out)
+    assert_close(loss_out, (2.0 * 0.5 * (Y ** 2).mean()).reshape(1), 1e-5, 0)
+    assert float(D[0].abs().max()) == 0 and float(D[1].abs().max()) == 0
+
+
+def test_style_loss_average_mode(rt):
+    torch.manual_seed(3)
+    C = 64
+    Y = torch.randn(C, C); Y = (Y + Y.T) / 2
+    hist = torch.zeros(9, C, C).cuda()
+    cache = []
+    for step in range(12):
+        G = torch.randn(C, C); G = (G + G.T) / 2
+        Gt = G.clone().requires_grad_(True)
+        c = [g.detach() for g in cache[:9]]
+        c.insert(0, Gt)
+        cache = c
+        loss = 3.0 * 0.25 * F.mse_loss(Y, torch.stack(c).mean(0))
+        loss.backward()
+        N = 10.0
+        D0 = torch.empty(C, C).cuda()
+        loss_out = torch.zeros(1).cuda()
+        rt.ops.style_loss(dev(G * N), None, dev(torch.tensor([N, 0.0])), dev(torch.tensor([0.25])), [dev(Y)], [0],
+                          [0, 0], 3.0, C, D0, None, loss_out, history=hist, hist_len=min(step, 9), hist_slot=step % 9)
+        assert_close(loss_out, loss.detach().reshape(1), 1e-5, 0)
+        assert_close(D0, Gt.grad * 2 / N, 1e-4, 1e-7)   # D = 2 dL/dS = 2 dL/dG / N
+
+
+def test_mse_masked(rt):
+    torch.manual_seed(4)
+    C, H, W = 512, 5, 7
+    p = torch.randn(1, C, H, W, requires_grad=True)
+    t = torch.randn(1, C, H, W)
+    m = (torch.rand(1, 1, H, W) > 0.4).float()
+    weight, factor = 70.0, 0.6
+    loss = weight * factor * F.mse_loss(O.masked_features(t, m), O.masked_features(p, m))
+    loss.backward()
+    dp = rt.FMap(C, H, W)
+    loss_out = torch.zeros(1).cuda()
+    rt.ops.mse_masked(rt.FMap(C, H, W).from_dense(p.detach()[0]), rt.FMap(C, H, W).from_dense(t[0]),
+                      rt.FMap(1, H, W).from_dense(m[0]), dev(m.sum().reshape(1)), dev(torch.tensor([factor])), weight,
+                      dp, loss_out)
+    assert_close(loss_out, loss.detach().reshape(1), 1e-5, 0)
+    assert_close(dp.to_dense(), p.grad[0], 1e-5, 1e-6 * float(p.grad.abs().max()))
+    loss_out.zero_()
+    rt.ops.mse_masked(rt.FMap(C, H, W).from_dense(p.detach()[0]), rt.FMap(C, H, W).from_dense(t[0]),
+                      rt.FMap(1, H, W), dev(torch.zeros(1)), dev(torch.tensor([factor])), weight, dp, loss_out)
+    assert float(loss_out) == 0 and float(dp.to_dense().abs().max()) == 0
+
+
+# ------------------------------------------------------------------ K7
+def test_adam_fused_matches_oracle(rt):
+    torch.manual_seed(7)
+    sizes = [3 * 64 * 64, 3 * 32 * 32, 3 * 16 * 16, 3 * 8 * 8 + 5]   # last one not a multiple of 4*256
+    seg_end = np.cumsum(sizes).tolist()
+    n = seg_end[-1]
+    p = (torch.randn(n) * 60).clamp(O.CLAMP_LO, O.CLAMP_HI)
+    m, v = torch.zeros(n), torch.zeros(n)
+    reg = [0.41, 0.2, 0.05, 0.0]
+    regv = torch.cat([torch.full((s,), r) for s, r in zip(sizes, reg)])
+    P, M, V = dev(p), dev(m), dev(v)
+    for step in range(1, 5):
+        g = torch.randn(n) * 10 ** torch.randint(-5, 2, (n,)).float()
+        g[::7] = 0
+        G = dev(g)
+        lr = 1.0 if step < 3 else 0.1
+        sumsq = torch.zeros(4).cuda()
+        rt.ops.adam_fused(P, G, M, V, seg_end, reg, lr, step, grad_scale=0.5, sumsq_out=sumsq)
+        p, m, v = O.adam_step_explicit(p, 0.5 * g + regv * p, m, v, step, lr)
+        p = p.clamp(O.CLAMP_LO, O.CLAMP_HI)
+        assert_close(P, p, 1e-5, 1e-5)
+        assert_close(M, m, 1e-5, 1e-7)
+        assert_close(V, v, 1e-5, 1e-9)
+        assert float(G.abs().max()) == 0
+        ref_sq = [float((p[a:b] ** 2).sum()) for a, b in zip([0] + seg_end[:-1], seg_end)]
+        assert_close(sumsq, ref_sq, 1e-4, 0)
+    big = dev(torch.tensor([500.0, -500.0, 1.0, 2.0, 3.0]))
+    sq = torch.zeros(1).cuda()
+    rt.ops.clamp_sumsq(big, [5], sq)
+    assert_close(big, [O.CLAMP_HI, O.CLAMP_LO, 1, 2, 3], 1e-7, 0)
+
+
+# ------------------------------------------------------------------ per-view constants
+def test_view_constants_match_oracle(rt):
+    from golden_cases import SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW
+    from stylemesh_amd.data import synthetic as S
+    batch = S.make_view(3, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                        min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+    cfg = O.OracleConfig(use_angle_weight=True, use_depth_scaling=True, angle_threshold=30)
+    masks, weights = O.level_masks_and_weights(batch, SMALL_LEVEL_HW, cfg)
+    _, _, _, _, _, rounded, other, iw, _, _, mask, ag, adeg = batch
+    h, w = SMALL_VIEW_HW
+    E = torch.empty(2, h, w).cuda()
+    Wt = torch.empty(2, h, w).cuda()
+    rt.ops.level_masks(dev(rounded), dev(other), dev(iw), dev(mask.to(torch.uint8)), 2, E, Wt)
+    for i, (H, W) in enumerate(SMALL_LEVEL_HW):
+        M = torch.empty(H, W).cuda()
+        pw = torch.empty(H, W).cuda()
+        passed = torch.empty(H, W, dtype=torch.uint8).cuda()
+        msum = torch.zeros(1).cuda()
+        rt.ops.level_maps(E[i], Wt[i], dev(ag), dev(adeg), 30.0, h, w, H, W, M, pw, passed, msum)
+        assert_close(M, masks[i][0, 0], 0, 0)
+        assert float(msum) == float(masks[i].sum())
+        ref_pw = F.interpolate(ag, (H, W), mode="bilinear")[0, 0] * weights[i][0, 0]
+        assert_close(pw, ref_pw, 1e-5, 1e-6)
+        ref_passed = F.interpolate(adeg, (H, W), mode="bilinear")[0, 0] < 30
+        assert (passed.cpu().bool() != ref_passed).float().mean() < 1e-3
+        for (hl, wl) in [(H, W), (H // 2, W // 2), (H // 8, W // 8)]:
+            ma, mp, mf = rt.FMap(1, hl, wl), rt.FMap(1, hl, wl), rt.FMap(1, hl, wl)
+            counts = torch.zeros(3).cuda()
+            rt.ops.layer_masks(M, passed, H, W, hl, wl, ma, mp, mf, counts)
+            pb = passed.cpu().bool()[None, None]
+            r_all = F.interpolate(masks[i], (hl, wl), mode="nearest")
+            r_pass = F.interpolate(masks[i] * pb, (hl, wl), mode="nearest")
+            r_fail = F.interpolate(masks[i] * (~pb), (hl, wl), mode="nearest")
+            assert_close(ma.to_dense(), r_all[0], 0, 0)
+            assert_close(mp.to_dense(), r_pass[0], 0, 0)
+            assert_close(mf.to_dense(), r_fail[0], 0, 0)
+            assert_close(counts, [float(r_all.sum()), float(r_pass.sum()), float(r_fail.sum())], 0, 0)
+
+
+def test_resizes_and_factors(rt):
+    torch.manual_seed(9)
+    x = torch.randn(1, 6, 5, 7)
+    src = rt.FMap(6, 5, 7).from_dense(x[0])
+    for (H, W) in [(8, 11), (5, 7), (13, 30), (3, 4)]:
+        dst = rt.FMap(6, H, W)
+        rt.ops.fmap_resize_bilinear(src, dst)
+        assert_close(dst.to_dense(), F.interpolate(x, (H, W), mode="bilinear")[0], 1e-5, 1e-5)
+        dst2 = rt.FMap(6, H, W)
+        rt.ops.image_to_fmap(dev(x[0]), dst2)
+        assert_close(dst2.to_dense(), F.interpolate(x, (H, W), mode="bilinear")[0], 1e-5, 1e-5)
+        assert dst2.border_is_zero()
+    assert_close(rt.ops.fmap_to_image(src), x[0], 0, 0)
+    counts = [dev(torch.tensor([30.0])), dev(torch.tensor([10.0])), dev(torch.tensor([0.0]))]
+    factors = [torch.zeros(1).cuda() for _ in range(3)]
+    rt.ops.level_factors(counts, [60.0, 40.0, 20.0], factors)
+    assert_close(torch.cat(factors), [0.5 / 0.75, 0.25 / 0.75, 0.0], 1e-6, 0)
