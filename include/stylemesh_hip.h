@@ -127,10 +127,11 @@ int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, 
                      const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* stream);
 
 /* K6. Masked content MSE (:343-348): loss += coef * sum m (P-T)^2 / (C N); dP = coef * 2 m (P-T)/(C N),
- * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred. */
+ * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred.
+ * relu_gate: additionally zero dP where pred <= 0 (when this is the deepest layer, see K5c). */
 int sm_mse_masked(const float* pred, const float* target, const float* mask, const float* count,
                   const float* factor, float weight, float* dpred, float* loss_out, int C, int H, int W,
-                  void* stream);
+                  int relu_gate, void* stream);
 
 /* ---- per-view constants: model/model.py:188-254, content_and_style_losses.py:146-217 ---------------- */
 

@@ -175,8 +175,9 @@ def identity_grid(H, W):
 # ---------------------------------------------------------------------------------------------------
 # VGG / Gram / style pyramid (reference model/losses/content_and_style_losses.py)
 # ---------------------------------------------------------------------------------------------------
-def vgg_forward(state: dict, x: torch.Tensor, out_keys, explicit_pool=False) -> dict:
-    """``VGG.forward`` (content_and_style_losses.py:47-70): 3x3 pad-1 conv + ReLU, 2x2 max-pool."""
+def vgg_forward(state: dict, x: torch.Tensor, out_keys, explicit_pool=False, keep_all: dict | None = None) -> dict:
+    """``VGG.forward`` (content_and_style_losses.py:47-70): 3x3 pad-1 conv + ReLU, 2x2 max-pool.
+    ``keep_all`` (tests only) receives every intermediate activation with ``retain_grad()`` set."""
     out = {}
     block, idx = 1, 1
     for name in VGG_ORDER:
@@ -188,8 +189,12 @@ def vgg_forward(state: dict, x: torch.Tensor, out_keys, explicit_pool=False) -> 
             x = F.relu(F.conv2d(x, state[name + ".weight"], state[name + ".bias"], padding=1))
             out[f"r{block}{idx}"] = x
             idx += 1
+        if keep_all is not None and x.requires_grad:
+            x.retain_grad()
         if all(k in out for k in out_keys):
             break
+    if keep_all is not None:
+        keep_all.update(out)
     return {k: out[k] for k in out_keys}
 
 
@@ -279,24 +284,25 @@ def level_masks_and_weights(batch, pred_shapes, cfg: OracleConfig):
     Returns ``(masks, weights)``: lists over UV levels of [1,1,H_i,W_i] float tensors
     (``weights[i]`` is None without depth scaling)."""
     _, _, _, _, _, rounded, other, interp_w, _, _, mask, _, _ = batch
-    mask = mask.unsqueeze(1).float()
+    dt = interp_w.dtype   # fp32; fp64 only for the "is a mismatch a benign ReLU/pool flip?" diagnostics
+    mask = mask.unsqueeze(1).to(dt)
 
     def erode(x):
-        k = torch.ones(1, 1, 3, 3)
+        k = torch.ones(1, 1, 3, 3, dtype=dt)
         em = torch.clamp(F.conv2d(x, k, padding=(1, 1)) / 9, 0, 1)
         return x * (em == 1)
 
     if cfg.use_depth_scaling:
         masks, weights = [], []
         for i, hw in enumerate(pred_shapes):
-            m = ((rounded == i) + (other == i)).float() * mask
-            masks.append((F.interpolate(erode(m), hw, mode="nearest") > 0).float())
+            m = ((rounded == i) + (other == i)).to(dt) * mask
+            masks.append((F.interpolate(erode(m), hw, mode="nearest") > 0).to(dt))
             m1 = erode((rounded == i) * mask) * interp_w
             m2 = erode((other == i) * mask) * (1 - interp_w)
             weights.append(F.interpolate(m1 + m2, hw, mode="nearest"))
     else:
-        masks = [torch.zeros(1, 1, *hw) for hw in pred_shapes]
-        masks[-1] = (F.interpolate(mask, pred_shapes[-1], mode="nearest") > 0).float()
+        masks = [torch.zeros(1, 1, *hw, dtype=dt) for hw in pred_shapes]
+        masks[-1] = (F.interpolate(mask, pred_shapes[-1], mode="nearest") > 0).to(dt)
         weights = [None] * len(pred_shapes)
     return masks, weights
 
@@ -321,7 +327,10 @@ def content_and_style_loss(state, preds, target_content, pyramid_masks, angle_de
     ``preds``: active prediction levels; ``pyramid_masks``: their masks. Returns ``(style, content)``.
     ``record`` (dict) receives intermediates keyed by level index for the GPU tests."""
     layers = cfg.style_layers + cfg.content_layers
-    enc = [vgg_forward(state, p, layers) for p in preds]
+    all_acts = [dict() for _ in preds] if record is not None else [None] * len(preds)
+    enc = [vgg_forward(state, p, layers, keep_all=ka) for p, ka in zip(preds, all_acts)]
+    if record is not None:
+        record["all_acts"] = all_acts   # every activation, with .grad = dL/d(activation) after backward
     if content_enc is None:
         content_enc = vgg_forward(state, target_content, layers)
     mse = torch.nn.MSELoss()

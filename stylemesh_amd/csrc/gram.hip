@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
                                                          const float* __restrict__ mask, const float* __restrict__ count,
                                                          const float* __restrict__ factor, float weight,
                                                          float* __restrict__ dpred, float* loss_out, int C, int plane,
-                                                         int q_begin, int q_end) {
+                                                         int q_begin, int q_end, int relu_gate) {
     __shared__ float red[4];
     const int c = blockIdx.y;
     const int q = q_begin + (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -262,7 +262,14 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
         float4 d = make_float4(m.x * (p.x - t.x), m.y * (p.y - t.y), m.z * (p.z - t.z), m.w * (p.w - t.w));
         part = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;  // m in {0,1}: m^2 = m
         const float c2 = 2.f * coef;
-        *reinterpret_cast<float4*>(dpred + o) = make_float4(c2 * d.x, c2 * d.y, c2 * d.z, c2 * d.w);
+        float4 g = make_float4(c2 * d.x, c2 * d.y, c2 * d.z, c2 * d.w);
+        if (relu_gate) {  // pred is the post-ReLU activation itself
+            g.x = p.x > 0.f ? g.x : 0.f;
+            g.y = p.y > 0.f ? g.y : 0.f;
+            g.z = p.z > 0.f ? g.z : 0.f;
+            g.w = p.w > 0.f ? g.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(dpred + o) = g;
     }
     const float tot = block_sum256(part, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * coef);
@@ -330,12 +337,12 @@ int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, 
 }
 
 int sm_mse_masked(const float* pred, const float* target, const float* mask, const float* count, const float* factor,
-                  float weight, float* dpred, float* loss_out, int C, int H, int W, void* stream) {
+                  float weight, float* dpred, float* loss_out, int C, int H, int W, int relu_gate, void* stream) {
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     dim3 grid(((q_end - q_begin) / 4 + 255) / 256, C);
     hipLaunchKernelGGL(sm::mse_masked_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, target, mask, count, factor,
-                       weight, dpred, loss_out, C, plane, q_begin, q_end);
+                       weight, dpred, loss_out, C, plane, q_begin, q_end, relu_gate);
     SM_LAUNCH_CHECK();
     return 0;
 }

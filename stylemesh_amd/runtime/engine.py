@@ -1,0 +1,387 @@
+"""The texture-optimisation step on the GPU: texture sample -> VGG -> style / content losses -> hand-written
+backward -> atomic scatter into the texture gradient -> fused regulariser + Adam + clamp.
+
+This is the MI355X restatement of ``TextureOptimizationStyleTransferPipeline.forward_with_loss`` + autograd
+backward + ``Adam.step`` (reference model/model.py:143-327,387-401) for batch size 1. Python only sequences
+kernel launches of ``libstylemesh_hip.so`` on the current stream; there is no host synchronisation inside a
+step (the reference synchronises >= 6 times per step) - the only sync is one read-back
+of the per-level mask sums when a NEW view arrives (the reference's empty-level filter, model/model.py:256-257).
+
+Everything that depends only on the view (UV grids, level masks, angle / depth pixel weights, layer masks and
+their counts, level factors, the content target's VGG features) is computed once per view in ``set_view`` and
+reused for the 20-100 consecutive steps the reference's RepeatingSampler spends on it.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from .fmap import FMap
+from .vgg import PRE_POOL, LevelBuffers, VGGNet, depth_of, layer_hw
+
+DEFAULT_STYLE_LAYERS = ['r11', 'r21', 'r31', 'r41', 'r51']        # content_and_style_losses.py:222
+DEFAULT_CONTENT_LAYERS = ['r42']                                  # :223
+DEFAULT_STYLE_WEIGHTS = [1e3 / n ** 2 for n in [64, 128, 256, 512, 512]]  # :226
+LOSS_TYPES = ["tex_reg", "content", "style", "total"]             # model/model.py:18-22
+
+
+@dataclass
+class EngineConfig:
+    tex_w: int = 512
+    tex_h: int = 512
+    hierarchical: bool = True
+    n_layers: int = 4
+    style_layers: list = field(default_factory=lambda: list(DEFAULT_STYLE_LAYERS))
+    content_layers: list = field(default_factory=lambda: list(DEFAULT_CONTENT_LAYERS))
+    style_weights: list = field(default_factory=lambda: list(DEFAULT_STYLE_WEIGHTS))
+    content_weights: list = field(default_factory=lambda: [1])
+    angle_threshold: float = 60
+    style_pyramid_mode: str = "single"
+    gram_mode: str = "current"
+    use_angle_weight: bool = True
+    use_depth_scaling: bool = True
+    loss_weights: dict = field(default_factory=lambda: {"content": 0.0, "style": 0.0, "tex_reg": 0.0})
+    tex_reg_weights: list | None = None
+    learning_rate: float = 1.0
+    decay_gamma: float = 0.1
+    decay_step_size: int = 30
+
+    def validate(self):
+        if self.style_pyramid_mode not in ("single", "multi"):
+            raise ValueError(f"Unsupported style_pyramid_mode: {self.style_pyramid_mode}")
+        if self.gram_mode not in ("current", "average"):
+            raise ValueError(f"Unsupported gram_mode: {self.gram_mode}")
+        for l in self.style_layers + self.content_layers:
+            depth_of(l)
+            if not l.startswith("r") or l in PRE_POOL:
+                raise ValueError(f"unsupported loss layer {l}: must be a conv output that does not feed a pool")
+        if set(self.style_layers) & set(self.content_layers):
+            raise ValueError("a layer cannot be both a style and a content layer")
+        if len(self.style_weights) != len(self.style_layers) or len(self.content_weights) != len(self.content_layers):
+            raise ValueError("one weight per style / content layer is required")
+
+    def reg_weights(self):
+        n = self.n_layers if self.hierarchical else 1
+        if self.tex_reg_weights:
+            if len(self.tex_reg_weights) != n:
+                raise ValueError(f"Have {n} texture layers, but only {len(self.tex_reg_weights)} weights specified")
+            return list(self.tex_reg_weights)
+        w = [pow(2, n - i - 1) for i in range(n)]  # model/model.py:86-88
+        w[-1] = 0
+        return w
+
+
+class TextureArena:
+    """Texture, gradient and Adam moments of all layers back to back in four flat fp32 arenas; the layers are
+    [3,H_l,W_l] views (the reference's Parameter layout, texture.py:29-32)."""
+
+    def __init__(self, W, H, n_layers, device, random_init=False):
+        self.shapes = [(3, H // 2 ** i, W // 2 ** i) for i in range(n_layers)]
+        sizes = [c * h * w for c, h, w in self.shapes]
+        self.seg_end = []
+        tot = 0
+        for s in sizes:
+            tot += s
+            self.seg_end.append(tot)
+        self.n = tot
+        self.p = torch.rand(tot, device=device) if random_init else torch.zeros(tot, device=device)
+        self.g = torch.zeros(tot, device=device)
+        self.m = torch.zeros(tot, device=device)
+        self.v = torch.zeros(tot, device=device)
+
+    def views(self, flat):
+        out, start = [], 0
+        for shp, end in zip(self.shapes, self.seg_end):
+            out.append(flat[start:end].view(shp))
+            start = end
+        return out
+
+
+class _ViewLevel:
+    """Per-view constants of one UV pyramid level."""
+    pass
+
+
+class StepEngine:
+    def __init__(self, cfg: EngineConfig, vgg_state: dict, device="cuda", random_init=False):
+        cfg.validate()
+        self.cfg, self.device = cfg, device
+        self.vgg = VGGNet(vgg_state, device)
+        n_layers = cfg.n_layers if cfg.hierarchical else 1
+        self.arena = TextureArena(cfg.tex_w, cfg.tex_h, n_layers, device, random_init)
+        self.layers = self.arena.views(self.arena.p)
+        self.grads = self.arena.views(self.arena.g)
+        self.loss_layers = list(cfg.style_layers) + list(cfg.content_layers)
+        # layers that actually receive a loss gradient (a zero loss weight contributes an exactly-zero gradient:
+        # its kernels are skipped); the VGG pass stops at the deepest of them
+        w_style = float(cfg.loss_weights.get("style", 0.0))
+        w_content = float(cfg.loss_weights.get("content", 0.0))
+        self.injected = ([l for l in cfg.style_layers if w_style != 0.0]
+                         + [l for l in cfg.content_layers if w_content != 0.0])
+        self.deepest = max(self.injected, key=depth_of) if self.injected else None
+        self.deepest_content = max(cfg.content_layers, key=depth_of) if cfg.content_layers else None
+        self._bufs = {}            # (H, W) -> LevelBuffers with gradients
+        self._content_bufs = {}    # (h, w) -> LevelBuffers without gradients (content target pass)
+        self.targets = None        # targets[layer_index][pyramid_level] -> [C,C] device tensor
+        self.view = None
+        self.view_key = None
+        self.step_count = 0
+        self.epoch = 0
+        # device scalars: [content, style] weighted loss accumulators, per-layer sum of squares of the texture
+        self.loss_buf = torch.zeros(2, device=device)
+        self.sumsq = torch.zeros(n_layers, device=device)
+        self._gram = {}            # C -> scratch (S0, S1, D0, D1)
+        self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
+        numel = [c * h * w for c, h, w in self.arena.shapes]
+        lam = cfg.loss_weights.get("tex_reg", 0.0)
+        rw = cfg.reg_weights() if cfg.hierarchical else [0.0]
+        self.reg_active = lam > 0 and cfg.hierarchical   # model/model.py:163-171,264-267
+        # d/dp [lam * w_i * mean(p_i^2)] = (2 lam w_i / N_i) p
+        self.reg_coef = [2.0 * lam * w / n if self.reg_active else 0.0 for w, n in zip(rw, numel)]
+        self.reg_loss_coef = [lam * w / n if self.reg_active else 0.0 for w, n in zip(rw, numel)]
+        ops.clamp_sumsq(self.arena.p, self.arena.seg_end, self.sumsq)
+
+    # ------------------------------------------------------------------ texture access
+    def load_texture(self, layer_tensors):
+        """``from_tensor`` semantics (texture.py:34-39,83-94) + the clamp every forward starts with."""
+        for dst, src in zip(self.layers, layer_tensors):
+            assert tuple(dst.shape) == tuple(src.shape), (dst.shape, src.shape)
+            dst.copy_(src.to(self.device, torch.float32))
+        self.sumsq.zero_()
+        ops.clamp_sumsq(self.arena.p, self.arena.seg_end, self.sumsq)
+
+    @property
+    def lr(self):
+        """StepLR (model/model.py:397-399): lr * gamma ** (epoch // step_size)."""
+        return self.cfg.learning_rate * self.cfg.decay_gamma ** (self.epoch // self.cfg.decay_step_size)
+
+    # ------------------------------------------------------------------ buffers
+    def _level_bufs(self, H, W) -> LevelBuffers:
+        key = (H, W)
+        if key not in self._bufs:
+            self._bufs[key] = LevelBuffers(H, W, self.deepest, True, self.device)
+        return self._bufs[key]
+
+    def _gram_scratch(self, C):
+        if C not in self._gram:
+            self._gram[C] = tuple(torch.zeros(C, C, device=self.device) for _ in range(4))
+        return self._gram[C]
+
+    # ------------------------------------------------------------------ style targets
+    def set_style_image(self, style_image: torch.Tensor, num_levels=5):
+        """``ContentAndStyleLoss.set_style_image`` (content_and_style_losses.py:273-286): Gram matrices of the
+        VGG features of the reversed style-image pyramid (``image_pyramid``, :83-133)."""
+        from .pyramid import image_pyramid_sizes
+        img = style_image[0] if style_image.dim() == 4 else style_image
+        img = img.to(self.device, torch.float32).contiguous()
+        h, w = img.shape[1:]
+        sizes = image_pyramid_sizes(h, w, list(range(num_levels)))
+        self.style_pyramid_sizes = sizes
+        deepest_style = max(self.cfg.style_layers, key=depth_of)
+        cache = {}
+        for s in sizes:
+            if s in cache:
+                continue
+            b = LevelBuffers(s[0], s[1], deepest_style, False, self.device)
+            ops.image_to_fmap(img, b.act["img"])  # bilinear (align_corners=False) resize of the ORIGINAL image
+            self.vgg.forward(b)
+            grams = []
+            for layer in self.cfg.style_layers:
+                f = b.act[layer]
+                ones = FMap(1, f.H, f.W, self.device).from_dense(torch.ones(1, f.H, f.W))
+                S = torch.zeros(f.C, f.C, device=self.device)
+                ops.gram_masked(f, ones, None, S, None)
+                grams.append(_mirror_tiles(S) / float(f.H * f.W))
+            cache[s] = grams
+            del b
+        self.targets = [{lvl: cache[s][li] for lvl, s in enumerate(sizes)} for li in range(len(self.cfg.style_layers))]
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ per-view constants
+    def set_view(self, batch):
+        cfg = self.cfg
+        rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
+        dev = self.device
+        if rgb.shape[0] != 1:
+            raise ValueError("batch size 1 only (the reference's masked_features indexing requires it too)")
+        h, w = rgb.shape[2:]
+        to = lambda t, dt=torch.float32: t.to(dev, dt).contiguous()
+        mask_u8 = to(mask[0], torch.uint8)
+        ag, adeg = to(angle_guidance[0, 0]), to(angle_degrees[0, 0])
+        n_levels = len(uv_map)
+        if cfg.use_depth_scaling:
+            E = torch.empty(n_levels, h, w, device=dev)
+            Wt = torch.empty(n_levels, h, w, device=dev)
+            ops.level_masks(to(rounded[0, 0], torch.int64), to(other[0, 0], torch.int64), to(interp_w[0, 0]), mask_u8,
+                            n_levels, E, Wt)
+        else:
+            maskf = mask_u8.float()
+        levels = []
+        msums = torch.zeros(n_levels, device=dev)
+        for i, uv in enumerate(uv_map):
+            lv = _ViewLevel()
+            lv.grid = to(uv[0])
+            lv.H, lv.W = lv.grid.shape[:2]
+            lv.index = i
+            if not cfg.use_depth_scaling and i != n_levels - 1:
+                lv.active = False   # all-zero mask (model/model.py:253-254)
+                levels.append(lv)
+                continue
+            lv.M = torch.empty(lv.H, lv.W, device=dev)
+            want_pw = cfg.use_angle_weight or cfg.use_depth_scaling
+            lv.pixel_weight = torch.empty(lv.H, lv.W, device=dev) if want_pw else None
+            lv.passed = torch.empty(lv.H, lv.W, dtype=torch.uint8, device=dev)
+            ops.level_maps(E[i] if cfg.use_depth_scaling else maskf, Wt[i] if cfg.use_depth_scaling else None,
+                           ag if cfg.use_angle_weight else None, adeg, float(cfg.angle_threshold), h, w, lv.H, lv.W,
+                           lv.M, lv.pixel_weight, lv.passed, msums[i:i + 1])
+            levels.append(lv)
+        sums = msums.cpu()   # the one host sync per view: which levels are non-empty (model/model.py:256-257)
+        for lv in levels:
+            if hasattr(lv, "M"):
+                lv.active = bool(sums[lv.index] > 0)
+        active = [lv for lv in levels if lv.active]
+        # layer masks, counts, factors
+        n_act = len(active)
+        consts = torch.zeros(n_act, len(self.loss_layers), 4, device=dev)   # [N_all, N_pass, N_fail, factor]
+        for a, lv in enumerate(active):
+            lv.masks, lv.counts, lv.factor = {}, {}, {}
+            for k, layer in enumerate(self.loss_layers):
+                hl, wl = layer_hw(layer, lv.H, lv.W)
+                m = FMap(3, hl, wl, dev)   # planes: all, passed, failed
+                ops.layer_masks(lv.M, lv.passed, lv.H, lv.W, hl, wl, m.channel_ptr(0), m.channel_ptr(1),
+                                m.channel_ptr(2), consts[a, k, 0:3])
+                lv.masks[layer], lv.counts[layer], lv.factor[layer] = m, consts[a, k, 0:3], consts[a, k, 3:4]
+        for k, layer in enumerate(self.loss_layers):
+            if n_act:
+                sizes = [float(math.prod(layer_hw(layer, lv.H, lv.W))) for lv in active]
+                ops.level_factors([lv.counts[layer] for lv in active], sizes, [lv.factor[layer] for lv in active])
+        # content target: VGG features of the captured image, resized per level (losses :294, :176-177)
+        if cfg.content_layers and n_act:
+            key = (h, w)
+            if key not in self._content_bufs:
+                self._content_bufs[key] = LevelBuffers(h, w, self.deepest_content, False, dev)
+            cb = self._content_bufs[key]
+            ops.image_to_fmap(to(rgb[0]), cb.act["img"])
+            self.vgg.forward(cb)
+            for lv in active:
+                lv.content_target = {}
+                for layer in cfg.content_layers:
+                    src = cb.act[layer]
+                    hl, wl = layer_hw(layer, lv.H, lv.W)
+                    dst = FMap(src.C, hl, wl, dev)
+                    ops.fmap_resize_bilinear(src, dst)
+                    lv.content_target[layer] = dst
+        self.view = levels
+        self.view_consts = consts
+        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
+
+    # ------------------------------------------------------------------ the step
+    def forward_backward(self):
+        """Forward + backward of the current view; the data-term gradient ACCUMULATES into the gradient arena
+        (zeroed by the fused update), the weighted content / style losses into ``loss_buf``."""
+        if self.view is None or self.targets is None:
+            raise RuntimeError("set_style_image() and set_view() must be called first")
+        cfg = self.cfg
+        self.loss_buf.zero_()
+        w_style = float(cfg.loss_weights.get("style", 0.0))
+        w_content = float(cfg.loss_weights.get("content", 0.0))
+        for lv in self.view:
+            if not lv.active or self.deepest is None:
+                continue
+            b = self._level_bufs(lv.H, lv.W)
+            ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
+            self.vgg.forward(b)
+            injected = set()
+            if w_style != 0.0:
+                for li, layer in enumerate(cfg.style_layers):
+                    self._style_terms(lv, b, li, layer, w_style)
+                    injected.add(layer)
+            if w_content != 0.0:
+                for li, layer in enumerate(cfg.content_layers):
+                    m = lv.masks[layer]
+                    ops.mse_masked(b.act[layer], lv.content_target[layer], m.channel_ptr(0), lv.counts[layer][0:1],
+                                   lv.factor[layer], w_content * float(cfg.content_weights[li]), b.grad[layer],
+                                   self.loss_buf[0:1], relu_gate=(layer == self.deepest))
+                    injected.add(layer)
+            self.vgg.backward(b, injected - {self.deepest}, self.deepest)
+            ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
+
+    def _style_terms(self, lv, b, li, layer, w_style):
+        cfg = self.cfg
+        f = b.act[layer]
+        m = lv.masks[layer]
+        S0, S1, D0, D1 = self._gram_scratch(f.C)
+        multi = cfg.style_pyramid_mode == "multi"
+        weight = w_style * float(cfg.style_weights[li])
+        S0.zero_()
+        hist, hist_len, hist_slot = None, 0, 0
+        if cfg.gram_mode == "average":
+            if layer not in self._hist:
+                self._hist[layer] = [torch.zeros(9, f.C, f.C, device=self.device), 0]
+            hist, cnt = self._hist[layer]
+            hist_len, hist_slot = min(cnt, 9), cnt % 9
+            self._hist[layer][1] = cnt + 1
+        if multi:
+            S1.zero_()
+            ops.gram_masked(f, m.channel_ptr(1), m.channel_ptr(2), S0, S1)
+            targets = [self.targets[li][2], self.targets[li][2]]
+            term_mask = [0, 1]
+            if li > 2:   # content_and_style_losses.py:335-338
+                targets.append(self.targets[li][0])
+                term_mask.append(0)
+            ops.style_loss(S0, S1, lv.counts[layer][1:3], lv.factor[layer], targets, term_mask, [0, 1], weight, f.C,
+                           D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot)
+            ops.gram_backward(f, m.channel_ptr(1), m.channel_ptr(2), D0, D1, b.grad[layer],
+                              relu_gate=(layer == self.deepest))
+        else:
+            ops.gram_masked(f, m.channel_ptr(0), None, S0, None)
+            ops.style_loss(S0, None, lv.counts[layer][0:1], lv.factor[layer], [self.targets[li][0]], [0], [0, 0],
+                           weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot)
+            ops.gram_backward(f, m.channel_ptr(0), None, D0, None, b.grad[layer], relu_gate=(layer == self.deepest))
+
+    def optimizer_step(self, world_size: int = 1):
+        """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""
+        self.step_count += 1
+        self.sumsq.zero_()
+        ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
+                       self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq)
+
+    def end_epoch(self):
+        self.epoch += 1
+
+    def training_step(self, batch, world_size: int = 1, reducer=None):
+        """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order."""
+        key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
+        if self.view is None or key != self.view_key:
+            self.set_view(batch)
+        losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
+        self.forward_backward()
+        if reducer is not None:
+            reducer(self.arena.g)
+        self.optimizer_step(world_size)
+        return losses
+
+    def loss_tensors(self):
+        """Weighted losses as device tensors, names as the reference logs them (model/model.py:261-270).
+        content / style are filled by the forward_backward() that follows."""
+        reg = (self.sumsq * torch.tensor(self.reg_loss_coef, device=self.device)).sum().reshape(1)
+        return {"content": self.loss_buf[0:1], "style": self.loss_buf[1:2], "tex_reg": reg}
+
+    def losses(self, lt=None):
+        """Host floats (synchronises). Pass the dict returned by ``training_step`` to read that step's values."""
+        lt = lt or self.loss_tensors()
+        out = {k: float(v) for k, v in lt.items()}
+        out["total"] = out["content"] + out["style"] + out["tex_reg"]
+        return out
+
+
+def _mirror_tiles(S):
+    """Full symmetric matrix from the upper-triangular 64x64 tiles sm_gram_masked fills."""
+    C = S.shape[0]
+    T = C // 64
+    keep = torch.ones(T, T, device=S.device).triu().repeat_interleave(64, 0).repeat_interleave(64, 1)
+    strict = torch.ones(T, T, device=S.device).triu(1).repeat_interleave(64, 0).repeat_interleave(64, 1)
+    return S * keep + (S * strict).T

@@ -37,7 +37,7 @@ SIGNATURES = {
     "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_level_masks": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "sm_level_maps": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sm_layer_masks": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -107,9 +107,10 @@ def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool
                                    feat.W, int(relu_gate), hip.stream()), "sm_gram_backward")
 
 
-def mse_masked(pred: FMap, target: FMap, mask, count, factor, weight, dpred: FMap, loss_out):
+def mse_masked(pred: FMap, target: FMap, mask, count, factor, weight, dpred: FMap, loss_out, relu_gate=False):
     hip.check(lib.sm_mse_masked(pred.ptr, target.ptr, ptr(mask), ptr(count), ptr(factor), weight, dpred.ptr,
-                                ptr(loss_out), pred.C, pred.H, pred.W, hip.stream()), "sm_mse_masked")
+                                ptr(loss_out), pred.C, pred.H, pred.W, int(relu_gate), hip.stream()),
+              "sm_mse_masked")
 
 
 # ---- per-view constants ----------------------------------------------------------------------------------------

@@ -1,0 +1,107 @@
+"""The VGG-19 conv stack of the loss (reference model/losses/content_and_style_losses.py:7-70) as a plan of
+HIP kernel launches over padded-planar feature maps: forward (conv + bias + ReLU, 2x2 max-pool) and the
+hand-derived backward (data gradients only - the weights are frozen, :43-45).
+
+Only the layers that feed a requested output are ever computed (the reference runs all 16 convs and discards
+conv5_2..5_4).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip, ops
+from .fmap import FMap
+
+# network order; ("pool", k) = MaxPool2d(2,2) after block k
+NODES = [
+    ("conv1_1", "img", "r11", 3, 64), ("conv1_2", "r11", "r12", 64, 64), ("pool", "r12", "p1", 64, 64),
+    ("conv2_1", "p1", "r21", 64, 128), ("conv2_2", "r21", "r22", 128, 128), ("pool", "r22", "p2", 128, 128),
+    ("conv3_1", "p2", "r31", 128, 256), ("conv3_2", "r31", "r32", 256, 256), ("conv3_3", "r32", "r33", 256, 256),
+    ("conv3_4", "r33", "r34", 256, 256), ("pool", "r34", "p3", 256, 256),
+    ("conv4_1", "p3", "r41", 256, 512), ("conv4_2", "r41", "r42", 512, 512), ("conv4_3", "r42", "r43", 512, 512),
+    ("conv4_4", "r43", "r44", 512, 512), ("pool", "r44", "p4", 512, 512),
+    ("conv5_1", "p4", "r51", 512, 512), ("conv5_2", "r51", "r52", 512, 512), ("conv5_3", "r52", "r53", 512, 512),
+    ("conv5_4", "r53", "r54", 512, 512), ("pool", "r54", "p5", 512, 512),
+]
+OUT_NAMES = [n[2] for n in NODES]
+PRE_POOL = {"r12", "r22", "r34", "r44", "r54"}
+
+
+def depth_of(layer: str) -> int:
+    if layer not in OUT_NAMES:
+        raise ValueError(f"unknown VGG output key: {layer}")
+    return OUT_NAMES.index(layer)
+
+
+def layer_hw(layer: str, H: int, W: int):
+    """Spatial size of a VGG output for an H x W input (floor halving per pool)."""
+    h, w = H, W
+    for kind, _, out, _, _ in NODES:
+        if kind == "pool":
+            h, w = h // 2, w // 2
+        if out == layer:
+            return h, w
+    raise ValueError(layer)
+
+
+class LevelBuffers:
+    """All activation (and, if ``with_grad``, gradient) feature maps of one VGG pass at one input size.
+    Dedicated per size so that the zero borders written at allocation stay valid forever."""
+
+    def __init__(self, H: int, W: int, last_layer: str, with_grad: bool, device="cuda"):
+        self.H, self.W, self.last = H, W, depth_of(last_layer)
+        self.act = {"img": FMap(4, H, W, device)}  # 3 channels + 1 zero plane (K-chunk of 4)
+        self.grad = {"img": FMap(3, H, W, device)} if with_grad else {}
+        h, w = H, W
+        for kind, _, out, _, cout in NODES[:self.last + 1]:
+            if kind == "pool":
+                h, w = h // 2, w // 2
+            if h < 1 or w < 1:
+                raise ValueError(f"input {H}x{W} too small for VGG layer {out}")
+            self.act[out] = FMap(cout, h, w, device)
+            if with_grad:
+                self.grad[out] = FMap(cout, h, w, device)
+
+    def nbytes(self):
+        return sum(f.buf.numel() * 4 for f in list(self.act.values()) + list(self.grad.values()))
+
+
+class VGGNet:
+    def __init__(self, state_dict: dict, device="cuda"):
+        self.device = device
+        self.wf, self.wd, self.bias = {}, {}, {}
+        for kind, _, _, _, _ in NODES:
+            if kind == "pool":
+                continue
+            w = state_dict[kind + ".weight"].detach().to(device=device, dtype=torch.float32)
+            self.wf[kind] = ops.pack_conv_fwd(w)
+            self.wd[kind] = ops.pack_conv_dgrad(w)
+            self.bias[kind] = state_dict[kind + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def forward(self, b: LevelBuffers):
+        """conv + bias + ReLU / max-pool chain from ``b.act['img']`` through the last layer of ``b``."""
+        for kind, src, out, _, _ in NODES[:b.last + 1]:
+            if kind == "pool":
+                ops.maxpool_fwd(b.act[src], b.act[out])
+            else:
+                ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU)
+
+    def backward(self, b: LevelBuffers, injected: set, start_layer: str):
+        """Back-propagate to ``b.grad['img']``.
+
+        On entry ``b.grad[start_layer]`` holds the gradient w.r.t. the PRE-ReLU output of that (deepest) layer,
+        and for every other layer in ``injected`` the buffer holds the loss gradient w.r.t. its activation;
+        it is added to the gradient arriving from above and gated by the layer's ReLU in the data-gradient
+        kernel's epilogue."""
+        for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
+            if kind == "pool":
+                if src in injected:
+                    raise ValueError(f"style/content layer {src} directly below a pool is not supported")
+                ops.maxpool_bwd_relu(b.act[src], b.act[out], b.grad[out], b.grad[src])
+            elif src == "img":
+                ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
+            elif src.startswith("p"):
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0)
+            else:
+                flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src])

@@ -1,0 +1,220 @@
+"""End-to-end parity of the GPU step (StepEngine over libstylemesh_hip.so) against the committed goldens that
+the reference itself produced (tests/golden/g5_*, g6_*, g8_*) and against the oracle on the same seeded inputs.
+
+Stated fp32 tolerances
+* losses: rtol 2e-4.
+* texture gradients: |err| <= 1e-3*|ref| + 2e-4*max|ref| on >= 97 % of the texels and <= 2e-2*max|ref| everywhere
+  (at these tiny test sizes, 40x56 .. 64x88 pixel views, one flipped window's receptive field is a few % of the
+  image; the fraction shrinks with the view size).
+  The forward activations agree with the reference to ~2e-6 relative (MFMA k-ordered sums vs MKLDNN order), but
+  a max-pool window whose two largest activations are closer than that rounding noise can route its gradient
+  to the other pixel ("argmax flip"): the gradient then differs inside that pixel's receptive field by a few
+  1e-3 of max|g|. test_mismatches_originate_only_at_pool_near_ties checks that this is the ONLY source.
+* texture values (range +-150) after k <= 5 Adam steps at lr 1: step 1 exact to 1e-5 (<= 3 sign-flip texels, see
+  SURVEY.md section 7.2 hazard); later steps |err| <= 2e-3 on >= 97 % of the texels, <= 2e-2 on >= 99 %, <= 0.3
+  everywhere. Adam divides by sqrt(v): a RELATIVE gradient difference d becomes an ABSOLUTE update difference
+  ~ lr*d per step, so the 1e-3-level gradient differences above (and the flips) show up at the 1e-3..1e-1 level
+  in texels whose gradient is small. The Adam kernel itself is exact to 1e-5 given identical gradients
+  (tests/test_kernels_gpu.py::test_adam_fused_matches_oracle)."""
+import numpy as np
+import pytest
+import torch
+
+import stylemesh_oracle as O
+from conftest import batch_from_golden, load_golden
+from golden_cases import (FLAGSETS, LOSS_WEIGHTS, MULTIVIEW_SEEDS, SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW,
+                          STYLE_HW, STYLE_SEED, STYLE_WEIGHTS, TEX, VGG_SEED)
+from gpu_util import assert_close, require_gpu
+from stylemesh_amd.data import synthetic as S
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def make_engine(cfgd, init=None):
+    require_gpu()
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=cfgd["hier"], n_layers=4, style_weights=STYLE_WEIGHTS,
+                       angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
+                       use_angle_weight=cfgd["angle"], use_depth_scaling=cfgd["depth"], loss_weights=dict(LOSS_WEIGHTS),
+                       learning_rate=1, decay_gamma=0.1, decay_step_size=1)
+    eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED))
+    if init is not None:
+        eng.load_texture(init[:len(eng.layers)])
+    eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
+    return eng
+
+
+def grad_close(mine, ref, what):
+    ref = torch.as_tensor(ref)
+    mine = mine.detach().cpu()
+    mx = float(ref.abs().max())
+    err = (mine - ref).abs()
+    bad = err > 1e-3 * ref.abs() + 2e-4 * mx
+    msg = f"{what}: {int(bad.sum())} / {bad.numel()} beyond tolerance, max err {float(err.max()):.3e} vs max|ref| {mx:.3e}"
+    assert float(bad.float().mean()) <= 0.03 and float(err.max()) <= 2e-2 * mx, msg
+
+
+def texture_close(mine, ref, step, what):
+    err = (mine.detach().cpu() - ref).abs()
+    n = err.numel()
+    if step == 0:
+        assert int((err > 1e-5).sum()) <= 3, (what, int((err > 1e-5).sum()))
+        return
+    f3, f2 = float((err > 2e-3).float().mean()), float((err > 2e-2).float().mean())
+    assert (f3 <= 0.03 or (err > 2e-3).sum() <= 6) and (f2 <= 0.01 or (err > 2e-2).sum() <= 2) and float(err.max()) <= 0.3, \
+        f"{what}: {f3:.4f} of texels beyond 2e-3, {f2:.4f} beyond 2e-2, max {float(err.max()):.3e} (n = {n})"
+
+
+def full_grads(eng):
+    """data-term gradient + analytic regulariser gradient = what autograd gives the reference"""
+    return [g + c * p for g, c, p in zip(eng.grads, eng.reg_coef, eng.layers)]
+
+
+def test_style_targets_match_golden():
+    d = load_golden("g4_style")
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    require_gpu()
+    eng = StepEngine(EngineConfig(tex_w=64, tex_h=64, loss_weights={"style": 1.0, "content": 1.0}),
+                     S.seeded_vgg_state(VGG_SEED))
+    eng.set_style_image(S.style_image(int(d["style_seed"]), 600, 520))
+    assert eng.style_pyramid_sizes == [tuple(s) for s in d["shapes_600x520"]]
+    for li, layer in enumerate(eng.cfg.style_layers):
+        for lvl in (0, 1, 2):
+            g = eng.targets[li][lvl].cpu()
+            if f"target_{layer}_{lvl}" in d.files:
+                ref = d[f"target_{layer}_{lvl}"]
+                assert_close(g, ref, 2e-4, 2e-5 * float(np.abs(ref).max()), f"{layer}/{lvl}")
+            else:
+                ref = d[f"target_{layer}_{lvl}_sub"]
+                assert_close(g[::5, ::7], ref, 2e-4, 2e-5 * float(np.abs(ref).max()), f"{layer}/{lvl}")
+                np.testing.assert_allclose(float(g.double().sum()), float(d[f"target_{layer}_{lvl}_sum"]), rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(FLAGSETS))
+def test_forward_backward_matches_reference_golden(name):
+    d = load_golden("g5_" + name)
+    cfgd = FLAGSETS[name]
+    init = [T(d[f"init{i}"]) for i in range(4)]
+    eng = make_engine(cfgd, init)
+    batch = batch_from_golden(d)
+    eng.set_view(batch)
+    n_steps = 3 if cfgd["gram"] == "average" else 1
+    for s in range(n_steps):
+        tag = f"_s{s}" if n_steps > 1 else ""
+        eng.arena.g.zero_()
+        lt = eng.loss_tensors()
+        eng.forward_backward()
+        losses = eng.losses(lt)
+        for k in ("content", "style", "tex_reg", "total"):
+            np.testing.assert_allclose(losses[k], float(d[f"loss_{k}{tag}"].reshape(-1)[0]), rtol=2e-4, err_msg=k)
+        for i, g in enumerate(full_grads(eng)):
+            grad_close(g, d[f"grad{i}{tag}"], f"{name} grad{i}{tag}")
+    # sampled images per level
+    for k, lv in enumerate(eng.view):
+        if lv.active:
+            b = eng._level_bufs(lv.H, lv.W)
+            assert_close(b.act["img"].to_dense(3), d[f"pred{k}"][0], 1e-5, 2e-4, f"pred{k}")
+
+
+@pytest.mark.parametrize("name", ["with_angle_and_depth", "flat_single"])
+def test_intermediates_match_oracle(name):
+    """Feature maps, masks, factors and the per-layer gradients against the oracle; mismatches of the
+    gradients must originate only at max-pool windows whose top-2 activations are within rounding noise."""
+    cfgd = FLAGSETS[name]
+    d = load_golden("g5_" + name)
+    init = [T(d[f"init{i}"]) for i in range(4)]
+    eng = make_engine(cfgd, init)
+    batch = batch_from_golden(d)
+    ocfg = O.OracleConfig(hierarchical=cfgd["hier"], style_weights=STYLE_WEIGHTS, angle_threshold=cfgd["thr"],
+                          style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"], use_angle_weight=cfgd["angle"],
+                          use_depth_scaling=cfgd["depth"], loss_weights=dict(LOSS_WEIGHTS))
+    pipe = O.OraclePipeline(S.seeded_vgg_state(VGG_SEED), S.style_image(STYLE_SEED, *STYLE_HW), ocfg, (TEX, TEX),
+                            init_layers=init)
+    rec = {}
+    pipe.grads(batch, rec)
+    eng.set_view(batch)
+    eng.forward_backward()
+    assert [lv.index for lv in eng.view if lv.active] == rec["active"]
+    for a, i in enumerate(rec["active"]):
+        lv = eng.view[i]
+        b = eng._level_bufs(lv.H, lv.W)
+        assert_close(lv.M, rec["masks"][i][0, 0], 0, 0)
+        for layer in eng.loss_layers:
+            ref = rec["enc"][a][layer].detach()[0]
+            assert_close(b.act[layer].to_dense(), ref, 1e-4, 2e-4 * float(ref.abs().max()), f"feat {layer} level {i}")
+            np.testing.assert_allclose(float(lv.factor[layer]), float(rec["factors"][a][layer]), rtol=1e-5)
+            info = rec["info"][a][layer]
+            assert_close(lv.masks[layer].to_dense()[0], info["m"][0, 0], 0, 0)
+            # the angle filter compares an interpolated angle with the threshold: allow a pixel or two to flip
+            assert (lv.masks[layer].to_dense()[1].cpu() != info["m_pass"][0, 0]).float().mean() < 2e-3
+        # per-layer gradients, deepest first. dZ = dL/d(pre-ReLU output) for conv layers, dL/dp for pools.
+        clean = True   # no argmax flip met yet on the way down
+        order = [n for n in reversed(list(b.grad)) if n != "img"]
+        for layer in order:
+            t = rec["all_acts"][a][layer]
+            ref = (t.grad * (t.detach() > 0))[0] if layer.startswith("r") else t.grad[0]
+            mine = b.grad[layer].to_dense().cpu()
+            err = (mine - ref).abs()
+            n_bad = int((err > 1e-3 * float(ref.abs().max())).sum())
+            if clean and n_bad:
+                # first mismatch: must be a pre-pool layer, a handful of elements, all in near-tie windows
+                assert layer in ("r12", "r22", "r34", "r44"), f"level {i}: first gradient mismatch at {layer}"
+                assert n_bad <= 16, (layer, n_bad)
+                act = t.detach()[0]
+                ys, xs = torch.nonzero((err > 1e-3 * float(ref.abs().max())).any(0), as_tuple=True)
+                for c, y, x in torch.nonzero(err > 1e-3 * float(ref.abs().max())):
+                    wy, wx = int(y) // 2 * 2, int(x) // 2 * 2
+                    top2 = act[c, wy:wy + 2, wx:wx + 2].reshape(-1).topk(2).values
+                    assert float(top2[0] - top2[1]) <= 2e-5 * float(act.abs().max()), (layer, int(c), wy, wx, top2)
+                clean = False
+            elif clean:
+                assert n_bad == 0
+        ref = rec["pred_grads_raw"][i][0]
+        if clean:
+            grad_close(b.grad["img"].to_dense(), ref, f"raw image gradient level {i}")
+        else:   # a flipped window: its receptive field (tens of pixels wide at these sizes) carries the difference
+            err = (b.grad["img"].to_dense().cpu() - ref).abs()
+            assert float(err.max()) <= 0.2 * float(ref.abs().max())
+            assert float((err > 1e-3 * float(ref.abs().max())).float().mean()) <= 0.15
+
+
+@pytest.mark.parametrize("init_name", ["zero", "seeded"])
+def test_adam_steps_match_reference_golden(init_name):
+    d = load_golden("g6_adam_" + init_name)
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [T(g5[f"init{i}"]) for i in range(4)] if init_name == "seeded" else None
+    eng = make_engine(FLAGSETS["with_angle_and_depth"], init)
+    batch = batch_from_golden(g5)
+    for step in range(5):
+        lt = eng.training_step(batch)
+        np.testing.assert_allclose(eng.losses(lt)["total"], float(d[f"loss_total_step{step}"].reshape(-1)[0]), rtol=5e-4)
+        if step % 2 == 1:
+            eng.end_epoch()
+        if step in (0, 1, 4):
+            for i in range(4):
+                ref = T(d[f"p{i}_after{step + 1}"]).clamp(O.CLAMP_LO, O.CLAMP_HI)
+                texture_close(eng.layers[i], ref, step, f"{init_name} layer {i} after {step + 1} steps")
+    assert float(eng.arena.g.abs().max()) == 0.0   # the fused update leaves a zeroed gradient
+
+
+def test_multiview_mean_gradient_step_matches_golden():
+    """The R-GPU step on one GPU: gradients of R views accumulate in the arena, scaled by 1/R in the update."""
+    d = load_golden("g8_multiview")
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [T(g5[f"init{i}"]) for i in range(4)]
+    eng = make_engine(FLAGSETS["with_angle_and_depth"], init)
+    for s in MULTIVIEW_SEEDS:
+        batch = S.make_view(s, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                            min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+        eng.set_view(batch)
+        lt = eng.loss_tensors()
+        eng.forward_backward()
+        np.testing.assert_allclose(eng.losses(lt)["total"], float(d[f"loss_total_view{s}"].reshape(-1)[0]), rtol=5e-4)
+    R = len(MULTIVIEW_SEEDS)
+    for i in range(4):
+        grad_close(eng.grads[i] / R + eng.reg_coef[i] * eng.layers[i], d[f"mean_grad{i}"], f"mean grad {i}")
+    eng.optimizer_step(world_size=R)
+    for i in range(4):
+        ref = T(d[f"p{i}_after"]).clamp(O.CLAMP_LO, O.CLAMP_HI)
+        texture_close(eng.layers[i], ref, 1, f"multiview layer {i}")
