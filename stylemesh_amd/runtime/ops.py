@@ -10,6 +10,33 @@ from .hip import lib, ptr
 CLAMP_LO, CLAMP_HI = -123.6800, 151.0610  # reference model/texture/texture.py:43
 
 
+class KernelTimer:
+    """HIP-event timer around individual launches of one kernel family, on the stream the kernels are launched
+    on (torch's current stream). bench.py uses it to price the dominant kernel against its roofline."""
+
+    def __init__(self):
+        self.records = []   # (start_event, end_event, algorithmic_work)
+        self.enabled = True
+
+    def launch(self, fn, work):
+        if not self.enabled:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.append((a, b, work))
+
+    def summary(self):
+        """-> (n_launches, total_ms, total_work); synchronises."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        return len(self.records), ms, sum(w for _, _, w in self.records)
+
+
+CONV_TIMER: KernelTimer | None = None   # set by bench.py; None = no instrumentation
+
+
 # ---- weight packing (one-time setup; layout transforms only) ------------------------------------------------
 def pack_conv_fwd(weight: torch.Tensor) -> torch.Tensor:
     """[Cout,Cin,3,3] -> [9][Cin_pad][Cout] (tap-major, Cout fastest), Cin padded with zeros to 4 / 8k."""
@@ -69,8 +96,15 @@ def clamp_sumsq(p, seg_end, sumsq_out=None):
 def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None):
     cin_pad, cout = wt.shape[1], wt.shape[2]
     assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
-    hip.check(lib.sm_conv3x3(inp.ptr, ptr(wt), ptr(bias), out.ptr, ptr(gate), cin_pad, cout, inp.H, inp.W, flags,
-                             hip.stream()), "sm_conv3x3")
+
+    def run():
+        hip.check(lib.sm_conv3x3(inp.ptr, ptr(wt), ptr(bias), out.ptr, ptr(gate), cin_pad, cout, inp.H, inp.W,
+                                 flags, hip.stream()), "sm_conv3x3")
+    if CONV_TIMER is None:
+        run()
+    else:   # algorithmic FLOPs: true channel counts (the first layer has 3, not its padded 4) and true pixels
+        cin_true = 3 if cin_pad == 4 else cin_pad
+        CONV_TIMER.launch(run, 2.0 * 9 * cin_true * cout * inp.H * inp.W)
 
 
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):
