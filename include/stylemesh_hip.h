@@ -82,9 +82,12 @@ int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float c
  * out [Cout][plane]. Forward (nn.Conv2d + F.relu, :49-68): flags = SM_EPI_BIAS_RELU.
  * Data gradient (ATen convolution_backward + threshold_backward): call with the flipped / transposed
  * weights and flags = SM_EPI_RELU_MASK [| SM_EPI_ADD]; gate = the conv INPUT's forward activation.
- * Cin_pad must be a multiple of 4 (8 when > 4), Cout a multiple of 64. */
+ * Cin_pad must be a multiple of 4 (8 when > 4), Cout a multiple of 64.
+ * ws (optional, ws_floats floats of caller-owned scratch): when the natural grid of 128x128 output tiles cannot
+ * fill the chip the K dimension is split; every split stores its partial tile into its own slab of ws and a
+ * second kernel reduces the slabs and applies the epilogue (deterministic, no atomics). NULL = never split. */
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate,
-               int Cin_pad, int Cout, int H, int W, int flags, void* stream);
+               int Cin_pad, int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream);
 
 /* Data gradient of the first conv (64 -> 3 channels; conv1_1, :11,49): out [3][plane] from
  * dz [64][plane], wd [9][64][4] (tap-major, 3 real output channels + 1 zero). */

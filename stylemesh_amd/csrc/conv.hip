@@ -12,6 +12,8 @@
 // Block = 256 threads = 4 waves; every wave owns a 64x64 output tile = 2x2 MFMA 32x32 tiles (64 accumulator
 // VGPRs). A K-chunk = KC input channels x 9 taps. LDS: weights [9][KC][BM] + inputs [3][KC][BN+8] fp32
 // (49.9 KB for 128x128x8 -> 3 blocks per CU, whose MFMA phases cover each other's staging phases).
+#include <algorithm>
+
 #include "common.h"
 
 namespace sm {
@@ -23,10 +25,13 @@ struct ConvArgs {
     float* out;
     const float* gate;
     int Cin_pad, Cout, H, W, Wp, plane, n_tiles, m_tiles;
+    float* ws;          // split-K: [splits][Cout][plane] partial sums (plain stores), reduced by the epilogue kernel
+    int splits;         // 1 = direct epilogue
+    int chunks_per_split;
 };
 
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLITK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_mfma_kernel(ConvArgs a) {
     static_assert(BM / WGM == 64 && BN / WGN == 64 && WGM * WGN == 4, "wave tile is 64x64");
     constexpr int BNP = BN + 8;  // 4 floats of halo on each side keeps every segment 16-byte aligned
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -41,9 +46,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const int wm = (wave / WGN) * 64;
     const int wn = (wave % WGN) * 64;
 
-    const int item = xcd_linear(blockIdx.x, a.n_tiles * a.m_tiles);
+    // work item = (split, m_tile, n_tile), n fastest: neighbours in the XCD's share use the same weight slab
+    const int tiles = a.n_tiles * a.m_tiles;
+    int item = xcd_linear(blockIdx.x, tiles * (SPLITK ? a.splits : 1));
+    const int split = SPLITK ? item / tiles : 0;
+    item -= split * tiles;
     const int m_tile = item / a.n_tiles;
     const int n_tile = item - m_tile * a.n_tiles;
+    const int c_begin = SPLITK ? split * a.chunks_per_split * KC : 0;
+    const int c_end = SPLITK ? min(a.Cin_pad, c_begin + a.chunks_per_split * KC) : a.Cin_pad;
     const int m0 = m_tile * BM;
     const int q0 = a.Wp + n_tile * BN;  // first computed position = start of row 1
 
@@ -55,28 +66,64 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int c0 = 0; c0 < a.Cin_pad; c0 += KC) {
-        // ---- stage weights: rows (tap, ci) of BM contiguous floats
-        constexpr int A_F4_PER_ROW = BM / 4;
-        constexpr int A_F4 = 9 * KC * A_F4_PER_ROW;
-        for (int i = tid; i < A_F4; i += 256) {
-            int row = i / A_F4_PER_ROW, c4 = i - row * A_F4_PER_ROW;
-            int tap = row / KC, ci = row - tap * KC;
-            const float4 v = *reinterpret_cast<const float4*>(
-                a.wt + ((size_t)(tap * a.Cin_pad + c0 + ci) * a.Cout + m0 + c4 * 4));
-            *reinterpret_cast<float4*>(As + row * BM + c4 * 4) = v;
-        }
-        // ---- stage inputs: rows (ky, ci) of BNP contiguous floats starting at q0 + (ky-1)*Wp - 4
-        constexpr int B_F4_PER_ROW = BNP / 4;
-        constexpr int B_F4 = 3 * KC * B_F4_PER_ROW;
-        for (int i = tid; i < B_F4; i += 256) {
-            int row = i / B_F4_PER_ROW, c4 = i - row * B_F4_PER_ROW;
-            int ky = row / KC, ci = row - ky * KC;
-            const float4 v = *reinterpret_cast<const float4*>(
-                a.in + ((size_t)(c0 + ci) * a.plane + q0 + (ky - 1) * a.Wp - 4 + c4 * 4));
-            *reinterpret_cast<float4*>(Bs + row * BNP + c4 * 4) = v;
-        }
-        __syncthreads();
+    // ---- staging plan: every thread owns NA float4 of the weight slab and NB float4 of the input segments per
+    //      K-chunk. Source offsets are chunk-invariant up to a stride (Cout resp. plane floats per channel).
+    constexpr int A_F4_PER_ROW = BM / 4;
+    constexpr int A_F4 = 9 * KC * A_F4_PER_ROW;
+    constexpr int B_F4_PER_ROW = BNP / 4;
+    constexpr int B_F4 = 3 * KC * B_F4_PER_ROW;
+    constexpr int NA = (A_F4 + 255) / 256;
+    constexpr int NB = (B_F4 + 255) / 256;
+    // weights: a pass of 256 threads covers RPP = 1024/BM rows (tap, ci) of the slab; RPP is a multiple of KC, so a
+    // thread keeps its ci and advances by RPP/KC taps per pass: one base offset + a uniform stride.
+    constexpr int RPP = 256 / A_F4_PER_ROW;
+    static_assert(RPP % KC == 0, "a staging pass covers whole taps");
+    const int a_r0 = tid / A_F4_PER_ROW, a_c4 = tid % A_F4_PER_ROW;
+    const unsigned a_src0 = (unsigned)(((a_r0 / KC) * a.Cin_pad + (a_r0 % KC)) * a.Cout + m0 + a_c4 * 4);
+    const unsigned a_step = (unsigned)((RPP / KC) * a.Cin_pad * a.Cout);
+    const int a_dst0 = a_r0 * BM + a_c4 * 4;
+    // the last pass may be partial: threads beyond the slab re-load pass 0 (valid memory) and skip the LDS store
+    const bool a_tail_ok = A_F4 % 256 == 0 || tid < A_F4 - (NA - 1) * 256;
+    const int a_last = a_tail_ok ? NA - 1 : 0;
+    // inputs: rows (ky, ci) of BNP floats; generic split, 32-bit element offsets
+    int b_src[NB];   // signed: the first tile's halo starts 4 floats BEFORE the plane
+    int b_dst[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int i = min(tid + j * 256, B_F4 - 1);
+        const int row = i / B_F4_PER_ROW, c4 = i - row * B_F4_PER_ROW;
+        const int ky = row / KC, ci = row - ky * KC;
+        b_src[j] = ci * a.plane + q0 + (ky - 1) * a.Wp - 4 + c4 * 4;
+        b_dst[j] = row * BNP + c4 * 4;
+    }
+    f32x4 ra[NA], rb[NB];
+    // (macros, not lambdas: capturing the register arrays by reference sends them to scratch memory)
+#define SM_LOAD_CHUNK(c0_)                                                                          \
+    {                                                                                               \
+        const float* wsrc = a.wt + (size_t)(c0_) * a.Cout + a_src0;                                 \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j)                                              \
+            ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)((j == NA - 1) ? a_last : j) * a_step); \
+        const float* isrc = a.in + (size_t)(c0_) * a.plane;                                         \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j)                                              \
+            rb[j] = *reinterpret_cast<const f32x4*>(isrc + b_src[j]);                               \
+    }
+#define SM_STORE_CHUNK()                                                                            \
+    {                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j)                                              \
+            if (j < NA - 1 || a_tail_ok)                                                            \
+                *reinterpret_cast<f32x4*>(As + a_dst0 + j * RPP * BM) = ra[j];                      \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j)                                              \
+            if (B_F4 % 256 == 0 || tid + j * 256 < B_F4)                                            \
+                *reinterpret_cast<f32x4*>(Bs + b_dst[j]) = rb[j];                                   \
+    }
+
+    // software pipeline: the global loads of chunk c+1 are in flight while the MFMAs of chunk c run
+    SM_LOAD_CHUNK(c_begin);
+    SM_STORE_CHUNK();
+    __syncthreads();
+    for (int c0 = c_begin; c0 < c_end; c0 += KC) {
+        const bool more = c0 + KC < c_end;
+        if (more) SM_LOAD_CHUNK(c0 + KC);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -94,7 +141,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
+        if (more) {
+            SM_STORE_CHUNK();
+            __syncthreads();
+        }
     }
+#undef SM_LOAD_CHUNK
+#undef SM_STORE_CHUNK
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: column (pixel) = lane & 31,
     //      row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -112,6 +165,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
                 const int co = co_base + (r & 3) + 8 * (r >> 2);
                 const size_t o = (size_t)co * a.plane + q;
                 float v = acc[mi][nj][r];
+                if (SPLITK) {
+                    a.ws[(size_t)split * a.Cout * a.plane + o] = v;
+                    continue;
+                }
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + a.bias[co], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += a.out[o];
                 if (FLAGS & SM_EPI_RELU_MASK) v = (a.gate[o] > 0.f) ? v : 0.f;
@@ -121,30 +178,71 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     }
 }
 
+// Split-K second pass: out = epilogue(sum over splits of the partial slabs), 4 positions per thread.
+template <int FLAGS>
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a) {
+    const int co = blockIdx.y;
+    const int q = a.Wp + (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= (a.H + 1) * a.Wp) return;
+    const size_t o = (size_t)co * a.plane + q;
+    const size_t slab = (size_t)a.Cout * a.plane;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.ws + o);
+    for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(a.ws + s * slab + o);
+    f32x4 prev, gate;
+    if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(a.out + o);
+    if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(a.gate + o);
+    const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
+        if (FLAGS & SM_EPI_ADD) x += prev[j];
+        if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
+        v[j] = interior(q + j, a.H, a.W, a.Wp) ? x : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.out + o) = v;
+}
+
+constexpr int SM_CONV_SLOTS = 512;  // resident blocks the chip holds at 2 blocks per CU
+
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
-static int launch_conv(const ConvArgs& a0, hipStream_t s) {
+static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
     a.n_tiles = (a.H * a.Wp + BN - 1) / BN;
     constexpr size_t lds = (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
-    auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    // split K when the natural grid cannot fill the chip: each split keeps >= 4 K-chunks
+    const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
+    int splits = 1;
+    if (a.ws != nullptr && tiles < SM_CONV_SLOTS * 3 / 4 && chunks >= 8) {
+        splits = std::min(SM_CONV_SLOTS / tiles, chunks / 4);
+        const size_t slab = (size_t)a.Cout * a.plane;
+        splits = (int)std::min<size_t>((size_t)splits, ws_floats / slab);
     }
-    hipLaunchKernelGGL(k, dim3(a.m_tiles * a.n_tiles), dim3(256), lds, s, a);
+    if (splits > 1) {
+        a.chunks_per_split = (chunks + splits - 1) / splits;
+        a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+        auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS, true>;
+        hipLaunchKernelGGL(k, dim3(tiles * a.splits), dim3(256), lds, s, a);
+        SM_LAUNCH_CHECK();
+        const int n4 = (a.H * a.Wp + 3) / 4;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel<FLAGS>, dim3((n4 + 255) / 256, a.Cout), dim3(256), 0, s, a);
+        SM_LAUNCH_CHECK();
+        return 0;
+    }
+    a.splits = 1;
+    a.chunks_per_split = chunks;
+    auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS, false>;
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), lds, s, a);
     SM_LAUNCH_CHECK();
     return 0;
 }
 
 template <int FLAGS>
-static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
-    if (a.Cin_pad == 4) return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, s);
-    if (a.Cout % 128 != 0) return launch_conv<64, 256, 8, 1, 4, FLAGS>(a, s);
-    return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, s);
+static int dispatch_conv(const ConvArgs& a, size_t ws_floats, hipStream_t s) {
+    if (a.Cin_pad == 4) return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 256, 8, 1, 4, FLAGS>(a, ws_floats, s);
+    return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, ws_floats, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -228,16 +326,17 @@ int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
 int sm_abi_version(void) { return 1; }
 
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,
-               int Cout, int H, int W, int flags, void* stream) {
+               int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
     if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
-    sm::ConvArgs a{in, wt, bias, out, gate, Cin_pad, Cout, H, W, sm::row_stride(W), sm::plane_size(H, W), 0, 0};
+    sm::ConvArgs a{in, wt, bias, out, gate, Cin_pad, Cout, H, W, sm::row_stride(W), sm::plane_size(H, W), 0, 0,
+                   ws, 1, 0};
     hipStream_t s = (hipStream_t)stream;
     switch (flags) {
-        case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, s);
-        case 0: return sm::dispatch_conv<0>(a, s);
-        case SM_EPI_RELU_MASK: return sm::dispatch_conv<SM_EPI_RELU_MASK>(a, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, s);
-        case SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_ADD>(a, s);
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, ws_floats, s);
+        case 0: return sm::dispatch_conv<0>(a, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv<SM_EPI_RELU_MASK>(a, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, ws_floats, s);
+        case SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_ADD>(a, ws_floats, s);
         default: return (int)hipErrorInvalidValue;
     }
 }

@@ -93,13 +93,25 @@ def clamp_sumsq(p, seg_end, sumsq_out=None):
 
 
 # ---- VGG -----------------------------------------------------------------------------------------------------
+_SPLITK_WS = {}   # device -> scratch for split-K partial tiles (caller-owned, see sm_conv3x3)
+SPLITK_WS_FLOATS = 16 << 20
+
+
+def splitk_workspace(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+    return _SPLITK_WS[key]
+
+
 def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None):
     cin_pad, cout = wt.shape[1], wt.shape[2]
     assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
 
     def run():
+        ws = splitk_workspace(wt.device)
         hip.check(lib.sm_conv3x3(inp.ptr, ptr(wt), ptr(bias), out.ptr, ptr(gate), cin_pad, cout, inp.H, inp.W,
-                                 flags, hip.stream()), "sm_conv3x3")
+                                 flags, ptr(ws), ws.numel(), hip.stream()), "sm_conv3x3")
     if CONV_TIMER is None:
         run()
     else:   # algorithmic FLOPs: true channel counts (the first layer has 3, not its padded 4) and true pixels
