@@ -124,20 +124,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int c0 = c_begin; c0 < c_end; c0 += KC) {
         const bool more = c0 + KC < c_end;
         if (more) SM_LOAD_CHUNK(c0 + KC);
+        // 9 taps x KC/2 channel pairs = NSTEP k-steps of 4 MFMAs; the LDS fragments of step s+1 are requested
+        // before the MFMAs of step s are issued, so the matrix pipe never waits on an LDS round trip.
+        {
+            constexpr int NSTEP = 9 * (KC / 2);
+            const float* abase = As + lhi * BM + wm + l31;
+            const float* bbase = Bs + lhi * BNP + 3 + wn + l31;
+            float a0 = abase[0], a1 = abase[32], b0 = bbase[0], b1 = bbase[32];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int kp = 0; kp < KC / 2; ++kp) {
-                const int ci = kp * 2 + lhi;
-                const float* ap = As + (tap * KC + ci) * BM + wm + l31;
-                const float* bp = Bs + (ky * KC + ci) * BNP + 3 + kx + wn + l31;
-                const float a0 = ap[0], a1 = ap[32];
-                const float b0 = bp[0], b1 = bp[32];
+            for (int st = 0; st < NSTEP; ++st) {
+                float na0, na1, nb0, nb1;
+                if (st + 1 < NSTEP) {
+                    const int tap = (st + 1) / (KC / 2), kp = (st + 1) % (KC / 2);
+                    const int ky = tap / 3, kx = tap % 3;
+                    const float* ap = abase + (tap * KC + kp * 2) * BM;
+                    const float* bp = bbase + (ky * KC + kp * 2) * BNP + kx;
+                    na0 = ap[0]; na1 = ap[32]; nb0 = bp[0]; nb1 = bp[32];
+                }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                if (st + 1 < NSTEP) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+                // pin the emitted order: one MFMA, the next step's two LDS reads, the other three MFMAs - the reads
+                // complete under ~190 cycles of matrix-pipe time
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             }
         }
         __syncthreads();

@@ -1,6 +1,6 @@
 """Micro-benchmark of sm_conv3x3 on the VGG layer shapes of the four ScanNet UV levels (run on the GPU box)."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stylemesh_amd.runtime import hip, ops
 from stylemesh_amd.runtime.fmap import FMap
