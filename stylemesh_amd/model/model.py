@@ -1,0 +1,346 @@
+"""``TextureOptimizationStyleTransferPipeline`` with the reference's LightningModule surface
+(model/model.py:16-420) over the fused HIP step.
+
+Constructor arguments, attribute names, hook names, loss names and log keys are the reference's. Two ways to
+run a step:
+* ``training_step`` (what a Trainer calls) uses the fused engine (``stylemesh_amd.runtime.engine.StepEngine``):
+  forward + hand-written backward deposit the data-term gradient straight into ``param.grad`` (which aliases the
+  engine's gradient arena); the returned ``loss`` is a detached scalar whose ``backward()`` is a no-op, and
+  ``configure_optimizers`` returns the fused regulariser + Adam + clamp kernel wrapped as an optimizer.
+* ``forward`` / ``forward_with_loss`` reproduce the reference's autograd formulation through the differentiable
+  classes of ``model/texture`` and ``model/losses`` (used by the parity tests; slower: dense copies per call).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from ..runtime import ops
+from ..runtime.engine import EngineConfig, StepEngine
+from .losses.content_and_style_losses import ContentAndStyleLoss
+from .losses.rgb_transform import post
+from .texture.texture import HierarchicalNeuralTexture, NeuralTexture, to_image
+
+try:  # subclass the real LightningModule when it is installed (it is not in the build image)
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - exercised in this image
+    class _NullExperiment:
+        def add_scalar(self, *a, **k):
+            pass
+        add_scalars = add_image = add_scalar
+
+    class _NullLogger:
+        experiment = _NullExperiment()
+
+    class _Base(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.current_epoch = 0
+            self.logger = _NullLogger()
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+
+class FusedTextureAdam:
+    """Optimizer facade over ``sm_adam_fused`` (Adam lr/betas/eps of model/model.py:395, weight_decay 0)."""
+
+    def __init__(self, module, lr):
+        self.module = module
+        self.param_groups = [{"lr": lr, "initial_lr": lr, "params": list(module.texture.parameters())}]
+        self.world_size = 1
+
+    def zero_grad(self, set_to_none=False):
+        pass   # the fused update leaves a zeroed gradient arena
+
+    def step(self, closure=None):
+        if closure is not None:
+            closure()
+        eng = self.module._engine
+        eng.cfg.learning_rate = self.param_groups[0]["lr"]
+        eng.cfg.decay_gamma, eng.epoch = 1.0, 0    # the scheduler owns the learning rate
+        eng.optimizer_step(self.world_size)
+
+    def state_dict(self):
+        eng = self.module._engine
+        return {"step": eng.step_count, "m": eng.arena.m.clone(), "v": eng.arena.v.clone(), "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        eng = self.module._engine
+        eng.step_count = int(sd["step"])
+        eng.arena.m.copy_(sd["m"])
+        eng.arena.v.copy_(sd["v"])
+        self.param_groups[0]["lr"] = sd["lr"]
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR semantics (model/model.py:397-399) for any object with param_groups."""
+
+    def __init__(self, optimizer, step_size, gamma=0.1):
+        self.optimizer, self.step_size, self.gamma, self.last_epoch = optimizer, step_size, gamma, 0
+
+    def step(self):
+        self.last_epoch += 1
+        for g in self.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * self.gamma ** (self.last_epoch // self.step_size)
+
+
+class TextureOptimizationStyleTransferPipeline(_Base):
+    states = ["train", "val"]
+    loss_types = ["tex_reg", "content", "style", 'total']
+    default_loss_weights = {l: 0.0 for l in loss_types}
+
+    def __init__(self, W, H, hierarchical_texture=True, hierarchical_layers=4, random_texture_init=False,
+                 style_image=None, style_layers=ContentAndStyleLoss.style_layers,
+                 content_layers=ContentAndStyleLoss.content_layers, style_weights=ContentAndStyleLoss.style_weights,
+                 content_weights=ContentAndStyleLoss.content_weights, vgg_gatys_model_path=None,
+                 use_angle_weight=True, use_depth_scaling=True, style_pyramid_mode='single', gram_mode='current',
+                 angle_threshold=60, log_images_nth=-1, save_texture=True, texture_dir="", texture_prefix="",
+                 learning_rate=1e-3, decay_gamma=0.1, decay_step_size=30, loss_weights=default_loss_weights,
+                 tex_reg_weights=None, extra_args={}):
+        super().__init__()
+        orig_style_image, style_image = style_image, None
+        self.save_hyperparameters()
+        style_image = orig_style_image
+
+        self.hierarchical_texture, self.hierarchical_layers, self.C = hierarchical_texture, hierarchical_layers, 3
+        self.random_texture_init = random_texture_init
+        if hierarchical_texture:
+            self.texture = HierarchicalNeuralTexture(W, H, self.C, hierarchical_layers, random_texture_init)
+        else:
+            self.texture = NeuralTexture(W, H, self.C, random_texture_init)
+        self.tex_reg_weights = tex_reg_weights
+        if hierarchical_texture and not tex_reg_weights:
+            self.tex_reg_weights = [pow(2, hierarchical_layers - i - 1) for i in range(hierarchical_layers)]
+            self.tex_reg_weights[-1] = 0
+            print(f"No tex_reg_weights specified. Setting them to {self.tex_reg_weights}")
+        if hierarchical_texture and hierarchical_layers != len(self.tex_reg_weights):
+            raise ValueError(
+                f"Have {hierarchical_layers} texture layers, but only {len(self.tex_reg_weights)} weights specified")
+
+        self.loss_history = {loss: {k: [] for k in self.states} for loss in self.loss_types}
+        self.loss_weights = dict(loss_weights) if loss_weights else {}
+        for loss in self.loss_history.keys():
+            if loss not in self.loss_weights:
+                self.loss_weights[loss] = self.default_loss_weights[loss]
+                print(f"No weight specified for the '{loss}' loss. Setting it to {self.loss_weights[loss]}")
+
+        self.vgg_gatys_model_path = vgg_gatys_model_path
+        self.vgg_loss = ContentAndStyleLoss(vgg_gatys_model_path, style_layers, content_layers, style_weights,
+                                            content_weights, angle_threshold=angle_threshold,
+                                            style_pyramid_mode=style_pyramid_mode, gram_mode=gram_mode)
+        self.style_image = style_image
+        self.orig_style_image = style_image.clone()
+        self.angle_threshold, self.style_pyramid_mode, self.gram_mode = angle_threshold, style_pyramid_mode, gram_mode
+        self.use_angle_weight, self.use_depth_scaling = use_angle_weight, use_depth_scaling
+        self.learning_rate, self.decay_gamma, self.decay_step_size = learning_rate, decay_gamma, decay_step_size
+        self.log_images_nth, self.save_texture = log_images_nth, save_texture
+        self.texture_prefix, self.texture_dir = texture_prefix, texture_dir
+        self.batches_per_epoch = {k: 0 for k in self.states}
+        self.train_epoch_end = False
+        self.val_epoch_end = False
+        self._engine = None
+        self.world_size = 1
+        self.grad_reducer = None   # callable(flat_gradient_arena) for the multi-GPU all-reduce
+
+    # ------------------------------------------------------------------ fused engine plumbing
+    def _texture_params(self):
+        return [l.data for l in self.texture.layers] if self.hierarchical_texture else [self.texture.data]
+
+    def _ensure_engine(self, device) -> StepEngine:
+        """Create the fused engine on first use and make the texture Parameters (and their ``.grad``) views of its
+        arenas, so that the module's parameters ARE the memory the kernels update."""
+        if self._engine is None:
+            cfg = EngineConfig(tex_w=self.texture.W, tex_h=self.texture.H, hierarchical=self.hierarchical_texture,
+                               n_layers=self.hierarchical_layers, style_layers=list(self.vgg_loss.style_layers),
+                               content_layers=list(self.vgg_loss.content_layers),
+                               style_weights=list(self.vgg_loss.style_weights),
+                               content_weights=list(self.vgg_loss.content_weights), angle_threshold=self.angle_threshold,
+                               style_pyramid_mode=self.style_pyramid_mode, gram_mode=self.gram_mode,
+                               use_angle_weight=self.use_angle_weight, use_depth_scaling=self.use_depth_scaling,
+                               loss_weights=dict(self.loss_weights), tex_reg_weights=self.tex_reg_weights,
+                               learning_rate=self.learning_rate, decay_gamma=self.decay_gamma,
+                               decay_step_size=self.decay_step_size)
+            eng = StepEngine(cfg, self.vgg_loss.vgg.state_dict(), device)
+            eng.load_texture([p.detach() for p in self._texture_params()])
+            for p, view, g in zip(self._texture_params(), eng.layers, eng.grads):
+                p.data = view
+                p.grad = g
+            style = self.style_image
+            eng.set_style_image(style if style.dim() == 3 else style[0])
+            self._engine = eng
+        return self._engine
+
+    # ------------------------------------------------------------------ reference-formulation forward
+    def forward(self, x):
+        image, _, _, _, _, _, _, _, _, uv_map, _, _, _ = x
+        if self.style_image.shape != image.shape and len(self.style_image.shape) != 4:
+            self.style_image = self.style_image.repeat(image.shape[0], 1, 1, 1).type_as(image)
+            self.vgg_loss.vgg.to(image.device)
+            self.vgg_loss.set_style_image(self.style_image)
+        return [self.texture(v) for v in uv_map]
+
+    def tex_reg_loss(self):
+        if self.hierarchical_texture:
+            return self.texture.regularizer(self.tex_reg_weights)
+        return torch.zeros(1).type_as(self.texture.data)
+
+    def update_batch_count(self, batch_idx, state):
+        self.batches_per_epoch[state] = max(self.batches_per_epoch[state], batch_idx + 1)
+
+    def forward_with_loss(self, batch, batch_idx, state):
+        """The reference's formulation (model/model.py:178-327): differentiable sampling, hooks on the predicted
+        images, ``ContentAndStyleLoss`` - every operator a HIP kernel, glue by autograd."""
+        log_idx = batch_idx + self.current_epoch * self.batches_per_epoch[state]
+        self.update_batch_count(batch_idx, state)
+        (input_rgb_image, _, _, depth, depth_level, rounded_depth_level, other_depth_level,
+         depth_level_interpolation_weight, _, uv_map, mask, angle_guidance, angle_degrees) = batch
+        pred_pyramid = self.forward(batch)
+        mask = mask.unsqueeze(1).float()
+        losses = {}
+
+        if self.use_angle_weight:
+            for p in pred_pyramid:
+                if p.requires_grad:
+                    p.register_hook(lambda g: g * F.interpolate(angle_guidance, g.shape[2:], mode='bilinear'))
+
+        def erode(x, kernel_size=3):
+            k = torch.ones(1, 1, kernel_size, kernel_size).type_as(x)
+            em = torch.clamp(F.conv2d(x, k, padding=(1, 1)) / kernel_size ** 2, 0, 1)
+            return x * (em == 1)
+
+        if self.use_depth_scaling:
+            pyramid_masks, weights = [], []
+            for i, p in enumerate(pred_pyramid):
+                m = ((rounded_depth_level == i) + (other_depth_level == i)).float() * mask
+                pyramid_masks.append((F.interpolate(erode(m), p.shape[2:], mode='nearest') > 0).float())
+                m1 = erode((rounded_depth_level == i) * mask) * depth_level_interpolation_weight
+                m2 = erode((other_depth_level == i) * mask) * (1 - depth_level_interpolation_weight)
+                weights.append(F.interpolate(m1 + m2, p.shape[2:], mode='nearest'))
+            for p in pred_pyramid:
+                if p.requires_grad:
+                    p.register_hook(lambda g: g * find_pyramid_size(weights, g)[1])
+        else:
+            pyramid_masks = [(F.interpolate(torch.zeros_like(mask), p.shape[2:], mode='nearest') > 0).float()
+                             for p in pred_pyramid]
+            pyramid_masks[-1] = (F.interpolate(mask, pred_pyramid[-1].shape[2:], mode='nearest') > 0).float()
+
+        pred_pyramid = [p for p, m in zip(pred_pyramid, pyramid_masks) if torch.sum(m) > 0]
+        pyramid_masks = [m for m in pyramid_masks if torch.sum(m) > 0]
+        style_loss, content_loss, _ = self.vgg_loss(pred_pyramid, input_rgb_image, pyramid_masks,
+                                                    angle_unnormalized=angle_degrees)
+        losses["content"] = self.loss_weights["content"] * content_loss
+        losses["style"] = self.loss_weights["style"] * style_loss
+        if self.loss_weights["tex_reg"] > 0:
+            losses["tex_reg"] = self.loss_weights["tex_reg"] * self.tex_reg_loss()
+        else:
+            losses["tex_reg"] = torch.zeros_like(losses["content"])
+        losses["total"] = sum(losses.values())
+        self._log_losses(losses, state, log_idx)
+        return {"loss": losses["total"]}
+
+    def _log_losses(self, losses, state, log_idx):
+        for loss_type, loss in losses.items():
+            if loss_type in self.loss_history:
+                self.loss_history[loss_type][state].append(loss.detach())   # device tensor: no host sync per step
+                self.logger.experiment.add_scalar(f"Batch/Loss/{state}/{loss_type}", loss.detach(), log_idx)
+
+    # ------------------------------------------------------------------ Lightning hooks
+    def training_step(self, batch, batch_idx, optimizer_idx=0):
+        eng = self._ensure_engine(batch[0].device)
+        log_idx = batch_idx + self.current_epoch * self.batches_per_epoch["train"]
+        self.update_batch_count(batch_idx, "train")
+        key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
+        if eng.view is None or key != eng.view_key:
+            eng.set_view(batch)
+        for p, g in zip(self._texture_params(), eng.grads):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():   # a foreign optimizer dropped / replaced .grad
+                eng.arena.g.zero_()
+                p.grad = g
+        lt = eng.loss_tensors()
+        eng.forward_backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer(eng.arena.g)
+        losses = {k: v.clone() for k, v in lt.items()}
+        losses["total"] = losses["content"] + losses["style"] + losses["tex_reg"]
+        self._log_losses(losses, "train", log_idx)
+        return {"loss": losses["total"].detach().requires_grad_()}   # backward() of this scalar is a no-op
+
+    def validation_step(self, batch, batch_idx):
+        eng = self._ensure_engine(batch[0].device)
+        log_idx = batch_idx + self.current_epoch * self.batches_per_epoch["val"]
+        self.update_batch_count(batch_idx, "val")
+        eng.set_view(batch)
+        lt = eng.loss_tensors()
+        saved = eng.arena.g.clone()
+        eng.forward_backward()       # losses only; the gradient this adds is discarded
+        eng.arena.g.copy_(saved)
+        eng.view_key = None
+        losses = {k: v.clone() for k, v in lt.items()}
+        losses["total"] = losses["content"] + losses["style"] + losses["tex_reg"]
+        self._log_losses(losses, "val", log_idx)
+        return {"loss": losses["total"]}
+
+    def reset_loss_count(self, state):
+        for loss_type in self.loss_history.keys():
+            self.loss_history[loss_type][state].clear()
+
+    def compute_mean_loss(self, state):
+        for loss_type, loss in self.loss_history.items():
+            if isinstance(state, list):
+                mean_loss = {s: torch.stack(loss[s]).mean().cpu() for s in state if loss[s]}
+                self.logger.experiment.add_scalars(f"Loss/{'-'.join(state)}/{loss_type}", mean_loss, self.current_epoch)
+            elif loss[state]:
+                self.logger.experiment.add_scalar(f"Loss/{state}/{loss_type}", torch.stack(loss[state]).mean().cpu(),
+                                                  self.current_epoch)
+
+    def on_train_epoch_start(self) -> None:
+        self.train_epoch_end = False
+        self.val_epoch_end = False
+        self.reset_loss_count("train")
+
+    def on_validation_epoch_start(self) -> None:
+        self.val_epoch_end = False
+        self.reset_loss_count("val")
+
+    def on_train_epoch_end(self) -> None:
+        self.train_epoch_end = True
+
+    def on_validation_epoch_end(self) -> None:
+        self.val_epoch_end = True
+
+    def on_epoch_end(self) -> None:
+        if not self.train_epoch_end or not self.val_epoch_end:
+            return
+        self.compute_mean_loss("train")
+        self.compute_mean_loss("val")
+        self.compute_mean_loss(["train", "val"])
+        if self.save_texture:
+            with torch.no_grad():
+                self.texture.save_layers(self.texture_dir, f"{self.texture_prefix}epoch_{self.current_epoch}",
+                                         normalize_transform=post())
+                self.texture.save_image(self.texture_dir, f"{self.texture_prefix}epoch_{self.current_epoch}_",
+                                        normalize_transform=post())
+
+    def configure_optimizers(self):
+        optimizer = FusedTextureAdam(self, self.learning_rate)
+        scheduler = StepLR(optimizer, gamma=self.decay_gamma, step_size=self.decay_step_size)
+        return [optimizer], [scheduler]
+
+
+def to_tensor_image(t, idx=0):
+    if len(t.shape) == 4:
+        return torch.stack([to_tensor_image(t[b], idx) for b in range(t.shape[0])], dim=0)
+    import numpy as np
+    img = to_image(t, idx, normalize_transform=post())
+    return torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float() / 255
+
+
+def find_pyramid_size(pyramid, sample):
+    for i, p in enumerate(pyramid):
+        if p.shape[2] == sample.shape[2]:
+            return i, p
+    return 0, p[0]

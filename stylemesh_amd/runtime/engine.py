@@ -242,6 +242,14 @@ class StepEngine:
         for lv in levels:
             if hasattr(lv, "M"):
                 lv.active = bool(sums[lv.index] > 0)
+        self._finish_view(levels, to(rgb[0]))
+        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
+
+    def _finish_view(self, levels, rgb_dev):
+        """Layer-resolution masks + counts + level factors (calculate_pyramid, losses :146-217) and the content
+        target features, for levels whose ``M`` / ``passed`` maps are already on the device."""
+        cfg, dev = self.cfg, self.device
+        h, w = rgb_dev.shape[1:]
         active = [lv for lv in levels if lv.active]
         # layer masks, counts, factors
         n_act = len(active)
@@ -264,7 +272,7 @@ class StepEngine:
             if key not in self._content_bufs:
                 self._content_bufs[key] = LevelBuffers(h, w, self.deepest_content, False, dev)
             cb = self._content_bufs[key]
-            ops.image_to_fmap(to(rgb[0]), cb.act["img"])
+            ops.image_to_fmap(rgb_dev, cb.act["img"])
             self.vgg.forward(cb)
             for lv in active:
                 lv.content_target = {}
@@ -276,7 +284,6 @@ class StepEngine:
                     lv.content_target[layer] = dst
         self.view = levels
         self.view_consts = consts
-        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self):
@@ -294,28 +301,46 @@ class StepEngine:
             b = self._level_bufs(lv.H, lv.W)
             ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
             self.vgg.forward(b)
-            injected = set()
-            if w_style != 0.0:
-                for li, layer in enumerate(cfg.style_layers):
-                    self._style_terms(lv, b, li, layer, w_style)
-                    injected.add(layer)
-            if w_content != 0.0:
-                for li, layer in enumerate(cfg.content_layers):
-                    m = lv.masks[layer]
-                    ops.mse_masked(b.act[layer], lv.content_target[layer], m.channel_ptr(0), lv.counts[layer][0:1],
-                                   lv.factor[layer], w_content * float(cfg.content_weights[li]), b.grad[layer],
-                                   self.loss_buf[0:1], relu_gate=(layer == self.deepest))
-                    injected.add(layer)
+            injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward(b, injected - {self.deepest}, self.deepest)
             ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
+
+    def _inject_losses(self, lv, b, w_style, w_content, keep=None):
+        """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
+        layer's gradient already ReLU-gated). ``keep`` (dict) receives clones of the style derivative matrices."""
+        cfg = self.cfg
+        injected = set()
+        if w_style != 0.0:
+            for li, layer in enumerate(cfg.style_layers):
+                D = self._style_terms(lv, b, li, layer, w_style)
+                if keep is not None:
+                    keep[(lv.index, layer)] = tuple(None if d is None else d.clone() for d in D)
+                injected.add(layer)
+        if w_content != 0.0:
+            for li, layer in enumerate(cfg.content_layers):
+                self._content_term(lv, b, li, layer, w_content)
+                injected.add(layer)
+        return injected
+
+    def _content_term(self, lv, b, li, layer, w_content, loss_out=None):
+        m = lv.masks[layer]
+        ops.mse_masked(b.act[layer], lv.content_target[layer], m.channel_ptr(0), lv.counts[layer][0:1],
+                       lv.factor[layer], w_content * float(self.cfg.content_weights[li]), b.grad[layer],
+                       self.loss_buf[0:1] if loss_out is None else loss_out, relu_gate=(layer == self.deepest))
+
+    def _style_masks(self, lv, layer):
+        m = lv.masks[layer]
+        if self.cfg.style_pyramid_mode == "multi":
+            return m.channel_ptr(1), m.channel_ptr(2)
+        return m.channel_ptr(0), None
 
     def _style_terms(self, lv, b, li, layer, w_style):
         cfg = self.cfg
         f = b.act[layer]
-        m = lv.masks[layer]
         S0, S1, D0, D1 = self._gram_scratch(f.C)
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
+        m0, m1 = self._style_masks(lv, layer)
         S0.zero_()
         hist, hist_len, hist_slot = None, 0, 0
         if cfg.gram_mode == "average":
@@ -326,7 +351,7 @@ class StepEngine:
             self._hist[layer][1] = cnt + 1
         if multi:
             S1.zero_()
-            ops.gram_masked(f, m.channel_ptr(1), m.channel_ptr(2), S0, S1)
+            ops.gram_masked(f, m0, m1, S0, S1)
             targets = [self.targets[li][2], self.targets[li][2]]
             term_mask = [0, 1]
             if li > 2:   # content_and_style_losses.py:335-338
@@ -334,13 +359,72 @@ class StepEngine:
                 term_mask.append(0)
             ops.style_loss(S0, S1, lv.counts[layer][1:3], lv.factor[layer], targets, term_mask, [0, 1], weight, f.C,
                            D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot)
-            ops.gram_backward(f, m.channel_ptr(1), m.channel_ptr(2), D0, D1, b.grad[layer],
-                              relu_gate=(layer == self.deepest))
         else:
-            ops.gram_masked(f, m.channel_ptr(0), None, S0, None)
+            D1 = None
+            ops.gram_masked(f, m0, None, S0, None)
             ops.style_loss(S0, None, lv.counts[layer][0:1], lv.factor[layer], [self.targets[li][0]], [0], [0, 0],
                            weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot)
-            ops.gram_backward(f, m.channel_ptr(0), None, D0, None, b.grad[layer], relu_gate=(layer == self.deepest))
+        ops.gram_backward(f, m0, m1, D0, D1, b.grad[layer], relu_gate=(layer == self.deepest))
+        return D0, D1
+
+    # ------------------------------------------------------------------ explicit-image interface (class mirror)
+    def set_external_levels(self, masks, angle_degrees, target_content):
+        """Per-level constants from explicit ``pyramid_masks`` (the ``ContentAndStyleLoss.forward`` arguments,
+        content_and_style_losses.py:288) instead of a dataset batch."""
+        import torch.nn.functional as F
+        levels = []
+        for i, m in enumerate(masks):
+            lv = _ViewLevel()
+            lv.index, lv.active, lv.grid, lv.pixel_weight = i, True, None, None
+            lv.H, lv.W = m.shape[2:]
+            lv.M = (m[0, 0] > 0).to(self.device, torch.float32).contiguous()
+            if angle_degrees is not None:
+                a = F.interpolate(angle_degrees.to(self.device, torch.float32), (lv.H, lv.W), mode="bilinear")
+                lv.passed = (a[0, 0] < self.cfg.angle_threshold).to(torch.uint8).contiguous()
+            else:
+                lv.passed = torch.ones(lv.H, lv.W, dtype=torch.uint8, device=self.device)
+            levels.append(lv)
+        self._finish_view(levels, target_content[0].to(self.device, torch.float32).contiguous())
+
+    def images_forward(self, images, w_style=1.0, w_content=1.0):
+        """VGG + losses of explicit images (one per level of ``set_external_levels``). Returns
+        ``(loss_buf clone [content, style], kept derivative matrices)``; activations stay in the level buffers."""
+        self.loss_buf.zero_()
+        keep = {}
+        for lv, img in zip(self.view, images):
+            b = self._level_bufs(lv.H, lv.W)
+            ops.image_to_fmap(img[0].detach().to(self.device, torch.float32).contiguous(), b.act["img"])
+            self.vgg.forward(b)
+            self._inject_losses(lv, b, w_style, w_content, keep)
+        return self.loss_buf.clone(), keep
+
+    def images_backward(self, keep, g_style: float, g_content: float):
+        """d(g_style * style + g_content * content) / d image for every level (dense [1,3,H,W] tensors)."""
+        out = []
+        scratch = torch.zeros(1, device=self.device)
+        for lv in self.view:
+            b = self._level_bufs(lv.H, lv.W)
+            injected = set()
+            if g_style != 0.0:
+                for layer in self.cfg.style_layers:
+                    D0, D1 = keep[(lv.index, layer)]
+                    m0, m1 = self._style_masks(lv, layer)
+                    ops.gram_backward(b.act[layer], m0, m1, D0 * g_style, None if D1 is None else D1 * g_style,
+                                      b.grad[layer], relu_gate=(layer == self.deepest))
+                    injected.add(layer)
+            if g_content != 0.0:
+                for li, layer in enumerate(self.cfg.content_layers):
+                    self._content_term(lv, b, li, layer, g_content, loss_out=scratch)
+                    injected.add(layer)
+            if not injected:
+                out.append(torch.zeros(1, 3, lv.H, lv.W, device=self.device))
+                continue
+            start = max(injected, key=depth_of)
+            if start != self.deepest:
+                raise ValueError("a zero upstream gradient for the deepest loss layer is not supported")
+            self.vgg.backward(b, injected - {start}, start)
+            out.append(ops.fmap_to_image(b.grad["img"], 3)[None])
+        return out
 
     def optimizer_step(self, world_size: int = 1):
         """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""

@@ -1,0 +1,115 @@
+"""``MiniTrainer``: the slice of ``pytorch_lightning.Trainer`` (1.4.9, reference requirements.txt:76) that
+``model/optimize.py:30,165`` relies on - automatic optimisation with Lightning's hook order
+(SURVEY.md section 3.2-3.4), one process per GPU. pytorch_lightning is not installed in the target image; a
+module written for Lightning (``training_step`` / ``validation_step`` / ``configure_optimizers`` / epoch hooks)
+runs unchanged.
+
+Per epoch: on_train_epoch_start -> for each batch [optimizer.zero_grad -> training_step -> loss.backward ->
+optimizer.step] -> validation [on_validation_epoch_start -> validation_step* -> on_validation_epoch_end ->
+on_epoch_end] -> on_train_epoch_end -> on_epoch_end -> scheduler.step.
+
+Multi-GPU (``world_size > 1``): views shard over ranks by the sampler; the module's ``grad_reducer`` all-reduces
+the flat texture-gradient arena over RCCL between backward and the optimizer step (SURVEY.md section 8 e).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import torch
+
+
+class JsonlLogger:
+    """TensorBoard-shaped scalar logger (``logger.experiment.add_scalar(s)``) writing JSON lines; device tensors
+    are only converted when the line is written, every ``flush_every`` records (no per-step host sync)."""
+
+    def __init__(self, save_dir="lightning_logs", version=0, flush_every=200):
+        self.save_dir, self.version = save_dir, version
+        self.log_dir = os.path.join(save_dir, f"lightning_logs/version_{version}")
+        os.makedirs(self.log_dir, exist_ok=True)
+        self.experiment = self
+        self._pending, self._flush_every = [], flush_every
+
+    def add_scalar(self, tag, value, step):
+        self._pending.append((tag, value, step))
+        if len(self._pending) >= self._flush_every:
+            self.flush()
+
+    def add_scalars(self, tag, values, step):
+        for k, v in values.items():
+            self.add_scalar(f"{tag}/{k}", v, step)
+
+    def add_image(self, *a, **k):
+        pass
+
+    def flush(self):
+        with open(os.path.join(self.log_dir, "scalars.jsonl"), "a") as f:
+            for tag, value, step in self._pending:
+                f.write(json.dumps({"tag": tag, "step": int(step), "value": float(value)}) + "\n")
+        self._pending.clear()
+
+
+class MiniTrainer:
+    def __init__(self, max_epochs=1, logger=None, device=None, rank=0, world_size=1, limit_train_batches=None,
+                 limit_val_batches=None, progress=True):
+        self.max_epochs, self.rank, self.world_size = max_epochs, rank, world_size
+        self.logger = logger if logger is not None else JsonlLogger()
+        self.device = device if device is not None else (torch.device("cuda", 0) if torch.cuda.is_available() else "cpu")
+        self.limit_train_batches, self.limit_val_batches, self.progress = limit_train_batches, limit_val_batches, progress
+        self.global_step = 0
+        self.call_log = []   # hook names in call order (tests)
+
+    def _to_device(self, batch):
+        mv = lambda t: t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t
+        return tuple([mv(u) for u in x] if isinstance(x, (list, tuple)) else mv(x) for x in batch)
+
+    def _call(self, model, name, *a):
+        self.call_log.append(name)
+        fn = getattr(model, name, None)
+        return fn(*a) if fn is not None else None
+
+    def fit(self, model, datamodule):
+        try:
+            model.logger = self.logger
+        except AttributeError:   # a real LightningModule exposes ``logger`` as a read-only property
+            pass
+        model.world_size = self.world_size
+        if hasattr(model, "to") and self.device != "cpu":
+            model.to(self.device)
+        optimizers, schedulers = model.configure_optimizers()
+        opt, sched = optimizers[0], (schedulers[0] if schedulers else None)
+        if hasattr(opt, "world_size"):
+            opt.world_size = self.world_size
+        t0 = time.time()
+        for epoch in range(self.max_epochs):
+            model.current_epoch = epoch
+            self._call(model, "on_train_epoch_start")
+            for batch_idx, batch in enumerate(datamodule.train_dataloader()):
+                if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
+                    break
+                batch = self._to_device(batch)
+                opt.zero_grad()
+                out = self._call(model, "training_step", batch, batch_idx)
+                out["loss"].backward()
+                opt.step()
+                self.global_step += 1
+            val_loader = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
+            if val_loader is not None:
+                self._call(model, "on_validation_epoch_start")
+                with torch.no_grad():
+                    for batch_idx, batch in enumerate(val_loader):
+                        if self.limit_val_batches is not None and batch_idx >= self.limit_val_batches:
+                            break
+                        self._call(model, "validation_step", self._to_device(batch), batch_idx)
+                self._call(model, "on_validation_epoch_end")
+                self._call(model, "on_epoch_end")
+            self._call(model, "on_train_epoch_end")
+            self._call(model, "on_epoch_end")
+            if sched is not None:
+                sched.step()
+            if self.progress and self.rank == 0:
+                print(f"epoch {epoch}: {self.global_step} steps, {time.time() - t0:.1f} s")
+        if hasattr(self.logger, "flush"):
+            self.logger.flush()
+        return model
