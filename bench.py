@@ -123,10 +123,8 @@ def main():
     views = [to_device(v, dev) for v in views_cpu]
     schedule = [views[(i // wl["index_repeat"]) % len(views)] for i in range(total_steps)]
 
-    reducer = None
-    if world > 1:
-        def reducer(g):
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    from stylemesh_amd.runtime.distributed import make_grad_reducer
+    reducer = make_grad_reducer(dist, world)
 
     def barrier():
         if world > 1:

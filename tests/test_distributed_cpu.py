@@ -1,0 +1,69 @@
+"""The N > 1 protocol on CPU: 2 gloo ranks shard 4 views, accumulate per-view gradients (computed by the ORACLE
+here - there is no GPU), all-reduce the flat gradient arena, apply the update with grad_scale = 1/R, and land on
+the reference-generated golden G8 (mean of 4 independent B = 1 gradients + one Adam step)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, load_golden
+from golden_cases import FLAGSETS, MULTIVIEW_SEEDS, SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW
+from stylemesh_amd.runtime import distributed as D
+
+
+def test_sharding_and_schedule():
+    assert D.shard_views(range(7), 0, 2) == [0, 2, 4, 6]
+    assert D.shard_views(range(7), 1, 2) == [1, 3, 5]
+    assert D.steps_per_epoch(7, 20, 2) == 80
+    s0, s1 = D.rank_schedule(range(7), 0, 2, 3), D.rank_schedule(range(7), 1, 2, 3)
+    assert len(s0) == len(s1) == 12 and s1[-3:] == [5, 5, 5] and s0[:6] == [0, 0, 0, 2, 2, 2]
+    with pytest.raises(ValueError):
+        D.rank_schedule(range(1), 1, 2, 1)
+    assert D.make_grad_reducer(dist, 1) is None
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stylemesh_oracle as O
+    from stylemesh_amd.data import synthetic as S
+    from test_oracle_vs_golden import make_oracle
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [torch.from_numpy(g5[f"init{i}"]) for i in range(4)]
+    pipe = make_oracle(FLAGSETS["with_angle_and_depth"], init)
+    sizes = [l.numel() for l in pipe.layers]
+    arena = torch.zeros(sum(sizes))                       # the flat gradient arena of this rank
+    reg = [torch.zeros_like(l) for l in pipe.layers]
+    for seed in D.shard_views(MULTIVIEW_SEEDS, rank, world):
+        batch = S.make_view(seed, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                            min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+        _, grads = pipe.grads(batch)
+        # the data term only: the regulariser's gradient is a function of p and is added locally after the reduce
+        reg = [2 * 5e3 * w / l.numel() * l.detach() for w, l in zip([8, 4, 2, 0], pipe.layers)]
+        arena += torch.cat([(g - r).reshape(-1) for g, r in zip(grads, reg)])
+    D.make_grad_reducer(dist, world)(arena)
+    R = len(MULTIVIEW_SEEDS)
+    full = [a.view_as(l) / R + r for a, l, r in zip(arena.split(sizes), pipe.layers, reg)]
+    pipe.apply_adam(full)
+    torch.save({"grads": full, "layers": [l.detach().clone() for l in pipe.layers]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_mean_gradient_step(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = load_golden("g8_multiview")
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    for i in range(4):
+        ref = d[f"mean_grad{i}"]
+        np.testing.assert_allclose(r0["grads"][i].numpy(), ref, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()))
+        assert torch.equal(r0["layers"][i], r1["layers"][i])          # every rank applies the identical update
+        bad = (r0["layers"][i] - torch.from_numpy(d[f"p{i}_after"])).abs() > 2e-3
+        assert bad.sum() <= max(3, 2e-3 * bad.numel())
