@@ -106,11 +106,15 @@ int sm_maxpool2x2_bwd_relu(const float* act, const float* pooled, const float* d
 
 /* K5a. Masked Gram sums S_k = (m_k F)(m_k F)^T for up to two 0/1 masks (GramMatrix :74-80 on
  * masked_features :136-143, without the 1/N). feat [C][plane]; mask0/mask1 one plane each (mask1 may be
- * NULL); S0/S1 [C][C], pre-zeroed, upper-triangular 64x64 tiles are accumulated atomically. */
+ * NULL). The positions are split over n = sm_gram_num_slabs(C,H,W) blocks per tile; S0/S1 are
+ * [n][C][C] partial-sum slabs (plain stores, deterministic; S_k = sum over slabs), of which only the
+ * upper-triangular 64x64 tiles are written. No pre-zeroing needed. */
+int sm_gram_num_slabs(int C, int H, int W);
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                    int H, int W, void* stream);
 
 /* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
+ * S0/S1: the n_slabs partial slabs written by sm_gram_masked (summed here).
  * For each mask k: G_k = S_k / max(N_k,1) (N from counts[k]; N_k == 0 -> G_k = 0, and with
  * skip_if_empty[k] the term is dropped, :332). Terms: for t in 0..n_terms-1: mask k = term_mask[t],
  * target Y = targets[t] ([C][C]), loss += coef * mean((Y - G_k)^2), D_k += coef' * (G_k - Y).
@@ -122,7 +126,7 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty,
                   float weight, int C, float* D0, float* D1, float* loss_out, float* history, int hist_len,
-                  int hist_slot, void* stream);
+                  int hist_slot, int n_slabs, void* stream);
 
 /* K5c. dF[c][q] = m0[q] * (D0 F)[c][q] + m1[q] * (D1 F)[c][q], optionally gated by feat > 0
  * (for the top layer r51, whose ReLU gate no later dgrad applies). OVERWRITES dfeat. */

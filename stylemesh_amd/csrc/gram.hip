@@ -5,6 +5,8 @@
 // masked_features (:136-143, bool-mask gather -> here: multiply by the 0/1 mask, same sums), GramMatrix
 // (:74-80, torch.bmm), nn.MSELoss (:265) and the loss loops of ContentAndStyleLoss.forward (:301-348),
 // plus their autograd backward (bmm backward, index_put_, mse backward).
+#include <algorithm>
+
 #include "common.h"
 
 namespace sm {
@@ -14,12 +16,19 @@ namespace sm {
 // ---------------------------------------------------------------------------------------------------
 constexpr int GRAM_QC = 32;     // positions per LDS chunk
 constexpr int GRAM_LD = 33;     // padded row length: conflict-free column reads
-constexpr int GRAM_QB = 2048;   // positions per block
+
+// positions per block: enough blocks to fill the chip (>= ~1500), few enough that the partial slabs stay small
+__host__ inline int gram_qb(int C, int n_pos) {
+    const int T = C / 64, pairs = T * (T + 1) / 2;
+    int qb = (int)(((long long)n_pos * pairs) / 1536);
+    qb = (qb + GRAM_QC - 1) / GRAM_QC * GRAM_QC;
+    return std::max(256, std::min(qb, 4096));
+}
 
 template <int NMASK>
 __global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restrict__ feat, const float* __restrict__ mask0,
                                                           const float* __restrict__ mask1, float* S0, float* S1, int C,
-                                                          int plane, int q_begin, int q_end) {
+                                                          int plane, int q_begin, int q_end, int qb) {
     __shared__ float FsA[64 * GRAM_LD];
     __shared__ float FsB[64 * GRAM_LD];
     __shared__ float Ms[2][GRAM_QC];
@@ -37,8 +46,8 @@ __global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    const int qs = q_begin + blockIdx.x * GRAM_QB;
-    const int qe = min(qs + GRAM_QB, q_end);
+    const int qs = q_begin + blockIdx.x * qb;
+    const int qe = min(qs + qb, q_end);
     for (int q0 = qs; q0 < qe; q0 += GRAM_QC) {
         // stage 64 rows x 32 positions of each operand: 512 float4 per operand, 2 per thread
 #pragma unroll
@@ -76,22 +85,25 @@ __global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restric
         }
         __syncthreads();
     }
+    // partial sums of this position range go to slab blockIdx.x (plain stores; summed by style_loss_kernel)
 #pragma unroll
     for (int mk = 0; mk < NMASK; ++mk) {
-        float* S = mk == 0 ? S0 : S1;
+        float* S = (mk == 0 ? S0 : S1) + (size_t)blockIdx.x * C * C;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tm * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             const int col = tn * 64 + wn + l31;
-            const float v = acc[mk][r];
-            if (v != 0.f) atomicAdd(S + (size_t)row * C + col, v);
+            S[(size_t)row * C + col] = acc[mk][r];
         }
     }
 }
 
 // upper-triangular tile storage: element (i,j) lives at [i][j] when tile(i) <= tile(j), else at [j][i]
-__device__ __forceinline__ float sym_read(const float* S, int C, int i, int j) {
-    return ((i >> 6) <= (j >> 6)) ? S[(size_t)i * C + j] : S[(size_t)j * C + i];
+__device__ __forceinline__ float sym_read(const float* S, int C, int i, int j, int n_slabs) {
+    const size_t o = ((i >> 6) <= (j >> 6)) ? (size_t)i * C + j : (size_t)j * C + i;
+    float v = 0.f;
+    for (int s = 0; s < n_slabs; ++s) v += S[(size_t)s * C * C + o];
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
                                                          const float* __restrict__ factor, StyleTerms terms,
                                                          float weight, int C, float* __restrict__ D0,
                                                          float* __restrict__ D1, float* loss_out, float* history,
-                                                         int hist_len, int hist_slot) {
+                                                         int hist_len, int hist_slot, int n_slabs) {
     __shared__ float red[4];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int i = idx / C, j = idx - i * C;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
         const float N = (S != nullptr) ? counts[k] : 0.f;
         empty[k] = !(N > 0.f);
         invN[k] = empty[k] ? 0.f : 1.f / N;
-        G[k] = (S != nullptr && !empty[k]) ? sym_read(S, C, i, j) / N : 0.f;  // N == 0: masked_features -> zeros
+        G[k] = (S != nullptr && !empty[k]) ? sym_read(S, C, i, j, n_slabs) / N : 0.f;  // N == 0: masked_features -> zeros
     }
     float navg = 1.f;
     float Gavg0 = G[0];
@@ -279,19 +291,26 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
 
 extern "C" {
 
+int sm_gram_num_slabs(int C, int H, int W) {
+    const int n_pos = H * sm::row_stride(W);
+    const int qb = sm::gram_qb(C, n_pos);
+    return (n_pos + qb - 1) / qb;
+}
+
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H, int W,
                    void* stream) {
     if (C % 64 != 0) return (int)hipErrorInvalidValue;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     const int T = C / 64;
-    dim3 grid((q_end - q_begin + sm::GRAM_QB - 1) / sm::GRAM_QB, T * (T + 1) / 2);
+    const int qb = sm::gram_qb(C, q_end - q_begin);
+    dim3 grid((q_end - q_begin + qb - 1) / qb, T * (T + 1) / 2);
     if (mask1)
         hipLaunchKernelGGL(sm::gram_masked_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
-                           C, plane, q_begin, q_end);
+                           C, plane, q_begin, q_end, qb);
     else
         hipLaunchKernelGGL(sm::gram_masked_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
-                           C, plane, q_begin, q_end);
+                           C, plane, q_begin, q_end, qb);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -299,7 +318,7 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty, float weight,
                   int C, float* D0, float* D1, float* loss_out, float* history, int hist_len, int hist_slot,
-                  void* stream) {
+                  int n_slabs, void* stream) {
     if (n_terms < 1 || n_terms > 4 || (C * C) % 256 != 0) return (int)hipErrorInvalidValue;
     sm::StyleTerms t;
     t.n = n_terms;
@@ -311,7 +330,7 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
     t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
     t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
     hipLaunchKernelGGL(sm::style_loss_kernel, dim3(C * C / 256), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
-                       t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot);
+                       t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs);
     SM_LAUNCH_CHECK();
     return 0;
 }

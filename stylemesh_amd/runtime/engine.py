@@ -165,9 +165,12 @@ class StepEngine:
             self._bufs[key] = LevelBuffers(H, W, self.deepest, True, self.device)
         return self._bufs[key]
 
-    def _gram_scratch(self, C):
-        if C not in self._gram:
-            self._gram[C] = tuple(torch.zeros(C, C, device=self.device) for _ in range(4))
+    def _gram_scratch(self, C, n_slabs=1):
+        """(S0, S1, D0, D1): partial-sum slabs [n_slabs, C, C] for both masks and the derivative matrices."""
+        cur = self._gram.get(C)
+        if cur is None or cur[0].shape[0] < n_slabs:
+            self._gram[C] = (torch.zeros(n_slabs, C, C, device=self.device), torch.zeros(n_slabs, C, C, device=self.device),
+                             torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
         return self._gram[C]
 
     # ------------------------------------------------------------------ style targets
@@ -192,9 +195,9 @@ class StepEngine:
             for layer in self.cfg.style_layers:
                 f = b.act[layer]
                 ones = FMap(1, f.H, f.W, self.device).from_dense(torch.ones(1, f.H, f.W))
-                S = torch.zeros(f.C, f.C, device=self.device)
+                S = torch.zeros(ops.gram_num_slabs(f.C, f.H, f.W), f.C, f.C, device=self.device)
                 ops.gram_masked(f, ones, None, S, None)
-                grams.append(_mirror_tiles(S) / float(f.H * f.W))
+                grams.append(_mirror_tiles(S.sum(0)) / float(f.H * f.W))
             cache[s] = grams
             del b
         self.targets = [{lvl: cache[s][li] for lvl, s in enumerate(sizes)} for li in range(len(self.cfg.style_layers))]
@@ -337,11 +340,11 @@ class StepEngine:
     def _style_terms(self, lv, b, li, layer, w_style):
         cfg = self.cfg
         f = b.act[layer]
-        S0, S1, D0, D1 = self._gram_scratch(f.C)
+        n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
+        S0, S1, D0, D1 = self._gram_scratch(f.C, n_slabs)
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
         m0, m1 = self._style_masks(lv, layer)
-        S0.zero_()
         hist, hist_len, hist_slot = None, 0, 0
         if cfg.gram_mode == "average":
             if layer not in self._hist:
@@ -350,7 +353,6 @@ class StepEngine:
             hist_len, hist_slot = min(cnt, 9), cnt % 9
             self._hist[layer][1] = cnt + 1
         if multi:
-            S1.zero_()
             ops.gram_masked(f, m0, m1, S0, S1)
             targets = [self.targets[li][2], self.targets[li][2]]
             term_mask = [0, 1]
@@ -358,12 +360,12 @@ class StepEngine:
                 targets.append(self.targets[li][0])
                 term_mask.append(0)
             ops.style_loss(S0, S1, lv.counts[layer][1:3], lv.factor[layer], targets, term_mask, [0, 1], weight, f.C,
-                           D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot)
+                           D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
         else:
             D1 = None
             ops.gram_masked(f, m0, None, S0, None)
             ops.style_loss(S0, None, lv.counts[layer][0:1], lv.factor[layer], [self.targets[li][0]], [0], [0, 0],
-                           weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot)
+                           weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
         ops.gram_backward(f, m0, m1, D0, D1, b.grad[layer], relu_gate=(layer == self.deepest))
         return D0, D1
 

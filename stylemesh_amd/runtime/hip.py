@@ -34,8 +34,9 @@ SIGNATURES = {
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_gram_num_slabs": [_i, _i, _i],
     "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_level_masks": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],

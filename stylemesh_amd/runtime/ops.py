@@ -135,17 +135,25 @@ def maxpool_bwd_relu(act: FMap, pooled: FMap, dpooled: FMap, dact: FMap):
 
 
 # ---- losses --------------------------------------------------------------------------------------------------
+def gram_num_slabs(C: int, H: int, W: int) -> int:
+    return lib.sm_gram_num_slabs(C, H, W)
+
+
 def gram_masked(feat: FMap, mask0, mask1, S0, S1):
+    """S0 / S1: [gram_num_slabs(C,H,W), C, C] partial-sum slabs."""
+    n = gram_num_slabs(feat.C, feat.H, feat.W)
+    assert S0.numel() >= n * feat.C * feat.C and (S1 is None or S1.numel() >= n * feat.C * feat.C)
     hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
                                  hip.stream()), "sm_gram_masked")
+    return n
 
 
 def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight, C, D0, D1, loss_out,
-               history=None, hist_len=0, hist_slot=0):
+               history=None, hist_len=0, hist_slot=0, n_slabs=1):
     hip.check(lib.sm_style_loss(ptr(S0), ptr(S1), ptr(counts), ptr(factor), hip.ptr_array(targets),
                                 hip.int_array(term_mask), len(targets), hip.int_array(skip_if_empty), weight, C,
-                                ptr(D0), ptr(D1), ptr(loss_out), ptr(history), hist_len, hist_slot, hip.stream()),
-              "sm_style_loss")
+                                ptr(D0), ptr(D1), ptr(loss_out), ptr(history), hist_len, hist_slot, n_slabs,
+                                hip.stream()), "sm_style_loss")
 
 
 def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool):

@@ -176,18 +176,19 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi):
     loss.backward()
     f = rt.FMap(C, H, W).from_dense(feat.detach()[0])
     mk = [rt.FMap(1, H, W).from_dense(m[0]) if m is not None else None for m in masks]
-    S = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda() if multi else None]
-    rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1])
+    ns = rt.ops.gram_num_slabs(C, H, W)
+    S = [torch.full((ns, C, C), 7.0).cuda(), torch.full((ns, C, C), 7.0).cuda() if multi else None]   # no pre-zeroing needed
+    assert rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1]) == ns
     n0 = float(masks[0].sum())
     ref_S0 = gp[0] * n0
     T = C // 64
     tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
-    assert_close(S[0].cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
+    assert_close(S[0].sum(0).cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
     counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
     D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
     loss_out = torch.zeros(1).cuda()
     rt.ops.style_loss(S[0], S[1], counts, dev(torch.tensor([factor])), [dev(t) for t in targets], term_mask, skip,
-                      weight, C, D[0], D[1], loss_out)
+                      weight, C, D[0], D[1], loss_out, n_slabs=ns)
     assert_close(loss_out, loss.detach().reshape(1), 1e-4, 0)
     df = rt.FMap(C, H, W)
     rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=False)
@@ -204,12 +205,13 @@ def test_style_loss_empty_masks(rt):
     Y = torch.randn(C, C); Y = (Y + Y.T) / 2
     f = rt.FMap(C, H, W).from_dense(feat[0])
     zero = rt.FMap(1, H, W)
-    S = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda()]
+    ns = rt.ops.gram_num_slabs(C, H, W)
+    S = [torch.zeros(ns, C, C).cuda(), torch.zeros(ns, C, C).cuda()]
     rt.ops.gram_masked(f, zero, zero, S[0], S[1])
     D = [torch.ones(C, C).cuda(), torch.ones(C, C).cuda()]
     loss_out = torch.zeros(1).cuda()
     rt.ops.style_loss(S[0], S[1], dev(torch.zeros(2)), dev(torch.tensor([0.5])), [dev(Y), dev(Y)], [0, 1], [0, 1],
-                      2.0, C, D[0], D[1], loss_out)
+                      2.0, C, D[0], D[1], loss_out, n_slabs=ns)
     assert_close(loss_out, (2.0 * 0.5 * (Y ** 2).mean()).reshape(1), 1e-5, 0)
     assert float(D[0].abs().max()) == 0 and float(D[1].abs().max()) == 0
 
