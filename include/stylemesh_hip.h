@@ -106,10 +106,12 @@ int sm_maxpool2x2_bwd_relu(const float* act, const float* pooled, const float* d
 
 /* K5a. Masked Gram sums S_k = (m_k F)(m_k F)^T for up to two 0/1 masks (GramMatrix :74-80 on
  * masked_features :136-143, without the 1/N). feat [C][plane]; mask0/mask1 one plane each (mask1 may be
- * NULL). The positions are split over n = sm_gram_num_slabs(C,H,W) blocks per tile; S0/S1 are
- * [n][C][C] partial-sum slabs (plain stores, deterministic; S_k = sum over slabs), of which only the
- * upper-triangular 64x64 tiles are written. No pre-zeroing needed. */
+ * NULL). The positions are split over many blocks per tile; each writes its partial tile to its own slab
+ * (plain stores, deterministic) and, when there are more than 32, a second pass sums groups of 32. S0/S1 must
+ * hold sm_gram_workspace_slabs(C,H,W) slabs of [C][C]; afterwards S_k = sum of the FIRST
+ * sm_gram_num_slabs(C,H,W) slabs. Only the upper-triangular 64x64 tiles are valid. No pre-zeroing needed. */
 int sm_gram_num_slabs(int C, int H, int W);
+int sm_gram_workspace_slabs(int C, int H, int W);
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                    int H, int W, void* stream);
 

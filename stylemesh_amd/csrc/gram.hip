@@ -98,6 +98,28 @@ __global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restric
     }
 }
 
+// second level of the position split: sums groups of GRAM_GROUP raw slabs into the reduced slabs at the front
+constexpr int GRAM_GROUP = 32;
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ raw, float* __restrict__ red, int cc,
+                                                          int n_raw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int s0 = blockIdx.y * GRAM_GROUP, s1 = min(s0 + GRAM_GROUP, n_raw);
+    float v = 0.f;
+    for (int s = s0; s < s1; ++s) v += raw[(size_t)s * cc + idx];
+    red[(size_t)blockIdx.y * cc + idx] = v;
+}
+
+struct GramPlan {
+    int qb, n_raw, n_red;   // positions per block, raw slabs, slabs the consumer sums (== n_raw when no 2nd level)
+};
+__host__ inline GramPlan gram_plan(int C, int n_pos) {
+    GramPlan p;
+    p.qb = gram_qb(C, n_pos);
+    p.n_raw = (n_pos + p.qb - 1) / p.qb;
+    p.n_red = p.n_raw > GRAM_GROUP ? (p.n_raw + GRAM_GROUP - 1) / GRAM_GROUP : p.n_raw;
+    return p;
+}
+
 // upper-triangular tile storage: element (i,j) lives at [i][j] when tile(i) <= tile(j), else at [j][i]
 __device__ __forceinline__ float sym_read(const float* S, int C, int i, int j, int n_slabs) {
     const size_t o = ((i >> 6) <= (j >> 6)) ? (size_t)i * C + j : (size_t)j * C + i;
@@ -291,10 +313,11 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
 
 extern "C" {
 
-int sm_gram_num_slabs(int C, int H, int W) {
-    const int n_pos = H * sm::row_stride(W);
-    const int qb = sm::gram_qb(C, n_pos);
-    return (n_pos + qb - 1) / qb;
+int sm_gram_num_slabs(int C, int H, int W) { return sm::gram_plan(C, H * sm::row_stride(W)).n_red; }
+
+int sm_gram_workspace_slabs(int C, int H, int W) {
+    const sm::GramPlan p = sm::gram_plan(C, H * sm::row_stride(W));
+    return p.n_red == p.n_raw ? p.n_raw : p.n_red + p.n_raw;
 }
 
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H, int W,
@@ -303,15 +326,26 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     const int T = C / 64;
-    const int qb = sm::gram_qb(C, q_end - q_begin);
-    dim3 grid((q_end - q_begin + qb - 1) / qb, T * (T + 1) / 2);
+    const sm::GramPlan p = sm::gram_plan(C, q_end - q_begin);
+    const bool two_level = p.n_red != p.n_raw;
+    const size_t cc = (size_t)C * C;
+    float* raw0 = two_level ? S0 + p.n_red * cc : S0;   // reduced slabs first, raw slabs behind them
+    float* raw1 = (two_level && S1) ? S1 + p.n_red * cc : S1;
+    dim3 grid(p.n_raw, T * (T + 1) / 2);
+    hipStream_t s = (hipStream_t)stream;
     if (mask1)
-        hipLaunchKernelGGL(sm::gram_masked_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
-                           C, plane, q_begin, q_end, qb);
+        hipLaunchKernelGGL(sm::gram_masked_kernel<2>, grid, dim3(256), 0, s, feat, mask0, mask1, raw0, raw1, C, plane,
+                           q_begin, q_end, p.qb);
     else
-        hipLaunchKernelGGL(sm::gram_masked_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, feat, mask0, mask1, S0, S1,
-                           C, plane, q_begin, q_end, qb);
+        hipLaunchKernelGGL(sm::gram_masked_kernel<1>, grid, dim3(256), 0, s, feat, mask0, mask1, raw0, raw1, C, plane,
+                           q_begin, q_end, p.qb);
     SM_LAUNCH_CHECK();
+    if (two_level) {
+        dim3 rg((unsigned)(cc / 256), p.n_red);
+        hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw0, S0, (int)cc, p.n_raw);
+        if (mask1) hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw1, S1, (int)cc, p.n_raw);
+        SM_LAUNCH_CHECK();
+    }
     return 0;
 }
 

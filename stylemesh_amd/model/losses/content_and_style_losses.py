@@ -96,11 +96,11 @@ class _GramFn(torch.autograd.Function):
             raise ValueError("GramMatrix: batch 1 and a multiple of 64 channels only")
         f = FMap(c, h, w, feat.device).from_dense(feat[0].detach())
         ones = FMap(1, h, w, feat.device).from_dense(torch.ones(1, h, w))
-        S = torch.zeros(ops.gram_num_slabs(c, h, w), c, c, device=feat.device)
-        ops.gram_masked(f, ones, None, S, None)
+        S = torch.zeros(ops.gram_workspace_slabs(c, h, w), c, c, device=feat.device)
+        n = ops.gram_masked(f, ones, None, S, None)
         ctx.f, ctx.ones = f, ones
         from ...runtime.engine import _mirror_tiles
-        return (_mirror_tiles(S.sum(0)) / float(h * w))[None]
+        return (_mirror_tiles(S[:n].sum(0)) / float(h * w))[None]
 
     @staticmethod
     def backward(ctx, gG):

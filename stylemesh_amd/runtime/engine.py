@@ -195,9 +195,9 @@ class StepEngine:
             for layer in self.cfg.style_layers:
                 f = b.act[layer]
                 ones = FMap(1, f.H, f.W, self.device).from_dense(torch.ones(1, f.H, f.W))
-                S = torch.zeros(ops.gram_num_slabs(f.C, f.H, f.W), f.C, f.C, device=self.device)
-                ops.gram_masked(f, ones, None, S, None)
-                grams.append(_mirror_tiles(S.sum(0)) / float(f.H * f.W))
+                S = torch.zeros(ops.gram_workspace_slabs(f.C, f.H, f.W), f.C, f.C, device=self.device)
+                n = ops.gram_masked(f, ones, None, S, None)
+                grams.append(_mirror_tiles(S[:n].sum(0)) / float(f.H * f.W))
             cache[s] = grams
             del b
         self.targets = [{lvl: cache[s][li] for lvl, s in enumerate(sizes)} for li in range(len(self.cfg.style_layers))]
@@ -341,7 +341,7 @@ class StepEngine:
         cfg = self.cfg
         f = b.act[layer]
         n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
-        S0, S1, D0, D1 = self._gram_scratch(f.C, n_slabs)
+        S0, S1, D0, D1 = self._gram_scratch(f.C, ops.gram_workspace_slabs(f.C, f.H, f.W))
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
         m0, m1 = self._style_masks(lv, layer)

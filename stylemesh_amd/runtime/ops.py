@@ -139,10 +139,15 @@ def gram_num_slabs(C: int, H: int, W: int) -> int:
     return lib.sm_gram_num_slabs(C, H, W)
 
 
+def gram_workspace_slabs(C: int, H: int, W: int) -> int:
+    return lib.sm_gram_workspace_slabs(C, H, W)
+
+
 def gram_masked(feat: FMap, mask0, mask1, S0, S1):
-    """S0 / S1: [gram_num_slabs(C,H,W), C, C] partial-sum slabs."""
+    """S0 / S1: [gram_workspace_slabs(C,H,W), C, C]; returns how many leading slabs sum to S."""
     n = gram_num_slabs(feat.C, feat.H, feat.W)
-    assert S0.numel() >= n * feat.C * feat.C and (S1 is None or S1.numel() >= n * feat.C * feat.C)
+    na = gram_workspace_slabs(feat.C, feat.H, feat.W)
+    assert S0.numel() >= na * feat.C * feat.C and (S1 is None or S1.numel() >= na * feat.C * feat.C)
     hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
                                  hip.stream()), "sm_gram_masked")
     return n

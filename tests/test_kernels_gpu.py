@@ -153,7 +153,8 @@ def test_maxpool_forward_backward(rt, H, W):
 
 
 # ------------------------------------------------------------------ K5 / K6
-@pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False)])
+@pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False),
+                                           (64, 150, 200, True)])
 def test_gram_style_loss_and_backward(rt, C, H, W, multi):
     torch.manual_seed(C + H)
     feat = F.relu(torch.randn(1, C, H, W)).requires_grad_(True)
@@ -176,14 +177,14 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi):
     loss.backward()
     f = rt.FMap(C, H, W).from_dense(feat.detach()[0])
     mk = [rt.FMap(1, H, W).from_dense(m[0]) if m is not None else None for m in masks]
-    ns = rt.ops.gram_num_slabs(C, H, W)
-    S = [torch.full((ns, C, C), 7.0).cuda(), torch.full((ns, C, C), 7.0).cuda() if multi else None]   # no pre-zeroing needed
+    ns, na = rt.ops.gram_num_slabs(C, H, W), rt.ops.gram_workspace_slabs(C, H, W)
+    S = [torch.full((na, C, C), 7.0).cuda(), torch.full((na, C, C), 7.0).cuda() if multi else None]   # no pre-zeroing needed
     assert rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1]) == ns
     n0 = float(masks[0].sum())
     ref_S0 = gp[0] * n0
     T = C // 64
     tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
-    assert_close(S[0].sum(0).cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
+    assert_close(S[0][:ns].sum(0).cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
     counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
     D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
     loss_out = torch.zeros(1).cuda()
@@ -205,8 +206,8 @@ def test_style_loss_empty_masks(rt):
     Y = torch.randn(C, C); Y = (Y + Y.T) / 2
     f = rt.FMap(C, H, W).from_dense(feat[0])
     zero = rt.FMap(1, H, W)
-    ns = rt.ops.gram_num_slabs(C, H, W)
-    S = [torch.zeros(ns, C, C).cuda(), torch.zeros(ns, C, C).cuda()]
+    ns, na = rt.ops.gram_num_slabs(C, H, W), rt.ops.gram_workspace_slabs(C, H, W)
+    S = [torch.zeros(na, C, C).cuda(), torch.zeros(na, C, C).cuda()]
     rt.ops.gram_masked(f, zero, zero, S[0], S[1])
     D = [torch.ones(C, C).cuda(), torch.ones(C, C).cuda()]
     loss_out = torch.zeros(1).cuda()
