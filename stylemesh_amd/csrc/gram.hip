@@ -73,15 +73,22 @@ __global__ __launch_bounds__(256) void gram_masked_kernel(const float* __restric
             if (NMASK > 1) Ms[1][tid] = (q < qe) ? mask1[q] : 0.f;
         }
         __syncthreads();
+        // masks are 0/1: a mask that is zero on the whole chunk contributes exact zeros - skip its MFMAs
+        // (every wave reads the same 32 values, so the branch is block-uniform)
+        bool live[NMASK];
+#pragma unroll
+        for (int mk = 0; mk < NMASK; ++mk) live[mk] = __ballot(Ms[mk][lane & 31] != 0.f) != 0ull;
         const float* Bsrc = diag ? FsA : FsB;
 #pragma unroll
-        for (int kk = 0; kk < GRAM_QC / 2; ++kk) {
-            const int k = kk * 2 + lhi;
-            const float a = FsA[(wm + l31) * GRAM_LD + k];
-            const float b = Bsrc[(wn + l31) * GRAM_LD + k];
+        for (int mk = 0; mk < NMASK; ++mk) {
+            if (!live[mk]) continue;
 #pragma unroll
-            for (int mk = 0; mk < NMASK; ++mk)
+            for (int kk = 0; kk < GRAM_QC / 2; ++kk) {
+                const int k = kk * 2 + lhi;
+                const float a = FsA[(wm + l31) * GRAM_LD + k];
+                const float b = Bsrc[(wn + l31) * GRAM_LD + k];
                 acc[mk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a * Ms[mk][k], b, acc[mk], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -219,7 +226,26 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[k][a][b][r] = 0.f;
 
-    for (int k0 = 0; k0 < C; k0 += KC) {
+    // masks are 0/1 and partition the valid pixels: a 32-position tile that is all-passed needs only D0, all-failed
+    // only D1, outside the mask neither (its output is exactly 0). Wave-uniform flags per (mask, n-tile).
+    bool live[NMASK][2];
+    bool any_live = false;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int q = q0 + wn + nj * 32 + l31;
+        live[0][nj] = __ballot(q < q_end && mask0[q] != 0.f) != 0ull;
+        if (NMASK > 1) live[NMASK - 1][nj] = __ballot(q < q_end && mask1[q] != 0.f) != 0ull;
+        any_live |= live[0][nj] | live[NMASK - 1][nj];
+    }
+    // block-uniform: is any position of the 256-wide tile inside any mask?
+    __shared__ int block_live;
+    if (tid == 0) block_live = 0;
+    __syncthreads();
+    if (any_live && lane == 0) atomicOr(&block_live, 1);
+    __syncthreads();
+    const bool skip_block = block_live == 0;
+
+    for (int k0 = 0; k0 < (skip_block ? 0 : C); k0 += KC) {
         // D rows k0..k0+15, columns m0..m0+63 (D symmetric: D[k][m] == D[m][k]); 256 float4 per matrix
         {
             const int row = tid >> 4, c4 = (tid & 15) * 4;
@@ -246,10 +272,14 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
 #pragma unroll
             for (int mk = 0; mk < NMASK; ++mk) {
                 const float a0 = As[mk][k * 64 + l31], a1 = As[mk][k * 64 + 32 + l31];
-                acc[mk][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[mk][0][0], 0, 0, 0);
-                acc[mk][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[mk][0][1], 0, 0, 0);
-                acc[mk][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[mk][1][0], 0, 0, 0);
-                acc[mk][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[mk][1][1], 0, 0, 0);
+                if (live[mk][0]) {
+                    acc[mk][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[mk][0][0], 0, 0, 0);
+                    acc[mk][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[mk][1][0], 0, 0, 0);
+                }
+                if (live[mk][1]) {
+                    acc[mk][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[mk][0][1], 0, 0, 0);
+                    acc[mk][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[mk][1][1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
