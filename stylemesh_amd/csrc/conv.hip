@@ -25,13 +25,18 @@ struct ConvArgs {
     float* out;
     const float* gate;
     int Cin_pad, Cout, H, W, Wp, plane, n_tiles, m_tiles;
-    float* ws;          // split-K: [splits][Cout][plane] partial sums (plain stores), reduced by the epilogue kernel
-    int splits;         // 1 = direct epilogue
+    // Work decomposition. The first n_whole tiles (a multiple of the CU count) are computed whole; the remaining
+    // "tail" tiles - whose last, partially filled round would otherwise leave most CUs idle - are split along K
+    // into `splits` units each, so the tail is made of many small units that spread over all CUs. Split units
+    // store raw partial tiles to ws[(tail_tile * splits + split)][BM][BN]; conv_tail_epilogue_kernel reduces them.
+    float* ws;
+    int n_whole;
+    int splits;
     int chunks_per_split;
 };
 
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLITK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_mfma_kernel(ConvArgs a) {
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_mfma_kernel(ConvArgs a) {
     static_assert(BM / WGM == 64 && BN / WGN == 64 && WGM * WGN == 4, "wave tile is 64x64");
     constexpr int BNP = BN + 8;  // 4 floats of halo on each side keeps every segment 16-byte aligned
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -46,15 +51,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wm = (wave / WGN) * 64;
     const int wn = (wave % WGN) * 64;
 
-    // work item = (split, m_tile, n_tile), n fastest: neighbours in the XCD's share use the same weight slab
-    const int tiles = a.n_tiles * a.m_tiles;
-    int item = xcd_linear(blockIdx.x, tiles * (SPLITK ? a.splits : 1));
-    const int split = SPLITK ? item / tiles : 0;
-    item -= split * tiles;
-    const int m_tile = item / a.n_tiles;
-    const int n_tile = item - m_tile * a.n_tiles;
-    const int c_begin = SPLITK ? split * a.chunks_per_split * KC : 0;
-    const int c_end = SPLITK ? min(a.Cin_pad, c_begin + a.chunks_per_split * KC) : a.Cin_pad;
+    // unit -> (tile, split). Whole tiles: XCD-aware order (neighbours in an XCD's share use the same weight slab
+    // and adjacent positions); tail units keep the dispatcher's round-robin so every XCD gets its share of them.
+    int tile, split = -1;
+    if ((int)blockIdx.x < a.n_whole) {
+        tile = xcd_linear(blockIdx.x, a.n_whole);
+    } else {
+        const int v = blockIdx.x - a.n_whole;
+        tile = a.n_whole + v / a.splits;
+        split = v - (tile - a.n_whole) * a.splits;
+    }
+    const int m_tile = tile / a.n_tiles;
+    const int n_tile = tile - m_tile * a.n_tiles;
+    const int c_begin = split < 0 ? 0 : split * a.chunks_per_split * KC;
+    const int c_end = split < 0 ? a.Cin_pad : min(a.Cin_pad, c_begin + a.chunks_per_split * KC);
     const int m0 = m_tile * BM;
     const int q0 = a.Wp + n_tile * BN;  // first computed position = start of row 1
 
@@ -164,6 +174,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: column (pixel) = lane & 31,
     //      row (channel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    if (split >= 0) {   // tail unit: raw partial tile -> workspace, [BM][BN] row-major
+        float* wt = a.ws + ((size_t)(tile - a.n_whole) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] = acc[mi][nj][r];
+        return;
+    }
     const int q_end = (a.H + 1) * a.Wp;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
@@ -178,10 +199,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int co = co_base + (r & 3) + 8 * (r >> 2);
                 const size_t o = (size_t)co * a.plane + q;
                 float v = acc[mi][nj][r];
-                if (SPLITK) {
-                    a.ws[(size_t)split * a.Cout * a.plane + o] = v;
-                    continue;
-                }
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + a.bias[co], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += a.out[o];
                 if (FLAGS & SM_EPI_RELU_MASK) v = (a.gate[o] > 0.f) ? v : 0.f;
@@ -191,32 +208,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// Split-K second pass: out = epilogue(sum over splits of the partial slabs), 4 positions per thread.
-template <int FLAGS>
-__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvArgs a) {
-    const int co = blockIdx.y;
-    const int q = a.Wp + (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (q >= (a.H + 1) * a.Wp) return;
-    const size_t o = (size_t)co * a.plane + q;
-    const size_t slab = (size_t)a.Cout * a.plane;
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.ws + o);
-    for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(a.ws + s * slab + o);
-    f32x4 prev, gate;
-    if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(a.out + o);
-    if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(a.gate + o);
-    const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
+// Tail second pass: one block per tail tile; out = epilogue(sum over its K-splits), 4 positions per thread.
+template <int BM, int BN, int FLAGS>
+__global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
+    const int tile = a.n_whole + blockIdx.x;
+    const int m_tile = tile / a.n_tiles, n_tile = tile - m_tile * a.n_tiles;
+    const int m0 = m_tile * BM, q0 = a.Wp + n_tile * BN, q_end = (a.H + 1) * a.Wp;
+    const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
+    {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
+        const int e = blockIdx.y * 256 + threadIdx.x;
+        const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
+        const int q = q0 + c4;
+        if (q >= q_end) return;   // q_end and q are multiples of 4
+        f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
+        for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
+        const int co = m0 + row;
+        const size_t o = (size_t)co * a.plane + q;
+        f32x4 prev, gate;
+        if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(a.out + o);
+        if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(a.gate + o);
+        const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float x = v[j];
-        if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
-        if (FLAGS & SM_EPI_ADD) x += prev[j];
-        if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
-        v[j] = interior(q + j, a.H, a.W, a.Wp) ? x : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
+            if (FLAGS & SM_EPI_ADD) x += prev[j];
+            if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
+            v[j] = interior(q + j, a.H, a.W, a.Wp) ? x : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.out + o) = v;
     }
-    *reinterpret_cast<f32x4*>(a.out + o) = v;
 }
 
-constexpr int SM_CONV_SLOTS = 512;  // resident blocks the chip holds at 2 blocks per CU
+constexpr int SM_NUM_CU = 256;
 
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
 static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
@@ -224,30 +248,32 @@ static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
     a.m_tiles = a.Cout / BM;
     a.n_tiles = (a.H * a.Wp + BN - 1) / BN;
     constexpr size_t lds = (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
-    // split K when the natural grid cannot fill the chip: each split keeps >= 4 K-chunks
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
-    int splits = 1;
-    if (a.ws != nullptr && tiles < SM_CONV_SLOTS * 3 / 4 && chunks >= 8) {
-        splits = std::min(SM_CONV_SLOTS / tiles, chunks / 4);
-        const size_t slab = (size_t)a.Cout * a.plane;
-        splits = (int)std::min<size_t>((size_t)splits, ws_floats / slab);
-    }
-    if (splits > 1) {
-        a.chunks_per_split = (chunks + splits - 1) / splits;
-        a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-        auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS, true>;
-        hipLaunchKernelGGL(k, dim3(tiles * a.splits), dim3(256), lds, s, a);
-        SM_LAUNCH_CHECK();
-        const int n4 = (a.H * a.Wp + 3) / 4;
-        hipLaunchKernelGGL(conv_splitk_epilogue_kernel<FLAGS>, dim3((n4 + 255) / 256, a.Cout), dim3(256), 0, s, a);
-        SM_LAUNCH_CHECK();
-        return 0;
-    }
+    // full rounds of one tile per CU run whole; the tail of `rem` tiles is split along K so that it becomes
+    // about one more (short) round of rem * splits small units. Pick the split count that minimises the tail's
+    // duration ceil(rem * S / CUs) / S, each split keeping >= 2 K-chunks.
+    a.n_whole = tiles / SM_NUM_CU * SM_NUM_CU;
     a.splits = 1;
     a.chunks_per_split = chunks;
-    auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS, false>;
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), lds, s, a);
+    int rem = tiles - a.n_whole;
+    if (a.ws != nullptr && rem > 0 && chunks >= 4) {
+        const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)rem * BM * BN)});
+        // cost of the tail in units of one whole tile; every unit pays ~1 chunk of fixed prologue / epilogue time
+        float best = (chunks + 1.f) / chunks;   // S = 1: one more full round
+        for (int S = 2; S <= max_s; ++S) {
+            const int cps = (chunks + S - 1) / S, S_eff = (chunks + cps - 1) / cps;
+            const float cost = (float)((rem * S_eff + SM_NUM_CU - 1) / SM_NUM_CU) * (cps + 1.f) / chunks;
+            if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
+        }
+    }
+    if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
+    auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>;
+    hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256), lds, s, a);
     SM_LAUNCH_CHECK();
+    if (rem > 0) {
+        hipLaunchKernelGGL((conv_tail_epilogue_kernel<BM, BN, FLAGS>), dim3(rem, BM * BN / 1024), dim3(256), 0, s, a);
+        SM_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -342,7 +368,7 @@ int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, 
                int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
     if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{in, wt, bias, out, gate, Cin_pad, Cout, H, W, sm::row_stride(W), sm::plane_size(H, W), 0, 0,
-                   ws, 1, 0};
+                   ws, 0, 1, 0};
     hipStream_t s = (hipStream_t)stream;
     switch (flags) {
         case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, ws_floats, s);
