@@ -89,6 +89,18 @@ int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float c
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate,
                int Cin_pad, int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream);
 
+/* The same convolution over up to 8 feature maps of different sizes in ONE launch (the UV pyramid levels of
+ * a view share the VGG weights): the position tiles of all problems form one grid, which removes the
+ * per-level tail rounds and launch boundaries. problems: HOST array. */
+typedef struct {
+    const float* in;
+    float* out;
+    const float* gate;
+    int H, W;
+} sm_conv_problem;
+int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
+                       int Cin_pad, int Cout, int flags, float* ws, size_t ws_floats, void* stream);
+
 /* Data gradient of the first conv (64 -> 3 channels; conv1_1, :11,49): out [3][plane] from
  * dz [64][plane], wd [9][64][4] (tap-major, 3 real output channels + 1 zero). */
 int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream);

@@ -18,13 +18,23 @@
 
 namespace sm {
 
-struct ConvArgs {
+constexpr int SM_MAX_GROUP = 8;
+
+// One feature-map problem of a grouped launch (same weights, different planes: the UV levels of a view).
+struct ConvProblem {
     const float* in;
-    const float* wt;
-    const float* bias;
     float* out;
     const float* gate;
-    int Cin_pad, Cout, H, W, Wp, plane, n_tiles, m_tiles;
+    int H, W, Wp, plane;
+};
+
+struct ConvArgs {
+    ConvProblem p[SM_MAX_GROUP];
+    int tile_begin[SM_MAX_GROUP + 1];   // prefix sums of the problems' position-tile counts
+    int n_problems;
+    const float* wt;
+    const float* bias;
+    int Cin_pad, Cout, n_tiles, m_tiles;   // n_tiles = position tiles of ALL problems
     // Work decomposition. The first n_whole tiles (a multiple of the CU count) are computed whole; the remaining
     // "tail" tiles - whose last, partially filled round would otherwise leave most CUs idle - are split along K
     // into `splits` units each, so the tail is made of many small units that spread over all CUs. Split units
@@ -62,11 +72,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         split = v - (tile - a.n_whole) * a.splits;
     }
     const int m_tile = tile / a.n_tiles;
-    const int n_tile = tile - m_tile * a.n_tiles;
+    const int n_glob = tile - m_tile * a.n_tiles;
+    // which problem of the group does this position tile belong to (block-uniform scalar selects)
+    ConvProblem P = a.p[0];
+    int n_tile = n_glob;
+#pragma unroll
+    for (int g = 1; g < SM_MAX_GROUP; ++g)
+        if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+            P = a.p[g];
+            n_tile = n_glob - a.tile_begin[g];
+        }
     const int c_begin = split < 0 ? 0 : split * a.chunks_per_split * KC;
     const int c_end = split < 0 ? a.Cin_pad : min(a.Cin_pad, c_begin + a.chunks_per_split * KC);
     const int m0 = m_tile * BM;
-    const int q0 = a.Wp + n_tile * BN;  // first computed position = start of row 1
+    const int q0 = P.Wp + n_tile * BN;  // first computed position = start of row 1
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int i = min(tid + j * 256, B_F4 - 1);
         const int row = i / B_F4_PER_ROW, c4 = i - row * B_F4_PER_ROW;
         const int ky = row / KC, ci = row - ky * KC;
-        b_src[j] = ci * a.plane + q0 + (ky - 1) * a.Wp - 4 + c4 * 4;
+        b_src[j] = ci * P.plane + q0 + (ky - 1) * P.Wp - 4 + c4 * 4;
         b_dst[j] = row * BNP + c4 * 4;
     }
     f32x4 ra[NA], rb[NB];
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* wsrc = a.wt + (size_t)(c0_) * a.Cout + a_src0;                                 \
         _Pragma("unroll") for (int j = 0; j < NA; ++j)                                              \
             ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)((j == NA - 1) ? a_last : j) * a_step); \
-        const float* isrc = a.in + (size_t)(c0_) * a.plane;                                         \
+        const float* isrc = P.in + (size_t)(c0_) * P.plane;                                         \
         _Pragma("unroll") for (int j = 0; j < NB; ++j)                                              \
             rb[j] = *reinterpret_cast<const f32x4*>(isrc + b_src[j]);                               \
     }
@@ -185,24 +204,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] = acc[mi][nj][r];
         return;
     }
-    const int q_end = (a.H + 1) * a.Wp;
+    const int q_end = (P.H + 1) * P.Wp;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
         if (q >= q_end) continue;
-        const bool inside = interior(q, a.H, a.W, a.Wp);
+        const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int co_base = m0 + wm + mi * 32 + 4 * lhi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_base + (r & 3) + 8 * (r >> 2);
-                const size_t o = (size_t)co * a.plane + q;
+                const size_t o = (size_t)co * P.plane + q;
                 float v = acc[mi][nj][r];
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + a.bias[co], 0.f);
-                if (FLAGS & SM_EPI_ADD) v += a.out[o];
-                if (FLAGS & SM_EPI_RELU_MASK) v = (a.gate[o] > 0.f) ? v : 0.f;
-                a.out[o] = inside ? v : 0.f;
+                if (FLAGS & SM_EPI_ADD) v += P.out[o];
+                if (FLAGS & SM_EPI_RELU_MASK) v = (P.gate[o] > 0.f) ? v : 0.f;
+                P.out[o] = inside ? v : 0.f;
             }
         }
     }
@@ -212,8 +231,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 template <int BM, int BN, int FLAGS>
 __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     const int tile = a.n_whole + blockIdx.x;
-    const int m_tile = tile / a.n_tiles, n_tile = tile - m_tile * a.n_tiles;
-    const int m0 = m_tile * BM, q0 = a.Wp + n_tile * BN, q_end = (a.H + 1) * a.Wp;
+    const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
+    ConvProblem P = a.p[0];
+    int n_tile = n_glob;
+#pragma unroll
+    for (int g = 1; g < SM_MAX_GROUP; ++g)
+        if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+            P = a.p[g];
+            n_tile = n_glob - a.tile_begin[g];
+        }
+    const int m0 = m_tile * BM, q0 = P.Wp + n_tile * BN, q_end = (P.H + 1) * P.Wp;
     const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
     {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
         const int e = blockIdx.y * 256 + threadIdx.x;
@@ -223,10 +250,10 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
         f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
         for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
         const int co = m0 + row;
-        const size_t o = (size_t)co * a.plane + q;
+        const size_t o = (size_t)co * P.plane + q;
         f32x4 prev, gate;
-        if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(a.out + o);
-        if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(a.gate + o);
+        if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(P.out + o);
+        if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(P.gate + o);
         const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -234,9 +261,9 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
             if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
             if (FLAGS & SM_EPI_ADD) x += prev[j];
             if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
-            v[j] = interior(q + j, a.H, a.W, a.Wp) ? x : 0.f;
+            v[j] = interior(q + j, P.H, P.W, P.Wp) ? x : 0.f;
         }
-        *reinterpret_cast<f32x4*>(a.out + o) = v;
+        *reinterpret_cast<f32x4*>(P.out + o) = v;
     }
 }
 
@@ -246,7 +273,10 @@ template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
 static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
-    a.n_tiles = (a.H * a.Wp + BN - 1) / BN;
+    a.tile_begin[0] = 0;
+    for (int g = 0; g < a.n_problems; ++g)
+        a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + BN - 1) / BN;
+    a.n_tiles = a.tile_begin[a.n_problems];
     constexpr size_t lds = (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
     // full rounds of one tile per CU run whole; the tail of `rem` tiles is split along K so that it becomes
@@ -364,12 +394,7 @@ int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
 int sm_abi_version(void) { return 1; }
 
-int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,
-               int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
-    if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
-    sm::ConvArgs a{in, wt, bias, out, gate, Cin_pad, Cout, H, W, sm::row_stride(W), sm::plane_size(H, W), 0, 0,
-                   ws, 0, 1, 0};
-    hipStream_t s = (hipStream_t)stream;
+static int conv_dispatch_flags(sm::ConvArgs& a, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
         case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, ws_floats, s);
         case 0: return sm::dispatch_conv<0>(a, ws_floats, s);
@@ -378,6 +403,30 @@ int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, 
         case SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_ADD>(a, ws_floats, s);
         default: return (int)hipErrorInvalidValue;
     }
+}
+
+int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
+                       int Cin_pad, int Cout, int flags, float* ws, size_t ws_floats, void* stream) {
+    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
+    if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
+    sm::ConvArgs a{};
+    for (int g = 0; g < n_problems; ++g)
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
+                                 sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    a.n_problems = n_problems;
+    a.wt = wt;
+    a.bias = bias;
+    a.Cin_pad = Cin_pad;
+    a.Cout = Cout;
+    a.ws = ws;
+    a.splits = 1;
+    return conv_dispatch_flags(a, flags, ws_floats, (hipStream_t)stream);
+}
+
+int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,
+               int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
+    sm_conv_problem p{in, out, gate, H, W};
+    return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, ws, ws_floats, stream);
 }
 
 int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream) {

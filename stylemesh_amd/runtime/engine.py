@@ -298,14 +298,21 @@ class StepEngine:
         self.loss_buf.zero_()
         w_style = float(cfg.loss_weights.get("style", 0.0))
         w_content = float(cfg.loss_weights.get("content", 0.0))
-        for lv in self.view:
-            if not lv.active or self.deepest is None:
-                continue
-            b = self._level_bufs(lv.H, lv.W)
+        active = [lv for lv in self.view if lv.active]
+        if not active or self.deepest is None:
+            return
+        # layer-major over the active UV levels: every conv layer is ONE grouped launch over all levels
+        bufs = [self._level_bufs(lv.H, lv.W) for lv in active]
+        if len({(lv.H, lv.W) for lv in active}) != len(active):
+            raise ValueError("two UV levels of the same resolution are not supported")
+        for lv, b in zip(active, bufs):
             ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
-            self.vgg.forward(b)
+        self.vgg.forward_group(bufs)
+        injected = set()
+        for lv, b in zip(active, bufs):
             injected = self._inject_losses(lv, b, w_style, w_content)
-            self.vgg.backward(b, injected - {self.deepest}, self.deepest)
+        self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest)
+        for lv, b in zip(active, bufs):
             ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
 
     def _inject_losses(self, lv, b, w_style, w_content, keep=None):

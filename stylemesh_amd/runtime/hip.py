@@ -31,6 +31,7 @@ SIGNATURES = {
     "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp],
     "sm_clamp_sumsq": [_vp, _sz, _vp, _i, _f, _f, _vp, _vp],
     "sm_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
+    "sm_conv3x3_grouped": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp],
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -49,6 +50,11 @@ SIGNATURES = {
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
 }
+
+
+class ConvProblem(C.Structure):
+    """sm_conv_problem of include/stylemesh_hip.h"""
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int)]
 
 
 def _load():

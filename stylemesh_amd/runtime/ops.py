@@ -119,6 +119,26 @@ def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap
         CONV_TIMER.launch(run, 2.0 * 9 * cin_true * cout * inp.H * inp.W)
 
 
+def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int):
+    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps)."""
+    cin_pad, cout = wt.shape[1], wt.shape[2]
+    arr = (hip.ConvProblem * len(problems))()
+    flops = 0.0
+    for i, (inp, out, gate) in enumerate(problems):
+        assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
+        arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), inp.H, inp.W)
+        flops += 2.0 * 9 * (3 if cin_pad == 4 else cin_pad) * cout * inp.H * inp.W
+
+    def run():
+        ws = splitk_workspace(wt.device)
+        hip.check(lib.sm_conv3x3_grouped(arr, len(problems), ptr(wt), ptr(bias), cin_pad, cout, flags, ptr(ws),
+                                         ws.numel(), hip.stream()), "sm_conv3x3_grouped")
+    if CONV_TIMER is None:
+        run()
+    else:
+        CONV_TIMER.launch(run, flops)
+
+
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):
     assert wd.shape[2] == 4 and wd.shape[1] == dz.C and out.C >= 3
     hip.check(lib.sm_conv3x3_dgrad_c3(dz.ptr, ptr(wd), out.ptr, dz.C, dz.H, dz.W, hip.stream()), "sm_conv3x3_dgrad_c3")
