@@ -23,6 +23,9 @@ sys.path.insert(0, REPO)
 from stylemesh_amd.data import synthetic as S  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+# algorithmic HBM bytes of the 25 grouped conv launches of one step: every input / output / gate plane and the
+# layer's weights touched once
+ALG_CONV_BYTES = {"c3": 7743.4e6}
 WORKLOADS = {
     # SURVEY.md section 8 d. c3 = scripts/train/optimize_texture_scannet_with_angle_and_depth.sh at 4096^2
     "c3": dict(tex=4096, level_hw=S.SCANNET_LEVEL_HW, view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0, angle=True,
@@ -86,7 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=1, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-conv-timer", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--timer-every", type=int, default=10, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
@@ -160,8 +163,14 @@ def main():
         n, ms, flops = timer.summary()
         n_timed = len([i for i in range(args.steps) if i % args.timer_every == 0])
         ach = flops / (ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per conv launch from the committed PMC pass of this workload (offline: PMC
+        tf = os.path.join(REPO, "profiles", "r01", f"conv_traffic_{args.workload}.json")   # runs cannot be live)
+        if os.path.exists(tf):
+            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "conv3x3_mfma_kernel",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, "
+                    "profiles/r01/conv_traffic_*.json)", "algorithmic_bytes_per_launch": round(ALG_CONV_BYTES.get(args.workload, 0) / 25),
+                    "kernel": "conv3x3_mfma_kernel",
                     "launches_timed": n, "timed_steps": n_timed, "avg_launch_us": round(1e3 * ms / n, 2),
                     "algorithmic_gflop_per_step": round(flops / n_timed / 1e9, 1),
                     "share_of_step_time": round(ms * 1e-3 / n_timed / (dt / args.steps), 3)}
