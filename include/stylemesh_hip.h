@@ -65,11 +65,13 @@ int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* 
  * The arena holds n_seg layers back to back: seg_end[i] = end offset (floats) of layer i.
  * grad_scale multiplies the data-term gradient first (1/R after an all-reduce over R ranks).
  * bias_corr1 = 1-beta1^t and bias_corr2 = 1-beta2^t are computed by the caller in double; the betas are
- * doubles because torch derives the fp32 constants 1-beta from Python doubles. */
+ * doubles because torch derives the fp32 constants 1-beta from Python doubles.
+ * dev_hyper (optional, device, 2 floats): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2)}
+ * from it instead of the scalar arguments, so a captured launch (hipGraph) can be replayed across steps. */
 int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end,
                   const float* reg_coef, int n_seg, float lr, double beta1, double beta2, float eps,
                   double bias_corr1, double bias_corr2, float grad_scale, float clamp_lo, float clamp_hi,
-                  int zero_grad, float* sumsq_out, void* stream);
+                  int zero_grad, float* sumsq_out, const float* dev_hyper, void* stream);
 
 /* normalize() alone (texture.py:41-44) + per-segment sum of squares (for the first step's tex_reg). */
 int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float clamp_lo, float clamp_hi,

@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float one_minus_beta1, float beta2, float one_minus_beta2,
                                                    float eps, float inv_sqrt_bc2,
                                                    float grad_scale, float lo, float hi, int zero_grad,
-                                                   float* __restrict__ sumsq) {
+                                                   float* __restrict__ sumsq, const float* __restrict__ dev_hyper) {
+    if (ADAM && dev_hyper) {   // step-dependent scalars from device memory: the launch can be replayed from a hipGraph
+        lr_over_bc1 = dev_hyper[0];
+        inv_sqrt_bc2 = dev_hyper[1];
+    }
     const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     // sum(p^2) per segment: a block almost always lies inside one segment (k_blk); elements of a block that
     // straddles a boundary and belong to another segment are added one by one.
@@ -276,7 +280,8 @@ static int make_segs(sm::Segs& s, size_t n, const size_t* seg_end, const float* 
 
 int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end, const float* reg_coef,
                   int n_seg, float lr, double beta1, double beta2, float eps, double bias_corr1, double bias_corr2,
-                  float grad_scale, float clamp_lo, float clamp_hi, int zero_grad, float* sumsq_out, void* stream) {
+                  float grad_scale, float clamp_lo, float clamp_hi, int zero_grad, float* sumsq_out,
+                  const float* dev_hyper, void* stream) {
     sm::Segs s;
     if (int e = make_segs(s, n, seg_end, reg_coef, n_seg)) return e;
     const size_t blocks = (n + 1023) / 1024;
@@ -285,7 +290,7 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_corr2));
     hipLaunchKernelGGL(sm::adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        s, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, inv_sqrt_bc2,
-                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out);
+                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -297,7 +302,7 @@ int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float c
     const size_t blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(sm::adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, n, s, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, clamp_lo,
-                       clamp_hi, 0, sumsq_out);
+                       clamp_hi, 0, sumsq_out, (const float*)nullptr);
     SM_LAUNCH_CHECK();
     return 0;
 }

@@ -133,6 +133,11 @@ class StepEngine:
         # device scalars: [content, style] weighted loss accumulators, per-layer sum of squares of the texture
         self.loss_buf = torch.zeros(2, device=device)
         self.sumsq = torch.zeros(n_layers, device=device)
+        self._pbuf = {}            # persistent per-view buffers (fixed addresses)
+        self._graphs = {}          # view signature -> captured hipGraph of forward_backward
+        self._graph_warm = {}      # view signature -> eager runs so far
+        self._opt_graph = None
+        self.use_graphs = False    # replay captured hipGraphs instead of re-launching ~190 kernels per step
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
         numel = [c * h * w for c, h, w in self.arena.shapes]
@@ -204,6 +209,13 @@ class StepEngine:
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ per-view constants
+    def _persist(self, key, factory):
+        """Per-view buffers live at FIXED device addresses (allocated once per shape, overwritten by every
+        set_view): a captured hipGraph of the step stays valid across views."""
+        if key not in self._pbuf:
+            self._pbuf[key] = factory()
+        return self._pbuf[key]
+
     def set_view(self, batch):
         cfg = self.cfg
         rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
@@ -211,32 +223,40 @@ class StepEngine:
         if rgb.shape[0] != 1:
             raise ValueError("batch size 1 only (the reference's masked_features indexing requires it too)")
         h, w = rgb.shape[2:]
-        to = lambda t, dt=torch.float32: t.to(dev, dt).contiguous()
-        mask_u8 = to(mask[0], torch.uint8)
-        ag, adeg = to(angle_guidance[0, 0]), to(angle_degrees[0, 0])
         n_levels = len(uv_map)
+
+        def stage(name, src, dt=torch.float32):
+            dst = self._persist((name, tuple(src.shape), dt), lambda: torch.empty(src.shape, dtype=dt, device=dev))
+            dst.copy_(src, non_blocking=True)
+            return dst
+        mask_u8 = stage("mask", mask[0], torch.uint8)
+        ag, adeg = stage("ag", angle_guidance[0, 0]), stage("adeg", angle_degrees[0, 0])
+        rgb_dev = stage("rgb", rgb[0])
         if cfg.use_depth_scaling:
-            E = torch.empty(n_levels, h, w, device=dev)
-            Wt = torch.empty(n_levels, h, w, device=dev)
-            ops.level_masks(to(rounded[0, 0], torch.int64), to(other[0, 0], torch.int64), to(interp_w[0, 0]), mask_u8,
-                            n_levels, E, Wt)
+            E = self._persist(("E", n_levels, h, w), lambda: torch.empty(n_levels, h, w, device=dev))
+            Wt = self._persist(("Wt", n_levels, h, w), lambda: torch.empty(n_levels, h, w, device=dev))
+            ops.level_masks(stage("rounded", rounded[0, 0], torch.int64), stage("other", other[0, 0], torch.int64),
+                            stage("interp_w", interp_w[0, 0]), mask_u8, n_levels, E, Wt)
         else:
-            maskf = mask_u8.float()
+            maskf = self._persist(("maskf", h, w), lambda: torch.empty(h, w, device=dev))
+            maskf.copy_(mask_u8)
         levels = []
-        msums = torch.zeros(n_levels, device=dev)
+        msums = self._persist(("msums", n_levels), lambda: torch.zeros(n_levels, device=dev))
+        msums.zero_()
         for i, uv in enumerate(uv_map):
             lv = _ViewLevel()
-            lv.grid = to(uv[0])
+            lv.grid = stage(f"grid{i}", uv[0])
             lv.H, lv.W = lv.grid.shape[:2]
             lv.index = i
             if not cfg.use_depth_scaling and i != n_levels - 1:
                 lv.active = False   # all-zero mask (model/model.py:253-254)
                 levels.append(lv)
                 continue
-            lv.M = torch.empty(lv.H, lv.W, device=dev)
+            hw = (i, lv.H, lv.W)
+            lv.M = self._persist(("M",) + hw, lambda: torch.empty(lv.H, lv.W, device=dev))
             want_pw = cfg.use_angle_weight or cfg.use_depth_scaling
-            lv.pixel_weight = torch.empty(lv.H, lv.W, device=dev) if want_pw else None
-            lv.passed = torch.empty(lv.H, lv.W, dtype=torch.uint8, device=dev)
+            lv.pixel_weight = self._persist(("pw",) + hw, lambda: torch.empty(lv.H, lv.W, device=dev)) if want_pw else None
+            lv.passed = self._persist(("passed",) + hw, lambda: torch.empty(lv.H, lv.W, dtype=torch.uint8, device=dev))
             ops.level_maps(E[i] if cfg.use_depth_scaling else maskf, Wt[i] if cfg.use_depth_scaling else None,
                            ag if cfg.use_angle_weight else None, adeg, float(cfg.angle_threshold), h, w, lv.H, lv.W,
                            lv.M, lv.pixel_weight, lv.passed, msums[i:i + 1])
@@ -245,7 +265,7 @@ class StepEngine:
         for lv in levels:
             if hasattr(lv, "M"):
                 lv.active = bool(sums[lv.index] > 0)
-        self._finish_view(levels, to(rgb[0]))
+        self._finish_view(levels, rgb_dev)
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
 
     def _finish_view(self, levels, rgb_dev):
@@ -254,14 +274,16 @@ class StepEngine:
         cfg, dev = self.cfg, self.device
         h, w = rgb_dev.shape[1:]
         active = [lv for lv in levels if lv.active]
-        # layer masks, counts, factors
         n_act = len(active)
-        consts = torch.zeros(n_act, len(self.loss_layers), 4, device=dev)   # [N_all, N_pass, N_fail, factor]
-        for a, lv in enumerate(active):
+        n_lv, n_ll = len(levels), len(self.loss_layers)
+        consts = self._persist(("consts", n_lv, n_ll), lambda: torch.zeros(n_lv, n_ll, 4, device=dev))
+        consts.zero_()   # [N_all, N_pass, N_fail, factor] per (level, loss layer)
+        for lv in active:
+            a = lv.index
             lv.masks, lv.counts, lv.factor = {}, {}, {}
             for k, layer in enumerate(self.loss_layers):
                 hl, wl = layer_hw(layer, lv.H, lv.W)
-                m = FMap(3, hl, wl, dev)   # planes: all, passed, failed
+                m = self._persist(("lmask", a, layer, hl, wl), lambda: FMap(3, hl, wl, dev))   # all, passed, failed
                 ops.layer_masks(lv.M, lv.passed, lv.H, lv.W, hl, wl, m.channel_ptr(0), m.channel_ptr(1),
                                 m.channel_ptr(2), consts[a, k, 0:3])
                 lv.masks[layer], lv.counts[layer], lv.factor[layer] = m, consts[a, k, 0:3], consts[a, k, 3:4]
@@ -282,11 +304,12 @@ class StepEngine:
                 for layer in cfg.content_layers:
                     src = cb.act[layer]
                     hl, wl = layer_hw(layer, lv.H, lv.W)
-                    dst = FMap(src.C, hl, wl, dev)
+                    dst = self._persist(("ctarget", lv.index, layer, hl, wl), lambda: FMap(src.C, hl, wl, dev))
                     ops.fmap_resize_bilinear(src, dst)
                     lv.content_target[layer] = dst
         self.view = levels
         self.view_consts = consts
+        self.view_sig = tuple((lv.index, lv.H, lv.W) for lv in active)   # identifies the step's launch sequence
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self):
@@ -438,9 +461,54 @@ class StepEngine:
     def optimizer_step(self, world_size: int = 1):
         """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""
         self.step_count += 1
+        if self._can_graph():
+            # step-dependent scalars go through device memory so that the captured launch can be replayed
+            if not hasattr(self, "_hyper_dev"):
+                self._hyper_dev = torch.zeros(2, device=self.device)
+                self._hyper_host = torch.zeros(2).pin_memory()
+            self._hyper_host[0], self._hyper_host[1] = ops.adam_hyper(self.lr, self.step_count)
+            self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+            key = world_size
+            if self._opt_graph is None or self._opt_graph[0] != key:
+                if getattr(self, "_opt_warm", 0) < 1:      # one eager run before capturing
+                    self._opt_warm = 1
+                    self._optimizer_launch(world_size, self._hyper_dev)
+                    return
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._optimizer_launch(world_size, self._hyper_dev)
+                self._opt_graph = (key, g)
+            self._opt_graph[1].replay()
+            return
+        self._optimizer_launch(world_size, None)
+
+    def _optimizer_launch(self, world_size, dev_hyper):
         self.sumsq.zero_()
         ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
-                       self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq)
+                       self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
+                       dev_hyper=dev_hyper)
+
+    def _can_graph(self):
+        # 'average' changes launch arguments (history length / slot) every step; the conv timer records events
+        return (self.use_graphs and self.cfg.gram_mode == "current"
+                and not (ops.CONV_TIMER is not None and ops.CONV_TIMER.enabled))
+
+    def step_forward_backward(self):
+        """forward_backward(), replayed from a hipGraph when enabled (captured on the 2nd step of each distinct
+        set of active levels; per-view buffers keep their addresses, so the graph survives view changes)."""
+        if not self._can_graph():
+            return self.forward_backward()
+        sig = self.view_sig
+        g = self._graphs.get(sig)
+        if g is None:
+            if self._graph_warm.get(sig, 0) < 1:
+                self._graph_warm[sig] = 1
+                return self.forward_backward()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward_backward()
+            self._graphs[sig] = g
+        g.replay()
 
     def end_epoch(self):
         self.epoch += 1
@@ -451,7 +519,7 @@ class StepEngine:
         if self.view is None or key != self.view_key:
             self.set_view(batch)
         losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
-        self.forward_backward()
+        self.step_forward_backward()
         if reducer is not None:
             reducer(self.arena.g)
         self.optimizer_step(world_size)

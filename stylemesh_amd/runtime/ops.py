@@ -76,15 +76,21 @@ def tex_sample_bwd(grad_layers, grid: torch.Tensor, grad_img: FMap, pixel_weight
                                     h, w, grad_img.ptr, ptr(pixel_weight), hip.stream()), "sm_tex_sample_bwd")
 
 
+def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
+    """The two step-dependent fp32 scalars of the update, computed in double as torch does:
+    (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t))."""
+    return lr / (1.0 - beta1 ** step), 1.0 / (1.0 - beta2 ** step) ** 0.5
+
+
 def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
-               zero_grad=True, sumsq_out=None):
+               zero_grad=True, sumsq_out=None, dev_hyper=None):
     n = p.numel()
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     hip.check(lib.sm_adam_fused(ptr(p), ptr(g), ptr(m), ptr(v), n, hip.size_array(seg_end),
                                 hip.float_array(reg_coef), len(seg_end), lr, beta1, beta2, eps, bc1, bc2,
-                                grad_scale, CLAMP_LO, CLAMP_HI, int(zero_grad), ptr(sumsq_out), hip.stream()),
-              "sm_adam_fused")
+                                grad_scale, CLAMP_LO, CLAMP_HI, int(zero_grad), ptr(sumsq_out), ptr(dev_hyper),
+                                hip.stream()), "sm_adam_fused")
 
 
 def clamp_sumsq(p, seg_end, sumsq_out=None):
