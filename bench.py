@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-conv-timer", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--dense", action="store_true", help="run the VGG convs on every tile instead of only the tiles that "
+                    "can influence the loss (stylemesh_amd/runtime/sparsity.py); results are identical")
     ap.add_argument("--graphs", action="store_true", help="replay the captured hipGraph of the step instead of launching "
                     "its ~150 kernels eagerly (measured: no gain, the step is GPU-bound; event-timed steps run eagerly)")
     ap.add_argument("--timer-every", type=int, default=10, help="HIP-event-time the conv launches of every n-th timed "
@@ -121,6 +123,7 @@ def main():
     eng = StepEngine(cfg, S.seeded_vgg_state(0), device=dev)
     eng.set_style_image(S.style_image(1, *STYLE_HW))
     eng.use_graphs = args.graphs
+    eng.sparse_tiles = not args.dense
 
     # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
     total_steps = args.warmup + args.steps

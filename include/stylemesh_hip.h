@@ -101,7 +101,15 @@ typedef struct {
     int H, W;
 } sm_conv_problem;
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
-                       int Cin_pad, int Cout, int flags, float* ws, size_t ws_floats, void* stream);
+                       int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
+                       size_t ws_floats, void* stream);
+/* tile_list (optional, DEVICE array of n_list entries (problem << 24) | tile): compute only these position
+ * tiles; a tile covers sm_conv_tile_positions(Cin_pad, Cout) consecutive positions q starting at row 1 of the
+ * problem's plane. Positions of absent tiles are neither read nor written. NULL = every tile. The caller uses
+ * it to skip tiles that cannot influence the loss (outside the receptive-field-dilated mask of a UV level);
+ * gradient planes must then be zero outside the listed tiles (they are: zero-initialised and only ever
+ * written inside listed tiles until the caller re-zeroes them for a new view). */
+int sm_conv_tile_positions(int Cin_pad, int Cout);
 
 /* Data gradient of the first conv (64 -> 3 channels; conv1_1, :11,49): out [3][plane] from
  * dz [64][plane], wd [9][64][4] (tap-major, 3 real output channels + 1 zero). */

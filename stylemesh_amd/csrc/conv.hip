@@ -32,6 +32,9 @@ struct ConvArgs {
     ConvProblem p[SM_MAX_GROUP];
     int tile_begin[SM_MAX_GROUP + 1];   // prefix sums of the problems' position-tile counts
     int n_problems;
+    // optional compact list of ACTIVE position tiles, entry = (problem << 24) | tile-in-problem; NULL = all tiles.
+    // Tiles that cannot influence the loss (outside the receptive-field-dilated level mask) are simply absent.
+    const int* tile_list;
     const float* wt;
     const float* bias;
     int Cin_pad, Cout, n_tiles, m_tiles;   // n_tiles = position tiles of ALL problems
@@ -76,12 +79,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // which problem of the group does this position tile belong to (block-uniform scalar selects)
     ConvProblem P = a.p[0];
     int n_tile = n_glob;
+    if (a.tile_list) {
+        const int e = a.tile_list[n_glob];
+        const int gsel = e >> 24;
+        n_tile = e & 0xFFFFFF;
 #pragma unroll
-    for (int g = 1; g < SM_MAX_GROUP; ++g)
-        if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
-            P = a.p[g];
-            n_tile = n_glob - a.tile_begin[g];
-        }
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g == gsel) P = a.p[g];
+    } else {
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+                P = a.p[g];
+                n_tile = n_glob - a.tile_begin[g];
+            }
+    }
     const int c_begin = split < 0 ? 0 : split * a.chunks_per_split * KC;
     const int c_end = split < 0 ? a.Cin_pad : min(a.Cin_pad, c_begin + a.chunks_per_split * KC);
     const int m0 = m_tile * BM;
@@ -234,12 +246,21 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
     ConvProblem P = a.p[0];
     int n_tile = n_glob;
+    if (a.tile_list) {
+        const int e = a.tile_list[n_glob];
+        const int gsel = e >> 24;
+        n_tile = e & 0xFFFFFF;
 #pragma unroll
-    for (int g = 1; g < SM_MAX_GROUP; ++g)
-        if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
-            P = a.p[g];
-            n_tile = n_glob - a.tile_begin[g];
-        }
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g == gsel) P = a.p[g];
+    } else {
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+                P = a.p[g];
+                n_tile = n_glob - a.tile_begin[g];
+            }
+    }
     const int m0 = m_tile * BM, q0 = P.Wp + n_tile * BN, q_end = (P.H + 1) * P.Wp;
     const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
     {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
@@ -270,13 +291,14 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
 constexpr int SM_NUM_CU = 256;
 
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
-static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
+static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
     a.tile_begin[0] = 0;
     for (int g = 0; g < a.n_problems; ++g)
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + BN - 1) / BN;
-    a.n_tiles = a.tile_begin[a.n_problems];
+    a.n_tiles = a.tile_list ? n_list : a.tile_begin[a.n_problems];
+    if (a.n_tiles == 0) return 0;
     constexpr size_t lds = (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
     // full rounds of one tile per CU run whole; the tail of `rem` tiles is split along K so that it becomes
@@ -308,10 +330,10 @@ static int launch_conv(const ConvArgs& a0, size_t ws_floats, hipStream_t s) {
 }
 
 template <int FLAGS>
-static int dispatch_conv(const ConvArgs& a, size_t ws_floats, hipStream_t s) {
-    if (a.Cin_pad == 4) return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, ws_floats, s);
-    if (a.Cout % 128 != 0) return launch_conv<64, 256, 8, 1, 4, FLAGS>(a, ws_floats, s);
-    return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, ws_floats, s);
+static int dispatch_conv(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
+    if (a.Cin_pad == 4) return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, n_list, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 256, 8, 1, 4, FLAGS>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, n_list, ws_floats, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -394,19 +416,22 @@ int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
 int sm_abi_version(void) { return 1; }
 
-static int conv_dispatch_flags(sm::ConvArgs& a, int flags, size_t ws_floats, hipStream_t s) {
+static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
-        case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, ws_floats, s);
-        case 0: return sm::dispatch_conv<0>(a, ws_floats, s);
-        case SM_EPI_RELU_MASK: return sm::dispatch_conv<SM_EPI_RELU_MASK>(a, ws_floats, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, ws_floats, s);
-        case SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_ADD>(a, ws_floats, s);
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
+        case 0: return sm::dispatch_conv<0>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
+        case SM_EPI_ADD: return sm::dispatch_conv<SM_EPI_ADD>(a, n_list, ws_floats, s);
         default: return (int)hipErrorInvalidValue;
     }
 }
 
+int sm_conv_tile_positions(int Cin_pad, int Cout) { return (Cin_pad == 4 || Cout % 128 != 0) ? 256 : 128; }
+
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
-                       int Cin_pad, int Cout, int flags, float* ws, size_t ws_floats, void* stream) {
+                       int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
+                       size_t ws_floats, void* stream) {
     if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
     if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
@@ -420,13 +445,14 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
     a.Cout = Cout;
     a.ws = ws;
     a.splits = 1;
-    return conv_dispatch_flags(a, flags, ws_floats, (hipStream_t)stream);
+    a.tile_list = tile_list;
+    return conv_dispatch_flags(a, n_list, flags, ws_floats, (hipStream_t)stream);
 }
 
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,
                int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
     sm_conv_problem p{in, out, gate, H, W};
-    return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, ws, ws_floats, stream);
+    return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, nullptr, 0, ws, ws_floats, stream);
 }
 
 int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream) {

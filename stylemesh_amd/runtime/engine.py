@@ -138,6 +138,8 @@ class StepEngine:
         self._graph_warm = {}      # view signature -> eager runs so far
         self._opt_graph = None
         self.use_graphs = False    # replay captured hipGraphs instead of re-launching ~190 kernels per step
+        self.sparse_tiles = True   # run the VGG convs only on tiles that can influence the loss (runtime/sparsity.py)
+        self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
         numel = [c * h * w for c, h, w in self.arena.shapes]
@@ -309,7 +311,24 @@ class StepEngine:
                     lv.content_target[layer] = dst
         self.view = levels
         self.view_consts = consts
-        self.view_sig = tuple((lv.index, lv.H, lv.W) for lv in active)   # identifies the step's launch sequence
+        self.view_tiles = None
+        if self.sparse_tiles and active and self.deepest is not None and all(lv.grid is not None for lv in active):
+            from .sparsity import build_tile_lists, need_maps
+            needs = [need_maps(lv.M, lv.H, lv.W, set(self.injected), self.deepest) for lv in active]
+            shapes = tuple((lv.H, lv.W) for lv in active)
+            self.view_tiles = {}
+            for key, (lst, frac, cap) in build_tile_lists(needs, self.deepest).items():
+                # fixed-address storage (a captured graph keeps the pointer); capacity = all tiles of the launch
+                buf = self._persist(("tiles", key, shapes), lambda: torch.zeros(max(cap, 1), dtype=torch.int32, device=dev))
+                buf[:lst.numel()].copy_(lst)
+                self.view_tiles[key] = (buf[:lst.numel()], frac)
+            # gradient planes must be zero outside this view's active tiles: the previous view wrote elsewhere
+            for lv in active:
+                for g in self._level_bufs(lv.H, lv.W).grad.values():
+                    g.buf.zero_()
+        # identifies the step's launch sequence (grid sizes depend on the tile lists)
+        self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
+                         None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self):
@@ -330,11 +349,11 @@ class StepEngine:
             raise ValueError("two UV levels of the same resolution are not supported")
         for lv, b in zip(active, bufs):
             ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
-        self.vgg.forward_group(bufs)
+        self.vgg.forward_group(bufs, self.view_tiles)
         injected = set()
         for lv, b in zip(active, bufs):
             injected = self._inject_losses(lv, b, w_style, w_content)
-        self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest)
+        self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
         for lv, b in zip(active, bufs):
             ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
 

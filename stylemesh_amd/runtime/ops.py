@@ -125,9 +125,16 @@ def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap
         CONV_TIMER.launch(run, 2.0 * 9 * cin_true * cout * inp.H * inp.W)
 
 
-def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int):
-    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps)."""
+def conv_tile_positions(cin_pad: int, cout: int) -> int:
+    return lib.sm_conv_tile_positions(cin_pad, cout)
+
+
+def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0):
+    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps).
+    ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile)."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
+    if tile_list is not None and tile_list.numel() == 0:
+        return
     arr = (hip.ConvProblem * len(problems))()
     flops = 0.0
     for i, (inp, out, gate) in enumerate(problems):
@@ -137,12 +144,13 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int):
 
     def run():
         ws = splitk_workspace(wt.device)
-        hip.check(lib.sm_conv3x3_grouped(arr, len(problems), ptr(wt), ptr(bias), cin_pad, cout, flags, ptr(ws),
+        hip.check(lib.sm_conv3x3_grouped(arr, len(problems), ptr(wt), ptr(bias), cin_pad, cout, flags,
+                                         ptr(tile_list), 0 if tile_list is None else tile_list.numel(), ptr(ws),
                                          ws.numel(), hip.stream()), "sm_conv3x3_grouped")
     if CONV_TIMER is None:
         run()
-    else:
-        CONV_TIMER.launch(run, flops)
+    else:   # algorithmic FLOPs of the tiles actually required
+        CONV_TIMER.launch(run, flops * active_fraction)
 
 
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):

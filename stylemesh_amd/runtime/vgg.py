@@ -86,9 +86,10 @@ class VGGNet:
             else:
                 ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU)
 
-    def forward_group(self, bufs):
+    def forward_group(self, bufs, tiles=None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
-        weights), which fills the chip where a single small level cannot."""
+        weights), which fills the chip where a single small level cannot. ``tiles``: optional active-tile
+        lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed)."""
         last = bufs[0].last
         assert all(b.last == last for b in bufs)
         for kind, src, out, _, _ in NODES[:last + 1]:
@@ -96,10 +97,11 @@ class VGGNet:
                 for b in bufs:
                     ops.maxpool_fwd(b.act[src], b.act[out])
             else:
+                tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
-                                    hip.EPI_BIAS_RELU)
+                                    hip.EPI_BIAS_RELU, tl, frac)
 
-    def backward_group(self, bufs, injected: set, start_layer: str):
+    def backward_group(self, bufs, injected: set, start_layer: str, tiles=None):
         """``backward`` for several levels at once (same injected layers on every level)."""
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if kind == "pool":
@@ -111,10 +113,13 @@ class VGGNet:
                 for b in bufs:
                     ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
             elif src.startswith("p"):
-                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0)
+                tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
+                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac)
             else:
+                tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
-                ops.conv3x3_grouped([(b.grad[out], b.grad[src], b.act[src]) for b in bufs], self.wd[kind], None, flags)
+                ops.conv3x3_grouped([(b.grad[out], b.grad[src], b.act[src]) for b in bufs], self.wd[kind], None, flags,
+                                    tl, frac)
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
         """Back-propagate to ``b.grad['img']``.
