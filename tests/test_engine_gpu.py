@@ -272,3 +272,38 @@ def test_sparse_tiles_equal_dense():
             np.testing.assert_allclose(ls[k], ld[k], rtol=1e-5)
         for a, b in zip(gs, gd):
             grad_close(a, b.cpu(), "sparse vs dense")
+
+
+def test_content_only_plumbing_config_matches_oracle():
+    """BASELINE config 1: one view, 256^2 texture, content loss only (style weight 0): the VGG pass stops at r42
+    and only the content term injects a gradient."""
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    require_gpu()
+    lw = {"content": 7e1, "style": 0.0, "tex_reg": 0.0}
+    batch = S.make_view(5, view_hw=(64, 85), level_hw=[(64, 85)], level_heights=[64], min_pyramid_depth=0.25,
+                        room=S.BoxRoom(SMALL_ROOM))
+    vgg = S.seeded_vgg_state(VGG_SEED)
+    style = S.style_image(STYLE_SEED, *STYLE_HW)
+    for hier in (True, False):
+        eng = StepEngine(EngineConfig(tex_w=256, tex_h=256, hierarchical=hier, loss_weights=dict(lw), angle_threshold=3000,
+                                      use_angle_weight=False, use_depth_scaling=False, learning_rate=1.0), vgg)
+        eng.set_style_image(style)
+        assert eng.deepest == "r42"
+        pipe = O.OraclePipeline(vgg, style, O.OracleConfig(hierarchical=hier, loss_weights=dict(lw), angle_threshold=3000,
+                                                           use_angle_weight=False, use_depth_scaling=False), (256, 256))
+        rng = np.random.default_rng(1)
+        init = [torch.from_numpy(((S.smooth_noise(rng, 3, 256 >> i, 256 >> i) - 0.5) * 80).astype(np.float32))
+                for i in range(len(eng.layers))]
+        eng.load_texture(init)
+        with torch.no_grad():
+            for l, t in zip(pipe.layers, init):
+                l.copy_(t)
+        ref_losses, ref_grads = pipe.grads(batch)
+        eng.set_view(batch)
+        lt = eng.loss_tensors()
+        eng.forward_backward()
+        mine = eng.losses(lt)
+        np.testing.assert_allclose(mine["content"], float(ref_losses["content"]), rtol=2e-4)
+        assert mine["style"] == 0.0 and mine["tex_reg"] == 0.0
+        for g, r in zip(eng.grads, ref_grads):
+            grad_close(g, r, f"content-only hier={hier}")
