@@ -198,6 +198,16 @@ int sm_fmap_resize_bilinear(const float* in, int C, int h, int w, float* out, in
 int sm_image_to_fmap(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
 int sm_fmap_to_image(const float* in, int C, int H, int W, float* out, void* stream);
 
+/* ---- dead-tile analysis (which positions of a VGG layer can reach the loss) -------------- */
+
+/* need_src = (mode 1: 3x3 dilation of need_out | mode 2: 2x2 up-sampling of need_out | mode 0: nothing)
+ * OR (M != NULL: the level mask M [H][W] nearest-down-sampled to (hs,ws)). Dense [h][w] 0/1 float maps. */
+int sm_need_step(const float* need_out, int ho, int wo, int mode, const float* M, int H, int W, float* need_src,
+                 int hs, int ws, void* stream);
+/* flags[t] = does position tile t (bn positions, sm_conv_tile_positions) of an (h,w) plane hold a needed pixel;
+ * flags has ceil(h * sm_fmap_row_stride(w) / bn) entries. */
+int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void* stream);
+
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 
 /* Thin RCCL wrapper: in-place sum all-reduce of the texture-gradient arena (ncclAllReduce, fp32).

@@ -196,9 +196,66 @@ __global__ __launch_bounds__(256) void fmap_to_image_kernel(const float* __restr
     out[(size_t)c * H * W + i] = in[(size_t)c * plane + (y + 1) * Wp + x + 1];
 }
 
+// ---- dead-tile analysis (runtime/sparsity.py): which positions of a layer can reach the loss --------------
+// need_src[y][x] = (through a conv: max over the 3x3 neighbourhood of need_out; through a 2x2 pool: need_out[y/2][x/2])
+//                  OR (the layer is a loss layer: nearest-down-sampled level mask M)
+__global__ __launch_bounds__(256) void need_step_kernel(const float* __restrict__ need_out, int ho, int wo, int mode,
+                                                        const float* __restrict__ M, int H, int W,
+                                                        float* __restrict__ need_src, int hs, int ws) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hs * ws) return;
+    const int y = i / ws, x = i - y * ws;
+    float v = 0.f;
+    if (mode == 1) {          // conv 3x3, same size
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < ho && xx >= 0 && xx < wo) v = fmaxf(v, need_out[yy * wo + xx]);
+            }
+    } else if (mode == 2) {   // 2x2 max-pool, floor size: the pooled pixel needs its whole window
+        const int yy = y >> 1, xx = x >> 1;
+        if (yy < ho && xx < wo) v = need_out[yy * wo + xx];
+    }
+    if (M) v = fmaxf(v, M[nearest_src(y, H, hs) * W + nearest_src(x, W, ws)]);
+    need_src[i] = v > 0.f ? 1.f : 0.f;
+}
+
+// flags[t] = 1 if position tile t (bn consecutive positions q from row 1 of the padded plane) holds a needed pixel
+__global__ __launch_bounds__(256) void tile_flags_kernel(const float* __restrict__ need, int h, int w, int Wp, int bn,
+                                                         int n_tiles, uint8_t* __restrict__ flags) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    bool any = false;
+    for (int j = lane; j < bn; j += 64) {
+        const int q = t * bn + j;           // relative to row 1
+        const int r = q / Wp, x = q - r * Wp;
+        if (r < h && x >= 1 && x <= w) any |= need[r * w + x - 1] > 0.f;
+    }
+    if (__ballot(any) != 0ull && lane == 0) flags[t] = 1;
+    else if (lane == 0) flags[t] = 0;
+}
+
 }  // namespace sm
 
 extern "C" {
+
+int sm_need_step(const float* need_out, int ho, int wo, int mode, const float* M, int H, int W, float* need_src, int hs,
+                 int ws, void* stream) {
+    hipLaunchKernelGGL(sm::need_step_kernel, dim3((hs * ws + 255) / 256), dim3(256), 0, (hipStream_t)stream, need_out, ho,
+                       wo, mode, M, H, W, need_src, hs, ws);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void* stream) {
+    const int Wp = sm::row_stride(w);
+    const int n_tiles = (h * Wp + bn - 1) / bn;
+    hipLaunchKernelGGL(sm::tile_flags_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, need, h, w, Wp,
+                       bn, n_tiles, flags);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
 
 int sm_level_masks(const int64_t* rounded, const int64_t* other, const float* interp_w, const uint8_t* mask, int h,
                    int w, int n_levels, float* E, float* Wt, void* stream) {

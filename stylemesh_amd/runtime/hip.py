@@ -46,6 +46,8 @@ SIGNATURES = {
     "sm_level_maps": [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sm_layer_masks": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sm_level_factors": [_vp, _vp, _i, _vp, _vp],
+    "sm_need_step": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
+    "sm_tile_flags": [_vp, _i, _i, _i, _vp, _vp],
     "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],

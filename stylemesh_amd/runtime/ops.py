@@ -228,6 +228,20 @@ def level_factors(counts_all, sizes, factors):
                                    hip.ptr_array(factors), hip.stream()), "sm_level_factors")
 
 
+def need_step(need_out, mode, M, need_src):
+    """mode 0: mask only, 1: through a 3x3 conv, 2: through a 2x2 pool (see sm_need_step)."""
+    ho, wo = need_out.shape if need_out is not None else (0, 0)
+    H, W = M.shape if M is not None else (0, 0)
+    hs, ws = need_src.shape
+    hip.check(lib.sm_need_step(ptr(need_out), ho, wo, mode, ptr(M), H, W, ptr(need_src), hs, ws, hip.stream()),
+              "sm_need_step")
+
+
+def tile_flags(need, bn, flags):
+    h, w = need.shape
+    hip.check(lib.sm_tile_flags(ptr(need), h, w, bn, ptr(flags), hip.stream()), "sm_tile_flags")
+
+
 def fmap_resize_bilinear(inp: FMap, out: FMap):
     hip.check(lib.sm_fmap_resize_bilinear(inp.ptr, inp.C, inp.H, inp.W, out.ptr, out.H, out.W, hip.stream()),
               "sm_fmap_resize_bilinear")

@@ -13,70 +13,70 @@ whose value can reach the loss (and, equivalently, whose gradient can be non-zer
 The conv kernels then run only on the position tiles that intersect ``need`` (forward: of the conv's output;
 backward: of the conv's input, whose gradient it produces). Results in the needed region are identical to the
 dense computation; positions outside it are never read by anything that reaches the loss.
+
+Everything runs on the device (``sm_need_step`` / ``sm_tile_flags`` + one ``nonzero``); one host read-back of the
+list lengths per view (they are grid sizes).
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
-from . import hip, ops
+from . import ops
 from .vgg import NODES, depth_of, layer_hw
 
 
 def need_maps(M: torch.Tensor, H: int, W: int, injected, last_layer: str) -> dict:
     """``M``: level mask [H,W] (0/1 float, device). Returns {layer or 'img': [h,w] 0/1 float tensor}."""
+    nodes = NODES[:depth_of(last_layer) + 1]
     sizes = {"img": (H, W)}
-    for _, _, out, _, _ in NODES[:depth_of(last_layer) + 1]:
+    for _, _, out, _, _ in nodes:
         sizes[out] = layer_hw(out, H, W)
-    M4 = M[None, None]
-    need = {}
-    for kind, src, out, _, _ in reversed(NODES[:depth_of(last_layer) + 1]):
-        cur = need.get(out)
-        if cur is None:
-            cur = torch.zeros(1, 1, *sizes[out], device=M.device)
-        if out in injected:
-            cur = torch.maximum(cur, F.interpolate(M4, sizes[out], mode="nearest"))   # the layer mask (losses :172)
-        need[out] = cur
-        if kind == "pool":
-            up = cur.repeat_interleave(2, 2).repeat_interleave(2, 3)
-            add = torch.zeros(1, 1, *sizes[src], device=M.device)
-            add[:, :, :up.shape[2], :up.shape[3]] = up
-        else:
-            add = F.max_pool2d(cur, 3, 1, 1)
-        need[src] = add if src not in need else torch.maximum(need[src], add)
-    return {k: v[0, 0] for k, v in need.items()}
-
-
-def tile_flags(need_hw: torch.Tensor, bn: int) -> torch.Tensor:
-    """bool[n_tiles]: does tile t (positions q in [Wp + t*bn, Wp + (t+1)*bn) of the padded plane) hold a needed
-    position?"""
-    h, w = need_hw.shape
-    Wp = hip.row_stride(w)
-    plane = torch.zeros(h, Wp, device=need_hw.device)
-    plane[:, 1:w + 1] = need_hw            # rows 1..H of the padded plane, starting at q = Wp
-    q = plane.reshape(-1)
-    nt = (q.numel() + bn - 1) // bn
-    q = F.pad(q, (0, nt * bn - q.numel())).view(nt, bn)
-    return q.amax(1) > 0
+    need = {last_layer: torch.empty(sizes[last_layer], device=M.device)}
+    ops.need_step(None, 0, M if last_layer in injected else None, need[last_layer])
+    for kind, src, out, _, _ in reversed(nodes):
+        need[src] = torch.empty(sizes[src], device=M.device)
+        ops.need_step(need[out], 2 if kind == "pool" else 1, M if src in injected else None, need[src])
+    return need
 
 
 def build_tile_lists(needs, last_layer: str):
     """``needs``: one ``need_maps`` dict per level of the grouped launch (in problem order).
     Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, n_all_tiles)}."""
-    out = {}
+    from . import hip
+    dev = next(iter(needs[0].values())).device
+    jobs = []            # (key, layer, bn)
     for kind, src, dst, cin, cout in NODES[:depth_of(last_layer) + 1]:
         if kind == "pool":
             continue
-        jobs = [("f", dst, ops.conv_tile_positions(4 if cin == 3 else cin, cout))]
+        jobs.append(((kind, "f"), dst, ops.conv_tile_positions(4 if cin == 3 else cin, cout)))
         if src != "img":
-            jobs.append(("b", src, ops.conv_tile_positions(cout, cin)))
-        for direction, layer, bn in jobs:
-            entries, total = [], 0
-            for g, nd in enumerate(needs):
-                fl = tile_flags(nd[layer], bn)
-                total += fl.numel()
-                idx = torch.nonzero(fl).flatten().to(torch.int32)
-                entries.append(idx + (g << 24))
-            lst = torch.cat(entries).contiguous()
-            out[(kind, direction)] = (lst, lst.numel() / max(total, 1), total)
+            jobs.append(((kind, "b"), src, ops.conv_tile_positions(cout, cin)))
+    # flags of a (layer, tile size) pair are shared by the conv that produces the layer and the dgrad that produces
+    # its gradient; all flags go into ONE buffer so that a single nonzero + a single read-back serve every list
+    seg = {}             # (level, layer, bn) -> (offset, n_tiles)
+    total = 0
+    for _, layer, bn in jobs:
+        for g, nd in enumerate(needs):
+            if (g, layer, bn) not in seg:
+                h, w = nd[layer].shape
+                n = (h * hip.row_stride(w) + bn - 1) // bn
+                seg[(g, layer, bn)] = (total, n)
+                total += n
+    flags = torch.empty(total, dtype=torch.uint8, device=dev)
+    for (g, layer, bn), (off, n) in seg.items():
+        ops.tile_flags(needs[g][layer], bn, flags[off:off + n])
+    active = torch.nonzero(flags).flatten().to(torch.int32)            # ascending global tile ids
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(flags.to(torch.int64), 0)])
+    offs = sorted({o for o, _ in seg.values()} | {o + n for o, n in seg.values()})
+    cnt = dict(zip(offs, csum[torch.tensor(offs, device=dev)].tolist()))  # the one read-back
+    out = {}
+    for key, layer, bn in jobs:
+        parts, n_all = [], 0
+        for g in range(len(needs)):
+            off, n = seg[(g, layer, bn)]
+            a, b = cnt[off], cnt[off + n]
+            parts.append(active[a:b] - off + (g << 24))
+            n_all += n
+        lst = torch.cat(parts).contiguous()
+        out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
     return out
