@@ -139,6 +139,11 @@ class StepEngine:
         self._opt_graph = None
         self.use_graphs = False    # replay captured hipGraphs instead of re-launching ~190 kernels per step
         self.sparse_tiles = True   # run the VGG convs only on tiles that can influence the loss (runtime/sparsity.py)
+        # optional: style branches (Gram -> loss -> Gram backward) of the non-deepest layers on a second HIP stream,
+        # filling idle CUs at the tails of the conv launches. Measured +1.7 % on c3 only (the conv grids leave few
+        # idle CUs and no LDS for co-resident blocks), so it is off by default.
+        self.overlap_style = False
+        self._side = None
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
@@ -172,13 +177,15 @@ class StepEngine:
             self._bufs[key] = LevelBuffers(H, W, self.deepest, True, self.device)
         return self._bufs[key]
 
-    def _gram_scratch(self, C, n_slabs=1):
-        """(S0, S1, D0, D1): partial-sum slabs [n_slabs, C, C] for both masks and the derivative matrices."""
-        cur = self._gram.get(C)
+    def _gram_scratch(self, key, n_slabs=1):
+        """(S0, S1, D0, D1): partial-sum slabs [n_slabs, C, C] for both masks and the derivative matrices; one set
+        per (C, level, layer) so that style branches can run concurrently."""
+        C = key[0]
+        cur = self._gram.get(key)
         if cur is None or cur[0].shape[0] < n_slabs:
-            self._gram[C] = (torch.zeros(n_slabs, C, C, device=self.device), torch.zeros(n_slabs, C, C, device=self.device),
-                             torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
-        return self._gram[C]
+            self._gram[key] = (torch.zeros(n_slabs, C, C, device=self.device), torch.zeros(n_slabs, C, C, device=self.device),
+                               torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
+        return self._gram[key]
 
     # ------------------------------------------------------------------ style targets
     def set_style_image(self, style_image: torch.Tensor, num_levels=5):
@@ -349,27 +356,65 @@ class StepEngine:
             raise ValueError("two UV levels of the same resolution are not supported")
         for lv, b in zip(active, bufs):
             ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
-        self.vgg.forward_group(bufs, self.view_tiles)
-        injected = set()
-        for lv, b in zip(active, bufs):
-            injected = self._inject_losses(lv, b, w_style, w_content)
-        self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
+        style_on = w_style != 0.0
+        side_layers = [l for l in cfg.style_layers if l != self.deepest] if (style_on and self.overlap_style) else []
+        if side_layers:
+            # A style layer's branch (masked Gram -> loss + derivative matrices -> Gram backward into grad[layer])
+            # only has to finish before the backward pass reaches that layer: fork it onto a side stream right
+            # after the layer's forward conv and join right before the dgrad that consumes grad[layer].
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            done = {}
+
+            def fork(layer):
+                if layer not in side_layers:
+                    return
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    for lv, b in zip(active, bufs):
+                        self._style_terms(lv, b, cfg.style_layers.index(layer), layer, w_style)
+                    done[layer] = torch.cuda.Event()
+                    done[layer].record(self._side)
+
+            def join(layer):
+                if layer in done:
+                    main.wait_event(done.pop(layer))
+            self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork)
+            injected = set(side_layers)
+            for lv, b in zip(active, bufs):
+                injected |= self._inject_losses(lv, b, w_style, w_content, only_layers={self.deepest} | set(cfg.content_layers))
+            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, before_layer=join)
+            for layer in list(done):
+                join(layer)
+        else:
+            self.vgg.forward_group(bufs, self.view_tiles)
+            injected = set()
+            for lv, b in zip(active, bufs):
+                injected = self._inject_losses(lv, b, w_style, w_content)
+            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
         for lv, b in zip(active, bufs):
             ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
 
-    def _inject_losses(self, lv, b, w_style, w_content, keep=None):
+    def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
         layer's gradient already ReLU-gated). ``keep`` (dict) receives clones of the style derivative matrices."""
         cfg = self.cfg
         injected = set()
         if w_style != 0.0:
             for li, layer in enumerate(cfg.style_layers):
+                if only_layers is not None and layer not in only_layers:
+                    continue
                 D = self._style_terms(lv, b, li, layer, w_style)
                 if keep is not None:
                     keep[(lv.index, layer)] = tuple(None if d is None else d.clone() for d in D)
                 injected.add(layer)
         if w_content != 0.0:
             for li, layer in enumerate(cfg.content_layers):
+                if only_layers is not None and layer not in only_layers:
+                    continue
                 self._content_term(lv, b, li, layer, w_content)
                 injected.add(layer)
         return injected
@@ -390,7 +435,7 @@ class StepEngine:
         cfg = self.cfg
         f = b.act[layer]
         n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
-        S0, S1, D0, D1 = self._gram_scratch(f.C, ops.gram_workspace_slabs(f.C, f.H, f.W))
+        S0, S1, D0, D1 = self._gram_scratch((f.C, lv.index, layer), ops.gram_workspace_slabs(f.C, f.H, f.W))
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
         m0, m1 = self._style_masks(lv, layer)

@@ -86,7 +86,7 @@ class VGGNet:
             else:
                 ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU)
 
-    def forward_group(self, bufs, tiles=None):
+    def forward_group(self, bufs, tiles=None, on_layer=None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
         weights), which fills the chip where a single small level cannot. ``tiles``: optional active-tile
         lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed)."""
@@ -100,10 +100,14 @@ class VGGNet:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
                                     hip.EPI_BIAS_RELU, tl, frac)
+                if on_layer is not None:
+                    on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
-    def backward_group(self, bufs, injected: set, start_layer: str, tiles=None):
+    def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None):
         """``backward`` for several levels at once (same injected layers on every level)."""
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
+            if before_layer is not None and kind != "pool":
+                before_layer(src)      # the injected gradient of ``src`` is about to be consumed
             if kind == "pool":
                 if src in injected:
                     raise ValueError(f"style/content layer {src} directly below a pool is not supported")

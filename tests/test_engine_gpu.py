@@ -307,3 +307,24 @@ def test_content_only_plumbing_config_matches_oracle():
         assert mine["style"] == 0.0 and mine["tex_reg"] == 0.0
         for g, r in zip(eng.grads, ref_grads):
             grad_close(g, r, f"content-only hier={hier}")
+
+
+def test_side_stream_style_branches_equal_serial():
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [T(g5[f"init{i}"]) for i in range(4)]
+    batch = batch_from_golden(g5)
+    res = []
+    for overlap in (False, True):
+        eng = make_engine(FLAGSETS["with_angle_and_depth"], init)
+        eng.overlap_style = overlap
+        eng.set_view(batch)
+        for _ in range(2):
+            eng.arena.g.zero_()
+            lt = eng.loss_tensors()
+            eng.forward_backward()
+        torch.cuda.synchronize()
+        res.append((eng.losses(lt), [g.clone() for g in eng.grads]))
+    for k in res[0][0]:
+        np.testing.assert_allclose(res[1][0][k], res[0][0][k], rtol=1e-5)
+    for a, b in zip(res[1][1], res[0][1]):
+        grad_close(a, b.cpu(), "side-stream vs serial")
