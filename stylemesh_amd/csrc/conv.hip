@@ -397,7 +397,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(const float* __re
     const float g = (pm > 0.f) ? dpooled[qo] : 0.f;  // max <= 0 -> every ReLU gate in the window is closed
     const size_t base = (size_t)c * plane + (2 * yo + 1) * Wp + 2 * xo + 1;
     const float v00 = act[base], v01 = act[base + 1], v10 = act[base + Wp], v11 = act[base + Wp + 1];
-    // first maximum in row-major order gets the gradient (ATen max_pool2d_with_indices)
+    // The first maximum in row-major order gets the gradient (ATen max_pool2d_with_indices: strict '>' scan).
+    // NOTE on exact ties: a constant image region (background pixels, the all-zero initial texture) makes every
+    // window an exact 4-way tie in exact arithmetic; which copy is largest in fp32 then depends on last-bit
+    // summation-order differences between tiles (here: whole vs K-split tiles; in the reference: on its conv
+    // backend). A tolerance-based rule was tried and rejected: it fixes the degenerate case but flips genuine
+    // near-ties away from the reference's choice (tests/test_engine_gpu.py would fail).
     const bool s00 = v00 == pm;
     const bool s01 = !s00 && v01 == pm;
     const bool s10 = !s00 && !s01 && v10 == pm;
