@@ -26,6 +26,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-l
 # algorithmic HBM bytes of the 25 grouped conv launches of one step: every input / output / gate plane and the
 # layer's weights touched once
 ALG_CONV_BYTES = {"c3": 7743.4e6}
+DENSE_CONV_GFLOP = {"c3": 2369.8}   # all tiles of all levels; the active-tile lists execute a fraction of it
 WORKLOADS = {
     # SURVEY.md section 8 d. c3 = scripts/train/optimize_texture_scannet_with_angle_and_depth.sh at 4096^2
     "c3": dict(tex=4096, level_hw=S.SCANNET_LEVEL_HW, view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0, angle=True,
@@ -175,7 +176,8 @@ def main():
             traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, "
-                    "profiles/r01/conv_traffic_*.json)", "algorithmic_bytes_per_launch": round(ALG_CONV_BYTES.get(args.workload, 0) / 25),
+                    "profiles/r01/conv_traffic_*.json)", "algorithmic_bytes_per_launch": round(ALG_CONV_BYTES.get(args.workload, 0) / 25 * min(1.0, flops / n_timed / 1e9 /
+                                                                DENSE_CONV_GFLOP.get(args.workload, 1e30))) or None,
                     "kernel": "conv3x3_mfma_kernel",
                     "launches_timed": n, "timed_steps": n_timed, "avg_launch_us": round(1e3 * ms / n, 2),
                     "algorithmic_gflop_per_step": round(flops / n_timed / 1e9, 1),
