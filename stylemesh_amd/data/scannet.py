@@ -46,12 +46,30 @@ def _numbered(folder, pred):
 
 
 class ScanNetSceneDataset:
+    depth_scale = 1000.0        # sensor depth png units per metre (scannet_dataset.py:300)
+    mask_uses_depth = True      # calculate_mask ANDs "resized depth > 0" (scannet_dataset.py:322-324)
+
     def __init__(self, root_path, scene, resize_size=256, pyramid_levels=5, min_pyramid_depth=0.25,
                  min_pyramid_height=32, max_images=-1):
         self.scene_path = join(root_path, scene)
         if not os.path.isdir(self.scene_path):
             raise ValueError(f"scene folder not found: {self.scene_path}")
         self.scene, self.resize_size, self.min_pyramid_depth = scene, resize_size, min_pyramid_depth
+        self._scan(pyramid_levels, min_pyramid_height)
+        n = len(self.rgb_images)
+        sp = self.scene_path
+        if not (n > 0 and n == len(self.depth_images) == len(self.extrinsics) == len(self.angle_maps)
+                and all(len(u) == n for u in self.uv_maps)):
+            raise ValueError(f"Scene {sp} rendered incomplete: colors {n}, depth {len(self.depth_images)}, "
+                             f"uvs {[len(u) for u in self.uv_maps]}, angles {len(self.angle_maps)}, "
+                             f"extr {len(self.extrinsics)}")
+        if max_images > 0:
+            n = min(n, max_images)
+        self.size = n
+        self.intrinsics, self.intrinsic_image_size = self._read_intrinsics()
+
+    def _scan(self, pyramid_levels, min_pyramid_height):
+        """Collect the sorted file lists of the scene (scannet_dataset.py:102-251)."""
         sp = self.scene_path
         self.rgb_images = _numbered(join(sp, "color"), lambda f: f.endswith("jpg") or f.endswith("png"))
         sensor = _numbered(join(sp, "depth"), lambda f: True)
@@ -70,16 +88,6 @@ class ScanNetSceneDataset:
         self.levels = np.array([float(f.split("_")[1]) for f in folders])
         is_uv = lambda f: "npy" in f and "angle" not in f and "depth" not in f
         self.uv_maps = [_numbered(join(sp, f), is_uv) for f in folders]
-        n = len(self.rgb_images)
-        if not (n > 0 and n == len(self.depth_images) == len(self.extrinsics) == len(self.angle_maps)
-                and all(len(u) == n for u in self.uv_maps)):
-            raise ValueError(f"Scene {sp} rendered incomplete: colors {n}, depth {len(self.depth_images)}, "
-                             f"uvs {[len(u) for u in self.uv_maps]}, angles {len(self.angle_maps)}, "
-                             f"extr {len(self.extrinsics)}")
-        if max_images > 0:
-            n = min(n, max_images)
-        self.size = n
-        self.intrinsics, self.intrinsic_image_size = self._read_intrinsics()
 
     def _read_intrinsics(self):
         K, w, h = np.identity(4, dtype=np.float32), 0, 0
@@ -107,10 +115,10 @@ class ScanNetSceneDataset:
         if self.rendered_depth:
             depth = np.load(self.depth_images[i])[:, :, 0].astype(np.float32)
         else:
-            depth = (np.asarray(Image.open(self.depth_images[i])) / 1000.0).astype(np.float32)   # mm -> m
+            depth = (np.asarray(Image.open(self.depth_images[i])) / self.depth_scale).astype(np.float32)
         uvs = [np.load(u[i]) for u in self.uv_maps]
         angle = np.load(self.angle_maps[i])[:, :, 0]
-        mask_big = vc.calculate_mask(uvs[-1], depth)                     # on the largest UV map (:288)
+        mask_big = vc.calculate_mask(uvs[-1], depth if self.mask_uses_depth else None)   # largest UV map (:288)
         w, h = rgb.size
         h_new = self.resize_size
         w_new = round(w * h_new / h)

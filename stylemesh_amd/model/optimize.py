@@ -3,7 +3,8 @@ for the MI355X path: same flag names / defaults / parsing (``--loss_weight k=v``
 ``--texture_size W,H`` ...), same construction order (DataModule -> style image -> pipeline -> ``trainer.fit``).
 
 Differences, all outside the hot path: ``--dataset synthetic`` (seeded box-room views; ``--dataset scannet`` reads
-the reference's on-disk scene layout, the Matterport loader is not built), ``--vgg_gatys_model_path random:<seed>`` for seeded He-normal weights
+and ``--dataset matterport`` read
+the reference's on-disk scene / region layouts), ``--vgg_gatys_model_path random:<seed>`` for seeded He-normal weights
 when ``vgg_conv.pth`` is unavailable, ``--style_image_path synthetic:<seed>:<H>x<W>``, and no post-hoc mip-map
 render / video / evaluation (reference :167-234, out of scope). Multi-GPU: launch under
 ``torch.distributed.run``; views shard over ranks and the texture gradient is all-reduced over RCCL.
@@ -77,8 +78,13 @@ def main(args):
                                           split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
                                           sampler_mode=args.sampler_mode, rank=rank, world_size=world)
     elif args.dataset == "matterport":
-        raise NotImplementedError("--dataset matterport: the Matterport region loader is not built yet "
-                                  "(SURVEY.md section 8 f1); use --dataset scannet or synthetic")
+        from ..data.matterport import MatterportSingleRegionDataModule
+        dm = MatterportSingleRegionDataModule(args.root_path, args.scene, region_index=args.matterport_region_index,
+                                              resize_size=args.resize_size, pyramid_levels=args.pyramid_levels,
+                                              min_pyramid_depth=args.min_pyramid_depth,
+                                              min_pyramid_height=args.min_pyramid_height, max_images=args.max_images,
+                                              split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
+                                              sampler_mode=args.sampler_mode, rank=rank, world_size=world)
     else:
         raise ValueError(f"Unsupported dataset: {args.dataset}")
     dm.prepare_data()

@@ -60,3 +60,41 @@ def test_datamodule_split_and_sharding(tmp_path):
     assert [int(b[8]) for b in dm.val_dataloader()] == [4]
     with pytest.raises(ValueError):
         ScanNetSceneDataset(str(tmp_path / "train/images"), "missing")
+
+
+def test_matterport_region_layout(tmp_path):
+    """Same views written in the Matterport region layout (names <pano>_i<cam>_<yaw>, uv_<W>_<H>, depth / 4000)."""
+    import os
+    from PIL import Image
+    from stylemesh_amd.data.matterport import MatterportRegionDataset, MatterportSingleRegionDataModule
+    views = render_views(4)
+    rp = tmp_path / "v1" / "scans" / "house1" / "rendered" / "region_2"
+    names = ["aaa_i0_1", "aaa_i1_0", "aaa_i0_0", "bbb_i0_3"]            # sorted order: aaa_i0_0, aaa_i0_1, aaa_i1_0, bbb_i0_3
+    order = [2, 0, 1, 3]
+    for d in ["color", "depth", "pose", "angle", "uv_85_64", "uv_144_108"]:
+        os.makedirs(rp / d)
+    for n, v in zip(names, views):
+        Image.fromarray((v["rgb01"].transpose(1, 2, 0) * 255).astype(np.uint8)).save(rp / "color" / f"{n}.png")
+        Image.fromarray(np.round(v["depth"] * 4000).astype(np.uint16)).save(rp / "depth" / f"{n.replace('_i', '_d')}.png")
+        np.savetxt(rp / "pose" / f"{n}.txt", v["pose"], fmt="%.6f", delimiter=" ")
+        np.save(rp / "angle" / f"{n}.angle.npy", np.repeat(v["angle_full"][:, :, None], 3, 2).astype(np.float32))
+        for folder, u in zip(["uv_85_64", "uv_144_108"], v["uv_levels"]):
+            np.save(rp / folder / f"{n}.uvs.npy", u.astype(np.float32))
+    with open(rp / "pose" / "aaa_i0_0.intrinsics.txt", "w") as f:
+        f.write("70 0 40\n0 70 30\n0 0 1\n80 60\n")
+    ds = MatterportRegionDataset(str(tmp_path / "v1" / "scans"), "house1", region_index=2, resize_size=64, pyramid_levels=4,
+                                 min_pyramid_depth=0.2, min_pyramid_height=32)
+    assert len(ds) == 4 and list(ds.levels) == [64.0, 108.0]
+    for i, src in enumerate(order):
+        b = ds[i]
+        np.testing.assert_allclose(b[1][0].numpy(), views[src]["pose"], atol=1e-5)
+    b = ds[0]
+    v = views[order[0]]
+    ref_depth = vc.resize_bilinear_np(np.round(v["depth"] * 4000) / 4000.0, (64, 85))
+    np.testing.assert_allclose(b[3][0, 0].numpy(), ref_depth, atol=1e-6)
+    expected_mask = vc.resize_nearest_np(vc.calculate_mask(v["uv_levels"][1]), (64, 85))   # no depth test
+    np.testing.assert_array_equal(b[10][0].numpy(), expected_mask)
+    np.testing.assert_allclose(b[2][0, 0, 0].item(), 70 * 85 / 80, rtol=1e-6)
+    dm = MatterportSingleRegionDataModule(str(tmp_path), "house1", region_index=2, resize_size=64, split=(0.75, 0.25))
+    dm.setup()
+    assert dm.train_indices == [0, 1, 2] and dm.val_indices == [3]
