@@ -103,6 +103,16 @@ typedef struct {
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
                        size_t ws_floats, void* stream);
+/* The same grouped convolution on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split into three
+ * bf16 parts (x = h + m + l, 24 significand bits) and each product is evaluated as its six partial products of
+ * weight >= 2^-16 with fp32 accumulation (stylemesh_amd/csrc/conv_split_kernel.h). Activations / outputs are
+ * the same fp32 planes; wt3 = the weights pre-split by the host: [9 taps][Cin/16][3 parts][2][Cout][8] bf16 (as
+ * uint16 bit patterns; runtime/ops.py:pack_conv_split builds it from the fp32 tap-major pack). Cin % 16 == 0,
+ * Cout % 128 == 0; tiles cover 128 positions. Same flags / tile_list / ws semantics as sm_conv3x3_grouped.
+ * Replaces the same reference operators (F.conv2d forward / backward of content_and_style_losses.py:11-32). */
+int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,
+                             const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
+                             float* ws, size_t ws_floats, void* stream);
 /* tile_list (optional, DEVICE array of n_list entries (problem << 24) | tile): compute only these position
  * tiles; a tile covers sm_conv_tile_positions(Cin_pad, Cout) consecutive positions q starting at row 1 of the
  * problem's plane. Positions of absent tiles are neither read nor written. NULL = every tile. The caller uses

@@ -8,7 +8,11 @@ mkdir -p ../../build
 objs=()
 for f in conv texture gram prep comm; do
   o=../../build/$f.o
-  if [ ! -f "$o" ] || [ "$f.hip" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/stylemesh_hip.h -nt "$o" ]; then
+  stale=0
+  for dep in "$f.hip" *.h ../../include/stylemesh_hip.h; do
+    if [ ! -f "$o" ] || [ "$dep" -nt "$o" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o $o &
   fi
   objs+=("$o")

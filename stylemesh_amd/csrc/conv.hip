@@ -13,40 +13,12 @@
 // VGPRs). A K-chunk = KC input channels x 9 taps. LDS: weights [9][KC][BM] + inputs [3][KC][BN+8] fp32
 // (49.9 KB for 128x128x8 -> 3 blocks per CU, whose MFMA phases cover each other's staging phases).
 #include <algorithm>
+#include <cstdlib>
 
-#include "common.h"
+#include "conv_common.h"
+#include "conv_split_kernel.h"
 
 namespace sm {
-
-constexpr int SM_MAX_GROUP = 8;
-
-// One feature-map problem of a grouped launch (same weights, different planes: the UV levels of a view).
-struct ConvProblem {
-    const float* in;
-    float* out;
-    const float* gate;
-    int H, W, Wp, plane;
-};
-
-struct ConvArgs {
-    ConvProblem p[SM_MAX_GROUP];
-    int tile_begin[SM_MAX_GROUP + 1];   // prefix sums of the problems' position-tile counts
-    int n_problems;
-    // optional compact list of ACTIVE position tiles, entry = (problem << 24) | tile-in-problem; NULL = all tiles.
-    // Tiles that cannot influence the loss (outside the receptive-field-dilated level mask) are simply absent.
-    const int* tile_list;
-    const float* wt;
-    const float* bias;
-    int Cin_pad, Cout, n_tiles, m_tiles;   // n_tiles = position tiles of ALL problems
-    // Work decomposition. The first n_whole tiles (a multiple of the CU count) are computed whole; the remaining
-    // "tail" tiles - whose last, partially filled round would otherwise leave most CUs idle - are split along K
-    // into `splits` units each, so the tail is made of many small units that spread over all CUs. Split units
-    // store raw partial tiles to ws[(tail_tile * splits + split)][BM][BN]; conv_tail_epilogue_kernel reduces them.
-    float* ws;
-    int n_whole;
-    int splits;
-    int chunks_per_split;
-};
 
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv3x3_mfma_kernel(ConvArgs a) {
@@ -288,9 +260,10 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     }
 }
 
-constexpr int SM_NUM_CU = 256;
 
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
+
+// SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -299,7 +272,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + BN - 1) / BN;
     a.n_tiles = a.tile_list ? n_list : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
-    constexpr size_t lds = (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
+    constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN)
+                                 : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
     // full rounds of one tile per CU run whole; the tail of `rem` tiles is split along K so that it becomes
     // about one more (short) round of rem * splits small units. Pick the split count that minimises the tail's
@@ -319,14 +293,33 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         }
     }
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
-    auto k = conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>;
-    hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256), lds, s, a);
+    if constexpr (SPLIT) {
+        static_assert(KC == 16, "one bf16 MFMA K-step per tap");
+        // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
+        static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
+        auto k = stamp ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true> : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>), dim3(a.n_whole + rem * a.splits),
+                           dim3(256), lds, s, a);
+    }
     SM_LAUNCH_CHECK();
     if (rem > 0) {
         hipLaunchKernelGGL((conv_tail_epilogue_kernel<BM, BN, FLAGS>), dim3(rem, BM * BN / 1024), dim3(256), 0, s, a);
         SM_LAUNCH_CHECK();
     }
     return 0;
+}
+
+template <int FLAGS>
+static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
+    return launch_conv<128, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
 }
 
 template <int FLAGS>
@@ -421,6 +414,17 @@ int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
 int sm_abi_version(void) { return 1; }
 
+static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
+    switch (flags) {
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
+        case 0: return sm::dispatch_conv_split<0>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
+        case SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_ADD>(a, n_list, ws_floats, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
 static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
         case SM_EPI_BIAS_RELU: return sm::dispatch_conv<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
@@ -452,6 +456,26 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
     a.splits = 1;
     a.tile_list = tile_list;
     return conv_dispatch_flags(a, n_list, flags, ws_floats, (hipStream_t)stream);
+}
+
+int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3, const float* bias,
+                             int Cin, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
+                             size_t ws_floats, void* stream) {
+    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
+    if (Cout % 128 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
+    sm::ConvArgs a{};
+    for (int g = 0; g < n_problems; ++g)
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
+                                 sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    a.n_problems = n_problems;
+    a.wt = reinterpret_cast<const float*>(wt3);
+    a.bias = bias;
+    a.Cin_pad = Cin;
+    a.Cout = Cout;
+    a.ws = ws;
+    a.splits = 1;
+    a.tile_list = tile_list;
+    return conv_dispatch_flags_split(a, n_list, flags, ws_floats, (hipStream_t)stream);
 }
 
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,

@@ -1,0 +1,39 @@
+// Launch arguments shared by the conv kernels (conv.hip: exact fp32 MFMA; conv_split.hip: bf16x3-split MFMA).
+#pragma once
+#include "common.h"
+
+namespace sm {
+
+constexpr int SM_MAX_GROUP = 8;
+
+// One feature-map problem of a grouped launch (same weights, different planes: the UV levels of a view).
+struct ConvProblem {
+    const float* in;
+    float* out;
+    const float* gate;
+    int H, W, Wp, plane;
+};
+
+struct ConvArgs {
+    ConvProblem p[SM_MAX_GROUP];
+    int tile_begin[SM_MAX_GROUP + 1];   // prefix sums of the problems' position-tile counts
+    int n_problems;
+    // optional compact list of ACTIVE position tiles, entry = (problem << 24) | tile-in-problem; NULL = all tiles.
+    // Tiles that cannot influence the loss (outside the receptive-field-dilated level mask) are simply absent.
+    const int* tile_list;
+    const float* wt;
+    const float* bias;
+    int Cin_pad, Cout, n_tiles, m_tiles;   // n_tiles = position tiles of ALL problems
+    // Work decomposition. The first n_whole tiles (a multiple of the CU count) are computed whole; the remaining
+    // "tail" tiles - whose last, partially filled round would otherwise leave most CUs idle - are split along K
+    // into `splits` units each, so the tail is made of many small units that spread over all CUs. Split units
+    // store raw partial tiles to ws[(tail_tile * splits + split)][BM][BN]; conv_tail_epilogue_kernel reduces them.
+    float* ws;
+    int n_whole;
+    int splits;
+    int chunks_per_split;
+};
+
+constexpr int SM_NUM_CU = 256;
+
+}  // namespace sm

@@ -1,0 +1,298 @@
+// K3s/K4s: the 3x3 convolutions on the bf16 matrix cores at fp32 accuracy ("bf16x3 split, 6 products").
+//
+// Every fp32 operand x is written as h + m + l, three bf16 numbers (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
+// 3 x 8 = 24 significand bits, i.e. the split is exact up to the last rounding of l), and a product x*y is evaluated
+// as the six partial products of weight >= 2^-16:  hh' + (hm' + mh') + (mm' + hl' + lh').  The dropped terms
+// (ml', lm', ll') are below 2^-23 |xy|, each partial product of two bf16 numbers is exact in fp32, and all sums are
+// taken in the MFMA's fp32 accumulators. The result is as close to the exact dot product as the fp32 MFMA chain of
+// conv.hip (tests/test_kernels_gpu.py measures both against an fp64 convolution) - but
+// v_mfma_f32_32x32x16_bf16 retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32, so six of them per fp32 MAC
+// still leave a 2.67x higher ceiling (2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent, against 157 TFLOP/s).
+//
+// Same GEMM view, tile scheduling, grouped launch, active-tile list, tail split-K and epilogues as conv.hip.
+// Differences: weights arrive pre-split from the host ([9][Cin/16][3 parts][2 k-groups][Cout][8 ci] bf16, the exact
+// image of an LDS weight stage); activations stay fp32 in HBM and are split when they are staged into LDS, as
+// [ky slice][3 parts][2 k-groups][BN+2 positions][8 ci] bf16 - a tap shift is again a pure offset (16 bytes per
+// position). One K-stage = one tap of a 16-channel chunk = ONE bf16 MFMA K-step (24 MFMAs per wave):
+//   * weights: the global stage image is the MFMA A-fragment layout, so each wave loads its fragments straight into
+//     a register ring three stages ahead - no LDS copy, no per-stage barrier;
+//   * activations: the three ky slices of a chunk live in a ring of FOUR LDS slots; the next chunk's slice k is
+//     loaded at tap 3k and written at the end of tap 3k+2 into the slot that the current chunk stopped reading
+//     three taps earlier (one barrier per three stages); the next stage's fragments are read under the current
+//     stage's MFMAs.
+// LDS: 4 x 12.2 KB = 48.8 KB; two blocks per CU (register-limited): the two waves that share a SIMD's matrix pipe
+// belong to different blocks and cover each other's store / barrier phases.
+#pragma once
+#include "conv_common.h"
+
+namespace sm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x -> (h, m, l) bf16 with h + m + l == x to 24 bits; round-to-nearest conversions (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN + 2)) * 16; }
+
+// STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(ConvArgs a) {
+    static_assert(BM / WGM == 64 && BN / WGN == 64 && WGM * WGN == 4, "wave tile is 64x64");
+    static_assert(BN == 128, "activation staging: one (k-group, position) unit per thread + a 2 x 2 x 8 halo");
+    constexpr int KC = 16;
+    constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
+    constexpr int SLICE = 6 * BNP;        // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    f32x4* Bs = smem4;                    // [4 slots][SLICE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int wm = (wave / WGN) * 64;
+    const int wn = (wave % WGN) * 64;
+#define SM_TS(slot_)                                                                                     \
+    if (STAMP && lane == 0) {                                                                            \
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)blockIdx.x * 4 + wave) * 64 + (slot_)] = \
+            __builtin_readcyclecounter();                                                                \
+    }
+
+    int tile, split = -1;
+    if ((int)blockIdx.x < a.n_whole) {
+        tile = xcd_linear(blockIdx.x, a.n_whole);
+    } else {
+        const int v = blockIdx.x - a.n_whole;
+        tile = a.n_whole + v / a.splits;
+        split = v - (tile - a.n_whole) * a.splits;
+    }
+    const int m_tile = tile / a.n_tiles;
+    const int n_glob = tile - m_tile * a.n_tiles;
+    ConvProblem P = a.p[0];
+    int n_tile = n_glob;
+    if (a.tile_list) {
+        const int e = a.tile_list[n_glob];
+        const int gsel = e >> 24;
+        n_tile = e & 0xFFFFFF;
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g == gsel) P = a.p[g];
+    } else {
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+                P = a.p[g];
+                n_tile = n_glob - a.tile_begin[g];
+            }
+    }
+    const int n_chunks = a.Cin_pad / KC;
+    const int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
+    const int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
+    const int m0 = m_tile * BM;
+    const int q0 = P.Wp + n_tile * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- staging plan
+    // weights: the global image of a stage, [part][kgroup][Cout] units of 8 bf16, IS the MFMA A-fragment layout
+    // (row = lane & 31, k-group = lane >> 5), so every wave loads its own 6 fragments (2 row tiles x 3 parts) of a
+    // stage straight into registers, three stages ahead: no LDS copy of the weights and no per-stage barrier.
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wt) + lhi * a.Cout + m0 + wm + l31;
+    const int a_part = 2 * a.Cout;            // units between the parts of a stage
+    const int a_stage_units = 6 * a.Cout;     // units per (tap, chunk) stage
+    // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
+    // k-group at stride `plane`; the 2 remaining halo positions x 2 k-groups x 8 channels = 32 single elements are
+    // fetched one per lane (every half-wave does the same 32: identical values to identical addresses)
+    const int b_kg = tid >> 7, b_px = tid & 127;
+    const int b_src = b_kg * 8 * P.plane + q0 - 1 + b_px;     // centre row (ky = 1); may be -1: plane guard
+    const int b_dst = b_kg * BNP + b_px;                      // + part * 2 * BNP (+ slot * SLICE)
+    const int h_kg = l31 >> 4, h_px = 128 + ((l31 >> 3) & 1), h_c = l31 & 7;
+    const int h_src = (h_kg * 8 + h_c) * P.plane + q0 - 1 + h_px;
+    const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
+    constexpr int AD = 3;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
+    static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
+    f32x4 ra[AD][2][3];
+    float rb[8], rh;
+
+#define SM_LOAD_A(tap_, chunk_)                                                                          \
+    {                                                                                                    \
+        const f32x4* s_ = wsrc + (size_t)((tap_) * n_chunks + (chunk_)) * a_stage_units;                 \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) ra[(tap_) % AD][i][s] = s_[s * a_part + i * 32]; \
+    }
+#define SM_LOAD_B(ky_, chunk_)                                                                           \
+    {                                                                                                    \
+        const float* s_ = P.in + (size_t)(chunk_) * KC * P.plane + ((ky_) - 1) * P.Wp;                   \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[c] = s_[b_src + c * P.plane];                   \
+        rh = s_[h_src];                                                                                  \
+    }
+#define SM_STORE_B(slot_)                                                                                \
+    {                                                                                                    \
+        bf16x8 vh, vm, vl;                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                  \
+            __bf16 h, m, l;                                                                              \
+            split3(rb[c], h, m, l);                                                                      \
+            vh[c] = h; vm[c] = m; vl[c] = l;                                                             \
+        }                                                                                                \
+        f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
+        d_[b_dst] = __builtin_bit_cast(f32x4, vh);                                                       \
+        d_[b_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                                             \
+        d_[b_dst + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                                             \
+        __bf16 h, m, l;                                                                                  \
+        split3(rh, h, m, l);                                                                             \
+        __bf16* e_ = reinterpret_cast<__bf16*>(d_);                                                      \
+        e_[h_dst] = h;                                                                                   \
+        e_[h_dst + 2 * BNP * 8] = m;                                                                     \
+        e_[h_dst + 4 * BNP * 8] = l;                                                                     \
+    }
+#define SM_READ_B(dst_, slot_, kx_)                                                                      \
+    {                                                                                                    \
+        const f32x4* bf_ = b_frag + (slot_) * SLICE + (kx_);                                             \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+                dst_[i][s] = __builtin_bit_cast(bf16x8, bf_[s * 2 * BNP + i * 32]);                      \
+    }
+
+    SM_TS(0)
+    // prologue: the first AD weight stages into the register ring, chunk ch_begin's three slices into slots 0..2
+#pragma unroll
+    for (int t = 0; t < AD; ++t) SM_LOAD_A(t, ch_begin);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        SM_LOAD_B(ky, ch_begin);
+        SM_STORE_B(ky);
+    }
+    __syncthreads();
+    SM_TS(1)
+    int base = 0;   // ring slot of the current chunk's ky = 0 slice
+    const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
+    bf16x8 fb[2][3], fb_next[2][3];
+    SM_READ_B(fb, 0, 0)
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        // Every load below is issued UNCONDITIONALLY (the last chunk re-reads its own data instead of the next
+        // chunk's): a load under `if (more)` makes the compiler's waitcnt pass assume the no-load path at the join,
+        // and every later wait for an OLDER load then drains the whole queue (vmcnt(0) instead of vmcnt(N)).
+        const int ch_next = ch + 1 < ch_end ? ch + 1 : ch;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            // the next stage's activation fragments are read under this stage's MFMAs (its slice is complete: slices
+            // are written a full barrier before their first use)
+            if (tap < 8) {
+                SM_READ_B(fb_next, (base + (tap + 1) / 3) & 3, (tap + 1) % 3)
+            } else {
+                SM_READ_B(fb_next, (base + 3) & 3, 0)
+            }
+            bf16x8 fa[2][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i][s] = __builtin_bit_cast(bf16x8, ra[tap % AD][i][s]);
+            // six partial products per output tile, smallest first; consecutive MFMAs target different accumulators
+#define SM_PRODUCT(pa_, pb_)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
+            SM_PRODUCT(2, 0)
+            SM_PRODUCT(0, 2)
+            SM_PRODUCT(1, 1)
+            SM_PRODUCT(1, 0)
+            SM_PRODUCT(0, 1)
+            SM_PRODUCT(0, 0)
+#undef SM_PRODUCT
+            // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
+            // the loads would need a fourth set of fragment registers)
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + AD < 9) {
+                SM_LOAD_A(tap + AD, ch);
+            } else {
+                SM_LOAD_A(tap + AD - 9, ch_next);
+            }
+            if (kx == 0) SM_LOAD_B(ky, ch_next);
+            // next chunk's slice ky -> slot (base + 3 + ky) & 3: for ky = 0 the spare slot (the previous chunk's
+            // ky = 2), for ky = 1, 2 the slot of this chunk's slice ky - 1, whose last readers passed the barrier of
+            // tap 3 ky - 1. One barrier per three stages publishes the slice.
+            if (kx == 2) {
+                SM_STORE_B((base + 3 + ky) & 3);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fb[i][s] = fb_next[i][s];
+            if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
+        }
+        base = (base + 3) & 3;
+    }
+    SM_TS(30)
+#undef SM_LOAD_A
+#undef SM_LOAD_B
+#undef SM_STORE_B
+#undef SM_READ_B
+
+    // ---- epilogue (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31,
+    //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    if (split >= 0) {
+        float* wt = a.ws + ((size_t)(tile - a.n_whole) * a.splits + split) * (BM * BN);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] = acc[mi][nj][r];
+        return;
+    }
+    const int q_end = (P.H + 1) * P.Wp;
+    // the 32 bias values of this lane's rows, fetched up front as 8 float4 (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4)
+    f32x4 bias4[2][4];
+    if (FLAGS & SM_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int q = q0 + wn + nj * 32 + l31;
+        if (q >= q_end) continue;
+        const bool inside = interior(q, P.H, P.W, P.Wp);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
+            // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
+            float prev[16], gate[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
+                if (FLAGS & SM_EPI_RELU_MASK) gate[r] = P.gate[o];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                float v = acc[mi][nj][r];
+                if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
+                if (FLAGS & SM_EPI_ADD) v += prev[r];
+                if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
+                P.out[o] = inside ? v : 0.f;
+            }
+        }
+    }
+    SM_TS(31)
+#undef SM_TS
+}
+
+}  // namespace sm

@@ -1,6 +1,8 @@
 """One thin Python function per C-ABI entry point (argument marshalling only, no arithmetic)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip
@@ -59,6 +61,30 @@ def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
+def split_eligible(cin_pad: int, cout: int) -> bool:
+    """Shapes the bf16x3-split conv kernel takes (sm_conv3x3_grouped_split)."""
+    return cin_pad % 16 == 0 and cout % 128 == 0
+
+
+def pack_conv_split(wt: torch.Tensor) -> torch.Tensor:
+    """fp32 tap-major pack [9][Cin][Cout] (``pack_conv_fwd`` / ``pack_conv_dgrad``) -> the pre-split weights of
+    sm_conv3x3_grouped_split: [9][Cin/16][3 parts][2 k-groups][Cout][8 ci] bf16 bit patterns (int16), where
+    w = part0 + part1 + part2 to 24 significand bits (round-to-nearest at every step)."""
+    taps, cin, cout = wt.shape
+    assert taps == 9 and split_eligible(cin, cout)
+    w = wt.view(9, cin // 16, 2, 8, cout).permute(0, 1, 2, 4, 3)            # [9][chunk][kgroup][cout][8]
+    h = w.bfloat16()
+    r1 = w - h.float()
+    m = r1.bfloat16()
+    l = (r1 - m.float()).bfloat16()
+    return torch.stack([h, m, l], dim=2).contiguous().view(torch.int16)      # [9][chunk][3][2][cout][8]
+
+
+# 'f32' = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains); 'split' = bf16x3-split MFMA (6 partial
+# products, fp32 accumulate, same accuracy class) wherever a layer's shape allows and its split pack is given.
+CONV_MODE = os.environ.get("STYLEMESH_CONV_MODE", "split")
+
+
 # ---- texture -------------------------------------------------------------------------------------------------
 def tex_sample_fwd(layers, grid: torch.Tensor, out: FMap):
     h, w = grid.shape[-3], grid.shape[-2]
@@ -110,9 +136,11 @@ def splitk_workspace(device) -> torch.Tensor:
     return _SPLITK_WS[key]
 
 
-def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None):
+def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None, wt3=None):
     cin_pad, cout = wt.shape[1], wt.shape[2]
     assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
+    if wt3 is not None and CONV_MODE == "split":
+        return conv3x3_grouped([(inp, out, gate)], wt, bias, flags, None, 1.0, wt3)
 
     def run():
         ws = splitk_workspace(wt.device)
@@ -129,9 +157,10 @@ def conv_tile_positions(cin_pad: int, cout: int) -> int:
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 
-def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0):
+def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps).
-    ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile)."""
+    ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
+    ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
     if tile_list is not None and tile_list.numel() == 0:
         return
@@ -142,11 +171,14 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), inp.H, inp.W)
         flops += 2.0 * 9 * (3 if cin_pad == 4 else cin_pad) * cout * inp.H * inp.W
 
+    use_split = wt3 is not None and CONV_MODE == "split"
+
     def run():
         ws = splitk_workspace(wt.device)
-        hip.check(lib.sm_conv3x3_grouped(arr, len(problems), ptr(wt), ptr(bias), cin_pad, cout, flags,
-                                         ptr(tile_list), 0 if tile_list is None else tile_list.numel(), ptr(ws),
-                                         ws.numel(), hip.stream()), "sm_conv3x3_grouped")
+        fn, w = (lib.sm_conv3x3_grouped_split, wt3) if use_split else (lib.sm_conv3x3_grouped, wt)
+        hip.check(fn(arr, len(problems), ptr(w), ptr(bias), cin_pad, cout, flags, ptr(tile_list),
+                     0 if tile_list is None else tile_list.numel(), ptr(ws), ws.numel(), hip.stream()),
+                  "sm_conv3x3_grouped")
     if CONV_TIMER is None:
         run()
     else:   # algorithmic FLOPs of the tiles actually required

@@ -70,12 +70,16 @@ class VGGNet:
     def __init__(self, state_dict: dict, device="cuda"):
         self.device = device
         self.wf, self.wd, self.bias = {}, {}, {}
+        self.wf3, self.wd3 = {}, {}     # bf16x3-split packs of the layers whose shape the split kernel takes
         for kind, _, _, _, _ in NODES:
             if kind == "pool":
                 continue
             w = state_dict[kind + ".weight"].detach().to(device=device, dtype=torch.float32)
             self.wf[kind] = ops.pack_conv_fwd(w)
             self.wd[kind] = ops.pack_conv_dgrad(w)
+            for packs, splits in ((self.wf, self.wf3), (self.wd, self.wd3)):
+                p = packs[kind]
+                splits[kind] = ops.pack_conv_split(p) if ops.split_eligible(p.shape[1], p.shape[2]) else None
             self.bias[kind] = state_dict[kind + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
 
     def forward(self, b: LevelBuffers):
@@ -84,7 +88,8 @@ class VGGNet:
             if kind == "pool":
                 ops.maxpool_fwd(b.act[src], b.act[out])
             else:
-                ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU)
+                ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU,
+                            wt3=self.wf3[kind])
 
     def forward_group(self, bufs, tiles=None, on_layer=None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
@@ -99,7 +104,7 @@ class VGGNet:
             else:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
-                                    hip.EPI_BIAS_RELU, tl, frac)
+                                    hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind])
                 if on_layer is not None:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
@@ -118,12 +123,13 @@ class VGGNet:
                     ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
-                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac)
+                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
+                                    self.wd3[kind])
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
                 ops.conv3x3_grouped([(b.grad[out], b.grad[src], b.act[src]) for b in bufs], self.wd[kind], None, flags,
-                                    tl, frac)
+                                    tl, frac, self.wd3[kind])
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
         """Back-propagate to ``b.grad['img']``.
@@ -140,7 +146,7 @@ class VGGNet:
             elif src == "img":
                 ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
             elif src.startswith("p"):
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0)
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0, wt3=self.wd3[kind])
             else:
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src])
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src], wt3=self.wd3[kind])

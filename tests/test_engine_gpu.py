@@ -158,15 +158,21 @@ def test_intermediates_match_oracle(name):
             err = (mine - ref).abs()
             n_bad = int((err > 1e-3 * float(ref.abs().max())).sum())
             if clean and n_bad:
-                # first mismatch: must be a pre-pool layer, a handful of elements, all in near-tie windows
-                assert layer in ("r12", "r22", "r34", "r44"), f"level {i}: first gradient mismatch at {layer}"
+                # first mismatch: a handful of elements, every one a rounding-level tie of a non-smooth operator -
+                # either a max-pool window (pre-pool layer) whose top-2 activations coincide, or a ReLU gate whose
+                # pre-activation is zero to rounding (one side computes +3e-6, the other 0 at max|act| ~ 1e2)
                 assert n_bad <= 16, (layer, n_bad)
                 act = t.detach()[0]
-                ys, xs = torch.nonzero((err > 1e-3 * float(ref.abs().max())).any(0), as_tuple=True)
+                mine_act = b.act[layer].to_dense().cpu() if layer.startswith("r") else None
+                tie = 2e-5 * float(act.abs().max())
                 for c, y, x in torch.nonzero(err > 1e-3 * float(ref.abs().max())):
+                    relu_tie = mine_act is not None and max(abs(float(act[c, y, x])), abs(float(mine_act[c, y, x]))) <= tie
+                    if relu_tie:
+                        continue
+                    assert layer in ("r12", "r22", "r34", "r44"), f"level {i}: first gradient mismatch at {layer}"
                     wy, wx = int(y) // 2 * 2, int(x) // 2 * 2
                     top2 = act[c, wy:wy + 2, wx:wx + 2].reshape(-1).topk(2).values
-                    assert float(top2[0] - top2[1]) <= 2e-5 * float(act.abs().max()), (layer, int(c), wy, wx, top2)
+                    assert float(top2[0] - top2[1]) <= tie, (layer, int(c), wy, wx, top2)
                 clean = False
             elif clean:
                 assert n_bad == 0

@@ -117,6 +117,59 @@ def test_conv3x3_dgrad_with_gate_and_add(rt, cin, cout, H, W):
     assert out.border_is_zero()
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77)])
+def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypatch):
+    """bf16x3-split conv (6 partial products on the bf16 matrix cores) against an fp64 convolution: its error must
+    be in the same class as the fp32-MFMA kernel's (<= 2x its rms error, and inside the fp32 tolerance)."""
+    torch.manual_seed(cin + cout + W)
+    x = F.relu(torch.randn(1, cin, H, W) * 3)
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout) * 0.3
+    ref = F.relu(F.conv2d(x.double(), wgt.double(), b.double(), padding=1))[0]
+    xin = rt.FMap(cin, H, W).from_dense(x[0])
+    w = dev(rt.ops.pack_conv_fwd(wgt))
+    w3 = rt.ops.pack_conv_split(w)
+    errs = {}
+    for mode in ("f32", "split"):
+        monkeypatch.setattr(rt.ops, "CONV_MODE", mode)
+        out = rt.FMap(cout, H, W)
+        out.planes.fill_(7.0)
+        out.planes[:, :out.Wp] = 0
+        out.planes[:, (H + 1) * out.Wp:] = 0
+        rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3)
+        assert out.border_is_zero()
+        d = out.to_dense().double().cpu() - ref
+        errs[mode] = float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+        assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max()), mode
+    assert errs["split"] <= 2.0 * errs["f32"] + 1e-9, errs
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 13, 131), (256, 512, 6, 9)])
+def test_conv3x3_split_dgrad_with_gate_and_add(rt, cin, cout, H, W, monkeypatch):
+    monkeypatch.setattr(rt.ops, "CONV_MODE", "split")
+    torch.manual_seed(cin * 3 + W)
+    x = F.relu(torch.randn(1, cin, H, W)).requires_grad_(True)
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    dy = torch.randn(1, cout, H, W)
+    addend = torch.randn(cin, H, W)
+    F.conv2d(x, wgt, None, padding=1).backward(dy)
+    gate = (x.detach()[0] > 0).float()
+    wd = dev(rt.ops.pack_conv_dgrad(wgt))
+    wd3 = rt.ops.pack_conv_split(wd)
+    dyf = rt.FMap(cout, H, W).from_dense(dy[0])
+    act = rt.FMap(cin, H, W).from_dense(x.detach()[0])
+    scale = float(x.grad.abs().max())
+    out = rt.FMap(cin, H, W)
+    rt.ops.conv3x3(dyf, wd, None, out, 0, wt3=wd3)
+    assert_close(out.to_dense(), x.grad[0], 1e-4, 1e-4 * scale, "plain dgrad")
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK, gate=act, wt3=wd3)
+    assert_close(out.to_dense(), x.grad[0] * gate, 1e-4, 1e-4 * scale, "gated dgrad")
+    out.from_dense(addend)
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK | rt.hip.EPI_ADD, gate=act, wt3=wd3)
+    assert_close(out.to_dense(), (x.grad[0] + addend) * gate, 1e-4, 1e-4 * scale, "gated dgrad + add")
+    assert out.border_is_zero()
+
+
 def test_conv3x3_first_layer_dgrad(rt):
     torch.manual_seed(5)
     H, W = 23, 37
