@@ -108,8 +108,9 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
  * weight >= 2^-16 with fp32 accumulation (stylemesh_amd/csrc/conv_split_kernel.h). Activations / outputs are
  * the same fp32 planes; wt3 = the weights pre-split by the host: [9 taps][Cin/16][3 parts][2][Cout][8] bf16 (as
  * uint16 bit patterns; runtime/ops.py:pack_conv_split builds it from the fp32 tap-major pack). Cin % 16 == 0,
- * Cout % 128 == 0; tiles cover 128 positions. Same flags / tile_list / ws semantics as sm_conv3x3_grouped.
+ * Cout % 64 == 0; tiles cover sm_conv_split_tile_positions() = 128 positions. Same flags / tile_list / ws semantics as sm_conv3x3_grouped.
  * Replaces the same reference operators (F.conv2d forward / backward of content_and_style_losses.py:11-32). */
+int sm_conv_split_tile_positions(void);
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,
                              const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
                              float* ws, size_t ws_floats, void* stream);

@@ -275,10 +275,12 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
-    // full rounds of one tile per CU run whole; the tail of `rem` tiles is split along K so that it becomes
-    // about one more (short) round of rem * splits small units. Pick the split count that minimises the tail's
-    // duration ceil(rem * S / CUs) / S, each split keeping >= 2 K-chunks.
-    a.n_whole = tiles / SM_NUM_CU * SM_NUM_CU;
+    // Full rounds of one tile per resident block slot run whole; the tail of `rem` tiles is split along K so that
+    // it becomes about one more (short) round of rem * splits small units. Pick the split count that minimises the
+    // tail's duration ceil(rem * S / slots) / S, each split keeping >= 2 K-chunks. (The split kernel keeps two
+    // blocks resident per CU, but they share the matrix pipes: measured, rounds of 2 x CUs tiles are slower.)
+    constexpr int SLOTS = SM_NUM_CU;
+    a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;
     int rem = tiles - a.n_whole;
@@ -288,7 +290,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         float best = (chunks + 1.f) / chunks;   // S = 1: one more full round
         for (int S = 2; S <= max_s; ++S) {
             const int cps = (chunks + S - 1) / S, S_eff = (chunks + cps - 1) / cps;
-            const float cost = (float)((rem * S_eff + SM_NUM_CU - 1) / SM_NUM_CU) * (cps + 1.f) / chunks;
+            const float cost = (float)((rem * S_eff + SLOTS - 1) / SLOTS) * (cps + 1.f) / chunks;
             if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
         }
     }
@@ -319,6 +321,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 
 template <int FLAGS>
 static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
+    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
     return launch_conv<128, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
 }
 
@@ -437,6 +440,7 @@ static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws
 }
 
 int sm_conv_tile_positions(int Cin_pad, int Cout) { return (Cin_pad == 4 || Cout % 128 != 0) ? 256 : 128; }
+int sm_conv_split_tile_positions(void) { return 128; }
 
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
@@ -462,7 +466,7 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
                              int Cin, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
                              size_t ws_floats, void* stream) {
     if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
-    if (Cout % 128 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
+    if (Cout % 64 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
     for (int g = 0; g < n_problems; ++g)
         a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,

@@ -42,7 +42,9 @@ constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(ConvArgs a) {
-    static_assert(BM / WGM == 64 && BN / WGN == 64 && WGM * WGN == 4, "wave tile is 64x64");
+    constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
+    static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && BN / WGN == 64 && WGM * WGN == 4,
+                  "wave tile is (32 MI) x 64");
     static_assert(BN == 128, "activation staging: one (k-group, position) unit per thread + a 2 x 2 x 8 halo");
     constexpr int KC = 16;
     constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wave = tid >> 6;
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
-    const int wm = (wave / WGN) * 64;
+    const int wm = (wave / WGN) * (32 * MI);
     const int wn = (wave % WGN) * 64;
 #define SM_TS(slot_)                                                                                     \
     if (STAMP && lane == 0) {                                                                            \
@@ -96,9 +98,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m0 = m_tile * BM;
     const int q0 = P.Wp + n_tile * BN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- staging plan
     // weights: the global image of a stage, [part][kgroup][Cout] units of 8 bf16, IS the MFMA A-fragment layout
-    // (row = lane & 31, k-group = lane >> 5), so every wave loads its own 6 fragments (2 row tiles x 3 parts) of a
+    // (row = lane & 31, k-group = lane >> 5), so every wave loads its own 3 MI fragments (MI row tiles x 3 parts) of a
     // stage straight into registers, three stages ahead: no LDS copy of the weights and no per-stage barrier.
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wt) + lhi * a.Cout + m0 + wm + l31;
     const int a_part = 2 * a.Cout;            // units between the parts of a stage
@@ -122,14 +124,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
     constexpr int AD = 3;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
-    f32x4 ra[AD][2][3];
+    f32x4 ra[AD][MI][3];
     float rb[8], rh;
 
 #define SM_LOAD_A(tap_, chunk_)                                                                          \
     {                                                                                                    \
         const f32x4* s_ = wsrc + (size_t)((tap_) * n_chunks + (chunk_)) * a_stage_units;                 \
         _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) ra[(tap_) % AD][i][s] = s_[s * a_part + i * 32]; \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) ra[(tap_) % AD][i][s] = s_[s * a_part + i * 32]; \
     }
 #define SM_LOAD_B(ky_, chunk_)                                                                           \
     {                                                                                                    \
@@ -194,14 +196,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
                 SM_READ_B(fb_next, (base + 3) & 3, 0)
             }
-            bf16x8 fa[2][3];
+            bf16x8 fa[MI][3];
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i][s] = __builtin_bit_cast(bf16x8, ra[tap % AD][i][s]);
+                for (int i = 0; i < MI; ++i) fa[i][s] = __builtin_bit_cast(bf16x8, ra[tap % AD][i][s]);
             // six partial products per output tile, smallest first; consecutive MFMAs target different accumulators
 #define SM_PRODUCT(pa_, pb_)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
             SM_PRODUCT(2, 0)
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] = acc[mi][nj][r];
@@ -256,10 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int q_end = (P.H + 1) * P.Wp;
     // the 32 bias values of this lane's rows, fetched up front as 8 float4 (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4)
-    f32x4 bias4[2][4];
+    f32x4 bias4[MI][4];
     if (FLAGS & SM_EPI_BIAS_RELU) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
             // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
             float prev[16], gate[16];

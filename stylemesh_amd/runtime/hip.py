@@ -34,6 +34,7 @@ SIGNATURES = {
     "sm_conv3x3_grouped": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "sm_conv3x3_grouped_split": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "sm_conv_tile_positions": [_i, _i],
+    "sm_conv_split_tile_positions": [],
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

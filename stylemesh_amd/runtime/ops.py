@@ -63,7 +63,7 @@ def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
 
 def split_eligible(cin_pad: int, cout: int) -> bool:
     """Shapes the bf16x3-split conv kernel takes (sm_conv3x3_grouped_split)."""
-    return cin_pad % 16 == 0 and cout % 128 == 0
+    return cin_pad % 16 == 0 and cout % 64 == 0
 
 
 def pack_conv_split(wt: torch.Tensor) -> torch.Tensor:
@@ -154,6 +154,9 @@ def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap
 
 
 def conv_tile_positions(cin_pad: int, cout: int) -> int:
+    """Positions per tile of the kernel that ``conv3x3_grouped`` will pick for this layer shape (``CONV_MODE``)."""
+    if CONV_MODE == "split" and split_eligible(cin_pad, cout):
+        return lib.sm_conv_split_tile_positions()
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 

@@ -117,7 +117,8 @@ def test_conv3x3_dgrad_with_gate_and_add(rt, cin, cout, H, W):
     assert out.border_is_zero()
 
 
-@pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77)])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77),
+                                          (64, 64, 17, 21), (128, 64, 33, 47)])
 def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypatch):
     """bf16x3-split conv (6 partial products on the bf16 matrix cores) against an fp64 convolution: its error must
     be in the same class as the fp32-MFMA kernel's (<= 2x its rms error, and inside the fp32 tolerance)."""
@@ -144,7 +145,7 @@ def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypa
     assert errs["split"] <= 2.0 * errs["f32"] + 1e-9, errs
 
 
-@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 13, 131), (256, 512, 6, 9)])
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 13, 131), (256, 512, 6, 9), (64, 64, 17, 21), (64, 128, 20, 28)])
 def test_conv3x3_split_dgrad_with_gate_and_add(rt, cin, cout, H, W, monkeypatch):
     monkeypatch.setattr(rt.ops, "CONV_MODE", "split")
     torch.manual_seed(cin * 3 + W)

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from stylemesh_amd.runtime import hip, ops
 from stylemesh_amd.runtime.fmap import FMap
 
-LAYERS = [(64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 512, 8), (512, 512, 8), (512, 512, 16)]
+LAYERS = [(64, 64, 1), (128, 64, 2), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 512, 8), (512, 512, 8), (512, 512, 16)]
 LEVELS = [(256, 341), (432, 576), (608, 811), (784, 1045)]
 sel = [int(a) for a in sys.argv[1:]] or [0, 3]
 tot = {"f32": [0.0, 0.0], "split": [0.0, 0.0]}
