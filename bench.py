@@ -23,10 +23,9 @@ sys.path.insert(0, REPO)
 from stylemesh_amd.data import synthetic as S  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: dense bf16 MFMA
 # algorithmic HBM bytes of the 25 grouped conv launches of one step: every input / output / gate plane and the
 # layer's weights touched once
-ALG_CONV_BYTES = {"c3": 7743.4e6}
-DENSE_CONV_GFLOP = {"c3": 2369.8}   # all tiles of all levels; the active-tile lists execute a fraction of it
 WORKLOADS = {
     # SURVEY.md section 8 d. c3 = scripts/train/optimize_texture_scannet_with_angle_and_depth.sh at 4096^2
     "c3": dict(tex=4096, level_hw=S.SCANNET_LEVEL_HW, view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0, angle=True,
@@ -167,28 +166,46 @@ def main():
 
     roofline = None
     if timer is not None:
-        n, ms, flops = timer.summary()
         n_timed = len([i for i in range(args.steps) if i % args.timer_every == 0])
+        n_all, ms_all, flops_all = timer.summary()
+        # the dominant kernel: the bf16x3-split conv when the engine runs in split mode, else the fp32-MFMA conv
+        tag = "split" if ops.CONV_MODE == "split" else "f32"
+        n, ms, flops = timer.summary(tag)
         ach = flops / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS / 6 if tag == "split" else PEAK_FP32_MFMA_TFLOPS
         traffic = None   # HBM bytes per conv launch from the committed PMC pass of this workload (offline: PMC
-        tf = os.path.join(REPO, "profiles", "r01", f"conv_traffic_{args.workload}.json")   # runs cannot be live)
+        tf = os.path.join(REPO, "profiles", "r01", f"conv_traffic_{args.workload}_{tag}.json")   # runs cannot be live)
         if os.path.exists(tf):
             traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, "
-                    "profiles/r01/conv_traffic_*.json)", "algorithmic_bytes_per_launch": round(ALG_CONV_BYTES.get(args.workload, 0) / 25 * min(1.0, flops / n_timed / 1e9 /
-                                                                DENSE_CONV_GFLOP.get(args.workload, 1e30))) or None,
-                    "kernel": "conv3x3_mfma_kernel",
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/conv_traffic_*.json)",
+                    "algorithmic_bytes_per_launch": round(timer.bytes.get(tag, 0.0) / max(n, 1)),
+                    "kernel": "conv3x3_split_kernel" if tag == "split" else "conv3x3_mfma_kernel",
+                    "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 MFMA products per fp32 multiply-add "
+                                   "(operands split into 3 bf16 parts, fp32 accumulate); achieved = algorithmic fp32 "
+                                   "FLOPs / time, i.e. frac = executed bf16 MFMA FLOPs / 2500") if tag == "split" else
+                                  "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)",
+                    "achieved_vs_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     "launches_timed": n, "timed_steps": n_timed, "avg_launch_us": round(1e3 * ms / n, 2),
                     "algorithmic_gflop_per_step": round(flops / n_timed / 1e9, 1),
-                    "share_of_step_time": round(ms * 1e-3 / n_timed / (dt / args.steps), 3)}
+                    "share_of_step_time": round(ms * 1e-3 / n_timed / (dt / args.steps), 3),
+                    "all_conv_launches": {"launches_timed": n_all, "achieved": round(flops_all / (ms_all * 1e-3) / 1e12, 2),
+                                          "algorithmic_gflop_per_step": round(flops_all / n_timed / 1e9, 1),
+                                          "share_of_step_time": round(ms_all * 1e-3 / n_timed / (dt / args.steps), 3)}}
 
     if rank == 0:
         value = world * args.steps / dt
         out = {"metric": "views/sec (fwd+bwd into 4096^2 texture)" if wl["tex"] == 4096 else
                f"views/sec (fwd+bwd into {wl['tex']}^2 texture)", "value": round(value, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "dtype_note": ("all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the bf16 matrix "
+                              "cores with every fp32 operand split exactly into 3 bf16 parts (6 partial products, fp32 "
+                              "accumulate): error vs an fp64 convolution equals the fp32-MFMA kernel's "
+                              "(tests/test_kernels_gpu.py); STYLEMESH_CONV_MODE=f32 selects the fp32-MFMA kernel")
+               if ops.CONV_MODE == "split" else "fp32 throughout (v_mfma_f32_32x32x2_f32 convolutions)",
+               "data": "synthetic",
                "config": {"workload": f"{args.workload}: {wl['desc']}", "texture": f"{wl['tex']}x{wl['tex']} x 4 layers",
                           "active_uv_levels": active_levels, "views_per_step": world,
                           "index_repeat": wl["index_repeat"], "style_image": f"synthetic {STYLE_HW[1]}x{STYLE_HW[0]}",

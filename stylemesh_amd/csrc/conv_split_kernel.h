@@ -25,6 +25,17 @@
 #pragma once
 #include "conv_common.h"
 
+// tuning knobs (A/B builds: build.sh -DSM_SPLIT_AD=1 ...)
+#ifndef SM_SPLIT_AD
+#define SM_SPLIT_AD 3          // weight prefetch distance in stages (must divide 9)
+#endif
+#ifndef SM_SPLIT_PREFETCH_B
+#define SM_SPLIT_PREFETCH_B 1  // read the next stage's activation fragments under this stage's MFMAs
+#endif
+#ifndef SM_SPLIT_WAVES
+#define SM_SPLIT_WAVES 2       // resident waves per SIMD the register budget is set for
+#endif
+
 namespace sm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -41,7 +52,7 @@ constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN
 
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_split_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WAVES, SM_SPLIT_WAVES))) void conv3x3_split_kernel(ConvArgs a) {
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && BN / WGN == 64 && WGM * WGN == 4,
                   "wave tile is (32 MI) x 64");
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int h_kg = l31 >> 4, h_px = 128 + ((l31 >> 3) & 1), h_c = l31 & 7;
     const int h_src = (h_kg * 8 + h_c) * P.plane + q0 - 1 + h_px;
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
-    constexpr int AD = 3;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
+    constexpr int AD = SM_SPLIT_AD;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
     f32x4 ra[AD][MI][3];
     float rb[8], rh;
@@ -180,7 +191,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
     const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
     bf16x8 fb[2][3], fb_next[2][3];
+#if SM_SPLIT_PREFETCH_B
     SM_READ_B(fb, 0, 0)
+#endif
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         // Every load below is issued UNCONDITIONALLY (the last chunk re-reads its own data instead of the next
         // chunk's): a load under `if (more)` makes the compiler's waitcnt pass assume the no-load path at the join,
@@ -191,11 +204,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int ky = tap / 3, kx = tap % 3;
             // the next stage's activation fragments are read under this stage's MFMAs (its slice is complete: slices
             // are written a full barrier before their first use)
+#if SM_SPLIT_PREFETCH_B
             if (tap < 8) {
                 SM_READ_B(fb_next, (base + (tap + 1) / 3) & 3, (tap + 1) % 3)
             } else {
                 SM_READ_B(fb_next, (base + 3) & 3, 0)
             }
+#else
+            SM_READ_B(fb, (base + ky) & 3, kx)
+#endif
             bf16x8 fa[MI][3];
 #pragma unroll
             for (int s = 0; s < 3; ++s)
@@ -229,10 +246,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 SM_STORE_B((base + 3 + ky) & 3);
                 __syncthreads();
             }
+#if SM_SPLIT_PREFETCH_B
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fb[i][s] = fb_next[i][s];
+#endif
             if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
         }
         base = (base + 3) & 3;

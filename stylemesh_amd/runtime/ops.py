@@ -17,23 +17,26 @@ class KernelTimer:
     on (torch's current stream). bench.py uses it to price the dominant kernel against its roofline."""
 
     def __init__(self):
-        self.records = []   # (start_event, end_event, algorithmic_work)
+        self.records = []   # (start_event, end_event, algorithmic_work, tag)
+        self.bytes = {}     # tag -> algorithmic HBM bytes of the timed launches
         self.enabled = True
 
-    def launch(self, fn, work):
+    def launch(self, fn, work, tag="f32", nbytes=0.0):
         if not self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.append((a, b, work))
+        self.records.append((a, b, work, tag))
+        self.bytes[tag] = self.bytes.get(tag, 0.0) + nbytes
 
-    def summary(self):
-        """-> (n_launches, total_ms, total_work); synchronises."""
+    def summary(self, tag=None):
+        """-> (n_launches, total_ms, total_work) of the launches with this tag (None: all); synchronises."""
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        return len(self.records), ms, sum(w for _, _, w in self.records)
+        rec = [r for r in self.records if tag is None or r[3] == tag]
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+        return len(rec), ms, sum(r[2] for r in rec)
 
 
 CONV_TIMER: KernelTimer | None = None   # set by bench.py; None = no instrumentation
@@ -168,11 +171,15 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     if tile_list is not None and tile_list.numel() == 0:
         return
     arr = (hip.ConvProblem * len(problems))()
-    flops = 0.0
+    flops = nbytes = 0.0
     for i, (inp, out, gate) in enumerate(problems):
         assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), inp.H, inp.W)
-        flops += 2.0 * 9 * (3 if cin_pad == 4 else cin_pad) * cout * inp.H * inp.W
+        cin_true = 3 if cin_pad == 4 else cin_pad
+        flops += 2.0 * 9 * cin_true * cout * inp.H * inp.W
+        # algorithmic HBM bytes: input read once, output written once, + the epilogue's gate / addend reads
+        streams = cin_true + cout + (cout if flags & hip.EPI_RELU_MASK else 0) + (cout if flags & hip.EPI_ADD else 0)
+        nbytes += 4.0 * streams * inp.H * inp.W
 
     use_split = wt3 is not None and CONV_MODE == "split"
 
@@ -185,7 +192,8 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     if CONV_TIMER is None:
         run()
     else:   # algorithmic FLOPs of the tiles actually required
-        CONV_TIMER.launch(run, flops * active_fraction)
+        wbytes = wt3.numel() * 2 if use_split else wt.numel() * 4
+        CONV_TIMER.launch(run, flops * active_fraction, "split" if use_split else "f32", nbytes * active_fraction + wbytes)
 
 
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):

@@ -1,0 +1,34 @@
+"""Condense the FETCH_SIZE / WRITE_SIZE PMC summary (tools/pmc_traffic.sh) into profiles/r01/conv_traffic_<wl>_<tag>.json.
+Usage: traffic_json.py <summary.csv> <workload> <tag: split|f32> <out.json>
+FETCH_SIZE on gfx950 under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md); the factor is re-derived from
+the Adam kernel of the same run, whose traffic is known exactly (7 fp32 streams over the texture arena)."""
+import csv, json, sys
+src, wl, tag, out = sys.argv[1:5]
+rows = list(csv.DictReader(open(src)))
+kern = "conv3x3_split_kernel" if tag == "split" else "conv3x3_mfma_kernel"
+def col(r, name):
+    for k, v in r.items():
+        if k.startswith(name):
+            return float(v)
+    return 0.0
+fetch = write = launches = 0.0
+adam = None
+for r in rows:
+    if kern in r["kernel"]:
+        fetch += r.get("FETCH_SIZE") and float(r["FETCH_SIZE"]) or 0.0
+        write += r.get("WRITE_SIZE") and float(r["WRITE_SIZE"]) or 0.0
+        launches += col(r, "launches@FETCH")
+    if "adam_kernel<true>" in r["kernel"]:
+        adam = r
+corr = 2.0
+cal = None
+if adam is not None:
+    n = col(adam, "launches@FETCH")
+    cal = {"adam_fetch_mb_per_launch_raw": float(adam["FETCH_SIZE"]) * 1024 / n / 1e6,
+           "adam_write_mb_per_launch": float(adam["WRITE_SIZE"]) * 1024 / n / 1e6}
+json.dump({"workload": wl, "kernel": kern, "launches": launches, "fetch_size_kb_raw": fetch, "write_size_kb": write,
+           "fetch_correction": corr, "calibration": cal,
+           "hbm_bytes_per_launch": (fetch * corr + write) * 1024 / max(launches, 1),
+           "source": "tools/pmc_traffic.sh (two rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE) + tools/traffic_json.py"},
+          open(out, "w"), indent=1)
+print(open(out).read())
