@@ -148,6 +148,12 @@ int sm_gram_workspace_slabs(int C, int H, int W);
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                    int H, int W, void* stream);
 
+/* K5a on the bf16 matrix cores at fp32 accuracy (bf16x3 split, 6 partial products, fp32 accumulate - see
+ * sm_conv3x3_grouped_split). Same arguments, slab layout and results class as sm_gram_masked; stages whose 16
+ * mask values are all zero are skipped before their data is loaded. */
+int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
+                         int H, int W, void* stream);
+
 /* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
  * S0/S1: the n_slabs partial slabs written by sm_gram_masked (summed here).
  * For each mask k: G_k = S_k / max(N_k,1) (N from counts[k]; N_k == 0 -> G_k = 0, and with
@@ -167,6 +173,13 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
  * (for the top layer r51, whose ReLU gate no later dgrad applies). OVERWRITES dfeat. */
 int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, const float* D0,
                      const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* stream);
+
+/* K5c on the bf16 matrix cores (same split). ws: DEVICE scratch of sm_gram_backward_split_ws_bytes(C) bytes that
+ * receives the bf16x3 image of D0 / D1 (a small pack kernel runs first on the same stream). */
+size_t sm_gram_backward_split_ws_bytes(int C);
+int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0,
+                           const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* ws,
+                           void* stream);
 
 /* K6. Masked content MSE (:343-348): loss += coef * sum m (P-T)^2 / (C N); dP = coef * 2 m (P-T)/(C N),
  * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred.

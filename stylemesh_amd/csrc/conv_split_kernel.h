@@ -38,16 +38,6 @@
 
 namespace sm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// x -> (h, m, l) bf16 with h + m + l == x to 24 bits; round-to-nearest conversions (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-
 constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN + 2)) * 16; }
 
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
@@ -181,10 +171,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
     // prologue: the first AD weight stages into the register ring, chunk ch_begin's three slices into slots 0..2
 #pragma unroll
     for (int t = 0; t < AD; ++t) SM_LOAD_A(t, ch_begin);
+    {   // all three slices' loads in flight together (one memory round trip instead of three)
+        float rb3[3][8], rh3[3];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        SM_LOAD_B(ky, ch_begin);
-        SM_STORE_B(ky);
+        for (int ky = 0; ky < 3; ++ky) {
+            SM_LOAD_B(ky, ch_begin);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rb3[ky][c] = rb[c];
+            rh3[ky] = rh;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rb[c] = rb3[ky][c];
+            rh = rh3[ky];
+            SM_STORE_B(ky);
+        }
     }
     __syncthreads();
     SM_TS(1)

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "gram_split_kernels.h"
 
 namespace sm {
 
@@ -376,6 +377,67 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
         if (mask1) hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw1, S1, (int)cc, p.n_raw);
         SM_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
+                         int W, void* stream) {
+    if (C % 64 != 0) return (int)hipErrorInvalidValue;
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
+    const int q_begin = Wp, q_end = (H + 1) * Wp;
+    const sm::GramPlan p = sm::gram_plan(C, q_end - q_begin);
+    const bool two_level = p.n_red != p.n_raw;
+    const size_t cc = (size_t)C * C;
+    float* raw0 = two_level ? S0 + p.n_red * cc : S0;   // reduced slabs first, raw slabs behind them
+    float* raw1 = (two_level && S1) ? S1 + p.n_red * cc : S1;
+    hipStream_t s = (hipStream_t)stream;
+    const int nmask = mask1 ? 2 : 1;
+    if (C % 128 == 0) {
+        const int T = C / 128;
+        hipLaunchKernelGGL(sm::gram_split_kernel<2>, dim3(p.n_raw, T * (T + 1) / 2, nmask), dim3(256), 0, s, feat, mask0,
+                           mask1, raw0, raw1, C, plane, q_begin, q_end, p.qb);
+    } else {
+        const int T = C / 64;
+        hipLaunchKernelGGL(sm::gram_split_kernel<1>, dim3(p.n_raw, T * (T + 1) / 2, nmask), dim3(256), 0, s, feat, mask0,
+                           mask1, raw0, raw1, C, plane, q_begin, q_end, p.qb);
+    }
+    SM_LAUNCH_CHECK();
+    if (two_level) {
+        dim3 rg((unsigned)(cc / 256), p.n_red);
+        hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw0, S0, (int)cc, p.n_raw);
+        if (mask1) hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw1, S1, (int)cc, p.n_raw);
+        SM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+size_t sm_gram_backward_split_ws_bytes(int C) { return (size_t)2 * 6 * C * C; }
+
+int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0, const float* D1,
+                           float* dfeat, int C, int H, int W, int relu_gate, void* ws, void* stream) {
+    if (C % 64 != 0 || ws == nullptr) return (int)hipErrorInvalidValue;
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
+    const int q_begin = Wp, q_end = (H + 1) * Wp;
+    hipStream_t s = (hipStream_t)stream;
+    const bool two = mask1 && D1;
+    sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(ws);
+    sm::f32x4* P1 = P0 + (size_t)6 * C * C / 16;
+    hipLaunchKernelGGL(sm::gram_d_pack_kernel, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1, P0, P1,
+                       C);
+    SM_LAUNCH_CHECK();
+    const float* m1 = two ? mask1 : nullptr;
+#define SM_GBS(MI_, RG)                                                                                               \
+    hipLaunchKernelGGL((sm::gram_backward_split_kernel<MI_, RG>), dim3((q_end - q_begin + 127) / 128, C / (64 * MI_)),  \
+                       dim3(256), 0, s, feat, mask0, m1, P0, P1, dfeat, C, plane, q_begin, q_end)
+    // 128-row tiles only when they still fill the chip: deep layers of small levels have a handful of position tiles,
+    // and a block's K loop (C x live masks) is serial
+    if (C % 128 == 0 && (long long)((q_end - q_begin + 127) / 128) * (C / 128) >= 256) {
+        if (relu_gate) SM_GBS(2, true); else SM_GBS(2, false);
+    } else {
+        if (relu_gate) SM_GBS(1, true); else SM_GBS(1, false);
+    }
+#undef SM_GBS
+    SM_LAUNCH_CHECK();
     return 0;
 }
 

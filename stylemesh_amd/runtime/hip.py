@@ -41,6 +41,7 @@ SIGNATURES = {
     "sm_gram_num_slabs": [_i, _i, _i],
     "sm_gram_workspace_slabs": [_i, _i, _i],
     "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_gram_masked_split": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -53,6 +54,8 @@ SIGNATURES = {
     "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
+    "sm_gram_backward_split_ws_bytes": [_i],
+    "sm_gram_backward_split": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
 }
 
@@ -71,7 +74,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = _i
+        fn.restype = _sz if name.endswith("_bytes") else _i
     return lib
 
 

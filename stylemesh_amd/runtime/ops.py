@@ -220,13 +220,19 @@ def gram_workspace_slabs(C: int, H: int, W: int) -> int:
     return lib.sm_gram_workspace_slabs(C, H, W)
 
 
+# 'split' = the Gram contraction and its backward GEMM on the bf16 matrix cores with bf16x3-split operands (fp32
+# accuracy class, see CONV_MODE); 'f32' = v_mfma_f32_32x32x2_f32 kernels.
+GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", "split")
+
+
 def gram_masked(feat: FMap, mask0, mask1, S0, S1):
     """S0 / S1: [gram_workspace_slabs(C,H,W), C, C]; returns how many leading slabs sum to S."""
     n = gram_num_slabs(feat.C, feat.H, feat.W)
     na = gram_workspace_slabs(feat.C, feat.H, feat.W)
     assert S0.numel() >= na * feat.C * feat.C and (S1 is None or S1.numel() >= na * feat.C * feat.C)
-    hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
-                                 hip.stream()), "sm_gram_masked")
+    fn = lib.sm_gram_masked_split if GRAM_MODE == "split" else lib.sm_gram_masked
+    hip.check(fn(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W, hip.stream()),
+              "sm_gram_masked")
     return n
 
 
@@ -238,7 +244,20 @@ def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight
                                 hip.stream()), "sm_style_loss")
 
 
+_GRAM_BWD_WS = {}   # device -> scratch for the bf16x3 image of D0 / D1 (largest C = 512: 3 MB)
+
+
 def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool):
+    if GRAM_MODE == "split":
+        key = (str(D0.device), hip.stream())   # one scratch per launch stream
+        need = lib.sm_gram_backward_split_ws_bytes(feat.C)
+        if key not in _GRAM_BWD_WS or _GRAM_BWD_WS[key].numel() < need:
+            _GRAM_BWD_WS[key] = torch.empty(max(need, lib.sm_gram_backward_split_ws_bytes(512)), dtype=torch.uint8,
+                                            device=D0.device)
+        hip.check(lib.sm_gram_backward_split(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C,
+                                             feat.H, feat.W, int(relu_gate), ptr(_GRAM_BWD_WS[key]), hip.stream()),
+                  "sm_gram_backward_split")
+        return
     hip.check(lib.sm_gram_backward(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C, feat.H,
                                    feat.W, int(relu_gate), hip.stream()), "sm_gram_backward")
 

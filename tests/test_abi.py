@@ -10,7 +10,7 @@ from conftest import REPO
 def declared_symbols():
     text = open(os.path.join(REPO, "include", "stylemesh_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(sm_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(sm_\w+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -207,9 +207,12 @@ def test_maxpool_forward_backward(rt, H, W):
 
 
 # ------------------------------------------------------------------ K5 / K6
+@pytest.mark.parametrize("gram_mode", ["f32", "split"])
 @pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False),
-                                           (64, 150, 200, True)])
-def test_gram_style_loss_and_backward(rt, C, H, W, multi):
+                                           (64, 150, 200, True), (512, 12, 17, True), (128, 40, 56, True),
+                                           (256, 33, 41, True)])
+def test_gram_style_loss_and_backward(rt, C, H, W, multi, gram_mode, monkeypatch):
+    monkeypatch.setattr(rt.ops, "GRAM_MODE", gram_mode)
     torch.manual_seed(C + H)
     feat = F.relu(torch.randn(1, C, H, W)).requires_grad_(True)
     m_all = (torch.rand(1, 1, H, W) > 0.3).float()
@@ -253,8 +256,10 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi):
     assert_close(df.to_dense(), feat.grad[0] * (feat.detach()[0] > 0), 1e-4, 2e-5 * float(feat.grad.abs().max()))
 
 
-def test_style_loss_empty_masks(rt):
+@pytest.mark.parametrize("gram_mode", ["f32", "split"])
+def test_style_loss_empty_masks(rt, gram_mode, monkeypatch):
     """N_pass == 0 -> Gram of zeros still compared with the target; N_fail == 0 -> term dropped (:332)."""
+    monkeypatch.setattr(rt.ops, "GRAM_MODE", gram_mode)
     C, H, W = 64, 6, 6
     feat = torch.rand(1, C, H, W)
     Y = torch.randn(C, C); Y = (Y + Y.T) / 2
