@@ -18,10 +18,12 @@ namespace sm {
 constexpr int GRAM_QC = 32;     // positions per LDS chunk
 constexpr int GRAM_LD = 33;     // padded row length: conflict-free column reads
 
-// positions per block: enough blocks to fill the chip (>= ~1500), few enough that the partial slabs stay small
+// positions per block: every block writes its own partial tile (a slab costs C^2 floats of HBM traffic, written here
+// and read back by the reduction), so as few position ranges as still fill the chip: ~512 blocks counting the tile
+// pairs of the split kernel (128-channel tiles) and two masks
 __host__ inline int gram_qb(int C, int n_pos) {
-    const int T = C / 64, pairs = T * (T + 1) / 2;
-    int qb = (int)(((long long)n_pos * pairs) / 1536);
+    const int T = (C % 128 == 0) ? C / 128 : C / 64, pairs = T * (T + 1) / 2;
+    int qb = (int)(((long long)n_pos * pairs * 2 + 511) / 512);
     qb = (qb + GRAM_QC - 1) / GRAM_QC * GRAM_QC;
     return std::max(256, std::min(qb, 4096));
 }

@@ -84,43 +84,104 @@ __global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const 
     out[2 * (size_t)plane + q] = acc2;
 }
 
-__global__ __launch_bounds__(256) void tex_sample_bwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
-                                                             const float* __restrict__ gimg,
-                                                             const float* __restrict__ pixel_weight, int Wp, int plane) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= h * w) return;
-    const int y = i / w, x = i - y * w;
-    const size_t q = (size_t)(y + 1) * Wp + x + 1;
-    float g0 = gimg[q], g1 = gimg[plane + q], g2 = gimg[2 * (size_t)plane + q];
-    if (pixel_weight) {
-        const float pw = pixel_weight[i];
-        g0 *= pw;
-        g1 *= pw;
-        g2 *= pw;
+// K2, tiled: one block = a 16x16 pixel tile of the view. Neighbouring pixels hit neighbouring (coarse layers: the
+// same) texels, and a device-scope atomic costs a fabric transaction whether or not it shares a cache line, so the
+// tile's contributions to one layer are first summed in an LDS window of WS x WS texels anchored at the tile's
+// smallest (x0, y0) (ds_add_f32), and only the window's non-zero texels go to memory - as row-contiguous atomics.
+// Pixels whose 2x2 taps fall outside the window (UV seams, strongly magnified views) use the direct path.
+template <int WS>
+__global__ __launch_bounds__(256) void tex_sample_bwd_tiled_kernel(TexLayers L, const float2* __restrict__ grid, int h,
+                                                                   int w, const float* __restrict__ gimg,
+                                                                   const float* __restrict__ pixel_weight, int Wp,
+                                                                   int plane, int tiles_x) {
+    __shared__ float win[3][WS][WS + 1];
+    __shared__ int bb[2];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x = tx * 16 + (tid & 15), y = ty * 16 + (tid >> 4);
+    bool valid = x < w && y < h;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float2 g = make_float2(0.f, 0.f);
+    if (valid) {
+        const size_t q = (size_t)(y + 1) * Wp + x + 1;
+        g0 = gimg[q]; g1 = gimg[plane + q]; g2 = gimg[2 * (size_t)plane + q];
+        if (pixel_weight) {
+            const float pw = pixel_weight[y * w + x];
+            g0 *= pw; g1 *= pw; g2 *= pw;
+        }
+        valid = !(g0 == 0.f && g1 == 0.f && g2 == 0.f);   // adding zero is a no-op: skip the atomics
+        if (valid) g = grid[y * w + x];
     }
-    if (g0 == 0.f && g1 == 0.f && g2 == 0.f) return;  // adding zero is a no-op: skip the atomics
-    const float2 g = grid[i];
+    if (__syncthreads_or(valid) == 0) return;
+    for (int i = tid; i < 3 * WS * (WS + 1); i += 256) (&win[0][0][0])[i] = 0.f;
     for (int l = 0; l < L.n; ++l) {
         const int W = L.w[l], H = L.h[l];
-        const Taps t = make_taps(g.x, g.y, W, H);
-        float* p = L.p[l] + (size_t)t.y0 * W + t.x0;
         const size_t cs = (size_t)W * H;
-        atomicAdd(p, g0 * t.nw);
-        atomicAdd(p + cs, g1 * t.nw);
-        atomicAdd(p + 2 * cs, g2 * t.nw);
-        if (t.x1_in) {
-            atomicAdd(p + 1, g0 * t.ne);
-            atomicAdd(p + cs + 1, g1 * t.ne);
-            atomicAdd(p + 2 * cs + 1, g2 * t.ne);
+        const Taps t = make_taps(g.x, g.y, W, H);
+        if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = 0x7fffffff; }
+        __syncthreads();   // also orders the previous layer's flush (window re-zeroed) before this layer's adds
+        {   // block minimum of (x0, y0) over the contributing pixels: wave shuffle reduction, one LDS atomic per wave
+            int mx = valid ? t.x0 : 0x7fffffff, my = valid ? t.y0 : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mx = min(mx, __shfl_xor(mx, o, 64));
+                my = min(my, __shfl_xor(my, o, 64));
+            }
+            if ((tid & 63) == 0) { atomicMin(&bb[0], mx); atomicMin(&bb[1], my); }
         }
-        if (t.y1_in) {
-            atomicAdd(p + W, g0 * t.sw);
-            atomicAdd(p + cs + W, g1 * t.sw);
-            atomicAdd(p + 2 * cs + W, g2 * t.sw);
-            if (t.x1_in) {
-                atomicAdd(p + W + 1, g0 * t.se);
-                atomicAdd(p + cs + W + 1, g1 * t.se);
-                atomicAdd(p + 2 * cs + W + 1, g2 * t.se);
+        __syncthreads();
+        const int wx = bb[0], wy = bb[1];
+        if (valid) {
+            const int dx = t.x0 - wx, dy = t.y0 - wy;
+            if (dx + 1 < WS && dy + 1 < WS) {
+                atomicAdd(&win[0][dy][dx], g0 * t.nw);
+                atomicAdd(&win[1][dy][dx], g1 * t.nw);
+                atomicAdd(&win[2][dy][dx], g2 * t.nw);
+                if (t.x1_in) {
+                    atomicAdd(&win[0][dy][dx + 1], g0 * t.ne);
+                    atomicAdd(&win[1][dy][dx + 1], g1 * t.ne);
+                    atomicAdd(&win[2][dy][dx + 1], g2 * t.ne);
+                }
+                if (t.y1_in) {
+                    atomicAdd(&win[0][dy + 1][dx], g0 * t.sw);
+                    atomicAdd(&win[1][dy + 1][dx], g1 * t.sw);
+                    atomicAdd(&win[2][dy + 1][dx], g2 * t.sw);
+                    if (t.x1_in) {
+                        atomicAdd(&win[0][dy + 1][dx + 1], g0 * t.se);
+                        atomicAdd(&win[1][dy + 1][dx + 1], g1 * t.se);
+                        atomicAdd(&win[2][dy + 1][dx + 1], g2 * t.se);
+                    }
+                }
+            } else {
+                float* p = L.p[l] + (size_t)t.y0 * W + t.x0;
+                atomicAdd(p, g0 * t.nw);
+                atomicAdd(p + cs, g1 * t.nw);
+                atomicAdd(p + 2 * cs, g2 * t.nw);
+                if (t.x1_in) {
+                    atomicAdd(p + 1, g0 * t.ne);
+                    atomicAdd(p + cs + 1, g1 * t.ne);
+                    atomicAdd(p + 2 * cs + 1, g2 * t.ne);
+                }
+                if (t.y1_in) {
+                    atomicAdd(p + W, g0 * t.sw);
+                    atomicAdd(p + cs + W, g1 * t.sw);
+                    atomicAdd(p + 2 * cs + W, g2 * t.sw);
+                    if (t.x1_in) {
+                        atomicAdd(p + W + 1, g0 * t.se);
+                        atomicAdd(p + cs + W + 1, g1 * t.se);
+                        atomicAdd(p + 2 * cs + W + 1, g2 * t.se);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush the window (and re-zero it for the next layer): consecutive threads -> consecutive texels of a row
+        for (int i = tid; i < 3 * WS * WS; i += 256) {
+            const int c = i / (WS * WS), r = i - c * WS * WS, yy = r / WS, xx = r - yy * WS;
+            const float v = win[c][yy][xx];
+            if (v != 0.f) {
+                win[c][yy][xx] = 0.f;
+                atomicAdd(L.p[l] + c * cs + (size_t)(wy + yy) * W + wx + xx, v);   // inside the texture: taps were
             }
         }
     }
@@ -260,10 +321,10 @@ int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* 
                       void* stream) {
     if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS) return (int)hipErrorInvalidValue;
     sm::TexLayers L = sm::make_layers(grad_layers, layer_w, layer_h, n_layers);
-    const int n = h * w;
-    hipLaunchKernelGGL(sm::tex_sample_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L,
-                       reinterpret_cast<const float2*>(grid), h, w, grad_img, pixel_weight, sm::row_stride(w),
-                       sm::plane_size(h, w));
+    const int tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
+    hipLaunchKernelGGL(sm::tex_sample_bwd_tiled_kernel<32>, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream,
+                       L, reinterpret_cast<const float2*>(grid), h, w, grad_img, pixel_weight, sm::row_stride(w),
+                       sm::plane_size(h, w), tiles_x);
     SM_LAUNCH_CHECK();
     return 0;
 }

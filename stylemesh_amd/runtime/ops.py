@@ -19,9 +19,10 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (start_event, end_event, algorithmic_work, tag)
         self.bytes = {}     # tag -> algorithmic HBM bytes of the timed launches
+        self.info = []      # per record: free-form description of the launch (diagnostics)
         self.enabled = True
 
-    def launch(self, fn, work, tag="f32", nbytes=0.0):
+    def launch(self, fn, work, tag="f32", nbytes=0.0, info=""):
         if not self.enabled:
             return fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +30,7 @@ class KernelTimer:
         fn()
         b.record()
         self.records.append((a, b, work, tag))
+        self.info.append(info)
         self.bytes[tag] = self.bytes.get(tag, 0.0) + nbytes
 
     def summary(self, tag=None):
@@ -193,7 +195,8 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         run()
     else:   # algorithmic FLOPs of the tiles actually required
         wbytes = wt3.numel() * 2 if use_split else wt.numel() * 4
-        CONV_TIMER.launch(run, flops * active_fraction, "split" if use_split else "f32", nbytes * active_fraction + wbytes)
+        CONV_TIMER.launch(run, flops * active_fraction, "split" if use_split else "f32", nbytes * active_fraction + wbytes,
+                          f"{cin_pad:3d}->{cout:3d} flags {flags} levels {len(problems)} active {active_fraction:.2f}")
 
 
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):
