@@ -95,6 +95,8 @@ def main():
                     "can influence the loss (stylemesh_amd/runtime/sparsity.py); results are identical")
     ap.add_argument("--graphs", action="store_true", help="replay the captured hipGraph of the step instead of launching "
                     "its ~150 kernels eagerly (measured: no gain, the step is GPU-bound; event-timed steps run eagerly)")
+    ap.add_argument("--overlap-style", action="store_true", help="run the style branches (Gram -> loss -> Gram backward) "
+                    "on a side stream concurrently with the conv trunk")
     ap.add_argument("--timer-every", type=int, default=10, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
                     "of the throughput, so the roofline is sampled)")
@@ -124,6 +126,7 @@ def main():
     eng.set_style_image(S.style_image(1, *STYLE_HW))
     eng.use_graphs = args.graphs
     eng.sparse_tiles = not args.dense
+    eng.overlap_style = args.overlap_style
 
     # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
     total_steps = args.warmup + args.steps

@@ -25,12 +25,25 @@
 #pragma once
 #include "conv_common.h"
 
-// tuning knobs (A/B builds: build.sh -DSM_SPLIT_AD=1 ...)
+// tuning knobs (A/B builds: build.sh -DSM_SPLIT_AD=1 ..., compared with tools/ab_libs.sh). Measured on c3 / the layer
+// micro-benchmark, relative to the defaults (187-190 TFLOP/s): AD=1 -22 %; no fragment prefetch -5 %; 3 waves per
+// SIMD (AD=1, no prefetch, 168 VGPRs) -14 %; PIN_READS=1 (fragment reads pinned a full stage ahead: the densest
+// MFMA stream, 245 VGPRs) -8 %; any s_setprio (MFMA cluster or the load/convert tail) -9 %: each of them fences the
+// compiler's own interleaving of the tail instructions with the MFMAs.
 #ifndef SM_SPLIT_AD
 #define SM_SPLIT_AD 3          // weight prefetch distance in stages (must divide 9)
 #endif
 #ifndef SM_SPLIT_PREFETCH_B
 #define SM_SPLIT_PREFETCH_B 1  // read the next stage's activation fragments under this stage's MFMAs
+#endif
+#ifndef SM_SPLIT_PIN_READS
+#define SM_SPLIT_PIN_READS 0
+#endif
+#ifndef SM_SPLIT_TAIL_PRIO
+#define SM_SPLIT_TAIL_PRIO 0
+#endif
+#ifndef SM_SPLIT_MFMA_PRIO
+#define SM_SPLIT_MFMA_PRIO 0
 #endif
 #ifndef SM_SPLIT_WAVES
 #define SM_SPLIT_WAVES 2       // resident waves per SIMD the register budget is set for
@@ -215,6 +228,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
 #else
             SM_READ_B(fb, (base + ky) & 3, kx)
 #endif
+#if SM_SPLIT_PIN_READS
+            // keep the fragment reads HERE, a full stage ahead of their use: left alone, the scheduler sinks them to the
+            // end of the stage (shorter live ranges) and the next stage's first MFMAs wait out the LDS round trip
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             bf16x8 fa[MI][3];
 #pragma unroll
             for (int s = 0; s < 3; ++s)
@@ -225,6 +243,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
+#if SM_SPLIT_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(SM_SPLIT_MFMA_PRIO);
+#endif
             SM_PRODUCT(2, 0)
             SM_PRODUCT(0, 2)
             SM_PRODUCT(1, 1)
@@ -235,6 +256,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
             __builtin_amdgcn_sched_barrier(0);
+#if SM_SPLIT_TAIL_PRIO
+            __builtin_amdgcn_s_setprio(SM_SPLIT_TAIL_PRIO);   // the load / convert / store tail outranks the partner's MFMAs
+#elif SM_SPLIT_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (tap + AD < 9) {
                 SM_LOAD_A(tap + AD, ch);
             } else {
@@ -248,6 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
                 SM_STORE_B((base + 3 + ky) & 3);
                 __syncthreads();
             }
+#if SM_SPLIT_TAIL_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #if SM_SPLIT_PREFETCH_B
 #pragma unroll
             for (int s = 0; s < 3; ++s)

@@ -23,7 +23,8 @@ constexpr int GRAM_LD = 33;     // padded row length: conflict-free column reads
 // pairs of the split kernel (128-channel tiles) and two masks
 __host__ inline int gram_qb(int C, int n_pos) {
     const int T = (C % 128 == 0) ? C / 128 : C / 64, pairs = T * (T + 1) / 2;
-    int qb = (int)(((long long)n_pos * pairs * 2 + 511) / 512);
+    const int target = C <= 64 ? 2048 : (C <= 128 ? 768 : 512);   // thin layers: slabs are small, ranges are latency-bound
+    int qb = (int)(((long long)n_pos * pairs * 2 + target - 1) / target);
     qb = (qb + GRAM_QC - 1) / GRAM_QC * GRAM_QC;
     return std::max(256, std::min(qb, 4096));
 }
