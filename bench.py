@@ -97,6 +97,8 @@ def main():
                     "its ~150 kernels eagerly (measured: no gain, the step is GPU-bound; event-timed steps run eagerly)")
     ap.add_argument("--overlap-style", action="store_true", help="run the style branches (Gram -> loss -> Gram backward) "
                     "on a side stream concurrently with the conv trunk")
+    ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole gradient arena instead of "
+                    "only the chunks the ranks' current views can touch")
     ap.add_argument("--timer-every", type=int, default=10, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
                     "of the throughput, so the roofline is sampled)")
@@ -108,12 +110,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    # STYLEMESH_DIST_BACKEND=gloo: functional test of the N > 1 protocol on a 1-GPU box (all ranks share cuda:0)
+    backend = os.environ.get("STYLEMESH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from stylemesh_amd.runtime import ops
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
@@ -138,8 +147,8 @@ def main():
     views = [to_device(v, dev) for v in views_cpu]
     schedule = [views[(i // wl["index_repeat"]) % len(views)] for i in range(total_steps)]
 
-    from stylemesh_amd.runtime.distributed import make_grad_reducer
-    reducer = make_grad_reducer(dist, world)
+    from stylemesh_amd.runtime.distributed import make_grad_reducer, make_sparse_grad_reducer
+    reducer = make_grad_reducer(dist, world) if args.dense_allreduce else make_sparse_grad_reducer(dist, world)
 
     def barrier():
         if world > 1:
@@ -213,7 +222,10 @@ def main():
                           "active_uv_levels": active_levels, "views_per_step": world,
                           "index_repeat": wl["index_repeat"], "style_image": f"synthetic {STYLE_HW[1]}x{STYLE_HW[0]}",
                           "vgg_weights": "He-normal, seeded", "parallelism": f"views sharded over {world} rank(s)"
-                          + (", RCCL all-reduce of the 267 MB texture gradient per step" if world > 1 else "")},
+                          + ((", RCCL all-reduce of the 267 MB texture gradient per step" if args.dense_allreduce else
+                              f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
+                              f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)")
+                             if world > 1 else "")},
                "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()}}
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)

@@ -58,6 +58,14 @@ int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* 
                       const float* grid, int h, int w, const float* grad_img, const float* pixel_weight,
                       void* stream);
 
+/* Multi-GPU helper (SURVEY.md section 8 e; the reference is single-GPU): sets flags[k] = 1 for every chunk k of
+ * 2^chunk_log2 floats of the flat gradient arena (starting at arena_base; grad_layers point into it) that
+ * sm_tex_sample_bwd can write for this grid / pixel_weight - a superset of the chunks it does write. flags is NOT
+ * cleared here. Evaluated once per view: the gradient exchange then covers only flagged chunks. */
+int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
+                       const float* arena_base, const float* grid, int h, int w, const float* pixel_weight,
+                       int32_t* flags, int chunk_log2, void* stream);
+
 /* K7. torch.optim.Adam.step (model/model.py:387-395) fused with the analytic gradient of
  * HierarchicalNeuralTexture.regularizer (texture.py:102-108: g += reg_coef[seg] * p), the next forward's
  * normalize() clamp (texture.py:41-44), zeroing of the gradient for the next step, and the reduction

@@ -187,6 +187,35 @@ __global__ __launch_bounds__(256) void tex_sample_bwd_tiled_kernel(TexLayers L, 
     }
 }
 
+// Which chunks of the gradient arena can a view's scatter write? One flag per 2^chunk_log2 floats, set for every
+// texel any tap of a contributing pixel (pixel_weight != 0) lands on. Depends only on the view's UV grid and weights,
+// so it is evaluated once per view; the multi-GPU path exchanges only the flagged chunks (runtime/distributed.py).
+__global__ __launch_bounds__(256) void tex_touch_flags_kernel(TexLayers L, const float* base,
+                                                              const float2* __restrict__ grid, int h, int w,
+                                                              const float* __restrict__ pixel_weight, int* flags,
+                                                              int chunk_log2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    if (pixel_weight && pixel_weight[i] == 0.f) return;
+    const float2 g = grid[i];
+    for (int l = 0; l < L.n; ++l) {
+        const int W = L.w[l], H = L.h[l];
+        const size_t cs = (size_t)W * H;
+        const Taps t = make_taps(g.x, g.y, W, H);
+        const size_t o = (size_t)(L.p[l] - base) + (size_t)t.y0 * W + t.x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t oc = o + c * cs;
+            flags[oc >> chunk_log2] = 1;
+            if (t.x1_in) flags[(oc + 1) >> chunk_log2] = 1;
+            if (t.y1_in) {
+                flags[(oc + W) >> chunk_log2] = 1;
+                if (t.x1_in) flags[(oc + W + 1) >> chunk_log2] = 1;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K7 fused update over the whole texture arena (all layers back to back), float4 per thread.
 // ---------------------------------------------------------------------------------------------------
@@ -325,6 +354,18 @@ int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* 
     hipLaunchKernelGGL(sm::tex_sample_bwd_tiled_kernel<32>, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream,
                        L, reinterpret_cast<const float2*>(grid), h, w, grad_img, pixel_weight, sm::row_stride(w),
                        sm::plane_size(h, w), tiles_x);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
+                       const float* arena_base, const float* grid, int h, int w, const float* pixel_weight,
+                       int32_t* flags, int chunk_log2, void* stream) {
+    if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS || chunk_log2 < 4 || chunk_log2 > 24) return (int)hipErrorInvalidValue;
+    sm::TexLayers L = sm::make_layers(grad_layers, layer_w, layer_h, n_layers);
+    const int n = h * w;
+    hipLaunchKernelGGL(sm::tex_touch_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L,
+                       arena_base, reinterpret_cast<const float2*>(grid), h, w, pixel_weight, flags, chunk_log2);
     SM_LAUNCH_CHECK();
     return 0;
 }

@@ -39,7 +39,8 @@ class SyntheticSceneDataModule:
         return self._cache[i]
 
     def train_dataloader(self):
-        mine = self.train_indices[self.rank::self.world_size]
+        from ..runtime.distributed import padded_shard
+        mine = padded_shard(self.train_indices, self.rank, self.world_size)   # equal step counts on every rank
         order = RepeatingSampler(mine, self.index_repeat) if self.sampler_mode == "repeat" else mine
         return (self._view(i) for i in order)
 

@@ -168,7 +168,8 @@ class ScanNetSingleSceneDataModule:
         self.train_indices, self.val_indices = list(range(n_train)), list(range(n_train, n))
 
     def train_dataloader(self):
-        mine = self.train_indices[self.rank::self.world_size]
+        from ..runtime.distributed import padded_shard
+        mine = padded_shard(self.train_indices, self.rank, self.world_size)   # equal step counts on every rank
         order = vc.RepeatingSampler(mine, self.index_repeat) if self.sampler_mode == "repeat" else mine
         return (self.train_dataset[i] for i in order)
 

@@ -256,6 +256,8 @@ class TextureOptimizationStyleTransferPipeline(_Base):
         key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
         if eng.view is None or key != eng.view_key:
             eng.set_view(batch)
+            if self.grad_reducer is not None and hasattr(self.grad_reducer, "new_view"):
+                self.grad_reducer.new_view(eng.touch_flags(self.grad_reducer.chunk_log2))   # collective, per view
         for p, g in zip(self._texture_params(), eng.grads):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():   # a foreign optimizer dropped / replaced .grad
                 eng.arena.g.zero_()

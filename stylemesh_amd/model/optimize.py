@@ -108,8 +108,8 @@ def main(args):
         tex_reg_weights=args.tex_reg_weights, decay_gamma=args.decay_gamma, decay_step_size=args.decay_step_size,
         loss_weights=args.loss_weights, extra_args=vars(args), log_images_nth=args.log_images_nth,
         save_texture=args.save_texture and rank == 0, texture_dir=log_dir)
-    from ..runtime.distributed import make_grad_reducer
-    model.grad_reducer = make_grad_reducer(dist, world)
+    from ..runtime.distributed import make_sparse_grad_reducer
+    model.grad_reducer = make_sparse_grad_reducer(dist, world)
 
     trainer = MiniTrainer(max_epochs=args.max_epochs, logger=logger, device=device, rank=rank, world_size=world)
     trainer.fit(model, dm)

@@ -1,7 +1,8 @@
 """Multi-GPU protocol of the view-sharded path (SURVEY.md section 8 e): one process per GPU, views of the scene
-shard over ranks, ONE exchange per step - a sum all-reduce of the flat texture-gradient arena (RCCL over xGMI on
-the GPU box: ``torch.distributed`` backend "nccl"; "gloo" in the CPU tests) - then the identical fused update on
-every rank with ``grad_scale = 1 / world_size`` (DDP-mean semantics).
+shard over ranks, ONE exchange per step - a sum all-reduce of the flat texture-gradient arena, restricted to the
+chunks the ranks' current views can touch (``SparseGradReducer``; RCCL over xGMI on the GPU box: ``torch.distributed``
+backend "nccl"; "gloo" in the CPU tests) - then the identical fused update on every rank with
+``grad_scale = 1 / world_size`` (DDP-mean semantics).
 
 Nothing here touches the kernels; it is the host logic around them, testable without a GPU.
 """
@@ -20,6 +21,16 @@ def shard_views(indices, rank: int, world_size: int):
     return list(indices)[rank::world_size]
 
 
+def padded_shard(indices, rank: int, world_size: int):
+    """``shard_views`` padded (by repeating the last view) to ceil(n / R) entries: every rank then takes the same
+    number of steps and changes views at the same steps - every step contains a collective."""
+    mine = shard_views(indices, rank, world_size)
+    per_rank = -(-len(list(indices)) // world_size)
+    if not mine:
+        raise ValueError("more ranks than views")
+    return mine + [mine[-1]] * (per_rank - len(mine))
+
+
 def steps_per_epoch(n_views: int, index_repeat: int, world_size: int) -> int:
     """All ranks must take the same number of steps (every step contains a collective): ranks with one view
     fewer repeat their last view."""
@@ -29,13 +40,7 @@ def steps_per_epoch(n_views: int, index_repeat: int, world_size: int) -> int:
 
 def rank_schedule(indices, rank, world_size, index_repeat):
     """View index per step for this rank, padded so that every rank has ``steps_per_epoch`` entries."""
-    mine = shard_views(indices, rank, world_size)
-    per_rank = -(-len(list(indices)) // world_size)
-    if not mine:
-        raise ValueError("more ranks than views")
-    while len(mine) < per_rank:
-        mine.append(mine[-1])
-    return [v for v in mine for _ in range(index_repeat)]
+    return [v for v in padded_shard(indices, rank, world_size) for _ in range(index_repeat)]
 
 
 def make_grad_reducer(dist_module, world_size: int):
@@ -46,3 +51,52 @@ def make_grad_reducer(dist_module, world_size: int):
     def reduce(flat_grad):
         dist_module.all_reduce(flat_grad, op=dist_module.ReduceOp.SUM)
     return reduce
+
+
+class SparseGradReducer:
+    """SUM all-reduce of the gradient arena restricted to the chunks any rank's current view can touch.
+
+    A view writes gradient only where its UV maps land (a few % - tens of % of a 4096^2 hierarchical texture), and
+    which chunks those are depends only on the view, not on the step: ``new_view(flags)`` (a collective, once per
+    view change - the ranks' schedules change views in lock-step, ``rank_schedule``) max-reduces the per-rank touch
+    flags and keeps the index list; every step then gathers the flagged chunks into a compact buffer, all-reduces
+    that, and copies the sums back. Untouched chunks are zero on every rank and stay zero. Falls back to the dense
+    all-reduce when most chunks are dirty or the arena is not a whole number of chunks. Chunks are 64 floats (256 B):
+    a view's footprint is a 2-D blob of scattered texels in row-major planes, so 4 KB chunks flag 49 % of the arena
+    where 256 B chunks flag 14-24 % (exact non-zero fraction 8-11 %; bench views, tools/touch_fraction.py).
+    """
+
+    def __init__(self, dist_module, world_size: int, chunk_log2: int = 6, dense_above: float = 0.75):
+        self.dist, self.world, self.chunk_log2, self.dense_above = dist_module, world_size, chunk_log2, dense_above
+        self.idx = None
+        self.fraction = 1.0
+        self.last_bytes = 0
+
+    @property
+    def chunk(self):
+        return 1 << self.chunk_log2
+
+    def n_chunks(self, numel: int) -> int:
+        return -(-numel // self.chunk)
+
+    def new_view(self, flags):
+        """``flags``: int32 [n_chunks], non-zero where THIS rank's view can write. Collective."""
+        self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
+        self.idx = flags.nonzero().flatten()          # one host sync per view change
+        self.fraction = self.idx.numel() / max(flags.numel(), 1)
+
+    def __call__(self, flat_grad):
+        n = flat_grad.numel()
+        if self.idx is None or self.fraction > self.dense_above or n % self.chunk != 0:
+            self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM)
+            self.last_bytes = 4 * n
+            return
+        g2 = flat_grad.view(-1, self.chunk)
+        buf = g2.index_select(0, self.idx)
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+        g2.index_copy_(0, self.idx, buf)
+        self.last_bytes = 4 * buf.numel()
+
+
+def make_sparse_grad_reducer(dist_module, world_size: int, **kw):
+    return None if world_size <= 1 else SparseGradReducer(dist_module, world_size, **kw)

@@ -582,12 +582,23 @@ class StepEngine:
         key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
         if self.view is None or key != self.view_key:
             self.set_view(batch)
+            if reducer is not None and hasattr(reducer, "new_view"):
+                reducer.new_view(self.touch_flags(reducer.chunk_log2))
         losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         self.step_forward_backward()
         if reducer is not None:
             reducer(self.arena.g)
         self.optimizer_step(world_size)
         return losses
+
+    def touch_flags(self, chunk_log2: int):
+        """int32 flag per 2^chunk_log2 floats of the gradient arena: can the current view's scatter write there?"""
+        n_chunks = -(-self.arena.n // (1 << chunk_log2))
+        flags = torch.zeros(n_chunks, dtype=torch.int32, device=self.device)
+        for lv in self.view:
+            if lv.active:
+                ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, flags, chunk_log2)
+        return flags
 
     def loss_tensors(self):
         """Weighted losses as device tensors, names as the reference logs them (model/model.py:261-270).

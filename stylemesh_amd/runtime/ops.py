@@ -107,6 +107,18 @@ def tex_sample_bwd(grad_layers, grid: torch.Tensor, grad_img: FMap, pixel_weight
                                     h, w, grad_img.ptr, ptr(pixel_weight), hip.stream()), "sm_tex_sample_bwd")
 
 
+def tex_touch_flags(grad_layers, arena_grad: torch.Tensor, grid: torch.Tensor, pixel_weight, flags: torch.Tensor,
+                    chunk_log2: int):
+    """ORs into ``flags`` (int32, one per 2^chunk_log2 floats of the flat gradient arena) the chunks that
+    ``tex_sample_bwd`` can write for this view level."""
+    h, w = grid.shape[-3], grid.shape[-2]
+    assert flags.dtype == torch.int32 and flags.numel() * (1 << chunk_log2) >= arena_grad.numel()
+    hip.check(lib.sm_tex_touch_flags(hip.ptr_array(grad_layers), hip.int_array([l.shape[2] for l in grad_layers]),
+                                     hip.int_array([l.shape[1] for l in grad_layers]), len(grad_layers),
+                                     ptr(arena_grad), ptr(grid), h, w, ptr(pixel_weight), ptr(flags), chunk_log2,
+                                     hip.stream()), "sm_tex_touch_flags")
+
+
 def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
     """The two step-dependent fp32 scalars of the update, computed in double as torch does:
     (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t))."""

@@ -67,3 +67,40 @@ def test_two_rank_gloo_mean_gradient_step(tmp_path):
         assert torch.equal(r0["layers"][i], r1["layers"][i])          # every rank applies the identical update
         bad = (r0["layers"][i] - torch.from_numpy(d[f"p{i}_after"])).abs() > 2e-3
         assert bad.sum() <= max(3, 2e-3 * bad.numel())
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = D.make_sparse_grad_reducer(dist, world, chunk_log2=4)
+    g = torch.Generator().manual_seed(100 + rank)
+    n_chunks, chunk = 64, 16
+    out = {}
+    for view in range(2):                                   # two "views": the dirty set changes between them
+        touched = torch.rand(n_chunks, generator=g) < (0.2 if view == 0 else 0.9)   # view 1 -> dense fallback
+        flags = touched.to(torch.int32)
+        red.new_view(flags)
+        for step in range(2):
+            arena = torch.zeros(n_chunks, chunk)
+            arena[touched] = torch.randn(int(touched.sum()), chunk, generator=g)
+            arena = arena.reshape(-1)
+            dense = arena.clone()
+            dist.all_reduce(dense)
+            red(arena)
+            out[(view, step)] = (arena.clone(), dense, red.fraction, red.last_bytes)
+    torch.save(out, os.path.join(out_dir, f"sparse{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sparse_grad_reducer_equals_dense_allreduce(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_sparse_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"sparse{r}.pt") for r in (0, 1))
+    for key in r0:
+        mine, dense, frac, nbytes = r0[key]
+        assert torch.equal(mine, dense) and torch.equal(mine, r1[key][0])
+        if key[0] == 0:
+            assert frac < 0.6 and nbytes == int(round(frac * 64)) * 16 * 4      # only the dirty chunks travelled
+        else:
+            assert nbytes == 64 * 16 * 4                                        # mostly dirty: dense fallback

@@ -206,6 +206,27 @@ def test_maxpool_forward_backward(rt, H, W):
     assert dact.border_is_zero()
 
 
+def test_touch_flags_cover_the_scatter(rt):
+    """Every chunk of the gradient arena that the scatter writes is flagged (the flags are a superset)."""
+    torch.manual_seed(11)
+    sizes = [(3, 64, 64), (3, 32, 32)]
+    arena = torch.zeros(sum(c * h * w for c, h, w in sizes)).cuda()
+    layers, o = [], 0
+    for c, h, w in sizes:
+        layers.append(arena[o:o + c * h * w].view(c, h, w)); o += c * h * w
+    H, W = 23, 31
+    grid = (torch.rand(1, H, W, 2) * 0.9 - 0.3).cuda()      # a corner of the texture, incl. border hits
+    pw = (torch.rand(H, W) > 0.5).float().cuda()
+    gimg = rt.FMap(3, H, W).from_dense(torch.randn(3, H, W))
+    rt.ops.tex_sample_bwd(layers, grid, gimg, pw)
+    chunk_log2 = 4
+    flags = torch.zeros((arena.numel() + 15) // 16, dtype=torch.int32).cuda()
+    rt.ops.tex_touch_flags(layers, arena, grid, pw, flags, chunk_log2)
+    written = (arena.view(-1, 16) != 0).any(1)
+    assert bool((flags.bool() | ~written).all())
+    assert 0 < int(flags.sum()) < flags.numel()             # and it is not trivially everything
+
+
 # ------------------------------------------------------------------ K5 / K6
 @pytest.mark.parametrize("gram_mode", ["f32", "split"])
 @pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False),
