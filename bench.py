@@ -99,7 +99,7 @@ def main():
                     "on a side stream concurrently with the conv trunk")
     ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole gradient arena instead of "
                     "only the chunks the ranks' current views can touch")
-    ap.add_argument("--timer-every", type=int, default=10, help="HIP-event-time the conv launches of every n-th timed "
+    ap.add_argument("--timer-every", type=int, default=20, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
                     "of the throughput, so the roofline is sampled)")
     args = ap.parse_args()

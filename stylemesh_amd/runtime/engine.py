@@ -144,6 +144,11 @@ class StepEngine:
         # idle CUs and no LDS for co-resident blocks), so it is off by default.
         self.overlap_style = False
         self._side = None
+        # the loss branches of the UV levels (5 x [Gram -> loss -> Gram backward] + content MSE each, ~25 small
+        # launches per level) are independent: one HIP stream per level lets the small levels' latency-bound kernels
+        # run beside the large level's instead of after them
+        self.level_streams = True
+        self._lv_streams = []
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
@@ -392,8 +397,31 @@ class StepEngine:
         else:
             self.vgg.forward_group(bufs, self.view_tiles)
             injected = set()
-            for lv, b in zip(active, bufs):
-                injected = self._inject_losses(lv, b, w_style, w_content)
+            concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
+                          and not torch.cuda.is_current_stream_capturing())
+            if concurrent:
+                main = torch.cuda.current_stream()
+                while len(self._lv_streams) < len(active) - 1:
+                    self._lv_streams.append(torch.cuda.Stream(device=self.device))
+                fork = torch.cuda.Event()
+                fork.record(main)
+                joins = []
+                # largest level stays on the main stream, the others fork
+                order = sorted(range(len(active)), key=lambda k: -active[k].H * active[k].W)
+                for n, k in enumerate(order[1:]):
+                    st = self._lv_streams[n]
+                    st.wait_event(fork)
+                    with torch.cuda.stream(st):
+                        injected = self._inject_losses(active[k], bufs[k], w_style, w_content)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        joins.append(ev)
+                injected = self._inject_losses(active[order[0]], bufs[order[0]], w_style, w_content)
+                for ev in joins:
+                    main.wait_event(ev)
+            else:
+                for lv, b in zip(active, bufs):
+                    injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
         for lv, b in zip(active, bufs):
             ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
