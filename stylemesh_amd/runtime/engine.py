@@ -368,25 +368,28 @@ class StepEngine:
             # only has to finish before the backward pass reaches that layer: fork it onto a side stream right
             # after the layer's forward conv and join right before the dgrad that consumes grad[layer].
             main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+            while len(self._lv_streams) < len(active):
+                self._lv_streams.append(torch.cuda.Stream(device=self.device))
             done = {}
 
-            def fork(layer):
+            def fork(layer):   # one side stream per UV level
                 if layer not in side_layers:
                     return
                 ev = torch.cuda.Event()
                 ev.record(main)
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(ev)
-                    for lv, b in zip(active, bufs):
+                done[layer] = []
+                for k, (lv, b) in enumerate(zip(active, bufs)):
+                    st = self._lv_streams[k]
+                    st.wait_event(ev)
+                    with torch.cuda.stream(st):
                         self._style_terms(lv, b, cfg.style_layers.index(layer), layer, w_style)
-                    done[layer] = torch.cuda.Event()
-                    done[layer].record(self._side)
+                        e2 = torch.cuda.Event()
+                        e2.record(st)
+                        done[layer].append(e2)
 
             def join(layer):
-                if layer in done:
-                    main.wait_event(done.pop(layer))
+                for e2 in done.pop(layer, []):
+                    main.wait_event(e2)
             self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork)
             injected = set(side_layers)
             for lv, b in zip(active, bufs):
