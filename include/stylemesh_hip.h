@@ -246,6 +246,22 @@ int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void*
  * comm is an ncclComm_t owned by the caller. Returns a ncclResult_t (0 = success). */
 int sm_allreduce_grad(void* comm, float* g, size_t n, void* stream);
 
+/* ---- E1: multi-view consistency metric --------------------------------------- */
+
+/* reproject() of data/utils.py:73-194 + the masked squared error of scripts/eval/eval_image_folders.py:286-305 for
+ * one view pair: every source pixel is un-projected with depth_src, moved by src2tar (HOST, 4x4 row-major fp32 =
+ * inverse(cam2world_tar) * cam2world_src), projected with intrinsics (HOST: fx, fy, cx, cy) and rejected when its
+ * depth is 0, it lands outside [0,W-1) x [0,H-1), none of the 4 neighbouring target depths is within depth_tol
+ * (reference: 0.1) of its target-space z, or the bilinearly warped mask_tar (float 0/1) is <= 0.99. Dense [H][W] /
+ * [3][H][W] fp32 images (not padded planes). color_out = warped color_tar (0 where rejected), mask_out = uint8
+ * validity; if styled_src is given, partial[2 b] / partial[2 b + 1] (DEVICE doubles, sm_reproject_blocks(H,W)
+ * pairs) receive block b's sum of squared differences styled_src - color_out over valid pixels and the number
+ * of summed elements (3 per valid pixel): MSE of the pair = sum / count. */
+int sm_reproject_blocks(int H, int W);
+int sm_reproject(const float* src2tar, const float* intrinsics, int H, int W, const float* depth_src,
+                 const float* depth_tar, const float* color_tar, const float* mask_tar, const float* styled_src,
+                 float* color_out, uint8_t* mask_out, double* partial, float depth_tol, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -477,3 +477,69 @@ class OraclePipeline:
 
     def end_epoch(self):
         self.epoch += 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# Reprojection warp of the evaluation metric (reference data/utils.py:36-194,
+# scripts/eval/eval_image_folders.py:286-330). Explicit index arithmetic, one view pair (B = 1).
+# ---------------------------------------------------------------------------------------------------
+def unproject_explicit(cam2world: torch.Tensor, K: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
+    """World-space points [H,W,4] of a depth map [H,W] (reference data/utils.py:36-70; the reference multiplies row
+    vectors with the matrix it is given, so its caller passes cam2world transposed - here: the plain matrix)."""
+    H, W = depth.shape
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    x = (xx - K[0, 2]) / K[0, 0] * depth
+    y = (yy - K[1, 2]) / K[1, 1] * depth
+    pts = torch.stack([x, y, depth, torch.ones_like(depth)], -1)
+    return (pts.reshape(-1, 4) @ cam2world.T).reshape(H, W, 4)
+
+
+def _unnormalize_align_corners(g, size):
+    return (g + 1.0) / 2.0 * (size - 1)
+
+
+def grid_sample_nearest_border_explicit(img: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor) -> torch.Tensor:
+    """``F.grid_sample(img[None], grid, mode='nearest', padding_mode='border', align_corners=True)`` for img [C,H,W]
+    and normalised coordinates gx, gy [h,w]: clip the source coordinate to the border, then round half to even."""
+    C, H, W = img.shape
+    ix = _unnormalize_align_corners(gx, W).clamp(0, W - 1)
+    iy = _unnormalize_align_corners(gy, H).clamp(0, H - 1)
+    xi = torch.round(ix).long().clamp(0, W - 1)      # torch.round = nearbyint (half to even), as ATen
+    yi = torch.round(iy).long().clamp(0, H - 1)
+    return img[:, yi, xi]
+
+
+def reproject_explicit(c2w_src, c2w_tar, K, depth_src, depth_tar, color_tar, mask_tar, depth_tol=0.1):
+    """``reproject`` (reference data/utils.py:73-194) for one pair: warp the target view's image into the source view
+    through the source depth. Returns (color [3,H,W], mask bool [H,W]); the colour is zero outside the mask.
+    Every source pixel is un-projected with its depth, moved into the target camera, projected, and rejected when
+    (0) its depth is 0, (1) it lands outside [0, W-1) x [0, H-1), (2) none of the 4 surrounding target depths is
+    within ``depth_tol`` of its own target-space z, or the bilinearly sampled target validity mask is <= 0.99.
+    Note the reference's pixel -> grid mapping ``2 x / W - 1`` (not W - 1) under align_corners=True: the sampled
+    location is x (W - 1) / W."""
+    H, W = depth_src.shape
+    f32 = torch.float32
+    src2tar = torch.linalg.inv(c2w_tar.to(f32)) @ c2w_src.to(f32)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=f32), torch.arange(W, dtype=f32), indexing="ij")
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    x = (xx - cx) / fx * depth_src
+    y = (yy - cy) / fy * depth_src
+    pts = torch.stack([x, y, depth_src, torch.ones_like(depth_src)], -1).reshape(-1, 4)
+    pts = (pts @ src2tar.T).reshape(H, W, 4)
+    z = pts[..., 2]
+    px = pts[..., 0] / (1e-8 + z) * fx + cx
+    py = pts[..., 1] / (1e-8 + z) * fy + cy
+    bad = (depth_src == 0) | (px < 0) | (py < 0) | (px >= W - 1) | (py >= H - 1)
+    lx, ly = torch.floor(px), torch.floor(py)
+    grid = lambda a, b: (2.0 * a / W - 1.0, 2.0 * b / H - 1.0)
+    dz = []
+    for a, b in ((lx, ly), (lx, ly + 1), (lx + 1, ly), (lx + 1, ly + 1)):
+        gx, gy = grid(a, b)
+        dz.append((z - grid_sample_nearest_border_explicit(depth_tar[None], gx, gy)[0]).abs())
+    bad |= torch.minimum(torch.minimum(dz[0], dz[1]), torch.minimum(dz[2], dz[3])) > depth_tol
+    gx, gy = grid(px, py)
+    g = torch.stack([gx, gy], -1)[None]
+    color = grid_sample_border_explicit(color_tar, g)[0]
+    msk = grid_sample_border_explicit(mask_tar.to(f32)[None], g)[0, 0]
+    mask = (msk > 0.99) & ~bad
+    return color * mask, mask

@@ -133,6 +133,25 @@ class BoxRoom:
         return uv, cos.astype(np.float32), depth
 
 
+def camera_matrices(cam_pos, yaw, pitch, hw, fov_deg=60.0):
+    """(K [4,4], cam2world [4,4]) fp32 of the pin-hole camera ``BoxRoom.render`` casts rays from: pixel (x, y)
+    looks along ((x - cx) / f, (y - cy) / f, 1) with cx = W/2 - 0.5, cy = H/2 - 0.5 (pixel centres), camera z
+    forward / y down - the ScanNet pose / intrinsics convention of the reference's evaluation scripts."""
+    H, W = hw
+    f = 0.5 * H / np.tan(np.radians(fov_deg) / 2)
+    cyaw, syaw, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    Ry = np.array([[cyaw, 0, syaw], [0, 1, 0], [-syaw, 0, cyaw]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    R = np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=np.float64) @ Ry @ Rx
+    c2w = np.eye(4)
+    c2w[:3, :3] = R
+    c2w[:3, 3] = np.asarray(cam_pos, dtype=np.float64)
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = f
+    K[0, 2], K[1, 2] = W / 2 - 0.5, H / 2 - 0.5
+    return K.astype(np.float32), c2w.astype(np.float32)
+
+
 def make_view(seed: int, view_hw=SCANNET_VIEW_HW, level_hw=None, level_heights=None,
               min_pyramid_depth: float = 0.25, room: BoxRoom | None = None, use_depth_in_mask=True,
               depth_holes: bool = True):

@@ -57,6 +57,8 @@ SIGNATURES = {
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
     "sm_gram_backward_split_ws_bytes": [_i],
     "sm_gram_backward_split": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "sm_reproject_blocks": [_i, _i],
+    "sm_reproject": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
 }
 

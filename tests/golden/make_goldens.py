@@ -155,6 +155,7 @@ from model.model import TextureOptimizationStyleTransferPipeline  # noqa: E402
 from model.losses.rgb_transform import pre as ref_pre  # noqa: E402
 import data.scannet_dataset as ref_scannet  # noqa: E402
 import data.matterport_dataset as ref_matterport  # noqa: E402
+import data.utils as ref_utils  # noqa: E402
 
 
 def save(name, **arrays):
@@ -471,11 +472,48 @@ def g7_contract():
          rgb01=rgb, rgb_pre=ref_pre()(rgb.clone()))
 
 
+# --------------------------------------------------------------------------------------------
+# G9: reprojection warp of the evaluation metric (reference data/utils.py:36-194)
+# --------------------------------------------------------------------------------------------
+def reproject_case(seed, hw=(48, 64)):
+    """Two nearby seeded cameras in the small box room: intrinsics, poses, depths, a smooth target image."""
+    rng = np.random.default_rng(seed)
+    room = S.BoxRoom(SMALL_ROOM)
+    L = np.asarray(SMALL_ROOM)
+    pos = L * np.array([0.35, 0.4, 0.5]) + rng.uniform(-0.2, 0.2, 3)
+    yaw, pitch = rng.uniform(0, 2 * np.pi), rng.uniform(-0.15, 0.15)
+    pos2 = pos + rng.uniform(-0.25, 0.25, 3) * np.array([1, 1, 0.3])
+    yaw2, pitch2 = yaw + rng.uniform(-0.25, 0.25), pitch + rng.uniform(-0.08, 0.08)
+    K, c2w_src = S.camera_matrices(pos, yaw, pitch, hw)
+    _, c2w_tar = S.camera_matrices(pos2, yaw2, pitch2, hw)
+    _, _, d_src = room.render(pos, yaw, pitch, hw)
+    _, _, d_tar = room.render(pos2, yaw2, pitch2, hw)
+    d_src[5:9, 10:20] = 0                                   # a sensor hole in the source depth
+    color_tar = S.smooth_noise(rng, 3, hw[0], hw[1]).astype(np.float32) * 100.0
+    return K, c2w_src, c2w_tar, d_src.astype(np.float32), d_tar.astype(np.float32), color_tar
+
+
+def g9_reproject():
+    arrays = {}
+    for n, seed in enumerate((3, 8, 21)):
+        K, c2w_s, c2w_t, d_s, d_t, col = reproject_case(seed)
+        H, W = d_s.shape
+        t = lambda a: torch.from_numpy(a)[None]
+        mask_tar = t(d_t) > 0
+        color, mask = ref_utils.reproject(t(c2w_s), t(c2w_t), W, H, t(K), t(d_s)[:, None], t(d_t)[:, None], t(col),
+                                          mask_tar)
+        pts = ref_utils.unproject(t(c2w_s).transpose(1, 2), t(K), t(d_s)[:, None])
+        arrays.update({f"K{n}": K, f"c2w_src{n}": c2w_s, f"c2w_tar{n}": c2w_t, f"depth_src{n}": d_s, f"depth_tar{n}": d_t,
+                       f"color_tar{n}": col, f"out_color{n}": color[0], f"out_mask{n}": mask[0],
+                       f"unproject{n}": pts[0]})
+    save("g9_reproject", **arrays)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_texture, g2=g2_vgg, g3=g3_gram, g4=g4_style, g5=g5_pipeline, g6=g6_adam, g7=g7_contract,
-               g8=g8_multiview)
+               g8=g8_multiview, g9=g9_reproject)
     for w in which:
         fns[w]()

@@ -276,3 +276,19 @@ def test_explicit_resize_and_erode_match_aten():
     close(O.erode_explicit(m), ref, 0, 0)
     y = torch.randn(1, 4, 9, 13)
     close(O.maxpool2x2_explicit(y), F.max_pool2d(y, 2, 2), 0, 0)
+
+
+def test_g9_reprojection_warp():
+    """Evaluation-metric warp against the reference's data/utils.py reproject / unproject."""
+    d = load_golden("g9_reproject")
+    for n in range(3):
+        t = lambda k: torch.from_numpy(d[f"{k}{n}"])
+        color, mask = O.reproject_explicit(t("c2w_src"), t("c2w_tar"), t("K"), t("depth_src"), t("depth_tar"),
+                                           t("color_tar"), t("depth_tar") > 0)
+        ref_mask = t("out_mask")
+        # threshold tests on fp32 coordinates (bounds, floor, |dz| > 0.1, mask > 0.99): allow a stray pixel
+        assert int((mask != ref_mask).sum()) <= 2, n
+        both = (mask & ref_mask)[None]
+        np.testing.assert_allclose((color * both).numpy(), (t("out_color") * both).numpy(), rtol=1e-4, atol=2e-3)
+        pts = O.unproject_explicit(t("c2w_src"), t("K"), t("depth_src"))
+        np.testing.assert_allclose(pts.numpy(), d[f"unproject{n}"], rtol=1e-5, atol=1e-5)
