@@ -262,6 +262,24 @@ int sm_reproject(const float* src2tar, const float* intrinsics, int H, int W, co
                  const float* depth_tar, const float* color_tar, const float* mask_tar, const float* styled_src,
                  float* color_out, uint8_t* mask_out, double* partial, float depth_tol, void* stream);
 
+/* ---- R1: UV / angle / depth rasteriser ----------------------------------------- */
+
+/* Replaces the OpenGL renderer scripts/scannet/render_uv (renderer.cpp:165-224, scannet_renderer.cpp:19-84,
+ * shader/{uvmap,angle,depth}.*, include/util.h:11-35) for one pose: per pixel the interpolated (u, v) of the
+ * nearest surface of the UV-parameterised mesh, the cosine between the interpolated vertex normal and the
+ * direction to the eye (clamped at 0) and the view-space depth; background = 0.
+ * verts / normals [V][3], uvs [V][2], faces [F][3] int32: DEVICE. world2cam: HOST 4x4 row-major (camera x right,
+ * y down, z forward = inverse of the ScanNet pose), intrinsics: HOST fx, fy, cx, cy at the render resolution
+ * (pixel (i, j) is sampled at (i + 0.5, j + 0.5), u = fx X/Z + cx). zbuf: DEVICE scratch of H*W uint64.
+ * big_scratch (optional): DEVICE scratch of 1 + 10 * big_cap floats - triangles whose screen box exceeds 256 pixels
+ * are queued there and rasterised by one block each instead of one lane.
+ * uv_out [H][W][3] (third channel 0), angle_out / depth_out [H][W]. Surfaces nearer than znear are clipped,
+ * beyond zfar dropped (reference: 0.1 / 10 in the depth shader). */
+int sm_raster_maps(const float* verts, const float* normals, const float* uvs, const int32_t* faces, int n_faces,
+                   const float* world2cam, const float* intrinsics, int H, int W, float znear, float zfar,
+                   uint64_t* zbuf, float* big_scratch, int big_cap, float* uv_out, float* angle_out,
+                   float* depth_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

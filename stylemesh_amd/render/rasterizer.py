@@ -1,0 +1,157 @@
+"""Host side of the HIP rasteriser ``sm_raster_maps``: the replacement of the reference's OpenGL renderer
+(scripts/scannet/render_uv, driven by scripts/scannet/render_uvs.py) that produces the per-frame inputs of the
+hot path - ``<frame>.npy`` UV maps at the pyramid resolutions, ``<frame>.angle.npy`` and
+``<frame>.rendered_depth.npy`` - from a UV-parameterised mesh, the poses and the intrinsics.
+
+GPU + HIP library only. The on-disk layout written by ``render_trajectory`` is the one
+``stylemesh_amd.data.scannet.ScanNetSceneDataset`` (and the reference's ``ScanNetDataset``) reads.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from ..runtime import hip
+from ..runtime.hip import lib, ptr
+
+
+class Mesh:
+    """Triangle mesh with per-vertex normal and texture coordinate (OBJ corners are unrolled by ``load_obj``)."""
+
+    def __init__(self, verts, normals, uvs, faces, device="cuda"):
+        self.verts = torch.as_tensor(verts, dtype=torch.float32).to(device).contiguous()
+        self.normals = torch.as_tensor(normals, dtype=torch.float32).to(device).contiguous()
+        self.uvs = torch.as_tensor(uvs, dtype=torch.float32).to(device).contiguous()
+        self.faces = torch.as_tensor(faces, dtype=torch.int32).to(device).contiguous()
+        V = self.verts.shape[0]
+        if self.verts.shape != (V, 3) or self.normals.shape != (V, 3) or self.uvs.shape != (V, 2):
+            raise ValueError("verts / normals [V,3] and uvs [V,2] expected")
+        if self.faces.ndim != 2 or self.faces.shape[1] != 3:
+            raise ValueError("faces [F,3] expected")
+        if self.faces.numel() and (int(self.faces.min()) < 0 or int(self.faces.max()) >= V):
+            raise ValueError("face index out of range")
+        self._scratch = {}
+
+
+def load_obj(path, device="cuda") -> Mesh:
+    """Wavefront OBJ with ``v`` / ``vt`` / ``vn`` / ``f a/b/c ...`` records (polygons are fanned); every face corner
+    becomes its own vertex, as Assimp hands them to the reference renderer (include/model.h). Missing normals are
+    replaced by the face normal."""
+    v, vt, vn, corners, faces = [], [], [], {}, []
+    out_v, out_t, out_n = [], [], []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                v.append([float(x) for x in p[1:4]])
+            elif p[0] == "vt":
+                vt.append([float(x) for x in p[1:3]])
+            elif p[0] == "vn":
+                vn.append([float(x) for x in p[1:4]])
+            elif p[0] == "f":
+                idx = []
+                for c in p[1:]:
+                    a = (c.split("/") + ["", ""])[:3]
+                    key = (int(a[0]), int(a[1]) if a[1] else 0, int(a[2]) if a[2] else 0)
+                    if key not in corners:
+                        corners[key] = len(out_v)
+                        out_v.append(key[0]); out_t.append(key[1]); out_n.append(key[2])
+                    idx.append(corners[key])
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    v = np.asarray(v, dtype=np.float32)
+    res = lambda i, n: i - 1 if i > 0 else n + i          # OBJ indices are 1-based, negative = relative
+    verts = v[[res(i, len(v)) for i in out_v]]
+    uvs = (np.asarray(vt, dtype=np.float32)[[res(i, len(vt)) for i in out_t]] if vt and all(out_t)
+           else np.zeros((len(out_v), 2), np.float32))
+    faces = np.asarray(faces, dtype=np.int32).reshape(-1, 3)
+    if vn and all(out_n):
+        normals = np.asarray(vn, dtype=np.float32)[[res(i, len(vn)) for i in out_n]]
+    else:
+        normals = np.zeros_like(verts)
+        fn = np.cross(verts[faces[:, 1]] - verts[faces[:, 0]], verts[faces[:, 2]] - verts[faces[:, 0]])
+        for k in range(3):
+            np.add.at(normals, faces[:, k], fn)
+        normals /= np.maximum(np.linalg.norm(normals, axis=1, keepdims=True), 1e-20)
+    return Mesh(verts, normals, uvs, faces, device)
+
+
+def box_room_mesh(room, device="cuda", subdiv: int = 1) -> Mesh:
+    """The synthetic box room (``stylemesh_amd.data.synthetic.BoxRoom``) as a mesh: 6 faces x ``subdiv``^2 quads, UVs
+    from the room's chart layout, normals pointing into the room."""
+    verts, normals, uvs, faces = [], [], [], []
+    L = room.size
+    for fi, (axis, side) in enumerate(room.faces):
+        a0, a1 = [a for a in range(3) if a != axis]
+        u0, v0, du, dv = room.chart(fi)
+        n = np.zeros(3); n[axis] = 1.0 if side == 0 else -1.0
+        base = len(verts)
+        for j in range(subdiv + 1):
+            for i in range(subdiv + 1):
+                s, r = i / subdiv, j / subdiv
+                p = np.zeros(3); p[axis] = L[axis] * side; p[a0] = s * L[a0]; p[a1] = r * L[a1]
+                verts.append(p); normals.append(n); uvs.append([u0 + du * s, v0 + dv * r])
+        for j in range(subdiv):
+            for i in range(subdiv):
+                q = base + j * (subdiv + 1) + i
+                faces += [[q, q + 1, q + subdiv + 2], [q, q + subdiv + 2, q + subdiv + 1]]
+    return Mesh(np.asarray(verts), np.asarray(normals), np.asarray(uvs), np.asarray(faces), device)
+
+
+def scaled_intrinsics(K, native_wh, render_wh):
+    """fx, fy, cx, cy of the render resolution: the reference's projection normalises the native intrinsics by the
+    native image size (include/util.h:11-35) and the viewport stretches them to the render size."""
+    K = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float64)
+    sx, sy = render_wh[0] / native_wh[0], render_wh[1] / native_wh[1]
+    return np.array([K[0, 0] * sx, K[1, 1] * sy, K[0, 2] * sx, K[1, 2] * sy], dtype=np.float32)
+
+
+def render_maps(mesh: Mesh, cam2world, intrinsics4, hw, znear=0.1, zfar=10.0):
+    """One pose. ``cam2world`` [4,4] (ScanNet pose: x right, y down, z forward), ``intrinsics4`` = (fx, fy, cx, cy) at
+    the render resolution in the OpenGL sample convention (pixel (i, j) sampled at (i + 0.5, j + 0.5)).
+    Returns device tensors uv [H,W,3], angle [H,W], depth [H,W]."""
+    H, W = hw
+    dev = mesh.verts.device
+    if dev.type != "cuda":
+        raise RuntimeError("the rasteriser runs on the GPU only")
+    c2w = torch.as_tensor(cam2world).detach().double().cpu()
+    w2c = torch.linalg.inv(c2w).float().contiguous()
+    intr = torch.as_tensor(np.asarray(intrinsics4, dtype=np.float32))
+    key = (H, W)
+    if key not in mesh._scratch:
+        cap = 4096
+        mesh._scratch[key] = (torch.empty(H * W, dtype=torch.int64, device=dev),
+                              torch.empty(1 + 10 * cap, dtype=torch.float32, device=dev), cap)
+    zbuf, big, cap = mesh._scratch[key]
+    uv = torch.empty(H, W, 3, device=dev)
+    ang = torch.empty(H, W, device=dev)
+    dep = torch.empty(H, W, device=dev)
+    hip.check(lib.sm_raster_maps(ptr(mesh.verts), ptr(mesh.normals), ptr(mesh.uvs), ptr(mesh.faces), mesh.faces.shape[0],
+                                 w2c.data_ptr(), intr.data_ptr(), H, W, float(znear), float(zfar), ptr(zbuf), ptr(big), cap,
+                                 ptr(uv), ptr(ang), ptr(dep), hip.stream()), "sm_raster_maps")
+    return uv, ang, dep
+
+
+def render_trajectory(mesh: Mesh, poses, names, K, native_wh, out_dir, heights, aspect=None, full_hw=None):
+    """Write what scripts/scannet/render_uvs.py produces for one scene: ``uv_<h>/<name>.npy`` (H,W,3 float32) for
+    every pyramid height, and in ``uv/`` (at ``full_hw``, default the largest level) ``<name>.npy``,
+    ``<name>.angle.npy`` and ``<name>.rendered_depth.npy`` (3 identical channels, as the reference's read-back)."""
+    aspect = aspect if aspect is not None else native_wh[0] / native_wh[1]
+    levels = [(int(h), int(round(h * aspect))) for h in heights]
+    full_hw = tuple(full_hw) if full_hw is not None else levels[-1]
+    os.makedirs(os.path.join(out_dir, "uv"), exist_ok=True)
+    for pose, name in zip(poses, names):
+        for (h, w), hh in zip(levels, heights):
+            d = os.path.join(out_dir, f"uv_{hh}")
+            os.makedirs(d, exist_ok=True)
+            uv, _, _ = render_maps(mesh, pose, scaled_intrinsics(K, native_wh, (w, h)), (h, w))
+            np.save(os.path.join(d, f"{name}.npy"), uv.cpu().numpy())
+        uv, ang, dep = render_maps(mesh, pose, scaled_intrinsics(K, native_wh, (full_hw[1], full_hw[0])), full_hw)
+        np.save(os.path.join(out_dir, "uv", f"{name}.npy"), uv.cpu().numpy())
+        np.save(os.path.join(out_dir, "uv", f"{name}.angle.npy"), ang[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
+        np.save(os.path.join(out_dir, "uv", f"{name}.rendered_depth.npy"),
+                dep[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
