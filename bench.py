@@ -226,6 +226,13 @@ def main():
                               f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
                               f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)")
                              if world > 1 else "")},
+               # BASELINE.json's second metric: the reference has no convergence criterion, a scene is trained for a
+               # fixed schedule (SURVEY.md section 8 d): 7 epochs x index_repeat x 0.99 V views, V = 276 for ScanNet
+               # scene0000_00 at every 20th frame. Projected from the measured rate (view changes are inside it).
+               "scene_schedule": {"views": 273, "epochs": 7, "index_repeat": wl["index_repeat"],
+                                  "steps": 7 * wl["index_repeat"] * 273,
+                                  "projected_wall_clock_s": round(7 * wl["index_repeat"] * 273 / value, 1),
+                                  "note": "fixed schedule of one scene / measured views per second"},
                "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()}}
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)

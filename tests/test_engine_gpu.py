@@ -336,6 +336,29 @@ def test_side_stream_style_branches_equal_serial():
         grad_close(a, b.cpu(), "side-stream vs serial")
 
 
+def test_level_streams_equal_serial():
+    """The UV levels' loss branches on separate HIP streams (default) give the serial result."""
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [T(g5[f"init{i}"]) for i in range(4)]
+    batch = batch_from_golden(g5)
+    res = []
+    for concurrent in (False, True):
+        eng = make_engine(FLAGSETS["with_angle_and_depth"], init)
+        eng.level_streams = concurrent
+        eng.set_view(batch)
+        assert sum(lv.active for lv in eng.view) > 1
+        for _ in range(3):
+            eng.arena.g.zero_()
+            lt = eng.loss_tensors()
+            eng.forward_backward()
+        torch.cuda.synchronize()
+        res.append((eng.losses(lt), [g.clone() for g in eng.grads]))
+    for k in res[0][0]:
+        np.testing.assert_allclose(res[1][0][k], res[0][0][k], rtol=1e-5)
+    for a, b in zip(res[1][1], res[0][1]):
+        grad_close(a, b.cpu(), "level streams vs serial")
+
+
 def test_full_size_properties():
     """BASELINE sizes (4096^2 hier-4 texture, UV levels 256x341 .. 784x1045, multi + angle + depth), checked through
     size-independent properties: (a) dead-tile elimination does not change losses / gradients, (b) the gradient
