@@ -157,8 +157,11 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
                    int H, int W, void* stream);
 
 /* K5a on the bf16 matrix cores at fp32 accuracy (bf16x3 split, 6 partial products, fp32 accumulate - see
- * sm_conv3x3_grouped_split). Same arguments, slab layout and results class as sm_gram_masked; stages whose 16
- * mask values are all zero are skipped before their data is loaded. */
+ * sm_conv3x3_grouped_split). Same arguments and results class as sm_gram_masked, but the position ranges add into
+ * ONE slab with fp32 atomics (no reduction pass): afterwards S_k = the first sm_gram_split_num_slabs() = 1 slab
+ * (upper-triangular 64x64 tiles valid; S0 / S1 need room for one [C][C] slab only). Stages whose 16 mask values
+ * are all zero are skipped before their data is loaded. */
+int sm_gram_split_num_slabs(void);
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                          int H, int W, void* stream);
 

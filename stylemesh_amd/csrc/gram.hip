@@ -383,34 +383,34 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
     return 0;
 }
 
+int sm_gram_split_num_slabs(void) { return 1; }
+
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
                          int W, void* stream) {
     if (C % 64 != 0) return (int)hipErrorInvalidValue;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     const sm::GramPlan p = sm::gram_plan(C, q_end - q_begin);
-    const bool two_level = p.n_red != p.n_raw;
     const size_t cc = (size_t)C * C;
-    float* raw0 = two_level ? S0 + p.n_red * cc : S0;   // reduced slabs first, raw slabs behind them
-    float* raw1 = (two_level && S1) ? S1 + p.n_red * cc : S1;
     hipStream_t s = (hipStream_t)stream;
     const int nmask = mask1 ? 2 : 1;
+    // several position ranges -> they all add into slab 0 (zeroed here); a single range stores it directly
+    const bool atomic = p.n_raw > 1;
+    if (atomic) {
+        hipError_t e = hipMemsetAsync(S0, 0, cc * sizeof(float), s);
+        if (e == hipSuccess && mask1) e = hipMemsetAsync(S1, 0, cc * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+#define SM_GS(MI_, AT_, T_)                                                                                          \
+    hipLaunchKernelGGL((sm::gram_split_kernel<MI_, AT_>), dim3(p.n_raw, (T_) * ((T_) + 1) / 2, nmask), dim3(256), 0, s, \
+                       feat, mask0, mask1, S0, S1, C, plane, q_begin, q_end, p.qb)
     if (C % 128 == 0) {
-        const int T = C / 128;
-        hipLaunchKernelGGL(sm::gram_split_kernel<2>, dim3(p.n_raw, T * (T + 1) / 2, nmask), dim3(256), 0, s, feat, mask0,
-                           mask1, raw0, raw1, C, plane, q_begin, q_end, p.qb);
+        if (atomic) SM_GS(2, true, C / 128); else SM_GS(2, false, C / 128);
     } else {
-        const int T = C / 64;
-        hipLaunchKernelGGL(sm::gram_split_kernel<1>, dim3(p.n_raw, T * (T + 1) / 2, nmask), dim3(256), 0, s, feat, mask0,
-                           mask1, raw0, raw1, C, plane, q_begin, q_end, p.qb);
+        if (atomic) SM_GS(1, true, C / 64); else SM_GS(1, false, C / 64);
     }
+#undef SM_GS
     SM_LAUNCH_CHECK();
-    if (two_level) {
-        dim3 rg((unsigned)(cc / 256), p.n_red);
-        hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw0, S0, (int)cc, p.n_raw);
-        if (mask1) hipLaunchKernelGGL(sm::gram_reduce_kernel, rg, dim3(256), 0, s, raw1, S1, (int)cc, p.n_raw);
-        SM_LAUNCH_CHECK();
-    }
     return 0;
 }
 

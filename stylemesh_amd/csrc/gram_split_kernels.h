@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // zero is skipped before anything is loaded (the masks of a level are sparse and disjoint). Partial sums of the
 // range go to slab blockIdx.x, exactly like gram_masked_kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int MI>
+// ATOMIC: all position ranges accumulate into ONE pre-zeroed slab with fp32 atomics instead of writing a slab each
+// (no reduction pass, C^2 floats of traffic per block instead of written + re-read; summation order - like the
+// texture scatter's - is then not fixed).
+template <int MI, bool ATOMIC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_split_kernel(
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1, float* S0, float* S1,
     int C, int plane, int q_begin, int q_end, int qb) {
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tn = tm + rem;
     const bool diag = tm == tn;
     const float* mask = blockIdx.z ? mask1 : mask0;
-    float* S = (blockIdx.z ? S1 : S0) + (size_t)blockIdx.x * C * C;
+    float* S = (blockIdx.z ? S1 : S0) + (ATOMIC ? (size_t)0 : (size_t)blockIdx.x * C * C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * MI);
     const int qs = q_begin + blockIdx.x * qb;
@@ -320,7 +323,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * TS + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int col = tn * TS + wn + nj * 32 + l31;
-                S[(size_t)row * C + col] = acc[mi][nj][r];
+                if (ATOMIC) {
+                    if (n_live > 0) atomicAdd(&S[(size_t)row * C + col], acc[mi][nj][r]);
+                } else {
+                    S[(size_t)row * C + col] = acc[mi][nj][r];
+                }
             }
 }
 

@@ -228,10 +228,14 @@ def maxpool_bwd_relu(act: FMap, pooled: FMap, dpooled: FMap, dact: FMap):
 
 # ---- losses --------------------------------------------------------------------------------------------------
 def gram_num_slabs(C: int, H: int, W: int) -> int:
+    """How many leading slabs of the Gram workspace sum to S (mode dependent: the split kernel accumulates into one)."""
+    if GRAM_MODE == "split":
+        return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_num_slabs(C, H, W)
 
 
 def gram_workspace_slabs(C: int, H: int, W: int) -> int:
+    """Slabs the workspace must hold (sized for either mode)."""
     return lib.sm_gram_workspace_slabs(C, H, W)
 
 
