@@ -143,6 +143,20 @@ int sm_maxpool2x2_fwd(const float* in, float* out, int C, int H, int W, void* st
 int sm_maxpool2x2_bwd_relu(const float* act, const float* pooled, const float* dpooled, float* dact, int C,
                            int H, int W, void* stream);
 
+/* The three per-level memory-bound VGG helpers over up to 8 feature maps in ONE launch (the UV levels of a view;
+ * per-level launches are latency-bound on the small levels). problems: HOST array; a / b / c / out per kernel:
+ * dgrad_c3: a = dz, out;  pool forward: a = in, out;  pool backward: a = act, b = pooled, c = dpooled, out = dact. */
+typedef struct {
+    const float* a;
+    const float* b;
+    const float* c;
+    float* out;
+    int H, W;
+} sm_plane_problem;
+int sm_conv3x3_dgrad_c3_grouped(const sm_plane_problem* problems, int n, const float* wd, int Cin, void* stream);
+int sm_maxpool2x2_fwd_grouped(const sm_plane_problem* problems, int n, int C, void* stream);
+int sm_maxpool2x2_bwd_relu_grouped(const sm_plane_problem* problems, int n, int C, void* stream);
+
 /* ---- Gram / style / content losses: content_and_style_losses.py:74-80,136-143,288-350 --------------- */
 
 /* K5a. Masked Gram sums S_k = (m_k F)(m_k F)^T for up to two 0/1 masks (GramMatrix :74-80 on

@@ -336,12 +336,11 @@ static int dispatch_conv(const ConvArgs& a, int n_list, size_t ws_floats, hipStr
 // First-layer data gradient (64 -> 3 channels): far too thin for the matrix cores (M = 3), so a VALU kernel:
 // one thread per position q, 3 accumulators, weights read through the scalar cache (wave-uniform).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(const float* __restrict__ dz,
-                                                               const float* __restrict__ wd, float* out, int Cin,
-                                                               int H, int W, int Wp, int plane) {
+__device__ __forceinline__ void dgrad_c3_body(const float* __restrict__ dz, const float* __restrict__ wd, float* out,
+                                              int Cin, int H, int W, int Wp, int plane, int block_x) {
     // four consecutive positions per thread: per channel and row one float4 + its two neighbours feed 4 x 3 taps
     // (1.5 loads per output instead of 9), weights through the scalar cache (wave-uniform)
-    const int q = Wp + (blockIdx.x * 256 + threadIdx.x) * 4;   // Wp % 4 == 0: 16-byte aligned
+    const int q = Wp + (block_x * 256 + threadIdx.x) * 4;   // Wp % 4 == 0: 16-byte aligned
     if (q >= (H + 1) * Wp) return;
     float acc[3][4];
 #pragma unroll
@@ -380,11 +379,10 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 // 2x2 max-pool, floor output size.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          int H, int W, int Wp, int plane, int Ho, int Wo, int Wpo,
-                                                          int plane_o) {
+__device__ __forceinline__ void maxpool_fwd_body(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                 int Wp, int plane, int Ho, int Wo, int Wpo, int plane_o, int block_x) {
     const int c = blockIdx.y;
-    const int q = Wpo + blockIdx.x * 256 + threadIdx.x;  // output position, rows 1..Ho
+    const int q = Wpo + block_x * 256 + threadIdx.x;  // output position, rows 1..Ho
     if (q >= (Ho + 1) * Wpo) return;
     const int r = q / Wpo, x = q - r * Wpo;
     float v = 0.f;
@@ -395,13 +393,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     out[(size_t)c * plane_o + q] = v;
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(const float* __restrict__ act,
-                                                               const float* __restrict__ pooled,
-                                                               const float* __restrict__ dpooled,
-                                                               float* __restrict__ dact, int H, int W, int Wp, int plane,
-                                                               int Ho, int Wo, int Wpo, int plane_o) {
+__device__ __forceinline__ void maxpool_bwd_relu_body(const float* __restrict__ act, const float* __restrict__ pooled,
+                                                      const float* __restrict__ dpooled, float* __restrict__ dact,
+                                                      int H, int W, int Wp, int plane, int Ho, int Wo, int Wpo,
+                                                      int plane_o, int block_x) {
     const int c = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;  // window index
+    const int i = block_x * 256 + threadIdx.x;  // window index
     if (i >= Ho * Wo) return;
     const int yo = i / Wo, xo = i - yo * Wo;
     const size_t qo = (size_t)c * plane_o + (yo + 1) * Wpo + xo + 1;
@@ -423,6 +420,51 @@ __global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(const float* __re
     dact[base + 1] = s01 ? g : 0.f;
     dact[base + Wp] = s10 ? g : 0.f;
     dact[base + Wp + 1] = s11 ? g : 0.f;
+}
+
+// Per-level launches of these memory-bound kernels are latency-bound on the small UV levels: the grouped forms take
+// the levels of a view in ONE launch (blockIdx.x runs over the concatenated block ranges of the problems).
+struct PlaneProblem {
+    const float* a;
+    const float* b;
+    const float* c;
+    float* out;
+    int H, W;
+};
+struct PlaneGroup {
+    PlaneProblem p[SM_MAX_GROUP];
+    int block_begin[SM_MAX_GROUP + 1];
+    int n;
+};
+__device__ __forceinline__ int locate_problem(const PlaneGroup& g, int bx, int& local) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < SM_MAX_GROUP; ++i)
+        if (i < g.n && bx >= g.block_begin[i]) k = i;
+    local = bx - g.block_begin[k];
+    return k;
+}
+
+__global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(PlaneGroup g, const float* __restrict__ wd, int Cin) {
+    int bx;
+    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    dgrad_c3_body(P.a, wd, P.out, Cin, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), bx);
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
+    int bx;
+    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    const int Ho = P.H / 2, Wo = P.W / 2;
+    maxpool_fwd_body(P.a, P.out, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), Ho, Wo, row_stride(Wo),
+                     plane_size(Ho, Wo), bx);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(PlaneGroup g) {
+    int bx;
+    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    const int Ho = P.H / 2, Wo = P.W / 2;
+    maxpool_bwd_relu_body(P.a, P.b, P.c, P.out, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), Ho, Wo, row_stride(Wo),
+                          plane_size(Ho, Wo), bx);
 }
 
 }  // namespace sm
@@ -504,38 +546,61 @@ int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, 
     return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, nullptr, 0, ws, ws_floats, stream);
 }
 
-int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream) {
-    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
-    const int n = H * Wp / 4;   // four positions per thread
-    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz, wd,
-                       out, Cin, H, W, Wp, plane);
+static int make_plane_group(sm::PlaneGroup& g, const sm_plane_problem* p, int n, int kind) {
+    if (n < 1 || n > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
+    g.n = n;
+    g.block_begin[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = sm::PlaneProblem{p[i].a, p[i].b, p[i].c, p[i].out, p[i].H, p[i].W};
+        const int H = p[i].H, W = p[i].W, Ho = H / 2, Wo = W / 2;
+        if (kind != 0 && (Ho < 1 || Wo < 1)) return (int)hipErrorInvalidValue;
+        int work;   // threads of the problem
+        if (kind == 0) work = H * sm::row_stride(W) / 4;            // dgrad_c3: four positions per thread
+        else if (kind == 1) work = Ho * sm::row_stride(Wo);          // pool forward: output positions
+        else work = Ho * Wo;                                         // pool backward: windows
+        g.block_begin[i + 1] = g.block_begin[i] + (work + 255) / 256;
+    }
+    return 0;
+}
+
+int sm_conv3x3_dgrad_c3_grouped(const sm_plane_problem* problems, int n, const float* wd, int Cin, void* stream) {
+    sm::PlaneGroup g;
+    if (int e = make_plane_group(g, problems, n, 0)) return e;
+    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(g.block_begin[n]), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
     SM_LAUNCH_CHECK();
     return 0;
 }
 
-int sm_maxpool2x2_fwd(const float* in, float* out, int C, int H, int W, void* stream) {
-    const int Ho = H / 2, Wo = W / 2;
-    if (Ho < 1 || Wo < 1) return (int)hipErrorInvalidValue;
-    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
-    const int Wpo = sm::row_stride(Wo), plane_o = sm::plane_size(Ho, Wo);
-    const int n = Ho * Wpo;
-    hipLaunchKernelGGL(sm::maxpool_fwd_kernel, dim3((n + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, in, out, H,
-                       W, Wp, plane, Ho, Wo, Wpo, plane_o);
+int sm_maxpool2x2_fwd_grouped(const sm_plane_problem* problems, int n, int C, void* stream) {
+    sm::PlaneGroup g;
+    if (int e = make_plane_group(g, problems, n, 1)) return e;
+    hipLaunchKernelGGL(sm::maxpool_fwd_kernel, dim3(g.block_begin[n], C), dim3(256), 0, (hipStream_t)stream, g);
     SM_LAUNCH_CHECK();
     return 0;
+}
+
+int sm_maxpool2x2_bwd_relu_grouped(const sm_plane_problem* problems, int n, int C, void* stream) {
+    sm::PlaneGroup g;
+    if (int e = make_plane_group(g, problems, n, 2)) return e;
+    hipLaunchKernelGGL(sm::maxpool_bwd_relu_kernel, dim3(g.block_begin[n], C), dim3(256), 0, (hipStream_t)stream, g);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_conv3x3_dgrad_c3(const float* dz, const float* wd, float* out, int Cin, int H, int W, void* stream) {
+    sm_plane_problem p{dz, nullptr, nullptr, out, H, W};
+    return sm_conv3x3_dgrad_c3_grouped(&p, 1, wd, Cin, stream);
+}
+
+int sm_maxpool2x2_fwd(const float* in, float* out, int C, int H, int W, void* stream) {
+    sm_plane_problem p{in, nullptr, nullptr, out, H, W};
+    return sm_maxpool2x2_fwd_grouped(&p, 1, C, stream);
 }
 
 int sm_maxpool2x2_bwd_relu(const float* act, const float* pooled, const float* dpooled, float* dact, int C, int H,
                            int W, void* stream) {
-    const int Ho = H / 2, Wo = W / 2;
-    if (Ho < 1 || Wo < 1) return (int)hipErrorInvalidValue;
-    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
-    const int Wpo = sm::row_stride(Wo), plane_o = sm::plane_size(Ho, Wo);
-    const int n = Ho * Wo;
-    hipLaunchKernelGGL(sm::maxpool_bwd_relu_kernel, dim3((n + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, act,
-                       pooled, dpooled, dact, H, W, Wp, plane, Ho, Wo, Wpo, plane_o);
-    SM_LAUNCH_CHECK();
-    return 0;
+    sm_plane_problem p{act, pooled, dpooled, dact, H, W};
+    return sm_maxpool2x2_bwd_relu_grouped(&p, 1, C, stream);
 }
 
 }  // extern "C"

@@ -37,6 +37,9 @@ SIGNATURES = {
     "sm_conv_tile_positions": [_i, _i],
     "sm_conv_split_tile_positions": [],
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_conv3x3_dgrad_c3_grouped": [_vp, _i, _vp, _i, _vp],
+    "sm_maxpool2x2_fwd_grouped": [_vp, _i, _i, _vp],
+    "sm_maxpool2x2_bwd_relu_grouped": [_vp, _i, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_num_slabs": [_i, _i, _i],
@@ -68,6 +71,12 @@ SIGNATURES = {
 class ConvProblem(C.Structure):
     """sm_conv_problem of include/stylemesh_hip.h"""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int)]
+
+
+class PlaneProblem(C.Structure):
+    """sm_plane_problem of include/stylemesh_hip.h"""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int),
+                ("W", C.c_int)]
 
 
 def _load():

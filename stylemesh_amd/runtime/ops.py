@@ -226,6 +226,36 @@ def maxpool_bwd_relu(act: FMap, pooled: FMap, dpooled: FMap, dact: FMap):
                                          hip.stream()), "sm_maxpool2x2_bwd_relu")
 
 
+def _plane_problems(items):
+    arr = (hip.PlaneProblem * len(items))()
+    for i, (a, b, c, out) in enumerate(items):
+        arr[i] = hip.PlaneProblem(a.ptr, None if b is None else b.ptr, None if c is None else c.ptr, out.ptr, a.H, a.W)
+    return arr
+
+
+def conv3x3_dgrad_c3_grouped(problems, wd: torch.Tensor):
+    """``problems``: [(dz, out), ...] FMaps of the UV levels - one launch."""
+    assert wd.shape[2] == 4 and all(dz.C == wd.shape[1] and out.C >= 3 for dz, out in problems)
+    arr = _plane_problems([(dz, None, None, out) for dz, out in problems])
+    hip.check(lib.sm_conv3x3_dgrad_c3_grouped(arr, len(problems), ptr(wd), wd.shape[1], hip.stream()),
+              "sm_conv3x3_dgrad_c3_grouped")
+
+
+def maxpool_fwd_grouped(problems):
+    """``problems``: [(inp, out), ...] with equal channel counts - one launch."""
+    C = problems[0][0].C
+    assert all((o.H, o.W, o.C) == (i.H // 2, i.W // 2, C) and i.C == C for i, o in problems)
+    arr = _plane_problems([(i, None, None, o) for i, o in problems])
+    hip.check(lib.sm_maxpool2x2_fwd_grouped(arr, len(problems), C, hip.stream()), "sm_maxpool2x2_fwd_grouped")
+
+
+def maxpool_bwd_relu_grouped(problems):
+    """``problems``: [(act, pooled, dpooled, dact), ...] - one launch."""
+    C = problems[0][0].C
+    arr = _plane_problems(problems)
+    hip.check(lib.sm_maxpool2x2_bwd_relu_grouped(arr, len(problems), C, hip.stream()), "sm_maxpool2x2_bwd_relu_grouped")
+
+
 # ---- losses --------------------------------------------------------------------------------------------------
 def gram_num_slabs(C: int, H: int, W: int) -> int:
     """How many leading slabs of the Gram workspace sum to S (mode dependent: the split kernel accumulates into one)."""

@@ -99,8 +99,7 @@ class VGGNet:
         assert all(b.last == last for b in bufs)
         for kind, src, out, _, _ in NODES[:last + 1]:
             if kind == "pool":
-                for b in bufs:
-                    ops.maxpool_fwd(b.act[src], b.act[out])
+                ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs])
             else:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
@@ -116,11 +115,9 @@ class VGGNet:
             if kind == "pool":
                 if src in injected:
                     raise ValueError(f"style/content layer {src} directly below a pool is not supported")
-                for b in bufs:
-                    ops.maxpool_bwd_relu(b.act[src], b.act[out], b.grad[out], b.grad[src])
+                ops.maxpool_bwd_relu_grouped([(b.act[src], b.act[out], b.grad[out], b.grad[src]) for b in bufs])
             elif src == "img":
-                for b in bufs:
-                    ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
+                ops.conv3x3_dgrad_c3_grouped([(b.grad[out], b.grad["img"]) for b in bufs], self.wd[kind])
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
