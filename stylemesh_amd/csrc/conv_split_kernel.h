@@ -29,7 +29,8 @@
 // micro-benchmark, relative to the defaults (187-190 TFLOP/s): AD=1 -22 %; no fragment prefetch -5 %; 3 waves per
 // SIMD (AD=1, no prefetch, 168 VGPRs) -14 %; PIN_READS=1 (fragment reads pinned a full stage ahead: the densest
 // MFMA stream, 245 VGPRs) -8 %; any s_setprio (MFMA cluster or the load/convert tail) -9 %: each of them fences the
-// compiler's own interleaving of the tail instructions with the MFMAs.
+// compiler's own interleaving of the tail instructions with the MFMAs. 3 waves per SIMD with AD=3 and no fragment
+// prefetch needs 168 VGPRs: the 128-row variant spills ~25 dwords and loses 14 %.
 #ifndef SM_SPLIT_AD
 #define SM_SPLIT_AD 3          // weight prefetch distance in stages (must divide 9)
 #endif
@@ -180,16 +181,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
                 dst_[i][s] = __builtin_bit_cast(bf16x8, bf_[s * 2 * BNP + i * 32]);                      \
     }
 
-    // the 32 bias values of this lane's rows (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4), fetched BEFORE the main loop:
-    // a load in the epilogue would first wait out the (unused) prefetches the last stages still have in flight
-    f32x4 bias4[MI][4];
-    if (FLAGS & SM_EPI_BIAS_RELU) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
-    }
     SM_TS(0)
     // prologue: the first AD weight stages into the register ring, chunk ch_begin's three slices into slots 0..2
 #pragma unroll
@@ -317,6 +308,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WA
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
+    // the 32 bias values of this lane's rows, as 8 float4 (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4). (Hoisting these
+    // loads above the main loop - so that they do not queue behind the last, unused prefetches - bought nothing.)
+    f32x4 bias4[MI][4];
+    if (FLAGS & SM_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
+    }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
