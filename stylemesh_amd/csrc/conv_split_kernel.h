@@ -46,6 +46,9 @@
 #ifndef SM_SPLIT_MFMA_PRIO
 #define SM_SPLIT_MFMA_PRIO 0
 #endif
+#ifndef SM_SPLIT_WAVES64
+#define SM_SPLIT_WAVES64 3
+#endif
 #ifndef SM_SPLIT_WAVES
 #define SM_SPLIT_WAVES 2       // resident waves per SIMD the register budget is set for
 #endif
@@ -55,8 +58,11 @@ namespace sm {
 constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN + 2)) * 16; }
 
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
+// the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SM_SPLIT_WAVES, SM_SPLIT_WAVES))) void conv3x3_split_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES, BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES)))
+void conv3x3_split_kernel(ConvArgs a) {
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && BN / WGN == 64 && WGM * WGN == 4,
                   "wave tile is (32 MI) x 64");
