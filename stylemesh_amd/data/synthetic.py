@@ -178,5 +178,22 @@ def make_view(seed: int, view_hw=SCANNET_VIEW_HW, level_hw=None, level_heights=N
             y0, x0 = int(rng.integers(0, H - hh)), int(rng.integers(0, W - ww))
             depth[y0:y0 + hh, x0:x0 + ww] = 0
     rgb = torch.from_numpy(smooth_noise(rng, 3, view_hw[0], view_hw[1]))
+    K, c2w = camera_matrices(pos, yaw, pitch, tuple(view_hw))
     return vc.assemble_batch(rgb, depth, uvs, cos, level_heights, min_pyramid_depth, idx=seed,
-                             use_depth_in_mask=use_depth_in_mask)
+                             use_depth_in_mask=use_depth_in_mask, extrinsics=torch.from_numpy(c2w).double()[None],
+                             intrinsics=torch.from_numpy(K).double()[None])
+
+
+def trajectory_poses(n: int, room: BoxRoom, seed: int = 0):
+    """``n`` camera poses (pos, yaw, pitch) along a smooth path through the room: neighbouring frames overlap, as the
+    consecutive frames of a scan do (what the reprojection-error pairs of the evaluation rely on)."""
+    rng = np.random.default_rng(seed)
+    L = room.size
+    p0 = np.array([0.3 * L[0], 0.35 * L[1], 1.4]) + rng.uniform(-0.1, 0.1, 3)
+    p1 = np.array([0.7 * L[0], 0.6 * L[1], 1.5]) + rng.uniform(-0.1, 0.1, 3)
+    yaw0 = rng.uniform(0, 2 * np.pi)
+    out = []
+    for i in range(n):
+        t = i / max(n - 1, 1)
+        out.append((p0 + t * (p1 - p0), yaw0 + 1.2 * t, 0.05 * np.sin(3.0 * t)))
+    return out
