@@ -91,6 +91,9 @@ class SparseGradReducer:
             self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM)
             self.last_bytes = 4 * n
             return
+        if self.idx.numel() == 0:      # no rank's view touches the texture: nothing to exchange (same on every rank)
+            self.last_bytes = 0
+            return
         g2 = flat_grad.view(-1, self.chunk)
         buf = g2.index_select(0, self.idx)
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
