@@ -297,6 +297,15 @@ int sm_raster_maps(const float* verts, const float* normals, const float* uvs, c
                    uint64_t* zbuf, float* big_scratch, int big_cap, float* uv_out, float* angle_out,
                    float* depth_out, void* stream);
 
+/* R2: textured re-render of a rasterised view (the rgb path of the same renderer: GL_LINEAR_MIPMAP_LINEAR lookup
+ * of the optimised texture, renderer.cpp:110-139, shader/rgb.frag; its constant lighting factor and the anisotropic
+ * extension are not reproduced). sm_mip_downsample: one 2x2 box-filter level (dst = [C][max(Hs/2,1)][max(Ws/2,1)]).
+ * sm_tex_sample_mip: levels = HOST array of n_levels DEVICE images [3][h_l][w_l] (level 0 first), uv = the
+ * [H][W][3] map of sm_raster_maps; out [3][H][W]; lod_out (optional) [H][W] = the level of detail used. */
+int sm_mip_downsample(const float* src, float* dst, int C, int Hs, int Ws, void* stream);
+int sm_tex_sample_mip(const float* const* levels, const int* level_w, const int* level_h, int n_levels,
+                      const float* uv, int H, int W, float* out, float* lod_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

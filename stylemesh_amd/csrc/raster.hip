@@ -169,6 +169,81 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(RasterCam c, const fl
     depth_out[i] = dep;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// R2: textured re-render of a rasterised view - trilinear mip-mapped lookup of an RGB texture at the UV map
+// (the reference's rgb shader path: GL_LINEAR_MIPMAP_LINEAR on a glGenerateMipmap pyramid, renderer.cpp:110-139,
+// shader/rgb.frag; its fixed ambient / diffuse lighting factor and the anisotropic extension are not reproduced).
+// Texel (i, j) of a W x H level is centred at ((i + 0.5) / W, (j + 0.5) / H); clamp to edge. The level of detail is
+// log2 of the larger screen-space UV footprint (forward differences of the UV map, in texels of level 0).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mip_downsample_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hs,
+                                                             int Ws, int Hd, int Wd) {
+    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (i >= Hd * Wd) return;
+    const int y = i / Wd, x = i - y * Wd;
+    const int y0 = min(2 * y, Hs - 1), y1 = min(2 * y + 1, Hs - 1), x0 = min(2 * x, Ws - 1), x1 = min(2 * x + 1, Ws - 1);
+    const float* p = src + (size_t)c * Hs * Ws;
+    dst[(size_t)c * Hd * Wd + i] = 0.25f * (p[y0 * Ws + x0] + p[y0 * Ws + x1] + p[y1 * Ws + x0] + p[y1 * Ws + x1]);
+}
+
+struct MipChain {
+    const float* p[16];
+    int w[16], h[16];
+    int n;
+};
+
+__device__ __forceinline__ void mip_bilinear(const MipChain& m, int l, float u, float v, float out[3]) {
+    const int W = m.w[l], H = m.h[l];
+    const float x = fminf(fmaxf(u * W - 0.5f, 0.f), (float)(W - 1)), y = fminf(fmaxf(v * H - 0.5f, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float fx = x - x0, fy = y - y0;
+    const size_t cs = (size_t)W * H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* p = m.p[l] + c * cs;
+        out[c] = (1.f - fy) * ((1.f - fx) * p[y0 * W + x0] + fx * p[y0 * W + x1]) +
+                 fy * ((1.f - fx) * p[y1 * W + x0] + fx * p[y1 * W + x1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tex_sample_mip_kernel(MipChain m, const float* __restrict__ uv, int H, int W,
+                                                             float* __restrict__ out, float* __restrict__ lod_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    const float u = uv[3 * (size_t)i], v = uv[3 * (size_t)i + 1];
+    float rgb[3] = {0.f, 0.f, 0.f}, lod = 0.f;
+    if (u != 0.f || v != 0.f) {   // background pixels carry uv = 0
+        // footprint from the neighbours that also hit the surface (forward, else backward difference)
+        auto duv = [&](int j, float& du, float& dv) {
+            const float uu = uv[3 * (size_t)j], vv = uv[3 * (size_t)j + 1];
+            const bool ok = uu != 0.f || vv != 0.f;
+            du = ok ? uu - u : 0.f;
+            dv = ok ? vv - v : 0.f;
+            return ok;
+        };
+        float dux = 0.f, dvx = 0.f, duy = 0.f, dvy = 0.f;
+        if (!(x + 1 < W && duv(i + 1, dux, dvx)) && x > 0) duv(i - 1, dux, dvx);
+        if (!(y + 1 < H && duv(i + W, duy, dvy)) && y > 0) duv(i - W, duy, dvy);
+        const float W0 = (float)m.w[0], H0 = (float)m.h[0];
+        const float rx = sqrtf(dux * dux * W0 * W0 + dvx * dvx * H0 * H0), ry = sqrtf(duy * duy * W0 * W0 + dvy * dvy * H0 * H0);
+        const float rho = fmaxf(rx, ry);
+        lod = fminf(fmaxf(rho > 0.f ? log2f(rho) : 0.f, 0.f), (float)(m.n - 1));
+        const int l0 = (int)floorf(lod), l1 = min(l0 + 1, m.n - 1);
+        const float f = lod - l0;
+        float a[3], b[3];
+        mip_bilinear(m, l0, u, v, a);
+        mip_bilinear(m, l1, u, v, b);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = (1.f - f) * a[c] + f * b[c];
+    }
+    const size_t n = (size_t)H * W;
+    out[i] = rgb[0];
+    out[n + i] = rgb[1];
+    out[2 * n + i] = rgb[2];
+    if (lod_out) lod_out[i] = lod;
+}
+
 }  // namespace sm
 
 extern "C" {
@@ -207,6 +282,27 @@ int sm_raster_maps(const float* verts, const float* normals, const float* uvs, c
     }
     hipLaunchKernelGGL(sm::raster_shade_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, c, verts, normals, uvs, faces,
                        reinterpret_cast<const unsigned long long*>(zbuf), uv_out, angle_out, depth_out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_mip_downsample(const float* src, float* dst, int C, int Hs, int Ws, void* stream) {
+    const int Hd = std::max(Hs / 2, 1), Wd = std::max(Ws / 2, 1);
+    if (C < 1 || Hs < 1 || Ws < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sm::mip_downsample_kernel, dim3((Hd * Wd + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       Hs, Ws, Hd, Wd);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_tex_sample_mip(const float* const* levels, const int* level_w, const int* level_h, int n_levels, const float* uv,
+                      int H, int W, float* out, float* lod_out, void* stream) {
+    if (n_levels < 1 || n_levels > 16) return (int)hipErrorInvalidValue;
+    sm::MipChain m;
+    m.n = n_levels;
+    for (int l = 0; l < n_levels; ++l) { m.p[l] = levels[l]; m.w[l] = level_w[l]; m.h[l] = level_h[l]; }
+    hipLaunchKernelGGL(sm::tex_sample_mip_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, uv, H, W, out,
+                       lod_out);
     SM_LAUNCH_CHECK();
     return 0;
 }

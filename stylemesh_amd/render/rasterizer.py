@@ -155,3 +155,32 @@ def render_trajectory(mesh: Mesh, poses, names, K, native_wh, out_dir, heights, 
         np.save(os.path.join(out_dir, "uv", f"{name}.angle.npy"), ang[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
         np.save(os.path.join(out_dir, "uv", f"{name}.rendered_depth.npy"),
                 dep[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
+
+
+def build_mipmaps(image: torch.Tensor, min_size: int = 1):
+    """2x2 box-filter pyramid of an RGB image [3,H,W] (``glGenerateMipmap`` of the reference's texture upload)."""
+    lv = [image.detach().float().contiguous()]
+    while min(lv[-1].shape[1:]) > min_size:
+        _, h, w = lv[-1].shape
+        dst = torch.empty(3, max(h // 2, 1), max(w // 2, 1), device=image.device)
+        hip.check(lib.sm_mip_downsample(ptr(lv[-1]), ptr(dst), 3, h, w, hip.stream()), "sm_mip_downsample")
+        lv.append(dst)
+    return lv
+
+
+def sample_mipmapped(mips, uv_map: torch.Tensor, return_lod=False):
+    """Trilinear lookup of the pyramid at a rasterised UV map [H,W,3] -> RGB [3,H,W] (background pixels: 0)."""
+    H, W = uv_map.shape[:2]
+    out = torch.empty(3, H, W, device=uv_map.device)
+    lod = torch.empty(H, W, device=uv_map.device) if return_lod else None
+    hip.check(lib.sm_tex_sample_mip(hip.ptr_array(mips), hip.int_array([m.shape[2] for m in mips]),
+                                    hip.int_array([m.shape[1] for m in mips]), len(mips), ptr(uv_map.contiguous()), H, W,
+                                    ptr(out), ptr(lod), hip.stream()), "sm_tex_sample_mip")
+    return (out, lod) if return_lod else out
+
+
+def render_textured(mesh: Mesh, texture_image: torch.Tensor, cam2world, intrinsics4, hw, znear=0.1, zfar=10.0):
+    """The reference renderer's textured re-render of one pose: rasterise, then mip-mapped lookup of ``texture_image``
+    [3,Ht,Wt] (row 0 = v = 0)."""
+    uv, _, _ = render_maps(mesh, cam2world, intrinsics4, hw, znear, zfar)
+    return sample_mipmapped(build_mipmaps(texture_image), uv)

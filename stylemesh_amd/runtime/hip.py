@@ -64,6 +64,8 @@ SIGNATURES = {
     "sm_reproject_blocks": [_i, _i],
     "sm_reproject": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "sm_raster_maps": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "sm_mip_downsample": [_vp, _vp, _i, _i, _i, _vp],
+    "sm_tex_sample_mip": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
 }
 

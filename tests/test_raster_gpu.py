@@ -109,3 +109,41 @@ def test_obj_loader_and_scene_writer_feed_the_loader(R, tmp_path):
     ang = np.load(out / "uv" / "0.angle.npy")
     assert ang.shape == (48, 64, 3) and float(ang.max()) <= 1.0 + 1e-6 and float(ang.min()) >= 0.0
     np.testing.assert_allclose(np.load(out / "uv" / "0.npy"), a[0].cpu().numpy())
+
+
+def test_mipmapped_textured_rerender(R):
+    """Trilinear mip-mapped lookup at the rasterised UV map: level of detail follows the screen-space footprint, a
+    magnified view reproduces the texture function, a minified one its box-filtered pyramid."""
+    room = S.BoxRoom((6.0, 4.5, 2.8))
+    mesh = R.box_room_mesh(room, subdiv=2)
+    T = 1024
+    vv, uu = torch.meshgrid((torch.arange(T) + 0.5) / T, (torch.arange(T) + 0.5) / T, indexing="ij")
+    f = lambda u, v: torch.stack([torch.sin(9 * u) * torch.cos(7 * v), u, v * v])         # smooth: bilinear-exact to 1e-3
+    tex = f(uu, vv).cuda()
+    mips = R.build_mipmaps(tex)
+    assert [m.shape[1] for m in mips][:3] == [1024, 512, 256] and mips[-1].shape == (3, 1, 1)
+    ref1 = torch.nn.functional.avg_pool2d(tex[None], 2)[0]
+    assert float((mips[1] - ref1).abs().max()) < 1e-6
+    hw = (120, 160)
+    K, c2w = S.camera_matrices((3.0, 2.2, 1.4), 0.3, 0.0, hw)
+    intr = np.array([K[0, 0], K[1, 1], K[0, 2] + 0.5, K[1, 2] + 0.5], dtype=np.float32)
+    uv, _, dep = R.render_maps(mesh, c2w, intr, hw, znear=0.05, zfar=50.0)
+    rgb, lod = R.sample_mipmapped(mips, uv, return_lod=True)
+    hit = (dep > 0)
+    # footprint: ~3 m away, 160 px over ~3.5 m of wall = 1/3 of a 1024-texel-wide atlas -> a few texels per pixel
+    assert 0.5 < float(lod[hit].median()) < 3.5
+    want = f(uv[..., 0], uv[..., 1])
+    smooth = hit & (lod < float(lod[hit].median()) + 1.0)
+    err = (rgb - want).abs()[:, smooth]
+    assert float(err.mean()) < 2e-2 and float(err.max()) < 0.3      # box-filtered smooth function ~ the function
+    assert float(rgb[:, ~hit].abs().max()) == 0.0 if bool((~hit).any()) else True
+    # magnified: a 16x larger render of the same view -> footprint below one texel -> level 0, plain bilinear
+    hw2 = (480, 640)
+    K2, _ = S.camera_matrices((3.0, 2.2, 1.4), 0.3, 0.0, hw2)
+    intr2 = np.array([K2[0, 0] * 4, K2[1, 1] * 4, (K2[0, 2] + 0.5), (K2[1, 2] + 0.5)], dtype=np.float32)  # 4x zoom
+    uv2, _, dep2 = R.render_maps(mesh, c2w, intr2, hw2, znear=0.05, zfar=50.0)
+    rgb2, lod2 = R.sample_mipmapped(mips, uv2, return_lod=True)
+    hit2 = dep2 > 0
+    assert float(lod2[hit2].median()) == 0.0
+    want2 = f(uv2[..., 0], uv2[..., 1])
+    assert float((rgb2 - want2).abs()[:, hit2].mean()) < 2e-3
