@@ -99,6 +99,9 @@ def main():
                     "on a side stream concurrently with the conv trunk")
     ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole gradient arena instead of "
                     "only the chunks the ranks' current views can touch")
+    ap.add_argument("--mfma", choices=["split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
+                    "'split' (default; bf16 MFMA on bf16x3-split operands, fp32 accuracy) or 'f32' (v_mfma_f32_32x32x2_f32 "
+                    "everywhere); same as STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
     ap.add_argument("--timer-every", type=int, default=20, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
                     "of the throughput, so the roofline is sampled)")
@@ -126,6 +129,8 @@ def main():
 
     from stylemesh_amd.runtime import ops
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    if args.mfma is not None:
+        ops.CONV_MODE = ops.GRAM_MODE = args.mfma
 
     cfg = EngineConfig(tex_w=wl["tex"], tex_h=wl["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                        angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"],
