@@ -18,6 +18,11 @@
 #include "conv_common.h"
 #include "conv_split_kernel.h"
 
+#ifndef SM_SPLIT_WGM
+#define SM_SPLIT_WGM 4   // waves along the channel dimension of the 128 x 128 split tile: 4 (32x128 wave tiles: half the
+                         // weight-fragment loads per MFMA, +2.5 %) or 2 (64x64)
+#endif
+
 namespace sm {
 
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS>
@@ -322,7 +327,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 template <int FLAGS>
 static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
     if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
-    return launch_conv<128, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true>(a, n_list, ws_floats, s);
 }
 
 template <int FLAGS>

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES, BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES)))
 void conv3x3_split_kernel(ConvArgs a) {
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
-    static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && BN / WGN == 64 && WGM * WGN == 4,
-                  "wave tile is (32 MI) x 64");
+    constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
+    static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
+                      WGM * WGN == 4,
+                  "wave tile is (32 MI) x (32 NJ)");
     static_assert(BN == 128, "activation staging: one (k-group, position) unit per thread + a 2 x 2 x 8 halo");
     constexpr int KC = 16;
     constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
@@ -79,7 +81,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
     const int wm = (wave / WGN) * (32 * MI);
-    const int wn = (wave % WGN) * 64;
+    const int wn = (wave % WGN) * (32 * NJ);
 #define SM_TS(slot_)                                                                                     \
     if (STAMP && lane == 0) {                                                                            \
         reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)blockIdx.x * 4 + wave) * 64 + (slot_)] = \
@@ -119,11 +121,11 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int m0 = m_tile * BM;
     const int q0 = P.Wp + n_tile * BN;
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -131,17 +133,24 @@ void conv3x3_split_kernel(ConvArgs a) {
     // weights: the global image of a stage, [part][kgroup][Cout] units of 8 bf16, IS the MFMA A-fragment layout
     // (row = lane & 31, k-group = lane >> 5), so every wave loads its own 3 MI fragments (MI row tiles x 3 parts) of a
     // stage straight into registers, three stages ahead: no LDS copy of the weights and no per-stage barrier.
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wt) + lhi * a.Cout + m0 + wm + l31;
-    const int a_part = 2 * a.Cout;            // units between the parts of a stage
-    const int a_stage_units = 6 * a.Cout;     // units per (tap, chunk) stage
+    // (buffer loads: scalar base in an SGPR resource + one 32-bit lane offset + a scalar stage offset - no 64-bit
+    // address arithmetic per load)
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wt), 0, 9 * (a.Cin_pad / KC) * 6 * a.Cout * 16, 0x00020000);
+    const int a_voff = (lhi * a.Cout + m0 + wm + l31) * 16;   // bytes
+    const int a_part = 2 * a.Cout * 16;            // bytes between the parts of a stage
+    const int a_stage_bytes = 6 * a.Cout * 16;     // bytes per (tap, chunk) stage
     // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
     // k-group at stride `plane`; the 2 remaining halo positions x 2 k-groups x 8 channels = 32 single elements are
     // fetched one per lane (every half-wave does the same 32: identical values to identical addresses)
     const int b_kg = tid >> 7, b_px = tid & 127;
-    const int b_src = b_kg * 8 * P.plane + q0 - 1 + b_px;     // centre row (ky = 1); may be -1: plane guard
+    // resource base one row + one float before the plane (inside the guard), so that every offset is >= 0
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P.in) - P.Wp - 1, 0, 0x7ffffff0, 0x00020000);
+    const int b_src = (b_kg * 8 * P.plane + q0 + b_px) * 4;   // bytes, relative to the shifted base, row ky = 0
     const int b_dst = b_kg * BNP + b_px;                      // + part * 2 * BNP (+ slot * SLICE)
     const int h_kg = l31 >> 4, h_px = 128 + ((l31 >> 3) & 1), h_c = l31 & 7;
-    const int h_src = (h_kg * 8 + h_c) * P.plane + q0 - 1 + h_px;
+    const int h_src = ((h_kg * 8 + h_c) * P.plane + q0 + h_px) * 4;   // bytes, same base
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
     constexpr int AD = SM_SPLIT_AD;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
@@ -150,15 +159,18 @@ void conv3x3_split_kernel(ConvArgs a) {
 
 #define SM_LOAD_A(tap_, chunk_)                                                                          \
     {                                                                                                    \
-        const f32x4* s_ = wsrc + (size_t)((tap_) * n_chunks + (chunk_)) * a_stage_units;                 \
+        const int so_ = ((tap_) * n_chunks + (chunk_)) * a_stage_bytes;                                  \
         _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i) ra[(tap_) % AD][i][s] = s_[s * a_part + i * 32]; \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+                ra[(tap_) % AD][i][s] = __builtin_bit_cast(                                              \
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_voff, so_ + s * a_part + i * 512, 0)); \
     }
 #define SM_LOAD_B(ky_, chunk_)                                                                           \
     {                                                                                                    \
-        const float* s_ = P.in + (size_t)(chunk_) * KC * P.plane + ((ky_) - 1) * P.Wp;                   \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[c] = s_[b_src + c * P.plane];                   \
-        rh = s_[h_src];                                                                                  \
+        const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                    \
+            rb[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4, 0)); \
+        rh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0));    \
     }
 #define SM_STORE_B(slot_)                                                                                \
     {                                                                                                    \
@@ -183,7 +195,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     {                                                                                                    \
         const f32x4* bf_ = b_frag + (slot_) * SLICE + (kx_);                                             \
         _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+            _Pragma("unroll") for (int i = 0; i < NJ; ++i)                                               \
                 dst_[i][s] = __builtin_bit_cast(bf16x8, bf_[s * 2 * BNP + i * 32]);                      \
     }
 
@@ -212,7 +224,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
     const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
-    bf16x8 fb[2][3], fb_next[2][3];
+    bf16x8 fb[NJ][3], fb_next[NJ][3];
 #if SM_SPLIT_PREFETCH_B
     SM_READ_B(fb, 0, 0)
 #endif
@@ -248,7 +260,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             // six partial products per output tile, smallest first; consecutive MFMAs target different accumulators
 #define SM_PRODUCT(pa_, pb_)                                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                    \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                   \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
 #if SM_SPLIT_MFMA_PRIO
             __builtin_amdgcn_s_setprio(SM_SPLIT_MFMA_PRIO);
@@ -288,7 +300,7 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fb[i][s] = fb_next[i][s];
+                for (int i = 0; i < NJ; ++i) fb[i][s] = fb_next[i][s];
 #endif
             if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
         }
@@ -305,7 +317,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     if (split >= 0) {
         float* wt = a.ws + ((size_t)(tile - a.n_whole) * a.splits + split) * (BM * BN);
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
+        for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -325,7 +337,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
     }
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
+    for (int nj = 0; nj < NJ; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
         if (q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
