@@ -30,7 +30,10 @@
 // SIMD (AD=1, no prefetch, 168 VGPRs) -14 %; PIN_READS=1 (fragment reads pinned a full stage ahead: the densest
 // MFMA stream, 245 VGPRs) -8 %; any s_setprio (MFMA cluster or the load/convert tail) -9 %: each of them fences the
 // compiler's own interleaving of the tail instructions with the MFMAs. 3 waves per SIMD with AD=3 and no fragment
-// prefetch needs 168 VGPRs: the 128-row variant spills ~25 dwords and loses 14 %.
+// prefetch needs 168 VGPRs: the 128-row variant spills ~25 dwords and loses 14 %. What the loop is sensitive to is the
+// NUMBER of vector-memory instructions (ablation: no weight loads +15 %, no activation loads +8 %, no conversion
+// arithmetic / no LDS fragment reads / no epilogue stores +-1 %): hence the 32 x 128 wave tiles (SM_SPLIT_WGM = 4 in
+// conv.hip) and the buffer loads.
 #ifndef SM_SPLIT_AD
 #define SM_SPLIT_AD 3          // weight prefetch distance in stages (must divide 9)
 #endif
@@ -220,6 +223,10 @@ void conv3x3_split_kernel(ConvArgs a) {
             SM_STORE_B(ky);
         }
     }
+    {
+        const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
+        SM_LOAD_B(0, ch1);      // stored at the end of tap 1 of the first chunk
+    }
     __syncthreads();
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
@@ -233,6 +240,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         // chunk's): a load under `if (more)` makes the compiler's waitcnt pass assume the no-load path at the join,
         // and every later wait for an OLDER load then drains the whole queue (vmcnt(0) instead of vmcnt(N)).
         const int ch_next = ch + 1 < ch_end ? ch + 1 : ch;
+        const int ch_next2 = ch + 2 < ch_end ? ch + 2 : ch_next;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -285,12 +293,18 @@ void conv3x3_split_kernel(ConvArgs a) {
             } else {
                 SM_LOAD_A(tap + AD - 9, ch_next);
             }
-            if (kx == 0) SM_LOAD_B(ky, ch_next);
             // next chunk's slice ky -> slot (base + 3 + ky) & 3: for ky = 0 the spare slot (the previous chunk's
             // ky = 2), for ky = 1, 2 the slot of this chunk's slice ky - 1, whose last readers passed the barrier of
-            // tap 3 ky - 1. One barrier per three stages publishes the slice.
+            // tap 3 ky - 1. The slice is loaded at the end of tap 3 ky - 1 (for ky = 0: tap 8 of the previous chunk),
+            // converted and written at the end of tap 3 ky + 1 - a stage WITHOUT a barrier, so that the conversion does
+            // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
+            if (kx == 1) SM_STORE_B((base + 3 + ky) & 3);
             if (kx == 2) {
-                SM_STORE_B((base + 3 + ky) & 3);
+                if (ky < 2) {
+                    SM_LOAD_B(ky + 1, ch_next);
+                } else {
+                    SM_LOAD_B(0, ch_next2);
+                }
                 __syncthreads();
             }
 #if SM_SPLIT_TAIL_PRIO
