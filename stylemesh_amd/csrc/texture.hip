@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const 
 
 // K2, tiled: one block = a 16x16 pixel tile of the view. Neighbouring pixels hit neighbouring (coarse layers: the
 // same) texels, and a device-scope atomic costs a fabric transaction whether or not it shares a cache line, so the
-// tile's contributions to one layer are first summed in an LDS window of WS x WS texels anchored at the tile's
+// tile's contributions to one layer are first summed in an LDS window of WS x WS texels (48: 28 KB) anchored at the tile's
 // smallest (x0, y0) (ds_add_f32), and only the window's non-zero texels go to memory - as row-contiguous atomics.
 // Pixels whose 2x2 taps fall outside the window (UV seams, strongly magnified views) use the direct path.
 template <int WS>
@@ -351,7 +351,7 @@ int sm_tex_sample_bwd(float* const* grad_layers, const int* layer_w, const int* 
     if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS) return (int)hipErrorInvalidValue;
     sm::TexLayers L = sm::make_layers(grad_layers, layer_w, layer_h, n_layers);
     const int tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
-    hipLaunchKernelGGL(sm::tex_sample_bwd_tiled_kernel<32>, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(sm::tex_sample_bwd_tiled_kernel<48>, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream,
                        L, reinterpret_cast<const float2*>(grid), h, w, grad_img, pixel_weight, sm::row_stride(w),
                        sm::plane_size(h, w), tiles_x);
     SM_LAUNCH_CHECK();
