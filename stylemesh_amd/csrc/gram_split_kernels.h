@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
 // masks accumulate into one set of accumulators; masks that are zero on the whole 128-position tile cost nothing
 // (the passed / failed angle masks partition the valid pixels, most tiles see one of them).
 // ---------------------------------------------------------------------------------------------------
+// MI = 1: 64-row blocks, waves 2 x 2 with 32 x 64 tiles; MI = 2: 128-row blocks, waves 4 x 1 with 32 x 128 tiles (one
+// 32-row weight fragment set per wave: the loop is sensitive to the number of vector-memory instructions per MFMA,
+// see conv_split_kernel.h)
 template <int MI, bool RELU_GATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_backward_split_kernel(
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int SLICE = KS * 6 * BN;    // [kstep][part][kgroup][position] units of 8 channels
     __shared__ __attribute__((aligned(16))) f32x4 Bs[2][SLICE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 64;
+    constexpr int NJ = 2 * MI;                       // 32-position MFMA tiles per wave
+    const int wm = (MI == 2 ? wave : (wave >> 1)) * 32, wn = (MI == 2 ? 0 : (wave & 1)) * 64;
     const int m0 = blockIdx.y * (64 * MI);
     const int q0 = q_begin + blockIdx.x * BN;
 
@@ -72,13 +76,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int live0 = __syncthreads_or(mv0 != 0.f), live1 = __syncthreads_or(mv1 != 0.f);
     const int nlive = (live0 != 0) + (live1 != 0);
 
-    f32x16 acc[MI][2];
+    f32x16 acc[1][NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
     if (nlive > 0) {
         const int n_chunks = C / (16 * KS);
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int kfix = live0 ? 0 : 1;
         const float* bsrc = feat + (size_t)b_kg * 8 * plane + q0 + b_px;
         const int a_off = lhi * C + m0 + wm + l31;
-        f32x4 ra[2][KS][MI][3];
+        f32x4 ra[2][KS][1][3];
         float rb[2][KS][8];
         // stage s -> (chunk, mask); beyond the last stage the last one is re-read (unconditional loads keep the
         // compiler's vmcnt bookkeeping exact, see conv_split_kernel.h)
@@ -100,8 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 6 * C + a_off;             \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
             _Pragma("unroll") for (int part = 0; part < 3; ++part)                          \
-                _Pragma("unroll") for (int i = 0; i < MI; ++i)                              \
-                    ra[set_][ks][i][part] = p_[(ks * 6 + part * 2) * C + i * 32];           \
+                ra[set_][ks][0][part] = p_[(ks * 6 + part * 2) * C];                        \
     }
 #define SM_LOAD_B(set_, s_)                                                                 \
     {                                                                                       \
@@ -133,14 +134,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         SM_LOAD_B(par_, (s_) + 2)                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
-            bf16x8 fa[MI][3], fb[2][3];                                                     \
+            bf16x8 fa[1][3], fb[NJ][3];                                                     \
             const f32x4* bf_ = &Bs[par_][ks * 6 * BN + lhi * BN + wn + l31];                \
             _Pragma("unroll") for (int part = 0; part < 3; ++part) {                        \
-                _Pragma("unroll") for (int i = 0; i < MI; ++i) fa[i][part] = __builtin_bit_cast(bf16x8, ra[par_][ks][i][part]); \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j][part] = __builtin_bit_cast(bf16x8, bf_[part * 2 * BN + j * 32]); \
+                fa[0][part] = __builtin_bit_cast(bf16x8, ra[par_][ks][0][part]);            \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb[j][part] = __builtin_bit_cast(bf16x8, bf_[part * 2 * BN + j * 32]); \
             }                                                                               \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                  \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) { SM_MFMA6(acc[i][j], fa[i], fb[j]) } \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) { SM_MFMA6(acc[0][j], fa[0], fb[j]) } \
         }                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         SM_LOAD_A(par_, (s_) + 2)                                                           \
@@ -164,23 +164,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // epilogue: 32x32 C/D layout, column (position) = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
+    for (int nj = 0; nj < NJ; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
         if (q >= q_end) continue;
+        const size_t o0 = (size_t)(m0 + wm + 4 * lhi) * plane + q;
+        float gate[16];
+        if (RELU_GATE) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * plane + q;
-            float gate[16];
-            if (RELU_GATE) {
+            for (int r = 0; r < 16; ++r) gate[r] = feat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane];
+        }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) gate[r] = feat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[mi][nj][r];
-                if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
-                dfeat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = v;
-            }
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[0][nj][r];
+            if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
+            dfeat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = v;
         }
     }
 }
