@@ -336,6 +336,27 @@ def test_side_stream_style_branches_equal_serial():
         grad_close(a, b.cpu(), "side-stream vs serial")
 
 
+def test_view_without_valid_pixels_is_a_noop_for_the_data_term():
+    """A view whose mask is empty (camera facing the window / all depth dropped out): every level is filtered out
+    (reference model/model.py:256-257), the data-term gradient stays exactly zero, content / style losses are 0 and
+    the update is driven by the regulariser alone."""
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [T(g5[f"init{i}"]) for i in range(4)]
+    batch = list(batch_from_golden(g5))
+    batch[9] = [torch.zeros_like(u) for u in batch[9]]          # uv = 0 everywhere -> mask false everywhere
+    batch[10] = torch.zeros_like(batch[10])
+    eng = make_engine(FLAGSETS["with_angle_and_depth"], init)
+    eng.set_view(tuple(batch))
+    assert not any(lv.active for lv in eng.view)
+    before = [l.clone() for l in eng.layers]
+    lt = eng.training_step(tuple(batch))
+    losses = eng.losses(lt)
+    assert losses["content"] == 0.0 and losses["style"] == 0.0 and losses["tex_reg"] > 0.0
+    assert float(eng.arena.g.abs().max()) == 0.0
+    moved = [float((a - b).abs().max()) for a, b in zip(eng.layers, before)]
+    assert moved[0] > 0.0 and all(torch.isfinite(l).all() for l in eng.layers)   # layer 0 has tex_reg weight 8
+
+
 def test_level_streams_equal_serial():
     """The UV levels' loss branches on separate HIP streams (default) give the serial result."""
     g5 = load_golden("g5_with_angle_and_depth")
