@@ -178,6 +178,11 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 int sm_gram_split_num_slabs(void);
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                          int H, int W, void* stream);
+/* Same kernel without the zero fill: the position ranges ADD into S0 / S1, which the caller has zeroed (one fill
+ * over the slabs of every level and layer of a step instead of two per call) or which hold a partial sum to
+ * continue. */
+int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
+                         int H, int W, void* stream);
 
 /* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
  * S0/S1: the n_slabs partial slabs written by sm_gram_masked (summed here).

@@ -385,8 +385,8 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 
 int sm_gram_split_num_slabs(void) { return 1; }
 
-int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
-                         int W, void* stream) {
+static int gram_masked_split_impl(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
+                                  int H, int W, bool zero_fill, void* stream) {
     if (C % 64 != 0) return (int)hipErrorInvalidValue;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
@@ -395,8 +395,8 @@ int sm_gram_masked_split(const float* feat, const float* mask0, const float* mas
     hipStream_t s = (hipStream_t)stream;
     const int nmask = mask1 ? 2 : 1;
     // several position ranges -> they all add into slab 0 (zeroed here); a single range stores it directly
-    const bool atomic = p.n_raw > 1;
-    if (atomic) {
+    const bool atomic = p.n_raw > 1 || !zero_fill;
+    if (atomic && zero_fill) {
         hipError_t e = hipMemsetAsync(S0, 0, cc * sizeof(float), s);
         if (e == hipSuccess && mask1) e = hipMemsetAsync(S1, 0, cc * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
@@ -412,6 +412,16 @@ int sm_gram_masked_split(const float* feat, const float* mask0, const float* mas
 #undef SM_GS
     SM_LAUNCH_CHECK();
     return 0;
+}
+
+int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
+                         int W, void* stream) {
+    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, true, stream);
+}
+
+int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
+                             int H, int W, void* stream) {
+    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, false, stream);
 }
 
 size_t sm_gram_backward_split_ws_bytes(int C) { return (size_t)2 * 6 * C * C; }

@@ -13,6 +13,8 @@ reused for the 20-100 consecutive steps the reference's RepeatingSampler spends 
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass, field
 
@@ -151,6 +153,7 @@ class StepEngine:
         self._lv_streams = []
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
+        self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
         numel = [c * h * w for c, h, w in self.arena.shapes]
         lam = cfg.loss_weights.get("tex_reg", 0.0)
@@ -190,7 +193,18 @@ class StepEngine:
         if cur is None or cur[0].shape[0] < n_slabs:
             self._gram[key] = (torch.zeros(n_slabs, C, C, device=self.device), torch.zeros(n_slabs, C, C, device=self.device),
                                torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
+            self._gram_clean.add(key)
         return self._gram[key]
+
+    def _zero_step_accumulators(self):
+        """ONE multi-tensor fill for everything a step accumulates into: the loss pair and the Gram slabs of every
+        (level, layer) the previous step added into (instead of two fills per masked-Gram call)."""
+        dirty = [k for k in self._gram if k not in self._gram_clean]
+        bufs = [self.loss_buf]
+        for k in dirty:
+            bufs += [self._gram[k][0], self._gram[k][1]]
+        torch._foreach_zero_(bufs)
+        self._gram_clean.update(dirty)
 
     # ------------------------------------------------------------------ style targets
     def set_style_image(self, style_image: torch.Tensor, num_levels=5):
@@ -349,7 +363,7 @@ class StepEngine:
         if self.view is None or self.targets is None:
             raise RuntimeError("set_style_image() and set_view() must be called first")
         cfg = self.cfg
-        self.loss_buf.zero_()
+        self._zero_step_accumulators()
         w_style = float(cfg.loss_weights.get("style", 0.0))
         w_content = float(cfg.loss_weights.get("content", 0.0))
         active = [lv for lv in self.view if lv.active]
@@ -466,7 +480,10 @@ class StepEngine:
         cfg = self.cfg
         f = b.act[layer]
         n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
-        S0, S1, D0, D1 = self._gram_scratch((f.C, lv.index, layer), ops.gram_workspace_slabs(f.C, f.H, f.W))
+        key = (f.C, lv.index, layer)
+        S0, S1, D0, D1 = self._gram_scratch(key, ops.gram_workspace_slabs(f.C, f.H, f.W))
+        pre = ops.GRAM_MODE == "split" and key in self._gram_clean   # zeroed by _zero_step_accumulators
+        self._gram_clean.discard(key)
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
         m0, m1 = self._style_masks(lv, layer)
@@ -478,7 +495,7 @@ class StepEngine:
             hist_len, hist_slot = min(cnt, 9), cnt % 9
             self._hist[layer][1] = cnt + 1
         if multi:
-            ops.gram_masked(f, m0, m1, S0, S1)
+            ops.gram_masked(f, m0, m1, S0, S1, prezeroed=pre)
             targets = [self.targets[li][2], self.targets[li][2]]
             term_mask = [0, 1]
             if li > 2:   # content_and_style_losses.py:335-338
@@ -488,7 +505,7 @@ class StepEngine:
                            D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
         else:
             D1 = None
-            ops.gram_masked(f, m0, None, S0, None)
+            ops.gram_masked(f, m0, None, S0, None, prezeroed=pre)
             ops.style_loss(S0, None, lv.counts[layer][0:1], lv.factor[layer], [self.targets[li][0]], [0], [0, 0],
                            weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
         ops.gram_backward(f, m0, m1, D0, D1, b.grad[layer], relu_gate=(layer == self.deepest))

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_split_num_slabs": [],
     "sm_gram_masked_split": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_gram_masked_split_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -274,12 +274,16 @@ def gram_workspace_slabs(C: int, H: int, W: int) -> int:
 GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", "split")
 
 
-def gram_masked(feat: FMap, mask0, mask1, S0, S1):
-    """S0 / S1: [gram_workspace_slabs(C,H,W), C, C]; returns how many leading slabs sum to S."""
+def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False):
+    """S0 / S1: [gram_workspace_slabs(C,H,W), C, C]; returns how many leading slabs sum to S. ``prezeroed`` (split
+    mode only): the caller has zeroed the slabs, the kernel adds into them without a fill of its own."""
     n = gram_num_slabs(feat.C, feat.H, feat.W)
     na = gram_workspace_slabs(feat.C, feat.H, feat.W)
     assert S0.numel() >= na * feat.C * feat.C and (S1 is None or S1.numel() >= na * feat.C * feat.C)
-    fn = lib.sm_gram_masked_split if GRAM_MODE == "split" else lib.sm_gram_masked
+    if GRAM_MODE == "split":
+        fn = lib.sm_gram_masked_split_acc if prezeroed else lib.sm_gram_masked_split
+    else:
+        fn = lib.sm_gram_masked
     hip.check(fn(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W, hip.stream()),
               "sm_gram_masked")
     return n

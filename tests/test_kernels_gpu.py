@@ -263,6 +263,13 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi, gram_mode, monkeypatch
     T = C // 64
     tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
     assert_close(S[0][:ns].sum(0).cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
+    if gram_mode == "split":
+        # accumulate variant: adds into caller-zeroed slabs (the engine zeroes every slab of a step with one fill)
+        A = [torch.zeros(na, C, C).cuda(), torch.zeros(na, C, C).cuda() if multi else None]
+        for rep in (1, 2):
+            rt.ops.gram_masked(f, mk[0], mk[1], A[0], A[1], prezeroed=True)
+            assert_close(A[0][0].cpu()[tile_upper], rep * S[0][:ns].sum(0).cpu()[tile_upper], 1e-5,
+                         1e-5 * float(ref_S0.abs().max()))
     counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
     D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
     loss_out = torch.zeros(1).cuda()
