@@ -13,8 +13,6 @@ reused for the 20-100 consecutive steps the reference's RepeatingSampler spends 
 """
 from __future__ import annotations
 
-import os
-
 import math
 from dataclasses import dataclass, field
 
