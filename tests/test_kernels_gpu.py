@@ -145,6 +145,32 @@ def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypa
     assert errs["split"] <= 2.0 * errs["f32"] + 1e-9, errs
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 60, 70), (512, 512, 33, 45), (256, 64, 40, 52)])
+def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, monkeypatch):
+    """Fewer tiles than CUs: every tile is a K-split tail reduced by the second pass. Repeated launches must be
+    bit-identical (fixed summation order) and match an fp64 convolution."""
+    monkeypatch.setattr(rt.ops, "CONV_MODE", "split")
+    torch.manual_seed(cin + H)
+    x = F.relu(torch.randn(1, cin, H, W) * 2)
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout) * 0.3
+    ref = F.relu(F.conv2d(x.double(), wgt.double(), b.double(), padding=1))[0]
+    xin = rt.FMap(cin, H, W).from_dense(x[0])
+    w = dev(rt.ops.pack_conv_fwd(wgt))
+    w3 = rt.ops.pack_conv_split(w)
+    first = None
+    for rep in range(25):
+        out = rt.FMap(cout, H, W)
+        rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3)
+        got = out.to_dense()
+        if first is None:
+            first = got
+            d = got.double().cpu() - ref
+            assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max())
+        else:
+            assert torch.equal(got, first), rep
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 13, 131), (256, 512, 6, 9), (64, 64, 17, 21), (64, 128, 20, 28)])
 def test_conv3x3_split_dgrad_with_gate_and_add(rt, cin, cout, H, W, monkeypatch):
     monkeypatch.setattr(rt.ops, "CONV_MODE", "split")
