@@ -99,6 +99,8 @@ def main():
                     "on a side stream concurrently with the conv trunk")
     ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole gradient arena instead of "
                     "only the chunks the ranks' current views can touch")
+    ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
+                    "with the update of each arena range issued as its sums arrive (default: exchange, then update)")
     ap.add_argument("--mfma", choices=["split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split' (default; bf16 MFMA on bf16x3-split operands, fp32 accuracy) or 'f32' (v_mfma_f32_32x32x2_f32 "
                     "everywhere); same as STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
@@ -141,6 +143,7 @@ def main():
     eng.use_graphs = args.graphs
     eng.sparse_tiles = not args.dense
     eng.overlap_style = args.overlap_style
+    eng.pipeline_exchange = args.pipeline_exchange
 
     # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
     total_steps = args.warmup + args.steps
@@ -229,7 +232,8 @@ def main():
                           "vgg_weights": "He-normal, seeded", "parallelism": f"views sharded over {world} rank(s)"
                           + ((", RCCL all-reduce of the 267 MB texture gradient per step" if args.dense_allreduce else
                               f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
-                              f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)")
+                              f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)"
+                              + (f", in {reducer.n_pieces} pieces overlapped with the update" if args.pipeline_exchange else ""))
                              if world > 1 else "")},
                # BASELINE.json's second metric: the reference has no convergence criterion, a scene is trained for a
                # fixed schedule (SURVEY.md section 8 d): 7 epochs x index_repeat x 0.99 V views, V = 276 for ScanNet

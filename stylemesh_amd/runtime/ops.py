@@ -126,7 +126,16 @@ def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
 
 
 def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
-               zero_grad=True, sumsq_out=None, dev_hyper=None):
+               zero_grad=True, sumsq_out=None, dev_hyper=None, lo=0, hi=None):
+    """``lo`` / ``hi``: update only arena elements [lo, hi) (multiples of 4; the pipelined multi-GPU exchange updates
+    the arena range by range) - same kernel on offset pointers, segment ends shifted and clipped to the range."""
+    if lo != 0 or (hi is not None and hi != p.numel()):
+        hi = p.numel() if hi is None else hi
+        assert lo % 4 == 0 and 0 <= lo <= hi <= p.numel()
+        if hi == lo:
+            return
+        p, g, m, v = p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi]
+        seg_end = [min(max(int(e) - lo, 0), hi - lo) for e in seg_end]
     n = p.numel()
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

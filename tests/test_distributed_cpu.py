@@ -89,6 +89,20 @@ def _sparse_worker(rank, world, port, out_dir):
             dist.all_reduce(dense)
             red(arena)
             out[(view, step)] = (arena.clone(), dense, red.fraction, red.last_bytes)
+            # pipelined exchange + update: ranges must tile the arena in order and see the summed gradient
+            local = torch.zeros(n_chunks, chunk)
+            local[touched] = torch.randn(int(touched.sum()), chunk, generator=g)
+            local = local.reshape(-1)
+            want = local.clone()
+            dist.all_reduce(want)
+            param, ranges = torch.ones(local.numel()), []
+
+            def update_range(lo, hi):
+                ranges.append((lo, hi))
+                param[lo:hi] -= 0.1 * local[lo:hi]
+                local[lo:hi] = 0
+            red.pipelined(local, update_range)
+            out[("pipe", view, step)] = (param, 1.0 - 0.1 * want, ranges, int(local.abs().sum()), red.last_bytes)
     torch.save(out, os.path.join(out_dir, f"sparse{rank}.pt"))
     dist.destroy_process_group()
 
@@ -97,6 +111,12 @@ def test_sparse_grad_reducer_equals_dense_allreduce(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_sparse_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"sparse{r}.pt") for r in (0, 1))
+    for key in [k for k in r0 if k[0] == "pipe"]:
+        param, want, ranges, left, nbytes = r0.pop(key)
+        r1.pop(key)
+        assert torch.equal(param, want) and left == 0
+        assert ranges[0][0] == 0 and ranges[-1][1] == 64 * 16 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert len(ranges) == (4 if key[1] == 0 else 1)      # view 1 is the dense fallback of a 1024-float arena
     for key in r0:
         mine, dense, frac, nbytes = r0[key]
         assert torch.equal(mine, dense) and torch.equal(mine, r1[key][0])

@@ -407,6 +407,29 @@ def test_adam_fused_matches_oracle(rt):
     assert_close(big, [O.CLAMP_HI, O.CLAMP_LO, 1, 2, 3], 1e-7, 0)
 
 
+def test_adam_fused_by_ranges_equals_one_launch(rt):
+    """The pipelined multi-GPU update runs the fused optimizer range by range (runtime/distributed.py): parameters and
+    moments must be bit-identical to one launch over the arena, the per-layer sums of squares equal up to summation order."""
+    torch.manual_seed(11)
+    sizes = [3 * 64 * 64, 3 * 32 * 32, 3 * 16 * 16, 3 * 8 * 8]
+    seg_end = np.cumsum(sizes).tolist()
+    n = seg_end[-1]
+    reg = [0.41, 0.2, 0.05, 0.0]
+    p0 = (torch.randn(n) * 60).clamp(O.CLAMP_LO, O.CLAMP_HI)
+    m0, v0, g0 = torch.randn(n) * 0.1, torch.rand(n) * 0.01, torch.randn(n)
+    res = []
+    for bounds in ([0, n], [0, 4096, 4096 + 64, seg_end[0] + 128, seg_end[2] - 64, n]):
+        P, M, V, G = dev(p0), dev(m0), dev(v0), dev(g0)
+        sumsq = torch.zeros(4).cuda()
+        for lo, hi in zip(bounds, bounds[1:]):
+            rt.ops.adam_fused(P, G, M, V, seg_end, reg, 0.5, 3, grad_scale=0.5, sumsq_out=sumsq, lo=lo, hi=hi)
+        assert float(G.abs().max()) == 0
+        res.append((P, M, V, sumsq))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert_close(res[1][3], res[0][3], 1e-5, 0)
+
+
 # ------------------------------------------------------------------ per-view constants
 def test_view_constants_match_oracle(rt):
     from golden_cases import SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW
