@@ -344,15 +344,18 @@ class StepEngine:
             needs = [need_maps(lv.M, lv.H, lv.W, set(self.injected), self.deepest) for lv in active]
             shapes = tuple((lv.H, lv.W) for lv in active)
             self.view_tiles = {}
+            dsts, srcs = [], []
             for key, (lst, frac, cap) in build_tile_lists(needs, self.deepest).items():
                 # fixed-address storage (a captured graph keeps the pointer); capacity = all tiles of the launch
                 buf = self._persist(("tiles", key, shapes), lambda: torch.zeros(max(cap, 1), dtype=torch.int32, device=dev))
-                buf[:lst.numel()].copy_(lst)
                 self.view_tiles[key] = (buf[:lst.numel()], frac)
+                if lst.numel():
+                    dsts.append(buf[:lst.numel()])
+                    srcs.append(lst)
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)
             # gradient planes must be zero outside this view's active tiles: the previous view wrote elsewhere
-            for lv in active:
-                for g in self._level_bufs(lv.H, lv.W).grad.values():
-                    g.buf.zero_()
+            torch._foreach_zero_([g.buf for lv in active for g in self._level_bufs(lv.H, lv.W).grad.values()])
         # identifies the step's launch sequence (grid sizes depend on the tile lists)
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
                          None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))

@@ -52,31 +52,37 @@ def build_tile_lists(needs, last_layer: str):
         if src != "img":
             jobs.append(((kind, "b"), src, ops.conv_tile_positions(cout, cin)))
     # flags of a (layer, tile size) pair are shared by the conv that produces the layer and the dgrad that produces
-    # its gradient; all flags go into ONE buffer so that a single nonzero + a single read-back serve every list
-    seg = {}             # (level, layer, bn) -> (offset, n_tiles)
+    # its gradient; all flags go into ONE buffer, the levels of a pair next to each other: every list is then one
+    # contiguous slice of the compacted buffer, and a single nonzero + a single read-back serve all of them
+    seg = {}             # (layer, bn) -> [offset of level 0, ..., offset of level n-1, end]
+    starts, shifts = [], []
     total = 0
     for _, layer, bn in jobs:
+        if (layer, bn) in seg:
+            continue
+        offs = []
         for g, nd in enumerate(needs):
-            if (g, layer, bn) not in seg:
-                h, w = nd[layer].shape
-                n = (h * hip.row_stride(w) + bn - 1) // bn
-                seg[(g, layer, bn)] = (total, n)
-                total += n
+            h, w = nd[layer].shape
+            offs.append(total)
+            starts.append(total)
+            shifts.append((g << 24) - total)          # global flag index -> (problem << 24) | tile-in-problem
+            total += (h * hip.row_stride(w) + bn - 1) // bn
+        seg[(layer, bn)] = offs + [total]
     flags = torch.empty(total, dtype=torch.uint8, device=dev)
-    for (g, layer, bn), (off, n) in seg.items():
-        ops.tile_flags(needs[g][layer], bn, flags[off:off + n])
-    active = torch.nonzero(flags).flatten().to(torch.int32)            # ascending global tile ids
+    for (layer, bn), offs in seg.items():
+        for g in range(len(needs)):
+            ops.tile_flags(needs[g][layer], bn, flags[offs[g]:offs[g + 1]])
+    active = torch.nonzero(flags).flatten()                            # ascending global flag indices
+    starts_d = torch.tensor(starts, device=dev)
+    which = torch.searchsorted(starts_d, active, right=True) - 1
+    entries = (active + torch.tensor(shifts, device=dev)[which]).to(torch.int32)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(flags.to(torch.int64), 0)])
-    offs = sorted({o for o, _ in seg.values()} | {o + n for o, n in seg.values()})
-    cnt = dict(zip(offs, csum[torch.tensor(offs, device=dev)].tolist()))  # the one read-back
+    bounds = sorted({o[0] for o in seg.values()} | {o[-1] for o in seg.values()})
+    cnt = dict(zip(bounds, csum[torch.tensor(bounds, device=dev)].tolist()))  # the one read-back
     out = {}
     for key, layer, bn in jobs:
-        parts, n_all = [], 0
-        for g in range(len(needs)):
-            off, n = seg[(g, layer, bn)]
-            a, b = cnt[off], cnt[off + n]
-            parts.append(active[a:b] - off + (g << 24))
-            n_all += n
-        lst = torch.cat(parts).contiguous()
+        offs = seg[(layer, bn)]
+        lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
+        n_all = offs[-1] - offs[0]
         out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
     return out
