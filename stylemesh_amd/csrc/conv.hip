@@ -410,7 +410,7 @@ __device__ __forceinline__ void maxpool_bwd_relu_body(const float* __restrict__ 
     const float pm = pooled[qo];
     const float g = (pm > 0.f) ? dpooled[qo] : 0.f;  // max <= 0 -> every ReLU gate in the window is closed
     const size_t base = (size_t)c * plane + (2 * yo + 1) * Wp + 2 * xo + 1;
-    const float v00 = act[base], v01 = act[base + 1], v10 = act[base + Wp], v11 = act[base + Wp + 1];
+    const float v00 = act[base], v01 = act[base + 1], v10 = act[base + Wp];   // the 4th wins by elimination
     // The first maximum in row-major order gets the gradient (ATen max_pool2d_with_indices: strict '>' scan).
     // NOTE on exact ties: a constant image region (background pixels, the all-zero initial texture) makes every
     // window an exact 4-way tie in exact arithmetic; which copy is largest in fp32 then depends on last-bit
