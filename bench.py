@@ -52,7 +52,9 @@ def make_views(wl, seeds):
 
 
 def to_device(batch, dev):
-    return tuple([u.to(dev) for u in x] if isinstance(x, list) else (x.to(dev) if torch.is_tensor(x) else x) for x in batch)
+    """Everything to the GPU except the view index (element 8: host-side bookkeeping, read by the host)."""
+    return tuple([u.to(dev) for u in x] if isinstance(x, list) else (x.to(dev) if torch.is_tensor(x) and i != 8 else x)
+                 for i, x in enumerate(batch))
 
 
 def cpu_baseline(wl, view_cpu, steps):

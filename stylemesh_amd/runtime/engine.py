@@ -128,6 +128,7 @@ class StepEngine:
         self.targets = None        # targets[layer_index][pyramid_level] -> [C,C] device tensor
         self.view = None
         self.view_key = None
+        self._last_batch = None
         self.step_count = 0
         self.epoch = 0
         # device scalars: [content, style] weighted loss accumulators, per-layer sum of squares of the texture
@@ -163,6 +164,7 @@ class StepEngine:
         # d/dp [lam * w_i * mean(p_i^2)] = (2 lam w_i / N_i) p
         self.reg_coef = [2.0 * lam * w / n if self.reg_active else 0.0 for w, n in zip(rw, numel)]
         self.reg_loss_coef = [lam * w / n if self.reg_active else 0.0 for w, n in zip(rw, numel)]
+        self._reg_loss_coef_dev = torch.tensor(self.reg_loss_coef, device=self.device)   # no per-step host copy
         ops.clamp_sumsq(self.arena.p, self.arena.seg_end, self.sumsq)
 
     # ------------------------------------------------------------------ texture access
@@ -296,6 +298,7 @@ class StepEngine:
                 lv.active = bool(sums[lv.index] > 0)
         self._finish_view(levels, rgb_dev)
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
+        self._last_batch = batch
 
     def _finish_view(self, levels, rgb_dev):
         """Layer-resolution masks + counts + level factors (calculate_pyramid, losses :146-217) and the content
@@ -643,7 +646,12 @@ class StepEngine:
 
     def training_step(self, batch, world_size: int = 1, reducer=None):
         """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order."""
-        key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
+        # the same batch object again = the same view (RepeatingSampler schedules): no read of the view index, which
+        # would be a device-to-host sync per step when the batch lives on the GPU
+        if self.view is None or batch is not self._last_batch:
+            key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
+        else:
+            key = self.view_key
         if self.view is None or key != self.view_key:
             self.set_view(batch)
             if reducer is not None and hasattr(reducer, "new_view"):
@@ -670,7 +678,7 @@ class StepEngine:
     def loss_tensors(self):
         """Weighted losses as device tensors, names as the reference logs them (model/model.py:261-270).
         content / style are filled by the forward_backward() that follows."""
-        reg = (self.sumsq * torch.tensor(self.reg_loss_coef, device=self.device)).sum().reshape(1)
+        reg = (self.sumsq * self._reg_loss_coef_dev).sum().reshape(1)
         return {"content": self.loss_buf[0:1], "style": self.loss_buf[1:2], "tex_reg": reg}
 
     def losses(self, lt=None):
