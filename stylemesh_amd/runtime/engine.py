@@ -292,17 +292,26 @@ class StepEngine:
                            ag if cfg.use_angle_weight else None, adeg, float(cfg.angle_threshold), h, w, lv.H, lv.W,
                            lv.M, lv.pixel_weight, lv.passed, msums[i:i + 1])
             levels.append(lv)
-        sums = msums.cpu()   # the one host sync per view: which levels are non-empty (model/model.py:256-257)
+        # Which levels are non-empty (model/model.py:256-257) is known only on the device. Everything below is
+        # launched on the assumption that all of them are, and the mask sums ride along in the ONE host read-back at
+        # the end (the tile-list lengths): the host reaches that sync with all of set_view's launches already queued
+        # behind the previous view's steps, instead of draining the queue first and then launching into an idle GPU.
         for lv in levels:
             if hasattr(lv, "M"):
-                lv.active = bool(sums[lv.index] > 0)
-        self._finish_view(levels, rgb_dev)
+                lv.active = True
+        sums = self._finish_view(levels, rgb_dev, msums)
+        if any(hasattr(lv, "M") and not sums[lv.index] > 0 for lv in levels):   # rare: an empty level -> redo without it
+            for lv in levels:
+                if hasattr(lv, "M"):
+                    lv.active = bool(sums[lv.index] > 0)
+            self._finish_view(levels, rgb_dev)
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
         self._last_batch = batch
 
-    def _finish_view(self, levels, rgb_dev):
+    def _finish_view(self, levels, rgb_dev, msums=None):
         """Layer-resolution masks + counts + level factors (calculate_pyramid, losses :146-217) and the content
-        target features, for levels whose ``M`` / ``passed`` maps are already on the device."""
+        target features, for levels whose ``M`` / ``passed`` maps are already on the device. ``msums`` (device, one
+        mask sum per level): returned as a host list, read together with the tile-list lengths."""
         cfg, dev = self.cfg, self.device
         h, w = rgb_dev.shape[1:]
         active = [lv for lv in levels if lv.active]
@@ -342,13 +351,17 @@ class StepEngine:
         self.view = levels
         self.view_consts = consts
         self.view_tiles = None
+        sums_host = None
         if self.sparse_tiles and active and self.deepest is not None and all(lv.grid is not None for lv in active):
             from .sparsity import build_tile_lists, need_maps
             needs = [need_maps(lv.M, lv.H, lv.W, set(self.injected), self.deepest) for lv in active]
             shapes = tuple((lv.H, lv.W) for lv in active)
             self.view_tiles = {}
             dsts, srcs = [], []
-            for key, (lst, frac, cap) in build_tile_lists(needs, self.deepest).items():
+            lists = build_tile_lists(needs, self.deepest, msums)
+            if msums is not None:
+                lists, sums_host = lists
+            for key, (lst, frac, cap) in lists.items():
                 # fixed-address storage (a captured graph keeps the pointer); capacity = all tiles of the launch
                 buf = self._persist(("tiles", key, shapes), lambda: torch.zeros(max(cap, 1), dtype=torch.int32, device=dev))
                 self.view_tiles[key] = (buf[:lst.numel()], frac)
@@ -362,6 +375,9 @@ class StepEngine:
         # identifies the step's launch sequence (grid sizes depend on the tile lists)
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
                          None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))
+        if msums is not None and sums_host is None:
+            sums_host = msums.tolist()   # no tile lists to read along with
+        return sums_host
 
     # ------------------------------------------------------------------ the step
     def forward_backward(self):

@@ -39,9 +39,10 @@ def need_maps(M: torch.Tensor, H: int, W: int, injected, last_layer: str) -> dic
     return need
 
 
-def build_tile_lists(needs, last_layer: str):
+def build_tile_lists(needs, last_layer: str, extra=None):
     """``needs``: one ``need_maps`` dict per level of the grouped launch (in problem order).
-    Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, n_all_tiles)}."""
+    Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, n_all_tiles)}.
+    ``extra``: optional 1-D float device tensor that rides along in the one read-back; then returns (dict, list)."""
     from . import hip
     dev = next(iter(needs[0].values())).device
     jobs = []            # (key, layer, bn)
@@ -78,11 +79,17 @@ def build_tile_lists(needs, last_layer: str):
     entries = (active + torch.tensor(shifts, device=dev)[which]).to(torch.int32)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(flags.to(torch.int64), 0)])
     bounds = sorted({o[0] for o in seg.values()} | {o[-1] for o in seg.values()})
-    cnt = dict(zip(bounds, csum[torch.tensor(bounds, device=dev)].tolist()))  # the one read-back
+    picked = csum[torch.tensor(bounds, device=dev)]
+    if extra is None:
+        host, extra_host = picked.tolist(), None                              # the one read-back
+    else:   # counts < 2^53 and the extras (mask sums) are exact in float64
+        both = torch.cat([picked.to(torch.float64), extra.to(torch.float64)]).tolist()
+        host, extra_host = [int(v) for v in both[:len(bounds)]], both[len(bounds):]
+    cnt = dict(zip(bounds, host))
     out = {}
     for key, layer, bn in jobs:
         offs = seg[(layer, bn)]
         lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
         n_all = offs[-1] - offs[0]
         out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
-    return out
+    return out if extra is None else (out, extra_host)
