@@ -156,6 +156,8 @@ class StepEngine:
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
+        self._gram_need = {}       # key -> slabs per mask
+        self._gram_arena = None    # backing store of every S0 / S1
         self._hist = {}            # layer -> (ring [9,C,C], count) for gram_mode 'average'
         numel = [c * h * w for c, h, w in self.arena.shapes]
         lam = cfg.loss_weights.get("tex_reg", 0.0)
@@ -190,24 +192,46 @@ class StepEngine:
 
     def _gram_scratch(self, key, n_slabs=1):
         """(S0, S1, D0, D1): partial-sum slabs [n_slabs, C, C] for both masks and the derivative matrices; one set
-        per (C, level, layer) so that style branches can run concurrently."""
-        C = key[0]
+        per (C, level, layer) so that style branches can run concurrently. All S slabs live in ONE arena, so that a
+        step zeroes them with a single fill."""
         cur = self._gram.get(key)
         if cur is None or cur[0].shape[0] < n_slabs:
-            self._gram[key] = (torch.zeros(n_slabs, C, C, device=self.device), torch.zeros(n_slabs, C, C, device=self.device),
-                               torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
-            self._gram_clean.add(key)
+            self._gram_need[key] = n_slabs
+            self._rebuild_gram_arena()
         return self._gram[key]
 
+    def _rebuild_gram_arena(self):
+        total = sum(2 * n * k[0] * k[0] for k, n in self._gram_need.items())
+        arena = torch.zeros(total, device=self.device)
+        off = 0
+        for k, n in self._gram_need.items():
+            C = k[0]
+            sz = n * C * C
+            S0, S1 = arena[off:off + sz].view(n, C, C), arena[off + sz:off + 2 * sz].view(n, C, C)
+            off += 2 * sz
+            old = self._gram.get(k)
+            D = old[2:] if old is not None else (torch.zeros(C, C, device=self.device), torch.zeros(C, C, device=self.device))
+            self._gram[k] = (S0, S1) + tuple(D)
+        self._gram_arena = arena
+        self._gram_clean = set(self._gram)   # a fresh arena holds zeros
+
+    def _reserve_gram_scratch(self, active, bufs):
+        """Create the slabs of every (level, style layer) of the step BEFORE its branches fork onto their streams:
+        growing the arena later would move slabs that queued kernels of another stream still use."""
+        if float(self.cfg.loss_weights.get("style", 0.0)) == 0.0:
+            return
+        for lv, b in zip(active, bufs):
+            for layer in self.cfg.style_layers:
+                f = b.act[layer]
+                self._gram_scratch((f.C, lv.index, layer), ops.gram_workspace_slabs(f.C, f.H, f.W))
+
     def _zero_step_accumulators(self):
-        """ONE multi-tensor fill for everything a step accumulates into: the loss pair and the Gram slabs of every
+        """Everything a step accumulates into: the loss pair and - one fill over the arena - the Gram slabs of every
         (level, layer) the previous step added into (instead of two fills per masked-Gram call)."""
-        dirty = [k for k in self._gram if k not in self._gram_clean]
-        bufs = [self.loss_buf]
-        for k in dirty:
-            bufs += [self._gram[k][0], self._gram[k][1]]
-        torch._foreach_zero_(bufs)
-        self._gram_clean.update(dirty)
+        self.loss_buf.zero_()
+        if self._gram_arena is not None and len(self._gram_clean) != len(self._gram):
+            self._gram_arena.zero_()
+            self._gram_clean = set(self._gram)
 
     # ------------------------------------------------------------------ style targets
     def set_style_image(self, style_image: torch.Tensor, num_levels=5):
@@ -386,14 +410,16 @@ class StepEngine:
         if self.view is None or self.targets is None:
             raise RuntimeError("set_style_image() and set_view() must be called first")
         cfg = self.cfg
-        self._zero_step_accumulators()
         w_style = float(cfg.loss_weights.get("style", 0.0))
         w_content = float(cfg.loss_weights.get("content", 0.0))
         active = [lv for lv in self.view if lv.active]
         if not active or self.deepest is None:
+            self._zero_step_accumulators()
             return
         # layer-major over the active UV levels: every conv layer is ONE grouped launch over all levels
         bufs = [self._level_bufs(lv.H, lv.W) for lv in active]
+        self._reserve_gram_scratch(active, bufs)
+        self._zero_step_accumulators()
         if len({(lv.H, lv.W) for lv in active}) != len(active):
             raise ValueError("two UV levels of the same resolution are not supported")
         for lv, b in zip(active, bufs):
