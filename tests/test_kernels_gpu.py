@@ -66,6 +66,7 @@ def test_tex_sample_backward_pixel_weight_and_accumulate(rt):
 CONV_CASES = [
     # (Cin, Cout, H, W)
     (3, 64, 17, 21),      # first layer, KC = 4
+    (3, 64, 40, 301),     # first layer, many 256-position tiles, ragged last tile
     (64, 64, 40, 56),     # BM = 64 tile
     (64, 128, 20, 28),    # BM = 128 tile
     (128, 128, 13, 131),  # wide & short, several N tiles per row
