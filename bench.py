@@ -101,6 +101,8 @@ def main():
                     "on a side stream concurrently with the conv trunk")
     ap.add_argument("--dense-allreduce", action="store_true", help="N > 1: all-reduce the whole gradient arena instead of "
                     "only the chunks the ranks' current views can touch")
+    ap.add_argument("--atomic-scatter", action="store_true", help="texture scatter with the tiled atomic kernel (one launch "
+                    "per UV level) instead of the sorted gather over the per-view plan")
     ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
                     "with the update of each arena range issued as its sums arrive (default: exchange, then update)")
     ap.add_argument("--mfma", choices=["split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
@@ -146,6 +148,7 @@ def main():
     eng.sparse_tiles = not args.dense
     eng.overlap_style = args.overlap_style
     eng.pipeline_exchange = args.pipeline_exchange
+    eng.planned_scatter = not args.atomic_scatter
 
     # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
     total_steps = args.warmup + args.steps

@@ -66,6 +66,37 @@ int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int*
                        const float* arena_base, const float* grid, int h, int w, const float* pixel_weight,
                        int32_t* flags, int chunk_log2, void* stream);
 
+/* K2 as a sorted gather (stylemesh_amd/csrc/scatter_plan.hip). Which texels the pixels of a view hit, and with which
+ * weights, depends only on the view - and the reference's RepeatingSampler (data/repeating_sampler.py) optimises a
+ * view for 20-100 consecutive steps. sm_tex_scatter_plan lists every (pixel, layer, tap) contribution of ALL levels
+ * of the view as key = arena offset of the texel (channel 0), value = (pixel, level, layer, tap weight x pixel weight),
+ * radix-sorts the list by key and lists the runs of equal texels that cross a 64-entry chunk boundary (once per view).
+ * sm_tex_scatter_planned then replaces the n_levels sm_tex_sample_bwd calls of a step: the planar image gradients
+ * are packed into one float4 per pixel, one lane per sorted entry gathers its pixel, a wave-wide segmented sum adds
+ * the runs of equal texels, a run inside a chunk writes its texel, and one thread per crossing run adds that run's
+ * pieces in chunk order. No atomics: every texel has one writer, the result is bit-reproducible. Same result as
+ * sm_tex_sample_bwd up to fp32 summation order.
+ *   n_entries = 4 * n_layers * sum_k(level_h[k] * level_w[k]); key_bits = bits of the arena size + 1 (<= 32; the
+ *   all-ones key marks zero-weight entries). Caller-owned DEVICE buffers: keys0/1 [n_entries] u32, vals0/1
+ *   [n_entries] u64, temp (sm_tex_scatter_plan_temp_bytes), cross (sm_tex_scatter_plan_cross_bytes: crossing-run
+ *   list + per-chunk partial sums; written by the plan, used by every planned call), packed_scratch (4 floats per
+ *   position of every level's padded plane: 4 * sum_k sm_fmap_plane(level_h[k], level_w[k])). *sorted_in (HOST)
+ *   receives 0 / 1 = which of the two key / value buffer pairs holds the sorted list. grids / pixel_weights /
+ *   grad_imgs: HOST arrays of device pointers (pixel_weights or its entries may be NULL). accumulate = 0: the caller
+ *   guarantees that the arena is ZERO where this view writes (sm_adam_fused zeroes it): texels are stored without
+ *   being read; 1: add into the arena like sm_tex_sample_bwd. */
+size_t sm_tex_scatter_plan_temp_bytes(size_t n_entries, int key_bits);
+size_t sm_tex_scatter_plan_cross_bytes(size_t n_entries);
+int sm_tex_scatter_plan(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
+                        const float* arena_base, const float* const* grids, const float* const* pixel_weights,
+                        const int* level_h, const int* level_w, int n_levels, uint32_t* keys0, uint32_t* keys1,
+                        uint64_t* vals0, uint64_t* vals1, void* temp, size_t temp_bytes, void* cross, int key_bits,
+                        int* sorted_in, void* stream);
+int sm_tex_scatter_planned(const uint32_t* keys, const uint64_t* vals, size_t n_entries, const float* const* grad_imgs,
+                           const int* level_h, const int* level_w, int n_levels, float* const* grad_layers,
+                           const int* layer_w, const int* layer_h, int n_layers, float* arena_base, int key_bits,
+                           float* packed_scratch, void* cross, int accumulate, void* stream);
+
 /* K7. torch.optim.Adam.step (model/model.py:387-395) fused with the analytic gradient of
  * HierarchicalNeuralTexture.regularizer (texture.py:102-108: g += reg_coef[seg] * p), the next forward's
  * normalize() clamp (texture.py:41-44), zeroing of the gradient for the next step, and the reduction

@@ -149,6 +149,12 @@ class StepEngine:
         # launches per level) are independent: one HIP stream per level lets the small levels' latency-bound kernels
         # run beside the large level's instead of after them
         self.level_streams = True
+        # texture scatter as a sorted gather over a per-view plan (csrc/scatter_plan.hip) instead of the tiled atomic
+        # kernel: no atomics, bit-reproducible, ~4x faster per step; the plan (radix sort) costs ~1 ms per view
+        self.planned_scatter = True
+        self._scatter_plan = None
+        self._scatter_levels = None
+        self._grad_dirty = False   # does the gradient arena hold anything since the last fused update?
         self._lv_streams = []
         # N > 1, opt-in: all-reduce the gradient in pieces and update each arena range as soon as its sums arrive
         # (functionally verified over gloo; not yet timed under RCCL, so the plain exchange-then-update is the default)
@@ -399,6 +405,12 @@ class StepEngine:
         # identifies the step's launch sequence (grid sizes depend on the tile lists)
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
                          None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))
+        self._scatter_levels = None
+        if self.planned_scatter and active and all(lv.grid is not None for lv in active):
+            if self._scatter_plan is None:
+                self._scatter_plan = ops.ScatterPlan(self.grads, self.arena.g)
+            self._scatter_plan.build([lv.grid for lv in active], [lv.pixel_weight for lv in active])
+            self._scatter_levels = [lv.index for lv in active]
         if msums is not None and sums_host is None:
             sums_host = msums.tolist()   # no tile lists to read along with
         return sums_host
@@ -489,8 +501,14 @@ class StepEngine:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
-        for lv, b in zip(active, bufs):
-            ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
+        if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
+            # sorted gather over the plan of this view (built by set_view); texels are stored without being read
+            # while the arena is known to be zero (the fused update zeroes it)
+            self._scatter_plan.scatter([b.grad["img"] for b in bufs], accumulate=self._grad_dirty)
+        else:
+            for lv, b in zip(active, bufs):
+                ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
+        self._grad_dirty = True
 
     def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
@@ -644,6 +662,7 @@ class StepEngine:
         self._optimizer_launch(world_size, None)
 
     def _optimizer_launch(self, world_size, dev_hyper):
+        self._grad_dirty = False   # the fused update zeroes the gradient arena
         self.sumsq.zero_()
         ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
                        self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
@@ -654,6 +673,7 @@ class StepEngine:
         the update of an arena range is issued as soon as its sums arrived, later pieces still on the links)."""
         self.step_count += 1
         self.sumsq.zero_()
+        self._grad_dirty = False   # every range is zeroed by its update
         a = self.arena
 
         def update_range(lo, hi):

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import os
 
+import ctypes as C
+
 import torch
 
 from . import hip
@@ -105,6 +107,58 @@ def tex_sample_bwd(grad_layers, grid: torch.Tensor, grad_img: FMap, pixel_weight
     hip.check(lib.sm_tex_sample_bwd(hip.ptr_array(grad_layers), hip.int_array([l.shape[2] for l in grad_layers]),
                                     hip.int_array([l.shape[1] for l in grad_layers]), len(grad_layers), ptr(grid),
                                     h, w, grad_img.ptr, ptr(pixel_weight), hip.stream()), "sm_tex_sample_bwd")
+
+
+class ScatterPlan:
+    """Sorted (texel, pixel, weight) list of one view over all its UV levels (``sm_tex_scatter_plan``): built once per
+    view, used by every step's ``tex_scatter_planned``. Buffers are allocated once per (entry count) and reused."""
+
+    def __init__(self, grad_layers, arena_grad: torch.Tensor):
+        self.grad_layers, self.arena = grad_layers, arena_grad
+        self.key_bits = max(1, int(arena_grad.numel()).bit_length())   # all-ones key > every arena offset
+        self.lw = hip.int_array([l.shape[2] for l in grad_layers])
+        self.lh = hip.int_array([l.shape[1] for l in grad_layers])
+        self.n_entries = 0
+        self.bufs = None
+        self.sorted_in = 0
+        self.level_hw = None
+
+    def build(self, grids, pixel_weights):
+        """``grids``: [h,w,2] tensors (one per level), ``pixel_weights``: [h,w] tensors or None entries."""
+        dev = self.arena.device
+        hw = [(g.shape[-3], g.shape[-2]) for g in grids]
+        n = 4 * len(self.grad_layers) * sum(h * w for h, w in hw)
+        if self.bufs is None or self.n_entries != n:
+            tb = lib.sm_tex_scatter_plan_temp_bytes(n, self.key_bits)
+            self.bufs = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
+                         torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev),
+                         torch.empty(max(tb, 16), dtype=torch.uint8, device=dev),
+                         torch.empty(lib.sm_tex_scatter_plan_cross_bytes(n), dtype=torch.uint8, device=dev))
+            self.n_entries = n
+        if self.level_hw != hw:
+            self.packed = torch.empty(4 * sum(hip.plane(h, w) for h, w in hw), device=dev)
+        self.level_hw = hw
+        k0, k1, v0, v1, tmp, cross = self.bufs
+        which = C.c_int(0)
+        hip.check(lib.sm_tex_scatter_plan(hip.ptr_array(self.grad_layers), self.lw, self.lh, len(self.grad_layers),
+                                          ptr(self.arena), hip.ptr_array(grids), hip.ptr_array(pixel_weights),
+                                          hip.int_array([h for h, _ in hw]), hip.int_array([w for _, w in hw]), len(hw),
+                                          ptr(k0), ptr(k1), ptr(v0), ptr(v1), ptr(tmp), tmp.numel(), ptr(cross),
+                                          self.key_bits, C.byref(which), hip.stream()), "sm_tex_scatter_plan")
+        self.sorted_in = which.value
+
+    def scatter(self, grad_imgs, accumulate=True):
+        """``grad_imgs``: the levels' image-gradient FMaps, in the order of ``build``. Adds into the gradient arena;
+        ``accumulate=False`` when the arena is known to be zero (texels are then stored without being read)."""
+        assert self.level_hw is not None and [(g.H, g.W) for g in grad_imgs] == self.level_hw
+        keys, vals = self.bufs[self.sorted_in], self.bufs[2 + self.sorted_in]
+        hip.check(lib.sm_tex_scatter_planned(ptr(keys), ptr(vals), self.n_entries, hip.ptr_array(grad_imgs),
+                                             hip.int_array([h for h, _ in self.level_hw]),
+                                             hip.int_array([w for _, w in self.level_hw]), len(self.level_hw),
+                                             hip.ptr_array(self.grad_layers), self.lw, self.lh, len(self.grad_layers),
+                                             ptr(self.arena), self.key_bits, ptr(self.packed), ptr(self.bufs[5]),
+                                             int(accumulate), hip.stream()),
+                  "sm_tex_scatter_planned")
 
 
 def tex_touch_flags(grad_layers, arena_grad: torch.Tensor, grid: torch.Tensor, pixel_weight, flags: torch.Tensor,

@@ -62,6 +62,54 @@ def test_tex_sample_backward_pixel_weight_and_accumulate(rt):
     assert_close(g - 0.5, ref, 1e-4, 1e-5 * float(ref.abs().max()))
 
 
+def test_tex_scatter_planned_matches_oracle_and_atomic_path(rt):
+    """The sorted-gather form of the scatter (plan once per view, walk the sorted list every step) over several UV
+    levels and a 3-layer hierarchical texture, with pixel weights (some zero), out-of-range UVs (border clamp),
+    a coarse layer (long runs of equal texels that cross wave boundaries) and a non-zero arena (it accumulates)."""
+    torch.manual_seed(3)
+    shapes = [(3, 64, 96), (3, 32, 48), (3, 4, 6)]
+    n = sum(c * h * w for c, h, w in shapes)
+    arena = torch.full((n,), 0.25).cuda()
+    arena2 = arena.clone()
+    views, off = [], 0
+    for c, h, w in shapes:
+        views.append((arena[off:off + c * h * w].view(c, h, w), arena2[off:off + c * h * w].view(c, h, w)))
+        off += c * h * w
+    g_plan, g_atomic = [v[0] for v in views], [v[1] for v in views]
+    levels = [(40, 56), (23, 31), (64, 64), (96, 128)]
+    grids = [torch.rand(1, h, w, 2) * 2.3 - 1.15 for h, w in levels]
+    grids[3][:] = 1.7      # 12288 pixels clamped onto ONE corner texel per layer: a run of thousands of entries
+    ups = [torch.randn(1, 3, h, w) for h, w in levels]
+    pws = [torch.rand(h, w) for h, w in levels]
+    pws[0][:7] = 0
+    pws[2] = None
+    pws[3] = None
+    gimgs = [rt.FMap(3, h, w).from_dense(u[0]) for (h, w), u in zip(levels, ups)]
+    dgrids = [dev(g) for g in grids]
+    dpws = [None if p is None else dev(p) for p in pws]
+    plan = rt.ops.ScatterPlan(g_plan, arena)
+    plan.build([g[0] for g in dgrids], dpws)
+    for rep in range(2):     # the same plan serves every step of the view
+        plan.scatter(gimgs)
+        for g, gi, p in zip(dgrids, gimgs, dpws):
+            rt.ops.tex_sample_bwd(g_atomic, g, gi, p)
+    for li, (c, h, w) in enumerate(shapes):
+        ref = sum(O.grid_sample_border_backward_explicit((3, h, w), g, u if p is None else u * p)
+                  for g, u, p in zip(grids, ups, pws))
+        scale = float(ref.abs().max())
+        assert_close(g_plan[li] - 0.25, 2 * ref, 1e-4, 2e-5 * scale, f"planned vs oracle, layer {li}")
+        assert_close(g_plan[li], g_atomic[li], 1e-4, 2e-5 * scale, f"planned vs atomic path, layer {li}")
+    # without monster runs every texel has exactly one writer: bit-reproducible, stored or accumulated
+    plan3 = rt.ops.ScatterPlan(g_plan, arena)
+    plan3.build([g[0] for g in dgrids[:3]], dpws[:3])
+    outs = []
+    for accumulate in (False, True, False):
+        arena.zero_()
+        plan3.scatter(gimgs[:3], accumulate=accumulate)
+        outs.append(arena.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 # ------------------------------------------------------------------ K3 / K4
 CONV_CASES = [
     # (Cin, Cout, H, W)
