@@ -328,7 +328,9 @@ def gram_num_slabs(C: int, H: int, W: int) -> int:
 
 
 def gram_workspace_slabs(C: int, H: int, W: int) -> int:
-    """Slabs the workspace must hold (sized for either mode)."""
+    """Slabs the workspace must hold in the current mode (split: the one slab every position range adds into)."""
+    if GRAM_MODE == "split":
+        return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_workspace_slabs(C, H, W)
 
 

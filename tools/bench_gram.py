@@ -20,7 +20,7 @@ for li in sel:
         m_all = ((yy > 0.2 * H) & (yy < 0.85 * H) & (xx > 0.1 * W) & (xx < 0.7 * W)).float()
         passed = (xx < 0.45 * W).float()
         m0 = FMap(1, H, W).from_dense((m_all * passed)[None]); m1 = FMap(1, H, W).from_dense((m_all * (1 - passed))[None])
-        na = ops.gram_workspace_slabs(C, H, W)
+        na = max(1, hip.lib.sm_gram_workspace_slabs(C, H, W))   # enough for either mode
         S0 = torch.zeros(na, C, C, device="cuda"); S1 = torch.zeros(na, C, C, device="cuda")
         D0 = torch.randn(C, C, device="cuda"); D0 = D0 + D0.T; D1 = torch.randn(C, C, device="cuda"); D1 = D1 + D1.T
         df = FMap(C, H, W)
