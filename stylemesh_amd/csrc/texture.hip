@@ -246,16 +246,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float one_minus_beta1, float beta2, float one_minus_beta2,
                                                    float eps, float inv_sqrt_bc2,
                                                    float grad_scale, float lo, float hi, int zero_grad,
-                                                   float* __restrict__ sumsq, const float* __restrict__ dev_hyper) {
+                                                   float* __restrict__ sumsq, const float* __restrict__ dev_hyper,
+                                                   int tiles_per_block) {
     if (ADAM && dev_hyper) {   // step-dependent scalars from device memory: the launch can be replayed from a hipGraph
         lr_over_bc1 = dev_hyper[0];
         inv_sqrt_bc2 = dev_hyper[1];
     }
-    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    // sum(p^2) per segment: a block almost always lies inside one segment (k_blk); elements of a block that
-    // straddles a boundary and belong to another segment are added one by one.
-    const int k_blk = seg_of(segs, (size_t)blockIdx.x * 1024);
+    // A block walks tiles_per_block consecutive tiles of 1024 elements and keeps sum(p^2) of the segment it is in in
+    // registers: one atomic per block and segment instead of one per tile - tens of thousands of atomics on the same
+    // few addresses serialise (~2 ns each) and cost more than the kernel's HBM time.
+    const size_t tile0 = (size_t)blockIdx.x * tiles_per_block;
+    int k_cur = seg_of(segs, tile0 * 1024);
     float sq = 0.f;
+    for (int t = 0; t < tiles_per_block; ++t) {
+    const size_t tile = tile0 + t;
+    if (tile * 1024 >= n) break;
+    const size_t i0 = (tile * 256 + threadIdx.x) * 4;
+    // a tile almost always lies inside one segment (k_blk); elements of a tile that straddles a boundary and belong
+    // to another segment are added one by one.
+    const int k_blk = seg_of(segs, tile * 1024);
+    if (k_blk != k_cur) {   // block-uniform
+        if (sumsq) {
+            __syncthreads();
+            const float s = block_sum(sq);
+            if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_cur, s);
+        }
+        sq = 0.f;
+        k_cur = k_blk;
+    }
     if (i0 < n) {
         const bool full = i0 + 4 <= n;
         float pv[4], gv[4], mv[4], vv[4];
@@ -313,10 +331,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             }
         }
     }
+    }   // tiles
     if (sumsq) {
+        __syncthreads();
         const float s = block_sum(sq);
-        if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_blk, s);
+        if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_cur, s);
     }
+}
+
+// tiles of 1024 elements per block: enough blocks to fill the chip several times over, few enough atomics
+static int adam_tiles_per_block(size_t n) {
+    const size_t tiles = (n + 1023) / 1024;
+    return (int)((tiles + 4095) / 4096);
 }
 
 static TexLayers make_layers(float* const* layers, const int* lw, const int* lh, int n) {
@@ -386,13 +412,14 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
                   const float* dev_hyper, void* stream) {
     sm::Segs s;
     if (int e = make_segs(s, n, seg_end, reg_coef, n_seg)) return e;
-    const size_t blocks = (n + 1023) / 1024;
+    const int tpb = sm::adam_tiles_per_block(n);
+    const size_t blocks = ((n + 1023) / 1024 + tpb - 1) / tpb;
     // step_size = lr / bias_correction1 and 1 / sqrt(bias_correction2) in double, as torch computes them
     const float lr_over_bc1 = (float)((double)lr / bias_corr1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_corr2));
     hipLaunchKernelGGL(sm::adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        s, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, inv_sqrt_bc2,
-                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper);
+                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper, tpb);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -401,10 +428,11 @@ int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float c
                    float* sumsq_out, void* stream) {
     sm::Segs s;
     if (int e = make_segs(s, n, seg_end, nullptr, n_seg)) return e;
-    const size_t blocks = (n + 1023) / 1024;
+    const int tpb = sm::adam_tiles_per_block(n);
+    const size_t blocks = ((n + 1023) / 1024 + tpb - 1) / tpb;
     hipLaunchKernelGGL(sm::adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, n, s, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, clamp_lo,
-                       clamp_hi, 0, sumsq_out, (const float*)nullptr);
+                       clamp_hi, 0, sumsq_out, (const float*)nullptr, tpb);
     SM_LAUNCH_CHECK();
     return 0;
 }
