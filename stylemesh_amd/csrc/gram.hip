@@ -157,6 +157,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+constexpr int STYLE_EPT = 8;   // elements per thread
 __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
                                                          const float* __restrict__ counts,
                                                          const float* __restrict__ factor, StyleTerms terms,
@@ -164,10 +165,14 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
                                                          float* __restrict__ D1, float* loss_out, float* history,
                                                          int hist_len, int hist_slot, int n_slabs) {
     __shared__ float red[4];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int i = idx / C, j = idx - i * C;
     const float f = *factor;
     const float inv_c2 = 1.f / ((float)C * (float)C);
+    float loss = 0.f;
+    // STYLE_EPT elements per thread: one atomic on the (single) loss address per 2048 elements
+    for (int it = 0; it < STYLE_EPT; ++it) {
+    const int idx = (blockIdx.x * STYLE_EPT + it) * 256 + threadIdx.x;
+    if (idx >= C * C) break;
+    const int i = idx / C, j = idx - i * C;
     float G[2], invN[2], d[2] = {0.f, 0.f};
     bool empty[2];
 #pragma unroll
@@ -187,7 +192,6 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
         Gavg0 /= navg;
         history[(size_t)hist_slot * cc + idx] = G[0];
     }
-    float loss = 0.f;
     for (int t = 0; t < terms.n; ++t) {
         const int k = terms.mask[t];
         if (empty[k] && terms.skip_if_empty[k]) continue;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     }
     D0[idx] = d[0];
     if (D1) D1[idx] = d[1];
+    }
     const float tot = block_sum256(loss, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * weight * f * inv_c2);
 }
@@ -311,24 +316,28 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // K6: masked content MSE + gradient
 // ---------------------------------------------------------------------------------------------------
+constexpr int MSE_CG = 16;   // channels per block
 __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                          const float* __restrict__ mask, const float* __restrict__ count,
                                                          const float* __restrict__ factor, float weight,
                                                          float* __restrict__ dpred, float* loss_out, int C, int plane,
                                                          int q_begin, int q_end, int relu_gate) {
     __shared__ float red[4];
-    const int c = blockIdx.y;
+    // a block covers MSE_CG channels of its 1024 positions: one atomic on the (single) loss address per block, and
+    // thousands of same-address atomics serialise at ~2 ns each
     const int q = q_begin + (blockIdx.x * 256 + threadIdx.x) * 4;
     const float N = *count;
     const float coef = (N > 0.f) ? weight * (*factor) / ((float)C * N) : 0.f;
     float part = 0.f;
     if (q < q_end) {
+        const float4 m = *reinterpret_cast<const float4*>(mask + q);
+        const int c_end = min(C, (int)(blockIdx.y + 1) * MSE_CG);
+        for (int c = blockIdx.y * MSE_CG; c < c_end; ++c) {
         const size_t o = (size_t)c * plane + q;
         const float4 p = *reinterpret_cast<const float4*>(pred + o);
         const float4 t = *reinterpret_cast<const float4*>(target + o);
-        const float4 m = *reinterpret_cast<const float4*>(mask + q);
         float4 d = make_float4(m.x * (p.x - t.x), m.y * (p.y - t.y), m.z * (p.z - t.z), m.w * (p.w - t.w));
-        part = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;  // m in {0,1}: m^2 = m
+        part += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;  // m in {0,1}: m^2 = m
         const float c2 = 2.f * coef;
         float4 g = make_float4(c2 * d.x, c2 * d.y, c2 * d.z, c2 * d.w);
         if (relu_gate) {  // pred is the post-ReLU activation itself
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
             g.w = p.w > 0.f ? g.w : 0.f;
         }
         *reinterpret_cast<float4*>(dpred + o) = g;
+        }
     }
     const float tot = block_sum256(part, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * coef);
@@ -468,7 +478,7 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
     }
     t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
     t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
-    hipLaunchKernelGGL(sm::style_loss_kernel, dim3(C * C / 256), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
+    hipLaunchKernelGGL(sm::style_loss_kernel, dim3((C * C + 256 * sm::STYLE_EPT - 1) / (256 * sm::STYLE_EPT)), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
                        t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs);
     SM_LAUNCH_CHECK();
     return 0;
@@ -498,7 +508,7 @@ int sm_mse_masked(const float* pred, const float* target, const float* mask, con
                   float weight, float* dpred, float* loss_out, int C, int H, int W, int relu_gate, void* stream) {
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
-    dim3 grid(((q_end - q_begin) / 4 + 255) / 256, C);
+    dim3 grid(((q_end - q_begin) / 4 + 255) / 256, (C + sm::MSE_CG - 1) / sm::MSE_CG);
     hipLaunchKernelGGL(sm::mse_masked_kernel, grid, dim3(256), 0, (hipStream_t)stream, pred, target, mask, count, factor,
                        weight, dpred, loss_out, C, plane, q_begin, q_end, relu_gate);
     SM_LAUNCH_CHECK();
