@@ -157,7 +157,10 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-constexpr int STYLE_EPT = 8;   // elements per thread
+#ifndef SM_STYLE_EPT
+#define SM_STYLE_EPT 4
+#endif
+constexpr int STYLE_EPT = SM_STYLE_EPT;   // elements per thread
 __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
                                                          const float* __restrict__ counts,
                                                          const float* __restrict__ factor, StyleTerms terms,
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     const float f = *factor;
     const float inv_c2 = 1.f / ((float)C * (float)C);
     float loss = 0.f;
-    // STYLE_EPT elements per thread: one atomic on the (single) loss address per 2048 elements
+    // STYLE_EPT elements per thread: one atomic on the (single) loss address per 1024 elements
     for (int it = 0; it < STYLE_EPT; ++it) {
     const int idx = (blockIdx.x * STYLE_EPT + it) * 256 + threadIdx.x;
     if (idx >= C * C) break;
