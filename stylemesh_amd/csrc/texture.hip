@@ -43,6 +43,8 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int W, int H) {
     return t;
 }
 
+struct __attribute__((aligned(4))) pair4 { float x, y; };   // two adjacent floats at 4-byte alignment
+
 __global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
                                                              float* __restrict__ out, int Wp, int plane) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -55,23 +57,28 @@ __global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const 
         const Taps t = make_taps(g.x, g.y, W, H);
         const float* p = L.p[l] + (size_t)t.y0 * W + t.x0;
         const size_t cs = (size_t)W * H;
+        // the west / east taps of a row are adjacent texels: one 8-byte load (4-byte aligned) instead of two gathers.
+        // Same products and the same order of additions as the scalar form.
         float v0, v1, v2;
-        v0 = p[0] * t.nw;
-        v1 = p[cs] * t.nw;
-        v2 = p[2 * cs] * t.nw;
         if (t.x1_in) {
-            v0 += p[1] * t.ne;
-            v1 += p[cs + 1] * t.ne;
-            v2 += p[2 * cs + 1] * t.ne;
-        }
-        if (t.y1_in) {
-            v0 += p[W] * t.sw;
-            v1 += p[cs + W] * t.sw;
-            v2 += p[2 * cs + W] * t.sw;
-            if (t.x1_in) {
-                v0 += p[W + 1] * t.se;
-                v1 += p[cs + W + 1] * t.se;
-                v2 += p[2 * cs + W + 1] * t.se;
+            const pair4 a0 = *reinterpret_cast<const pair4*>(p), a1 = *reinterpret_cast<const pair4*>(p + cs),
+                        a2 = *reinterpret_cast<const pair4*>(p + 2 * cs);
+            v0 = a0.x * t.nw; v1 = a1.x * t.nw; v2 = a2.x * t.nw;
+            v0 += a0.y * t.ne; v1 += a1.y * t.ne; v2 += a2.y * t.ne;
+            if (t.y1_in) {
+                const pair4 b0 = *reinterpret_cast<const pair4*>(p + W), b1 = *reinterpret_cast<const pair4*>(p + cs + W),
+                            b2 = *reinterpret_cast<const pair4*>(p + 2 * cs + W);
+                v0 += b0.x * t.sw; v1 += b1.x * t.sw; v2 += b2.x * t.sw;
+                v0 += b0.y * t.se; v1 += b1.y * t.se; v2 += b2.y * t.se;
+            }
+        } else {
+            v0 = p[0] * t.nw;
+            v1 = p[cs] * t.nw;
+            v2 = p[2 * cs] * t.nw;
+            if (t.y1_in) {
+                v0 += p[W] * t.sw;
+                v1 += p[cs + W] * t.sw;
+                v2 += p[2 * cs + W] * t.sw;
             }
         }
         acc0 += v0;
