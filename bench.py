@@ -170,7 +170,6 @@ def main():
 
     for i in range(args.warmup):
         eng.training_step(schedule[i], world_size=world, reducer=reducer)
-    active_levels = [lv.index for lv in eng.view if lv.active]
     timer = None if args.no_conv_timer else ops.KernelTimer()
     ops.CONV_TIMER = timer
     barrier()
@@ -181,6 +180,7 @@ def main():
         eng.training_step(schedule[i], world_size=world, reducer=reducer)
     barrier()
     dt = time.perf_counter() - t0
+    active_levels = [lv.index for lv in eng.view if lv.active]
     ops.CONV_TIMER = None
     losses = eng.losses()
 
