@@ -187,6 +187,18 @@ typedef struct {
 int sm_conv3x3_dgrad_c3_grouped(const sm_plane_problem* problems, int n, const float* wd, int Cin, void* stream);
 int sm_maxpool2x2_fwd_grouped(const sm_plane_problem* problems, int n, int C, void* stream);
 int sm_maxpool2x2_bwd_relu_grouped(const sm_plane_problem* problems, int n, int C, void* stream);
+/* The same three grouped kernels restricted to the blocks that can influence the loss (as the tile lists of the
+ * convolutions): tile_list = DEVICE array of n_list entries (problem << 24) | block, a block = sm_plane_tile_positions
+ * (kind) consecutive positions from row 1 of the plane the kernel is indexed by - kind 0: conv1_1's data gradient
+ * (1024 positions of the image plane), kind 1 / 2: pool forward / backward (256 positions of the POOLED plane; the
+ * same list serves both). NULL = all blocks. Positions outside the listed blocks are neither read nor written. */
+int sm_plane_tile_positions(int kind);
+int sm_conv3x3_dgrad_c3_tiles(const sm_plane_problem* problems, int n, const float* wd, int Cin,
+                              const int32_t* tile_list, int n_list, void* stream);
+int sm_maxpool2x2_fwd_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
+                            void* stream);
+int sm_maxpool2x2_bwd_relu_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
+                                 void* stream);
 
 /* ---- Gram / style / content losses: content_and_style_losses.py:74-80,136-143,288-350 --------------- */
 

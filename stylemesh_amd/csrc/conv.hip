@@ -403,9 +403,12 @@ __device__ __forceinline__ void maxpool_bwd_relu_body(const float* __restrict__ 
                                                       int H, int W, int Wp, int plane, int Ho, int Wo, int Wpo,
                                                       int plane_o, int block_x) {
     const int c = blockIdx.y;
-    const int i = block_x * 256 + threadIdx.x;  // window index
-    if (i >= Ho * Wo) return;
-    const int yo = i / Wo, xo = i - yo * Wo;
+    // one thread per position of the pooled plane, blocks of 256 positions from row 1 on - the forward kernel's blocks,
+    // so that one tile list serves both
+    const int qp = Wpo + block_x * 256 + threadIdx.x;
+    if (qp >= (Ho + 1) * Wpo) return;
+    const int yo = qp / Wpo - 1, xo = qp - (yo + 1) * Wpo - 1;
+    if (xo < 0 || xo >= Wo) return;
     const size_t qo = (size_t)c * plane_o + (yo + 1) * Wpo + xo + 1;
     const float pm = pooled[qo];
     const float g = (pm > 0.f) ? dpooled[qo] : 0.f;  // max <= 0 -> every ReLU gate in the window is closed
@@ -440,8 +443,16 @@ struct PlaneGroup {
     PlaneProblem p[SM_MAX_GROUP];
     int block_begin[SM_MAX_GROUP + 1];
     int n;
+    // optional list of the ACTIVE blocks, entry = (problem << 24) | block-in-problem (as the convs' tile lists: blocks
+    // whose positions cannot influence the loss are simply absent); NULL = every block
+    const int* tile_list;
 };
 __device__ __forceinline__ int locate_problem(const PlaneGroup& g, int bx, int& local) {
+    if (g.tile_list) {
+        const int e = g.tile_list[bx];
+        local = e & 0xFFFFFF;
+        return e >> 24;
+    }
     int k = 0;
 #pragma unroll
     for (int i = 1; i < SM_MAX_GROUP; ++i)
@@ -450,15 +461,23 @@ __device__ __forceinline__ int locate_problem(const PlaneGroup& g, int bx, int& 
     return k;
 }
 
+__device__ __forceinline__ PlaneProblem pick_problem(const PlaneGroup& g, int k) {
+    PlaneProblem P = g.p[0];
+#pragma unroll
+    for (int i = 1; i < SM_MAX_GROUP; ++i)
+        if (i == k) P = g.p[i];
+    return P;
+}
+
 __global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(PlaneGroup g, const float* __restrict__ wd, int Cin) {
     int bx;
-    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
     dgrad_c3_body(P.a, wd, P.out, Cin, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), bx);
 }
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
     int bx;
-    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
     const int Ho = P.H / 2, Wo = P.W / 2;
     maxpool_fwd_body(P.a, P.out, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), Ho, Wo, row_stride(Wo),
                      plane_size(Ho, Wo), bx);
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
 
 __global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(PlaneGroup g) {
     int bx;
-    const PlaneProblem P = g.p[locate_problem(g, blockIdx.x, bx)];
+    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
     const int Ho = P.H / 2, Wo = P.W / 2;
     maxpool_bwd_relu_body(P.a, P.b, P.c, P.out, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), Ho, Wo, row_stride(Wo),
                           plane_size(Ho, Wo), bx);
@@ -551,9 +570,10 @@ int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, 
     return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, nullptr, 0, ws, ws_floats, stream);
 }
 
-static int make_plane_group(sm::PlaneGroup& g, const sm_plane_problem* p, int n, int kind) {
+static int make_plane_group(sm::PlaneGroup& g, const sm_plane_problem* p, int n, int kind, const int32_t* tile_list = nullptr) {
     if (n < 1 || n > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
     g.n = n;
+    g.tile_list = tile_list;
     g.block_begin[0] = 0;
     for (int i = 0; i < n; ++i) {
         g.p[i] = sm::PlaneProblem{p[i].a, p[i].b, p[i].c, p[i].out, p[i].H, p[i].W};
@@ -562,32 +582,53 @@ static int make_plane_group(sm::PlaneGroup& g, const sm_plane_problem* p, int n,
         int work;   // threads of the problem
         if (kind == 0) work = H * sm::row_stride(W) / 4;            // dgrad_c3: four positions per thread
         else if (kind == 1) work = Ho * sm::row_stride(Wo);          // pool forward: output positions
-        else work = Ho * Wo;                                         // pool backward: windows
+        else work = Ho * sm::row_stride(Wo);                         // pool backward: the same blocks
         g.block_begin[i + 1] = g.block_begin[i] + (work + 255) / 256;
     }
     return 0;
 }
 
 int sm_conv3x3_dgrad_c3_grouped(const sm_plane_problem* problems, int n, const float* wd, int Cin, void* stream) {
-    sm::PlaneGroup g;
-    if (int e = make_plane_group(g, problems, n, 0)) return e;
-    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(g.block_begin[n]), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
-    SM_LAUNCH_CHECK();
-    return 0;
+    return sm_conv3x3_dgrad_c3_tiles(problems, n, wd, Cin, nullptr, 0, stream);
 }
-
 int sm_maxpool2x2_fwd_grouped(const sm_plane_problem* problems, int n, int C, void* stream) {
+    return sm_maxpool2x2_fwd_tiles(problems, n, C, nullptr, 0, stream);
+}
+int sm_maxpool2x2_bwd_relu_grouped(const sm_plane_problem* problems, int n, int C, void* stream) {
+    return sm_maxpool2x2_bwd_relu_tiles(problems, n, C, nullptr, 0, stream);
+}
+
+int sm_plane_tile_positions(int kind) { return kind == 0 ? 1024 : 256; }
+
+int sm_conv3x3_dgrad_c3_tiles(const sm_plane_problem* problems, int n, const float* wd, int Cin, const int32_t* tile_list,
+                              int n_list, void* stream) {
     sm::PlaneGroup g;
-    if (int e = make_plane_group(g, problems, n, 1)) return e;
-    hipLaunchKernelGGL(sm::maxpool_fwd_kernel, dim3(g.block_begin[n], C), dim3(256), 0, (hipStream_t)stream, g);
+    if (int e = make_plane_group(g, problems, n, 0, tile_list)) return e;
+    const int blocks = tile_list ? n_list : g.block_begin[n];
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
     SM_LAUNCH_CHECK();
     return 0;
 }
 
-int sm_maxpool2x2_bwd_relu_grouped(const sm_plane_problem* problems, int n, int C, void* stream) {
+int sm_maxpool2x2_fwd_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
+                            void* stream) {
     sm::PlaneGroup g;
-    if (int e = make_plane_group(g, problems, n, 2)) return e;
-    hipLaunchKernelGGL(sm::maxpool_bwd_relu_kernel, dim3(g.block_begin[n], C), dim3(256), 0, (hipStream_t)stream, g);
+    if (int e = make_plane_group(g, problems, n, 1, tile_list)) return e;
+    const int blocks = tile_list ? n_list : g.block_begin[n];
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(sm::maxpool_fwd_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, g);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_maxpool2x2_bwd_relu_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
+                                 void* stream) {
+    sm::PlaneGroup g;
+    if (int e = make_plane_group(g, problems, n, 2, tile_list)) return e;
+    const int blocks = tile_list ? n_list : g.block_begin[n];
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(sm::maxpool_bwd_relu_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, g);
     SM_LAUNCH_CHECK();
     return 0;
 }

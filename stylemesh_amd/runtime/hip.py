@@ -44,6 +44,10 @@ SIGNATURES = {
     "sm_conv3x3_dgrad_c3_grouped": [_vp, _i, _vp, _i, _vp],
     "sm_maxpool2x2_fwd_grouped": [_vp, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu_grouped": [_vp, _i, _i, _vp],
+    "sm_plane_tile_positions": [_i],
+    "sm_conv3x3_dgrad_c3_tiles": [_vp, _i, _vp, _i, _vp, _i, _vp],
+    "sm_maxpool2x2_fwd_tiles": [_vp, _i, _i, _vp, _i, _vp],
+    "sm_maxpool2x2_bwd_relu_tiles": [_vp, _i, _i, _vp, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_num_slabs": [_i, _i, _i],

@@ -296,27 +296,46 @@ def _plane_problems(items):
     return arr
 
 
-def conv3x3_dgrad_c3_grouped(problems, wd: torch.Tensor):
-    """``problems``: [(dz, out), ...] FMaps of the UV levels - one launch."""
+def plane_tile_positions(kind: int) -> int:
+    """Positions per block of the grouped plane kernels (0: conv1_1 dgrad, image plane; 1 / 2: pools, pooled plane)."""
+    return lib.sm_plane_tile_positions(kind)
+
+
+def _tile_args(tile_list):
+    return (None, 0) if tile_list is None else (ptr(tile_list), tile_list.numel())
+
+
+def conv3x3_dgrad_c3_grouped(problems, wd: torch.Tensor, tile_list=None):
+    """``problems``: [(dz, out), ...] FMaps of the UV levels - one launch. ``tile_list``: optional int32 device tensor
+    of active blocks ((problem << 24) | block of 1024 image positions); the others are neither read nor written."""
     assert wd.shape[2] == 4 and all(dz.C == wd.shape[1] and out.C >= 3 for dz, out in problems)
+    if tile_list is not None and tile_list.numel() == 0:
+        return
     arr = _plane_problems([(dz, None, None, out) for dz, out in problems])
-    hip.check(lib.sm_conv3x3_dgrad_c3_grouped(arr, len(problems), ptr(wd), wd.shape[1], hip.stream()),
-              "sm_conv3x3_dgrad_c3_grouped")
+    hip.check(lib.sm_conv3x3_dgrad_c3_tiles(arr, len(problems), ptr(wd), wd.shape[1], *_tile_args(tile_list),
+                                            hip.stream()), "sm_conv3x3_dgrad_c3_tiles")
 
 
-def maxpool_fwd_grouped(problems):
-    """``problems``: [(inp, out), ...] with equal channel counts - one launch."""
+def maxpool_fwd_grouped(problems, tile_list=None):
+    """``problems``: [(inp, out), ...] with equal channel counts - one launch. ``tile_list``: active blocks of 256
+    positions of the pooled planes."""
     C = problems[0][0].C
     assert all((o.H, o.W, o.C) == (i.H // 2, i.W // 2, C) and i.C == C for i, o in problems)
+    if tile_list is not None and tile_list.numel() == 0:
+        return
     arr = _plane_problems([(i, None, None, o) for i, o in problems])
-    hip.check(lib.sm_maxpool2x2_fwd_grouped(arr, len(problems), C, hip.stream()), "sm_maxpool2x2_fwd_grouped")
+    hip.check(lib.sm_maxpool2x2_fwd_tiles(arr, len(problems), C, *_tile_args(tile_list), hip.stream()),
+              "sm_maxpool2x2_fwd_tiles")
 
 
-def maxpool_bwd_relu_grouped(problems):
-    """``problems``: [(act, pooled, dpooled, dact), ...] - one launch."""
+def maxpool_bwd_relu_grouped(problems, tile_list=None):
+    """``problems``: [(act, pooled, dpooled, dact), ...] - one launch; ``tile_list`` as for the forward."""
     C = problems[0][0].C
+    if tile_list is not None and tile_list.numel() == 0:
+        return
     arr = _plane_problems(problems)
-    hip.check(lib.sm_maxpool2x2_bwd_relu_grouped(arr, len(problems), C, hip.stream()), "sm_maxpool2x2_bwd_relu_grouped")
+    hip.check(lib.sm_maxpool2x2_bwd_relu_tiles(arr, len(problems), C, *_tile_args(tile_list), hip.stream()),
+              "sm_maxpool2x2_bwd_relu_tiles")
 
 
 # ---- losses --------------------------------------------------------------------------------------------------

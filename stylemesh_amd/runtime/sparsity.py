@@ -48,10 +48,14 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     jobs = []            # (key, layer, bn)
     for kind, src, dst, cin, cout in NODES[:depth_of(last_layer) + 1]:
         if kind == "pool":
+            # forward and backward are both indexed by blocks of the POOLED plane: one list, key ('pool', output layer)
+            jobs.append((("pool", dst), dst, ops.plane_tile_positions(1)))
             continue
         jobs.append(((kind, "f"), dst, ops.conv_tile_positions(4 if cin == 3 else cin, cout)))
         if src != "img":
             jobs.append(((kind, "b"), src, ops.conv_tile_positions(cout, cin)))
+        else:
+            jobs.append((("img", "d"), "img", ops.plane_tile_positions(0)))   # conv1_1's data gradient
     # flags of a (layer, tile size) pair are shared by the conv that produces the layer and the dgrad that produces
     # its gradient; all flags go into ONE buffer, the levels of a pair next to each other: every list is then one
     # contiguous slice of the compacted buffer, and a single nonzero + a single read-back serve all of them

@@ -99,7 +99,8 @@ class VGGNet:
         assert all(b.last == last for b in bufs)
         for kind, src, out, _, _ in NODES[:last + 1]:
             if kind == "pool":
-                ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs])
+                ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
+                                        tiles[("pool", out)][0] if tiles else None)
             else:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
@@ -115,9 +116,11 @@ class VGGNet:
             if kind == "pool":
                 if src in injected:
                     raise ValueError(f"style/content layer {src} directly below a pool is not supported")
-                ops.maxpool_bwd_relu_grouped([(b.act[src], b.act[out], b.grad[out], b.grad[src]) for b in bufs])
+                ops.maxpool_bwd_relu_grouped([(b.act[src], b.act[out], b.grad[out], b.grad[src]) for b in bufs],
+                                             tiles[("pool", out)][0] if tiles else None)
             elif src == "img":
-                ops.conv3x3_dgrad_c3_grouped([(b.grad[out], b.grad["img"]) for b in bufs], self.wd[kind])
+                ops.conv3x3_dgrad_c3_grouped([(b.grad[out], b.grad["img"]) for b in bufs], self.wd[kind],
+                                             tiles[("img", "d")][0] if tiles else None)
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
