@@ -281,6 +281,71 @@ def test_maxpool_forward_backward(rt, H, W):
     assert dact.border_is_zero()
 
 
+def test_plane_kernels_with_tile_lists(rt):
+    """The `_tiles` forms of the pool kernels and of conv1_1's data gradient touch the listed blocks only: inside them
+    the result equals the dense launch, outside the output keeps what it held (two levels in one launch)."""
+    torch.manual_seed(21)
+    C = 6
+    sizes = [(40, 70), (24, 52)]
+    acts = [rt.FMap(C, h, w).from_dense(F.relu(torch.randn(C, h, w))) for h, w in sizes]
+    dys = [rt.FMap(C, h // 2, w // 2).from_dense(torch.randn(C, h // 2, w // 2)) for h, w in sizes]
+    bp = rt.ops.plane_tile_positions(1)
+    n_blocks = [(-(-(h // 2) * rt.hip.row_stride(w // 2) // bp)) for h, w in sizes]
+    assert min(n_blocks) >= 2
+    chosen = [(0, 0), (0, n_blocks[0] - 1), (1, 1)]                       # (problem, block of 256 pooled positions)
+    tl = torch.tensor([(g << 24) | b for g, b in chosen], dtype=torch.int32).cuda()
+
+    def run(tile_list):
+        pooled = [rt.FMap(C, h // 2, w // 2) for h, w in sizes]
+        dact = [rt.FMap(C, h, w) for h, w in sizes]
+        for f in pooled + dact:
+            f.planes.fill_(-7.0)
+        rt.ops.maxpool_fwd_grouped(list(zip(acts, pooled)), tile_list)
+        dense_pooled = [rt.FMap(C, h // 2, w // 2) for h, w in sizes]
+        rt.ops.maxpool_fwd_grouped(list(zip(acts, dense_pooled)))
+        rt.ops.maxpool_bwd_relu_grouped(list(zip(acts, dense_pooled, dys, dact)), tile_list)
+        return pooled, dact
+    (p_t, d_t), (p_d, d_d) = run(tl), run(None)
+    for g, (h, w) in enumerate(sizes):
+        Wpo = rt.hip.row_stride(w // 2)
+        inside = torch.zeros(p_t[g].planes.shape[1], dtype=torch.bool)
+        for gg, b in chosen:
+            if gg == g:
+                inside[Wpo + b * bp: Wpo + (b + 1) * bp] = True
+        inside[(h // 2 + 1) * Wpo:] = False
+        pt, pd = p_t[g].planes.cpu(), p_d[g].planes.cpu()
+        assert torch.equal(pt[:, inside], pd[:, inside]) and bool((pt[:, ~inside] == -7.0).all())
+        # backward: the windows of the listed pooled positions
+        qs = torch.nonzero(inside).flatten()
+        yo, xo = qs // Wpo - 1, qs % Wpo - 1
+        ok = (xo >= 0) & (xo < w // 2)
+        win = torch.zeros(h, w, dtype=torch.bool)
+        for dy_ in (0, 1):
+            for dx_ in (0, 1):
+                win[2 * yo[ok] + dy_, 2 * xo[ok] + dx_] = True
+        dt, dd = d_t[g].to_dense().cpu(), d_d[g].to_dense().cpu()
+        assert torch.equal(dt[:, win], dd[:, win]) and bool((dt[:, ~win] == -7.0).all())
+    # conv1_1 data gradient
+    dz = [rt.FMap(64, h, w).from_dense(torch.randn(64, h, w)) for h, w in sizes]
+    wd = dev(rt.ops.pack_conv_dgrad(torch.randn(64, 3, 3, 3) * 0.2))
+    b0 = rt.ops.plane_tile_positions(0)
+    tl0 = torch.tensor([(0 << 24) | 1, (1 << 24) | 0], dtype=torch.int32).cuda()
+    outs = []
+    for tile_list in (tl0, None):
+        o = [rt.FMap(4, h, w) for h, w in sizes]
+        for f in o:
+            f.planes.fill_(-7.0)
+        rt.ops.conv3x3_dgrad_c3_grouped(list(zip(dz, o)), wd, tile_list)
+        outs.append(o)
+    for g, (h, w) in enumerate(sizes):
+        Wp = rt.hip.row_stride(w)
+        inside = torch.zeros(outs[0][g].planes.shape[1], dtype=torch.bool)
+        b = 1 if g == 0 else 0
+        inside[Wp + b * b0: min(Wp + (b + 1) * b0, (h + 1) * Wp)] = True
+        a, d = outs[0][g].planes[:3].cpu(), outs[1][g].planes[:3].cpu()
+        assert torch.equal(a[:, inside], d[:, inside]) and bool((a[:, ~inside] == -7.0).all())
+
+
 def test_touch_flags_cover_the_scatter(rt):
     """Every chunk of the gradient arena that the scatter writes is flagged (the flags are a superset)."""
     torch.manual_seed(11)
