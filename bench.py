@@ -57,32 +57,94 @@ def to_device(batch, dev):
                  for i, x in enumerate(batch))
 
 
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, view_cpu, steps):
     """The oracle (CPU restatement of the reference path, parity-pinned against the reference's goldens) on the
-    same workload / view / seeds, on this host's cores."""
+    same workload / view / seeds, on this host's cores: the better of two thread counts (torch's CPU kernels stop
+    scaling - and with all 256 hardware threads of the GPU node's host oversubscribe badly - far below the core count)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import stylemesh_oracle as O
-    # cores this process may use, capped: torch's CPU kernels stop scaling (and oversubscribe badly) far below the
-    # 256 hardware threads of the GPU node's host
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(avail, int(os.environ.get("STYLEMESH_CPU_THREADS", 32))))
-    torch.set_num_threads(threads)
+    env = os.environ.get("STYLEMESH_CPU_THREADS")
+    counts = [int(env)] if env else sorted({max(1, min(avail, c)) for c in (32, 64)})
     cfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=wl["thr"],
                          style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"], use_depth_scaling=wl["depth"],
                          loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
+    torch.set_num_threads(counts[0])
     pipe = O.OraclePipeline(S.seeded_vgg_state(0), S.style_image(1, *STYLE_HW), cfg, (wl["tex"], wl["tex"]))
+    best, tried = None, []
+    for threads in counts:
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        pipe.training_step(view_cpu)   # warm-up (allocations, MKLDNN primitive caches)
+        warm = time.perf_counter() - t0
+        if warm > 30.0:   # keep the default bench run bounded: report the warm-up step itself
+            rate, sample = 1.0 / warm, f"1 step of the same workload and view, no warm-up ({warm:.1f} s)"
+        else:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe.training_step(view_cpu)
+            dt = time.perf_counter() - t0
+            rate, sample = steps / dt, f"{steps} step(s) of the same workload and view after 1 warm-up step ({dt:.1f} s)"
+        tried.append({"threads": threads, "views_per_s": round(rate, 4)})
+        if best is None or rate > best["value"]:
+            best = {"value": rate, "unit": "views/s", "cores": threads, "kind": "port", "sample": sample}
+    best["thread_counts_tried"] = tried
+    best["host_cpu"] = f"{cpu_model_string()} ({avail} hardware threads available)"
+    return best
+
+
+def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
+    """Warm-up + the timed region (barrier + synchronize on both sides). -> seconds of the timed region."""
+    from stylemesh_amd.runtime import ops
+    rep = wl["index_repeat"]
+    for i in range(args.warmup):
+        eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
+    ops.CONV_TIMER = timer
+    barrier()
     t0 = time.perf_counter()
-    pipe.training_step(view_cpu)   # warm-up (allocations, MKLDNN primitive caches)
-    warm = time.perf_counter() - t0
-    if warm > 45.0:   # keep the default bench run bounded: report the warm-up step itself
-        return {"value": 1.0 / warm, "unit": "views/s", "cores": threads, "kind": "port",
-                "sample": f"1 step of the same workload and view, no warm-up ({warm:.1f} s)"}
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.training_step(view_cpu)
+    for i in range(args.warmup, args.warmup + args.steps):
+        if timer is not None:
+            timer.enabled = (i - args.warmup) % args.timer_every == 0
+        eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
+    barrier()
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "views/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} step(s) of the same workload and view after 1 warm-up step ({dt:.1f} s)"}
+    ops.CONV_TIMER = None
+    return dt
+
+
+def f32_leg(args, wl, cfg, schedule, dev, barrier):
+    """The same workload on a second engine with v_mfma_f32_32x32x2_f32 convolutions and Gram kernels everywhere
+    (STYLEMESH_CONV_MODE = STYLEMESH_GRAM_MODE = f32): a short leg of the same run, priced against the fp32-MFMA peak."""
+    import copy
+    from stylemesh_amd.runtime import ops
+    from stylemesh_amd.runtime.engine import StepEngine
+    saved = ops.CONV_MODE, ops.GRAM_MODE
+    ops.CONV_MODE = ops.GRAM_MODE = "f32"
+    try:
+        eng = StepEngine(cfg, S.seeded_vgg_state(0), device=dev)
+        eng.set_style_image(S.style_image(1, *STYLE_HW))
+        a = copy.copy(args)
+        a.steps, a.warmup, a.timer_every = args.f32_steps, 3, max(1, args.f32_steps // 2)
+        timer = ops.KernelTimer()
+        dt = timed_leg(eng, schedule, a, wl, 1, None, barrier, timer)
+        n, ms, flops = timer.summary("f32")
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"value": round(a.steps / dt, 3), "unit": "views/s", "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(1e3 * dt / a.steps, 3), "conv_tflops": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "kernel": "conv3x3_mfma_kernel", "launches_timed": n}
+    finally:
+        ops.CONV_MODE, ops.GRAM_MODE = saved
 
 
 def main():
@@ -108,9 +170,13 @@ def main():
     ap.add_argument("--mfma", choices=["split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split' (default; bf16 MFMA on bf16x3-split operands, fp32 accuracy) or 'f32' (v_mfma_f32_32x32x2_f32 "
                     "everywhere); same as STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
-    ap.add_argument("--timer-every", type=int, default=20, help="HIP-event-time the conv launches of every n-th timed "
+    ap.add_argument("--timer-every", type=int, default=7, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
-                    "of the throughput, so the roofline is sampled)")
+                    "of the throughput, so the roofline is sampled; 7 -> 3 timed steps of --steps 20, 6 of 40)")
+    ap.add_argument("--f32-steps", type=int, default=10, help="N = 1: steps of the second, short leg that runs the same "
+                    "workload with v_mfma_f32_32x32x2_f32 everywhere (reported as 'f32_mode'; 0 = skip)")
+    ap.add_argument("--dense-adam", action="store_true", help="fused update over every texel instead of the chunks "
+                    "some view has touched so far")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -149,6 +215,7 @@ def main():
     eng.overlap_style = args.overlap_style
     eng.pipeline_exchange = args.pipeline_exchange
     eng.planned_scatter = not args.atomic_scatter
+    eng.sparse_update = not args.dense_adam
 
     # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
     total_steps = args.warmup + args.steps
@@ -160,29 +227,22 @@ def main():
     views = [to_device(v, dev) for v in views_cpu]
     schedule = [views[(i // wl["index_repeat"]) % len(views)] for i in range(total_steps)]
 
-    from stylemesh_amd.runtime.distributed import make_grad_reducer, make_sparse_grad_reducer
-    reducer = make_grad_reducer(dist, world) if args.dense_allreduce else make_sparse_grad_reducer(dist, world)
+    from stylemesh_amd.runtime.distributed import make_comm, make_grad_reducer, make_sparse_grad_reducer
+    # the gradient exchange runs on the product's own RCCL communicator (csrc/comm.hip); torch.distributed carries
+    # the unique id, the barriers and the max-over-ranks of the timing
+    comm = make_comm(dist, rank, world, dev) if world > 1 else None
+    reducer = make_grad_reducer(comm, world) if args.dense_allreduce else make_sparse_grad_reducer(comm, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        eng.training_step(schedule[i], world_size=world, reducer=reducer)
     timer = None if args.no_conv_timer else ops.KernelTimer()
-    ops.CONV_TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total_steps):
-        if timer is not None:
-            timer.enabled = (i - args.warmup) % args.timer_every == 0
-        eng.training_step(schedule[i], world_size=world, reducer=reducer)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer)
     active_levels = [lv.index for lv in eng.view if lv.active]
-    ops.CONV_TIMER = None
     losses = eng.losses()
+    touched_fraction = None if eng.touched is None else float(eng.touched.float().mean())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -198,13 +258,15 @@ def main():
         n, ms, flops = timer.summary(tag)
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if tag == "split" else PEAK_FP32_MFMA_TFLOPS
-        traffic = None   # HBM bytes per conv launch from the committed PMC pass of this workload (offline: PMC
-        tf = os.path.join(REPO, "profiles", "r01", f"conv_traffic_{args.workload}_{tag}.json")   # runs cannot be live)
-        if os.path.exists(tf):
-            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+        traffic, traffic_src = None, None   # HBM bytes per conv launch from the committed PMC pass of this workload
+        for rnd in ("r02", "r01"):          # (offline: PMC runs cannot be live inside bench.py)
+            tf = os.path.join(REPO, "profiles", rnd, f"conv_traffic_{args.workload}_{tag}.json")
+            if os.path.exists(tf):
+                traffic, traffic_src = round(json.load(open(tf))["hbm_bytes_per_launch"]), f"profiles/{rnd}/{os.path.basename(tf)}"
+                break
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/conv_traffic_*.json)",
+                    "traffic_unit": f"HBM bytes per launch (PMC pass, {traffic_src})",
                     "algorithmic_bytes_per_launch": round(timer.bytes.get(tag, 0.0) / max(n, 1)),
                     "kernel": "conv3x3_split_kernel" if tag == "split" else "conv3x3_mfma_kernel",
                     "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 MFMA products per fp32 multiply-add "
@@ -247,13 +309,22 @@ def main():
                                   "steps": 7 * wl["index_repeat"] * 273,
                                   "projected_wall_clock_s": round(7 * wl["index_repeat"] * 273 / value, 1),
                                   "note": "fixed schedule of one scene / measured views per second"},
-               "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()}}
+               "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()},
+               "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
+                                "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
+                                        "zero-initialised texture); the fraction grows with the views of the scene"},
+               "exchange": None if world == 1 else ("own RCCL communicator (sm_comm_init / sm_allreduce_grad)"
+                                                    if type(comm).__name__ == "RcclComm" else "torch.distributed")}
+        if world == 1 and args.f32_steps > 0 and ops.CONV_MODE == "split" and args.mfma is None:
+            out["f32_mode"] = f32_leg(args, wl, cfg, schedule, dev, barrier)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
+        if hasattr(comm, "destroy"):
+            comm.destroy()
         dist.destroy_process_group()
 
 

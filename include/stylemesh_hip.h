@@ -67,7 +67,7 @@ int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int*
                        int32_t* flags, int chunk_log2, void* stream);
 
 /* K2 as a sorted gather (stylemesh_amd/csrc/scatter_plan.hip). Which texels the pixels of a view hit, and with which
- * weights, depends only on the view - and the reference's RepeatingSampler (data/repeating_sampler.py) optimises a
+ * weights, depends only on the view - and the reference's RepeatingSampler (data/abstract_dataset.py:498-512) optimises a
  * view for 20-100 consecutive steps. sm_tex_scatter_plan lists every (pixel, layer, tap) contribution of ALL levels
  * of the view as key = arena offset of the texel (channel 0), value = (pixel, level, layer, tap weight x pixel weight),
  * radix-sorts the list by key and lists the runs of equal texels that cross a 64-entry chunk boundary (once per view).
@@ -106,11 +106,29 @@ int sm_tex_scatter_planned(const uint32_t* keys, const uint64_t* vals, size_t n_
  * bias_corr1 = 1-beta1^t and bias_corr2 = 1-beta2^t are computed by the caller in double; the betas are
  * doubles because torch derives the fp32 constants 1-beta from Python doubles.
  * dev_hyper (optional, device, 2 floats): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2)}
- * from it instead of the scalar arguments, so a captured launch (hipGraph) can be replayed across steps. */
+ * from it instead of the scalar arguments, so a captured launch (hipGraph) can be replayed across steps
+ * (sm_adam_hyper_step maintains it on the device).
+ * touched (optional, device, one int32 per 2^touched_chunk_log2 floats of the arena, log2 in [2, 24]): chunks whose
+ * flag is 0 are skipped without being read. Exact ONLY while every skipped element has p = g = m = v = 0 (a
+ * zero-initialised texture, texture.py:26-28, that no view has reached yet: its regulariser gradient
+ * reg_coef * p and its Adam update are then exactly 0); the caller ORs sm_tex_touch_flags of every view it has
+ * ever optimised into the flags and passes NULL for textures that start non-zero (random_init, from_tensor). */
 int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end,
                   const float* reg_coef, int n_seg, float lr, double beta1, double beta2, float eps,
                   double bias_corr1, double bias_corr2, float grad_scale, float clamp_lo, float clamp_hi,
-                  int zero_grad, float* sumsq_out, const float* dev_hyper, void* stream);
+                  int zero_grad, float* sumsq_out, const float* dev_hyper, const int32_t* touched,
+                  int touched_chunk_log2, void* stream);
+
+/* Device-side step counter of the fused update for hipGraph replay (torch.optim.Adam's state['step'] and the
+ * bias corrections of model/model.py:387-395's optimizer): state = {lr, step} (device, 2 doubles). Adds 1 to the
+ * step and writes dev_hyper = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} (2 floats, computed in double as
+ * torch does). Captured together with sm_adam_fused(dev_hyper=...), every replay advances one step with no
+ * step-dependent value crossing from the host. */
+int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream);
+
+/* dst[i] = 1 wherever src[i] != 0 (int32 flag arrays of n entries): accumulates a view's sm_tex_touch_flags (after
+ * the ranks' max-all-reduce, if any) into the ever-touched flags sm_adam_fused takes. */
+int sm_flags_or(int32_t* dst, const int32_t* src, size_t n, void* stream);
 
 /* normalize() alone (texture.py:41-44) + per-segment sum of squares (for the first step's tex_reg). */
 int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float clamp_lo, float clamp_hi,
@@ -307,9 +325,20 @@ int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void*
 
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 
-/* Thin RCCL wrapper: in-place sum all-reduce of the texture-gradient arena (ncclAllReduce, fp32).
- * comm is an ncclComm_t owned by the caller. Returns a ncclResult_t (0 = success). */
+/* RCCL over xGMI, one communicator per process (one process per GPU). The reference has no collective; this is the
+ * exchange of the R-GPU step defined in SURVEY.md section 8 e. All return a ncclResult_t (0 = success).
+ *   sm_comm_get_unique_id: rank 0 fills id_out (sm_comm_unique_id_bytes() bytes, HOST) and ships it to the other
+ *     ranks by any side channel (the Python host broadcasts it through torch.distributed).
+ *   sm_comm_init: collective over all ranks (ncclCommInitRank) on the CURRENT device; *comm_out = communicator handle.
+ *   sm_allreduce_grad: in-place fp32 SUM all-reduce of n floats (the gradient arena or its compacted dirty chunks),
+ *     enqueued on `stream` - ordered with the kernels that wrote g and the fused update that reads it.
+ *   sm_allreduce_flags_max: in-place int32 MAX all-reduce (the per-view touch flags of sm_tex_touch_flags). */
+size_t sm_comm_unique_id_bytes(void);
+int sm_comm_get_unique_id(void* id_out);
+int sm_comm_init(void** comm_out, int n_ranks, const void* unique_id, int rank);
+int sm_comm_destroy(void* comm);
 int sm_allreduce_grad(void* comm, float* g, size_t n, void* stream);
+int sm_allreduce_flags_max(void* comm, int32_t* flags, size_t n, void* stream);
 
 /* ---- E1: multi-view consistency metric --------------------------------------- */
 

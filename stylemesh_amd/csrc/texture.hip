@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float eps, float inv_sqrt_bc2,
                                                    float grad_scale, float lo, float hi, int zero_grad,
                                                    float* __restrict__ sumsq, const float* __restrict__ dev_hyper,
-                                                   int tiles_per_block) {
+                                                   int tiles_per_block, const int32_t* __restrict__ touched,
+                                                   int touched_log2) {
     if (ADAM && dev_hyper) {   // step-dependent scalars from device memory: the launch can be replayed from a hipGraph
         lr_over_bc1 = dev_hyper[0];
         inv_sqrt_bc2 = dev_hyper[1];
@@ -269,6 +270,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const size_t tile = tile0 + t;
     if (tile * 1024 >= n) break;
     const size_t i0 = (tile * 256 + threadIdx.x) * 4;
+    // Ever-touched chunks (zero-initialised textures): a texel no view has ever reached has p = g = m = v = 0, so its
+    // regulariser gradient, its update and its contribution to sum(p^2) are exactly zero - the chunk is skipped
+    // without being read. (A chunk is 2^touched_log2 >= 4 floats: a thread's four elements share one flag.)
+    const bool live = !ADAM || touched == nullptr || (i0 < n && touched[i0 >> touched_log2] != 0);
     // a tile almost always lies inside one segment (k_blk); elements of a tile that straddles a boundary and belong
     // to another segment are added one by one.
     const int k_blk = seg_of(segs, tile * 1024);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         sq = 0.f;
         k_cur = k_blk;
     }
-    if (i0 < n) {
+    if (i0 < n && live) {
         const bool full = i0 + 4 <= n;
         float pv[4], gv[4], mv[4], vv[4];
         if (full) {
@@ -344,6 +349,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         const float s = block_sum(sq);
         if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_cur, s);
     }
+}
+
+// Step-dependent Adam scalars kept ON THE DEVICE (hipGraph replay: the host may run many steps ahead of the GPU, so
+// nothing step-dependent may travel through a host buffer that a later step overwrites): state = {lr, step} in double;
+// one thread advances the step and writes {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} - the doubles torch computes.
+__global__ void adam_hyper_step_kernel(double* state, double beta1, double beta2, float* out2) {
+    const double t = state[1] + 1.0;
+    state[1] = t;
+    out2[0] = (float)(state[0] / (1.0 - pow(beta1, t)));
+    out2[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+}
+
+__global__ __launch_bounds__(256) void flags_or_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && src[i] != 0) dst[i] = 1;
 }
 
 // tiles of 1024 elements per block: enough blocks to fill the chip several times over, few enough atomics
@@ -416,7 +436,8 @@ static int make_segs(sm::Segs& s, size_t n, const size_t* seg_end, const float* 
 int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end, const float* reg_coef,
                   int n_seg, float lr, double beta1, double beta2, float eps, double bias_corr1, double bias_corr2,
                   float grad_scale, float clamp_lo, float clamp_hi, int zero_grad, float* sumsq_out,
-                  const float* dev_hyper, void* stream) {
+                  const float* dev_hyper, const int32_t* touched, int touched_chunk_log2, void* stream) {
+    if (touched != nullptr && (touched_chunk_log2 < 2 || touched_chunk_log2 > 24)) return (int)hipErrorInvalidValue;
     sm::Segs s;
     if (int e = make_segs(s, n, seg_end, reg_coef, n_seg)) return e;
     const int tpb = sm::adam_tiles_per_block(n);
@@ -426,7 +447,20 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_corr2));
     hipLaunchKernelGGL(sm::adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        s, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, inv_sqrt_bc2,
-                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper, tpb);
+                       grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper, tpb, touched, touched_chunk_log2);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream) {
+    hipLaunchKernelGGL(sm::adam_hyper_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2, dev_hyper);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_flags_or(int32_t* dst, const int32_t* src, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sm::flags_or_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -439,7 +473,7 @@ int sm_clamp_sumsq(float* p, size_t n, const size_t* seg_end, int n_seg, float c
     const size_t blocks = ((n + 1023) / 1024 + tpb - 1) / tpb;
     hipLaunchKernelGGL(sm::adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, n, s, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, clamp_lo,
-                       clamp_hi, 0, sumsq_out, (const float*)nullptr, tpb);
+                       clamp_hi, 0, sumsq_out, (const float*)nullptr, tpb, (const int32_t*)nullptr, 0);
     SM_LAUNCH_CHECK();
     return 0;
 }

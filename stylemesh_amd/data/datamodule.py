@@ -5,7 +5,6 @@ The real ScanNet / Matterport directory loaders are the next scope row (SURVEY.m
 from __future__ import annotations
 
 from . import synthetic as S
-from .view_contract import RepeatingSampler
 
 
 class SyntheticSceneDataModule:
@@ -39,10 +38,9 @@ class SyntheticSceneDataModule:
         return self._cache[i]
 
     def train_dataloader(self):
-        from ..runtime.distributed import padded_shard
-        mine = padded_shard(self.train_indices, self.rank, self.world_size)   # equal step counts on every rank
-        order = RepeatingSampler(mine, self.index_repeat) if self.sampler_mode == "repeat" else mine
-        return (self._view(i) for i in order)
+        from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes on every rank
+        return scheduled_batches(self._view, self.train_indices, self.rank, self.world_size, self.index_repeat,
+                                 repeat=self.sampler_mode == "repeat")
 
     def val_dataloader(self):
         return (self._view(i) for i in self.val_indices) if self.val_indices else None

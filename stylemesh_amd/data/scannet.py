@@ -168,10 +168,9 @@ class ScanNetSingleSceneDataModule:
         self.train_indices, self.val_indices = list(range(n_train)), list(range(n_train, n))
 
     def train_dataloader(self):
-        from ..runtime.distributed import padded_shard
-        mine = padded_shard(self.train_indices, self.rank, self.world_size)   # equal step counts on every rank
-        order = vc.RepeatingSampler(mine, self.index_repeat) if self.sampler_mode == "repeat" else mine
-        return (self.train_dataset[i] for i in order)
+        from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes on every rank
+        return scheduled_batches(lambda i: self.train_dataset[i], self.train_indices, self.rank, self.world_size,
+                                 self.index_repeat, repeat=self.sampler_mode == "repeat")
 
     def val_dataloader(self):
         return (self.val_dataset[i] for i in self.val_indices) if self.val_indices else None

@@ -66,13 +66,19 @@ class FusedTextureAdam:
 
     def state_dict(self):
         eng = self.module._engine
-        return {"step": eng.step_count, "m": eng.arena.m.clone(), "v": eng.arena.v.clone(), "lr": self.param_groups[0]["lr"]}
+        return {"step": eng.step_count, "m": eng.arena.m.clone(), "v": eng.arena.v.clone(), "lr": self.param_groups[0]["lr"],
+                "touched": None if eng.touched is None else eng.touched.clone()}
 
     def load_state_dict(self, sd):
+        """Restores step count, moments and learning rate. Load the texture itself FIRST (``from_tensor`` switches the
+        engine to the dense update; the saved ever-touched flags, taken at the same moment as the moments, switch the
+        sparse update back on)."""
         eng = self.module._engine
         eng.step_count = int(sd["step"])
         eng.arena.m.copy_(sd["m"])
         eng.arena.v.copy_(sd["v"])
+        t = sd.get("touched")
+        eng.touched = None if t is None else t.to(eng.device, torch.int32).clone()
         self.param_groups[0]["lr"] = sd["lr"]
 
 
@@ -253,11 +259,7 @@ class TextureOptimizationStyleTransferPipeline(_Base):
         eng = self._ensure_engine(batch[0].device)
         log_idx = batch_idx + self.current_epoch * self.batches_per_epoch["train"]
         self.update_batch_count(batch_idx, "train")
-        key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
-        if eng.view is None or key != eng.view_key:
-            eng.set_view(batch)
-            if self.grad_reducer is not None and hasattr(self.grad_reducer, "new_view"):
-                self.grad_reducer.new_view(eng.touch_flags(self.grad_reducer.chunk_log2))   # collective, per view
+        eng.begin_step(batch, self.grad_reducer)   # set_view on a new view key; per-view collective by schedule position
         for p, g in zip(self._texture_params(), eng.grads):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():   # a foreign optimizer dropped / replaced .grad
                 eng.arena.g.zero_()
@@ -277,9 +279,7 @@ class TextureOptimizationStyleTransferPipeline(_Base):
         self.update_batch_count(batch_idx, "val")
         eng.set_view(batch)
         lt = eng.loss_tensors()
-        saved = eng.arena.g.clone()
-        eng.forward_backward()       # losses only; the gradient this adds is discarded
-        eng.arena.g.copy_(saved)
+        eng.forward_backward(accumulate_grad=False)   # losses only: the texture scatter is skipped
         eng.view_key = None
         losses = {k: v.clone() for k, v in lt.items()}
         losses["total"] = losses["content"] + losses["style"] + losses["tex_reg"]

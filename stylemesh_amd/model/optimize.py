@@ -60,7 +60,7 @@ def main(args):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-    logger = JsonlLogger(save_dir=args.default_root_dir, version=args.version)
+    logger = JsonlLogger(save_dir=args.default_root_dir, version=args.version, rank=rank)
     log_dir = logger.log_dir
 
     if args.dataset == "synthetic":
@@ -108,12 +108,15 @@ def main(args):
         tex_reg_weights=args.tex_reg_weights, decay_gamma=args.decay_gamma, decay_step_size=args.decay_step_size,
         loss_weights=args.loss_weights, extra_args=vars(args), log_images_nth=args.log_images_nth,
         save_texture=args.save_texture and rank == 0, texture_dir=log_dir)
-    from ..runtime.distributed import make_sparse_grad_reducer
-    model.grad_reducer = make_sparse_grad_reducer(dist, world)
+    from ..runtime.distributed import make_comm, make_sparse_grad_reducer
+    comm = make_comm(dist, rank, world, device) if world > 1 else None   # the product's own RCCL communicator
+    model.grad_reducer = make_sparse_grad_reducer(comm, world)
 
     trainer = MiniTrainer(max_epochs=args.max_epochs, logger=logger, device=device, rank=rank, world_size=world)
     trainer.fit(model, dm)
     if world > 1:
+        if hasattr(comm, "destroy"):
+            comm.destroy()
         dist.destroy_process_group()
     return model
 

@@ -43,6 +43,135 @@ def rank_schedule(indices, rank, world_size, index_repeat):
     return [v for v in padded_shard(indices, rank, world_size) for _ in range(index_repeat)]
 
 
+class ViewBatch(tuple):
+    """The 13-tuple of the input contract (``view_contract.assemble_batch``) plus ``new_view``: True on the first step
+    of every ``index_repeat`` block of the rank's schedule. The flag is a function of the schedule POSITION only, so
+    it is the same on every rank at every step - a rank whose shard was padded by repeating its last view sees
+    ``new_view`` although its view key did not change, and still enters the per-view collective
+    (``SparseGradReducer.new_view``) that the other ranks are entering."""
+    new_view = None
+
+    def __new__(cls, items, new_view=None):
+        self = super().__new__(cls, items)
+        self.new_view = new_view
+        return self
+
+
+def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repeat=1, repeat=True):
+    """The rank's train schedule as ``ViewBatch``es: views ``padded_shard(indices)``, each ``index_repeat``
+    consecutive times (``repeat=False``: once, the 'sequential' sampler mode). Consecutive repeats yield the SAME
+    object (one decode / upload per view; callers may cache by identity), ``new_view`` marks the block boundaries."""
+    rep = index_repeat if repeat else 1
+    for i in padded_shard(indices, rank, world_size):
+        n = rep[i] if isinstance(rep, list) else rep
+        if n < 1:
+            continue
+        items = get_view(i)
+        yield ViewBatch(items, new_view=True)
+        rest = ViewBatch(items, new_view=False)
+        for _ in range(n - 1):
+            yield rest
+
+
+class _ReduceOp:
+    SUM, MAX = "sum", "max"
+
+
+class _Work:
+    """Handle of an asynchronous collective on the communicator's side stream: ``wait()`` orders the caller's current
+    stream behind it (no host block), as torch.distributed's NCCL work objects do."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class RcclComm:
+    """The product's own RCCL communicator (csrc/comm.hip: ``sm_comm_init`` = ncclCommInitRank, one per process /
+    GPU), exposing the slice of the ``torch.distributed`` module interface the reducers use (``all_reduce`` with
+    ``ReduceOp.SUM`` on fp32 / ``ReduceOp.MAX`` on int32, ``async_op``), so that ``SparseGradReducer`` runs unchanged
+    over it. Synchronous collectives are enqueued on the CURRENT HIP stream - ordered with the scatter that wrote the
+    gradient and the fused update that reads it, with no stream hop - asynchronous ones on a side stream.
+    ``torch.distributed`` (any backend) only carries the 128-byte unique id at start-up."""
+    ReduceOp = _ReduceOp
+
+    def __init__(self, dist_module, rank: int, world_size: int, device):
+        import ctypes
+        import torch
+        from . import hip
+        self._hip, self._torch = hip, torch
+        self.rank, self.world_size, self.device = rank, world_size, device
+        nbytes = hip.lib.sm_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(nbytes)
+        if rank == 0:
+            hip.check(hip.lib.sm_comm_get_unique_id(buf), "sm_comm_get_unique_id")
+        box = [bytes(buf.raw)]
+        if world_size > 1:
+            dist_module.broadcast_object_list(box, src=0)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            hip.check(hip.lib.sm_comm_init(ctypes.byref(handle), world_size, box[0], rank), "sm_comm_init")
+        self.handle = handle
+        self._side = None
+
+    def _launch(self, tensor, op):
+        hip, torch = self._hip, self._torch
+        assert tensor.is_cuda and tensor.is_contiguous()
+        if op == _ReduceOp.SUM and tensor.dtype == torch.float32:
+            hip.check(hip.lib.sm_allreduce_grad(self.handle, tensor.data_ptr(), tensor.numel(), hip.stream()),
+                      "sm_allreduce_grad")
+        elif op == _ReduceOp.MAX and tensor.dtype == torch.int32:
+            hip.check(hip.lib.sm_allreduce_flags_max(self.handle, tensor.data_ptr(), tensor.numel(), hip.stream()),
+                      "sm_allreduce_flags_max")
+        else:
+            raise ValueError(f"unsupported collective: {op} on {tensor.dtype}")
+
+    def all_reduce(self, tensor, op=_ReduceOp.SUM, async_op=False):
+        torch = self._torch
+        if not async_op:
+            self._launch(tensor, op)
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._launch(tensor, op)
+            done = torch.cuda.Event()
+            done.record()
+        tensor.record_stream(self._side)
+        return _Work(done)
+
+    def destroy(self):
+        if self.handle:
+            self._hip.lib.sm_comm_destroy(self.handle)
+            self.handle = None
+
+
+def make_comm(dist_module, rank: int, world_size: int, device, kind=None):
+    """The collective provider of the gradient exchange. ``kind`` (default: env STYLEMESH_COMM, else 'rccl' when the
+    process group's backend is nccl = RCCL): 'rccl' = the product's own communicator (``RcclComm``); 'torch' = the
+    ``torch.distributed`` module itself (the only choice over gloo: CPU tests, two ranks sharing one GPU). If the RCCL
+    communicator cannot be created the reason is printed and the torch path is used - a multi-GPU job never dies on it."""
+    if world_size <= 1:
+        return None
+    kind = kind or os.environ.get("STYLEMESH_COMM")
+    if kind is None:
+        kind = "rccl" if str(dist_module.get_backend()) == "nccl" else "torch"
+    if kind == "rccl":
+        try:
+            return RcclComm(dist_module, rank, world_size, device)
+        except Exception as e:   # noqa: BLE001 - any failure falls back to the torch path
+            import sys
+            print(f"[stylemesh_amd] rank {rank}: own RCCL communicator unavailable ({e}); using torch.distributed",
+                  file=sys.stderr)
+    return dist_module
+
+
 def make_grad_reducer(dist_module, world_size: int):
     """In-place SUM all-reduce of the gradient arena (None for a single rank)."""
     if world_size <= 1:

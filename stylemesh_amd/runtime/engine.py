@@ -174,6 +174,13 @@ class StepEngine:
         self.reg_loss_coef = [lam * w / n if self.reg_active else 0.0 for w, n in zip(rw, numel)]
         self._reg_loss_coef_dev = torch.tensor(self.reg_loss_coef, device=self.device)   # no per-step host copy
         ops.clamp_sumsq(self.arena.p, self.arena.seg_end, self.sumsq)
+        # Ever-touched chunks of the arena (64 floats = 256 B, the granularity of the multi-GPU exchange): a texel of a
+        # ZERO-initialised texture that no view has reached has p = g = m = v = 0 and an exactly-zero update, so the
+        # fused update skips chunks no view has ever touched (sm_adam_fused). None = dense update (textures that start
+        # non-zero: random_init, load_texture / from_tensor, a loaded optimizer state).
+        self.touched_log2 = 6
+        self.touched = None if random_init else torch.zeros(-(-self.arena.n // 64), dtype=torch.int32, device=device)
+        self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
     # ------------------------------------------------------------------ texture access
     def load_texture(self, layer_tensors):
@@ -181,6 +188,7 @@ class StepEngine:
         for dst, src in zip(self.layers, layer_tensors):
             assert tuple(dst.shape) == tuple(src.shape), (dst.shape, src.shape)
             dst.copy_(src.to(self.device, torch.float32))
+        self.touched = None   # arbitrary content: every texel takes part in the update from now on
         self.sumsq.zero_()
         ops.clamp_sumsq(self.arena.p, self.arena.seg_end, self.sumsq)
 
@@ -337,6 +345,10 @@ class StepEngine:
             self._finish_view(levels, rgb_dev)
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
         self._last_batch = batch
+        if self.touched is not None:
+            for lv in self.view:
+                if lv.active:
+                    ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, self.touched, self.touched_log2)
 
     def _finish_view(self, levels, rgb_dev, msums=None):
         """Layer-resolution masks + counts + level factors (calculate_pyramid, losses :146-217) and the content
@@ -416,9 +428,10 @@ class StepEngine:
         return sums_host
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self):
+    def forward_backward(self, accumulate_grad=True):
         """Forward + backward of the current view; the data-term gradient ACCUMULATES into the gradient arena
-        (zeroed by the fused update), the weighted content / style losses into ``loss_buf``."""
+        (zeroed by the fused update), the weighted content / style losses into ``loss_buf``.
+        ``accumulate_grad=False`` (validation): everything but the final texture scatter - the arena is untouched."""
         if self.view is None or self.targets is None:
             raise RuntimeError("set_style_image() and set_view() must be called first")
         cfg = self.cfg
@@ -501,6 +514,8 @@ class StepEngine:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
+        if not accumulate_grad:
+            return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
             # sorted gather over the plan of this view (built by set_view); texels are stored without being read
             # while the arena is known to be zero (the fused update zeroes it)
@@ -641,12 +656,21 @@ class StepEngine:
         """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""
         self.step_count += 1
         if self._can_graph():
-            # step-dependent scalars go through device memory so that the captured launch can be replayed
+            # The step-dependent scalars live ON THE DEVICE: a captured one-thread kernel advances {lr, step} and
+            # writes {lr / bc1, 1 / sqrt(bc2)} for the update that follows it in the same graph. (Sending them through
+            # a pinned host buffer raced: the host runs many steps ahead and overwrote the buffer before an earlier
+            # step's async copy had executed.) The host only pushes lr when StepLR changes it - as a fill kernel,
+            # whose value travels in the launch itself - and the step when it has advanced outside the graph.
             if not hasattr(self, "_hyper_dev"):
                 self._hyper_dev = torch.zeros(2, device=self.device)
-                self._hyper_host = torch.zeros(2).pin_memory()
-            self._hyper_host[0], self._hyper_host[1] = ops.adam_hyper(self.lr, self.step_count)
-            self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+                self._hyper_state = torch.zeros(2, dtype=torch.float64, device=self.device)
+                self._hyper_lr, self._hyper_step = None, None
+            if self._hyper_lr != self.lr:
+                self._hyper_state[0:1].fill_(self.lr)
+                self._hyper_lr = self.lr
+            if self._hyper_step != self.step_count - 1:
+                self._hyper_state[1:2].fill_(float(self.step_count - 1))
+            self._hyper_step = self.step_count
             key = world_size
             if self._opt_graph is None or self._opt_graph[0] != key:
                 if getattr(self, "_opt_warm", 0) < 1:      # one eager run before capturing
@@ -661,12 +685,18 @@ class StepEngine:
             return
         self._optimizer_launch(world_size, None)
 
+    def _touched_arg(self):
+        return (self.touched, self.touched_log2) if (self.sparse_update and self.touched is not None) else (None, 0)
+
     def _optimizer_launch(self, world_size, dev_hyper):
         self._grad_dirty = False   # the fused update zeroes the gradient arena
         self.sumsq.zero_()
+        if dev_hyper is not None:
+            ops.adam_hyper_step(self._hyper_state, dev_hyper)
+        touched, tl2 = self._touched_arg()
         ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
                        self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
-                       dev_hyper=dev_hyper)
+                       dev_hyper=dev_hyper, touched=touched, touched_log2=tl2)
 
     def exchange_and_update(self, world_size: int, reducer):
         """Multi-GPU tail of the step: gradient exchange overlapped with the fused update (``reducer.pipelined``:
@@ -676,9 +706,12 @@ class StepEngine:
         self._grad_dirty = False   # every range is zeroed by its update
         a = self.arena
 
+        touched, tl2 = self._touched_arg()
+
         def update_range(lo, hi):
             ops.adam_fused(a.p, a.g, a.m, a.v, a.seg_end, self.reg_coef, self.lr, self.step_count,
-                           grad_scale=1.0 / world_size, sumsq_out=self.sumsq, lo=lo, hi=hi)
+                           grad_scale=1.0 / world_size, sumsq_out=self.sumsq, lo=lo, hi=hi, touched=touched,
+                           touched_log2=tl2)
         reducer.pipelined(a.g, update_range)
 
     def _can_graph(self):
@@ -706,20 +739,16 @@ class StepEngine:
     def end_epoch(self):
         self.epoch += 1
 
-    def training_step(self, batch, world_size: int = 1, reducer=None):
-        """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order."""
-        # the same batch object again = the same view (RepeatingSampler schedules): no read of the view index, which
-        # would be a device-to-host sync per step when the batch lives on the GPU
-        if self.view is None or batch is not self._last_batch:
-            key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
-        else:
-            key = self.view_key
-        if self.view is None or key != self.view_key:
-            self.set_view(batch)
-            if reducer is not None and hasattr(reducer, "new_view"):
-                reducer.new_view(self.touch_flags(reducer.chunk_log2))
+    def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None):
+        """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.
+        ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
+        self.begin_step(batch, reducer, new_view)
         losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         self.step_forward_backward()
+        # content / style of loss_tensors() are views of the accumulators the NEXT step zeroes: hand out this step's
+        # values (one 2-float copy), so that a caller may read them any number of steps later
+        snap = self.loss_buf.clone()
+        losses["content"], losses["style"] = snap[0:1], snap[1:2]
         if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
             self.exchange_and_update(world_size, reducer)
             return losses
@@ -727,6 +756,33 @@ class StepEngine:
             reducer(self.arena.g)
         self.optimizer_step(world_size)
         return losses
+
+    def begin_step(self, batch, reducer=None, new_view=None):
+        """Per-view work at the head of a step. ``set_view`` runs when the batch's view KEY differs from the current
+        one. The per-view COLLECTIVE (``reducer.new_view``: max-all-reduce of the touch flags) is driven by the
+        schedule POSITION instead - ``new_view`` / ``batch.new_view`` (``distributed.ViewBatch``), identical on every
+        rank at every step - because a rank whose shard was padded by repeating its last view keeps its key while the
+        other ranks change theirs, and all of them must enter the collective. Without a schedule flag the key decides
+        (single rank, or callers whose ranks all change views together)."""
+        # the same batch object again = the same view (RepeatingSampler schedules): no read of the view index, which
+        # would be a device-to-host sync per step when the batch lives on the GPU
+        if self.view is None or batch is not self._last_batch:
+            key = int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
+        else:
+            key = self.view_key
+        changed = self.view is None or key != self.view_key
+        if changed:
+            self.set_view(batch)
+        if new_view is None:
+            new_view = getattr(batch, "new_view", None)
+        if reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view):
+            flags = self.touch_flags(reducer.chunk_log2)
+            reducer.new_view(flags)   # in place: now the union over the ranks' views
+            if self.touched is not None:
+                if reducer.chunk_log2 == self.touched_log2:
+                    ops.flags_or(self.touched, flags)   # the other ranks' gradients arrive with the exchange
+                else:
+                    self.touched = None
 
     def touch_flags(self, chunk_log2: int):
         """int32 flag per 2^chunk_log2 floats of the gradient arena: can the current view's scatter write there?"""

@@ -33,7 +33,9 @@ SIGNATURES = {
     "sm_tex_scatter_plan_cross_bytes": [_sz],
     "sm_tex_scatter_plan": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp],
     "sm_tex_scatter_planned": [_vp, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp],
-    "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp, _vp],
+    "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp],
+    "sm_adam_hyper_step": [_vp, _d, _d, _vp, _vp],
+    "sm_flags_or": [_vp, _vp, _sz, _vp],
     "sm_clamp_sumsq": [_vp, _sz, _vp, _i, _f, _f, _vp, _vp],
     "sm_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "sm_conv3x3_grouped": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
@@ -75,7 +77,12 @@ SIGNATURES = {
     "sm_raster_maps": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "sm_mip_downsample": [_vp, _vp, _i, _i, _i, _vp],
     "sm_tex_sample_mip": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "sm_comm_unique_id_bytes": [],
+    "sm_comm_get_unique_id": [_vp],
+    "sm_comm_init": [_vp, _i, _vp, _i],
+    "sm_comm_destroy": [_vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
+    "sm_allreduce_flags_max": [_vp, _vp, _sz, _vp],
 }
 
 

@@ -180,23 +180,42 @@ def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
 
 
 def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
-               zero_grad=True, sumsq_out=None, dev_hyper=None, lo=0, hi=None):
+               zero_grad=True, sumsq_out=None, dev_hyper=None, lo=0, hi=None, touched=None, touched_log2=0):
     """``lo`` / ``hi``: update only arena elements [lo, hi) (multiples of 4; the pipelined multi-GPU exchange updates
-    the arena range by range) - same kernel on offset pointers, segment ends shifted and clipped to the range."""
+    the arena range by range) - same kernel on offset pointers, segment ends shifted and clipped to the range.
+    ``touched``: int32 flag per 2^touched_log2 floats of the WHOLE arena; chunks with flag 0 are skipped (exact only for
+    elements with p = g = m = v = 0, see sm_adam_fused)."""
     if lo != 0 or (hi is not None and hi != p.numel()):
         hi = p.numel() if hi is None else hi
         assert lo % 4 == 0 and 0 <= lo <= hi <= p.numel()
         if hi == lo:
             return
+        if touched is not None:
+            assert lo % (1 << touched_log2) == 0, "range start must be chunk-aligned"
+            touched = touched[lo >> touched_log2:]
         p, g, m, v = p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi]
         seg_end = [min(max(int(e) - lo, 0), hi - lo) for e in seg_end]
     n = p.numel()
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
+    if touched is not None:
+        assert touched.dtype == torch.int32 and touched.numel() * (1 << touched_log2) >= n
     hip.check(lib.sm_adam_fused(ptr(p), ptr(g), ptr(m), ptr(v), n, hip.size_array(seg_end),
                                 hip.float_array(reg_coef), len(seg_end), lr, beta1, beta2, eps, bc1, bc2,
                                 grad_scale, CLAMP_LO, CLAMP_HI, int(zero_grad), ptr(sumsq_out), ptr(dev_hyper),
-                                hip.stream()), "sm_adam_fused")
+                                ptr(touched), touched_log2, hip.stream()), "sm_adam_fused")
+
+
+def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999):
+    """``state``: device float64 [lr, step]; advances the step and writes the two step-dependent scalars of the
+    fused update into ``dev_hyper`` (device float32 [2]) - on the device, so the launch can live in a hipGraph."""
+    assert state.dtype == torch.float64 and state.numel() == 2 and dev_hyper.dtype == torch.float32
+    hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), hip.stream()), "sm_adam_hyper_step")
+
+
+def flags_or(dst, src):
+    assert dst.dtype == src.dtype == torch.int32 and dst.numel() == src.numel()
+    hip.check(lib.sm_flags_or(ptr(dst), ptr(src), dst.numel(), hip.stream()), "sm_flags_or")
 
 
 def clamp_sumsq(p, seg_end, sumsq_out=None):

@@ -24,10 +24,13 @@ class JsonlLogger:
     """TensorBoard-shaped scalar logger (``logger.experiment.add_scalar(s)``) writing JSON lines; device tensors
     are only converted when the line is written, every ``flush_every`` records (no per-step host sync)."""
 
-    def __init__(self, save_dir="lightning_logs", version=0, flush_every=200):
+    def __init__(self, save_dir="lightning_logs", version=0, flush_every=200, rank=0):
+        """``rank``: with several ranks every rank logs ITS OWN views' losses; rank 0 writes ``scalars.jsonl``, rank r
+        ``scalars.rank{r}.jsonl`` (one shared file would interleave records with identical tags and steps)."""
         self.save_dir, self.version = save_dir, version
         self.log_dir = os.path.join(save_dir, f"lightning_logs/version_{version}")
         os.makedirs(self.log_dir, exist_ok=True)
+        self.file_name = "scalars.jsonl" if rank == 0 else f"scalars.rank{rank}.jsonl"
         self.experiment = self
         self._pending, self._flush_every = [], flush_every
 
@@ -44,7 +47,7 @@ class JsonlLogger:
         pass
 
     def flush(self):
-        with open(os.path.join(self.log_dir, "scalars.jsonl"), "a") as f:
+        with open(os.path.join(self.log_dir, self.file_name), "a") as f:
             for tag, value, step in self._pending:
                 f.write(json.dumps({"tag": tag, "step": int(step), "value": float(value)}) + "\n")
         self._pending.clear()
@@ -61,8 +64,19 @@ class MiniTrainer:
         self.call_log = []   # hook names in call order (tests)
 
     def _to_device(self, batch):
-        mv = lambda t: t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t
-        return tuple([mv(u) for u in x] if isinstance(x, (list, tuple)) else mv(x) for x in batch)
+        """Host batch -> device batch. The view index (element 8) stays on the host (reading it back would be a
+        device-to-host sync per step); consecutive repeats of one view (same host tensors) reuse the device copy; the
+        schedule's ``new_view`` flag (``runtime.distributed.ViewBatch``) is carried over."""
+        from .runtime.distributed import ViewBatch
+        last = getattr(self, "_last_dev", None)
+        if last is not None and last[0] is batch[0]:
+            items = last[1]
+        else:
+            mv = lambda t: t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t
+            items = tuple(x if k == 8 else ([mv(u) for u in x] if isinstance(x, (list, tuple)) else mv(x))
+                          for k, x in enumerate(batch))
+            self._last_dev = (batch[0], items)
+        return ViewBatch(items, new_view=getattr(batch, "new_view", None))
 
     def _call(self, model, name, *a):
         self.call_log.append(name)

@@ -124,3 +124,68 @@ def test_sparse_grad_reducer_equals_dense_allreduce(tmp_path):
             assert frac < 0.6 and nbytes == int(round(frac * 64)) * 16 * 4      # only the dirty chunks travelled
         else:
             assert nbytes == 64 * 16 * 4                                        # mostly dirty: dense fallback
+
+
+def test_scheduled_batches_mark_view_changes_by_position():
+    """Every rank sees ``new_view`` at the same schedule positions, padded ranks included (a padded rank
+    keeps its view key while the others change theirs, and must still enter the per-view collective)."""
+    scheds = []
+    for rank in range(2):
+        seq = list(D.scheduled_batches(lambda i: (f"view{i}",), range(5), rank, 2, index_repeat=2))
+        scheds.append([(b[0], b.new_view) for b in seq])
+    assert [v for v, _ in scheds[0]] == ["view0", "view0", "view2", "view2", "view4", "view4"]
+    assert [v for v, _ in scheds[1]] == ["view1", "view1", "view3", "view3", "view3", "view3"]   # padded: view3 again
+    assert [f for _, f in scheds[0]] == [f for _, f in scheds[1]] == [True, False] * 3
+    seq = list(D.scheduled_batches(lambda i: (i,), range(3), 0, 1, index_repeat=4, repeat=False))
+    assert [(b[0], b.new_view) for b in seq] == [(0, True), (1, True), (2, True)]
+    # repeats of one view are the same host object after the first (one decode / upload per view)
+    seq = list(D.scheduled_batches(lambda i: (object(),), range(2), 0, 1, index_repeat=3))
+    assert seq[1] is seq[2] and seq[0][0] is seq[1][0] and seq[3][0] is not seq[0][0]
+
+
+def _schedule_worker(rank, world, port, out_dir):
+    """The real ``StepEngine.begin_step`` + ``SparseGradReducer`` over an ODD view count: 5 views, 2 ranks, repeat 2.
+    Only the kernels are stubbed (no GPU here): ``set_view`` records the key, ``touch_flags`` flags a key-dependent
+    chunk set, the 'gradient' is the view key in the view's chunks."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stylemesh_amd.runtime.engine import StepEngine
+    n_chunks, chunk = 32, 16
+    eng = object.__new__(StepEngine)
+    eng.view, eng.view_key, eng._last_batch, eng.touched = None, None, None, None
+    log = []
+
+    def set_view(batch):
+        eng.view, eng.view_key, eng._last_batch = [batch], batch[8], batch
+        log.append(("set_view", batch[8]))
+
+    def touch_flags(chunk_log2):
+        f = torch.zeros(n_chunks, dtype=torch.int32)
+        f[(eng.view_key * 5) % n_chunks:(eng.view_key * 5) % n_chunks + 4] = 1
+        return f
+    eng.set_view, eng.touch_flags = set_view, touch_flags
+    red = D.make_sparse_grad_reducer(dist, world, chunk_log2=4)
+    sums = []
+    get_view = lambda i: tuple([None] * 8 + [i] + [None] * 4)
+    for batch in D.scheduled_batches(get_view, range(5), rank, world, index_repeat=2):
+        eng.begin_step(batch, red)
+        arena = torch.zeros(n_chunks, chunk)
+        arena[touch_flags(4).bool()] = float(batch[8] + 1)
+        arena = arena.reshape(-1)
+        want = arena.clone()
+        dist.all_reduce(want)
+        red(arena)
+        assert torch.equal(arena, want)
+        sums.append(float(arena.sum()))
+    torch.save({"log": log, "sums": sums}, os.path.join(out_dir, f"sched{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_odd_view_count_keeps_collectives_matched(tmp_path):
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_schedule_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"sched{r}.pt") for r in (0, 1))
+    assert [k for _, k in r0["log"]] == [0, 2, 4] and [k for _, k in r1["log"]] == [1, 3]   # rank 1: no 3rd set_view
+    assert r0["sums"] == r1["sums"] and len(r0["sums"]) == 6
