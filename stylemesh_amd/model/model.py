@@ -64,8 +64,11 @@ class FusedTextureAdam:
         eng.cfg.decay_gamma, eng.epoch = 1.0, 0    # the scheduler owns the learning rate
         eng.optimizer_step(self.world_size)
 
+    def _eng(self):
+        return self.module._ensure_engine(self.param_groups[0]["params"][0].device)
+
     def state_dict(self):
-        eng = self.module._engine
+        eng = self._eng()
         return {"step": eng.step_count, "m": eng.arena.m.clone(), "v": eng.arena.v.clone(), "lr": self.param_groups[0]["lr"],
                 "touched": None if eng.touched is None else eng.touched.clone()}
 
@@ -73,7 +76,7 @@ class FusedTextureAdam:
         """Restores step count, moments and learning rate. Load the texture itself FIRST (``from_tensor`` switches the
         engine to the dense update; the saved ever-touched flags, taken at the same moment as the moments, switch the
         sparse update back on)."""
-        eng = self.module._engine
+        eng = self._eng()
         eng.step_count = int(sd["step"])
         eng.arena.m.copy_(sd["m"])
         eng.arena.v.copy_(sd["v"])
@@ -171,7 +174,11 @@ class TextureOptimizationStyleTransferPipeline(_Base):
                                learning_rate=self.learning_rate, decay_gamma=self.decay_gamma,
                                decay_step_size=self.decay_step_size)
             eng = StepEngine(cfg, self.vgg_loss.vgg.state_dict(), device)
-            eng.load_texture([p.detach() for p in self._texture_params()])
+            params = [p.detach() for p in self._texture_params()]
+            # an untouched zero-initialised texture (texture.py:26-28) keeps the engine's sparse update; any other
+            # content (random_init, from_tensor, a loaded checkpoint) makes every texel part of the update
+            if any(bool(p.any()) for p in params):
+                eng.load_texture(params)
             for p, view, g in zip(self._texture_params(), eng.layers, eng.grads):
                 p.data = view
                 p.grad = g

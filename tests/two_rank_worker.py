@@ -1,0 +1,101 @@
+"""Worker of the two-rank GPU tests (tests/test_round2_gpu.py), launched by ``torch.distributed.run``.
+
+    two_rank_worker.py g8 <out_dir>        mean-gradient step of golden G8 with the HIP gradients
+    two_rank_worker.py trainer <out_dir>   MiniTrainer epoch over 5 train views (odd) with index_repeat 2
+
+STYLEMESH_TEST_BACKEND=nccl: one GPU per rank, exchange over the product's own RCCL communicator;
+gloo: both ranks on cuda:0, exchange through torch.distributed's gloo backend (1-GPU boxes)."""
+import os
+import sys
+import tempfile
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+
+from conftest import load_golden  # noqa: E402
+from golden_cases import (FLAGSETS, LOSS_WEIGHTS, MULTIVIEW_SEEDS, SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW,  # noqa: E402
+                          STYLE_HW, STYLE_SEED, STYLE_WEIGHTS, TEX, VGG_SEED)
+from stylemesh_amd.data import synthetic as S  # noqa: E402
+from stylemesh_amd.runtime import distributed as D  # noqa: E402
+
+
+def main():
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    rank, world, local = D.env_rank_world()
+    backend = os.environ.get("STYLEMESH_TEST_BACKEND", "gloo")
+    dev_index = local if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    comm = D.make_comm(dist, rank, world, dev)
+    exchange = type(comm).__name__ if comm is not dist else "torch.distributed"
+    if backend == "nccl":
+        assert exchange == "RcclComm", exchange
+    cfgd = FLAGSETS["with_angle_and_depth"]
+    g5 = load_golden("g5_with_angle_and_depth")
+    init = [torch.from_numpy(g5[f"init{i}"]) for i in range(4)]
+
+    if mode == "g8":
+        from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+        cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
+                           angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
+                           use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
+                           learning_rate=1, decay_gamma=0.1, decay_step_size=1)
+        eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
+        eng.load_texture(init)
+        eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
+        red = D.make_sparse_grad_reducer(comm, world)
+        flags = None
+        for seed in D.shard_views(MULTIVIEW_SEEDS, rank, world):
+            batch = S.make_view(seed, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                                min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+            eng.set_view(batch)
+            eng.forward_backward()                      # accumulates into the gradient arena
+            f = eng.touch_flags(red.chunk_log2)
+            flags = f if flags is None else torch.maximum(flags, f)
+        red.new_view(flags)                             # union of both ranks' (two-view) footprints
+        red(eng.arena.g)
+        R = len(MULTIVIEW_SEEDS)
+        mean_grad = [(g / R + c * p).cpu() for g, c, p in zip(eng.grads, eng.reg_coef, eng.layers)]
+        eng.optimizer_step(world_size=R)
+        torch.cuda.synchronize()
+        torch.save({"mean_grad": mean_grad, "layers": [l.cpu().clone() for l in eng.layers],
+                    "exchange": f"{exchange}, {red.last_bytes} bytes"}, os.path.join(out_dir, f"rank{rank}.pt"))
+    elif mode == "trainer":
+        from stylemesh_amd.data.datamodule import SyntheticSceneDataModule
+        from stylemesh_amd.model.model import TextureOptimizationStyleTransferPipeline
+        from stylemesh_amd.trainer import JsonlLogger, MiniTrainer
+        f = tempfile.NamedTemporaryFile(suffix=".pth", delete=False)
+        torch.save(S.seeded_vgg_state(VGG_SEED), f.name)
+        model = TextureOptimizationStyleTransferPipeline(
+            W=TEX, H=TEX, hierarchical_texture=True, hierarchical_layers=4, style_image=S.style_image(STYLE_SEED, *STYLE_HW),
+            style_weights=STYLE_WEIGHTS, vgg_gatys_model_path=f.name, use_angle_weight=True, use_depth_scaling=True,
+            style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"], angle_threshold=cfgd["thr"], save_texture=False,
+            learning_rate=1, decay_gamma=0.1, decay_step_size=1, loss_weights=dict(LOSS_WEIGHTS))
+        model.grad_reducer = D.make_sparse_grad_reducer(comm, world)
+        dm = SyntheticSceneDataModule(n_views=7, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, min_pyramid_depth=0.9,
+                                      split=(0.8, 0.2), index_repeat=2, room_size=SMALL_ROOM, rank=rank, world_size=world)
+        dm.setup()
+        assert len(dm.train_indices) == 5
+        tr = MiniTrainer(max_epochs=1, logger=JsonlLogger(out_dir, rank=rank), device=dev, rank=rank, world_size=world,
+                         progress=False)
+        tr.fit(model, dm)
+        torch.cuda.synchronize()
+        torch.save({"layers": [l.data.detach().cpu().clone() for l in model.texture.layers], "steps": tr.global_step},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    if hasattr(comm, "destroy"):
+        comm.destroy()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
