@@ -62,26 +62,36 @@ def test_adam_kernel_skips_unflagged_chunks_only():
 
 
 def test_sparse_update_equals_dense_and_touched_texels_keep_decaying():
-    """Zero-initialised texture, view A then view B: (i) the update over the ever-touched chunks is bit-identical to
-    the update over the whole arena; (ii) a texel only view A reaches keeps moving under the regulariser (and its
-    Adam moments) during view B's steps - it was touched once, so it stays in the update; (iii) texels no view has
-    reached stay exactly zero with zero moments."""
+    """Zero-initialised texture, view A then view B. (i) Every step's update over the ever-touched chunks is
+    bit-identical to the update over the whole arena (both applied to the SAME state and gradient: the Gram kernels'
+    atomics make two forward / backward passes differ in the last bits, so two free-running engines cannot be compared
+    bit for bit); (ii) a texel only view A reaches keeps moving under the regulariser (and its Adam moments) during
+    view B's steps - it was touched once, so it stays in the update; (iii) texels no view has reached stay exactly
+    zero with zero moments."""
     views = small_views((3, 4))
-    res = {}
-    for sparse in (True, False):
-        eng = make_engine(FLAGSETS["with_angle_and_depth"], None)
-        eng.planned_scatter = True     # bit-reproducible scatter: the two runs see identical gradients
-        eng.sparse_update = sparse
-        assert eng.touched is not None
-        snaps = []
-        for k, v in enumerate(views):
-            for _ in range(3):
-                eng.training_step(v)
-            snaps.append((eng.arena.p.clone(), eng.arena.m.clone(), eng.arena.v.clone(), eng.touched.clone()))
-        res[sparse] = snaps
-    for (ps, ms, vs, _), (pd, md, vd, _) in zip(res[True], res[False]):
-        assert torch.equal(ps, pd) and torch.equal(ms, md) and torch.equal(vs, vd)
-    (pA, _, _, tA), (pB, mB, vB, tB) = res[True]
+    eng = make_engine(FLAGSETS["with_angle_and_depth"], None)
+    assert eng.touched is not None
+    a = eng.arena
+    snaps = []
+    for v in views:
+        for _ in range(3):
+            eng.begin_step(v)
+            eng.forward_backward()
+            state = [t.clone() for t in (a.p, a.g, a.m, a.v, eng.sumsq)]
+            count = eng.step_count
+            eng.sparse_update = True
+            eng.optimizer_step()
+            sparse = [t.clone() for t in (a.p, a.g, a.m, a.v, eng.sumsq)]
+            for dst, src in zip((a.p, a.g, a.m, a.v, eng.sumsq), state):
+                dst.copy_(src)
+            eng.step_count = count
+            eng.sparse_update = False
+            eng.optimizer_step()
+            for got, want in zip(sparse[:4], (a.p, a.g, a.m, a.v)):
+                assert torch.equal(got, want)
+            assert_close(sparse[4], eng.sumsq, 1e-6, 0)
+        snaps.append((a.p.clone(), a.m.clone(), a.v.clone(), eng.touched.clone()))
+    (pA, _, _, tA), (pB, mB, vB, tB) = snaps
     assert int(tA.sum()) < int(tB.sum()) < tB.numel()          # B adds chunks, not everything is touched
     only_a = (pA != 0) & (tA.bool().repeat_interleave(64)[:pA.numel()])
     assert bool(only_a.any())
