@@ -132,7 +132,8 @@ def test_graph_steps_run_ahead_of_the_gpu_with_correct_bias_corrections():
         out[graphs] = (eng.arena.p.clone(), eng.arena.m.clone(), eng.step_count)
         if graphs:
             assert eng._opt_graph is not None
-            assert_close(eng._hyper_state.cpu(), [0.1, 12.0], 1e-12, 0)
+            lr_dev, step_dev = eng._hyper_state.tolist()     # the device-side {lr, step} followed both changes
+            assert abs(lr_dev - 0.1) < 1e-12 and step_dev == 12.0
     assert out[True][2] == out[False][2] == 12
     # same trajectory up to the scatter's summation-order noise amplified by Adam at lr 1 (see test_graph_replay_equals_eager)
     err = (out[True][0] - out[False][0]).abs()
@@ -171,10 +172,20 @@ def test_optimizer_state_dict_resume_round_trip():
     o2.load_state_dict(ckpt["opt"])
     s2.last_epoch = ckpt["sched_epoch"]
     assert m2._engine.touched is not None and m2._engine.step_count == 3
+    # the restored state is the saved state, bit for bit
+    assert torch.equal(m2._engine.arena.m, ckpt["opt"]["m"]) and torch.equal(m2._engine.arena.v, ckpt["opt"]["v"])
+    assert torch.equal(m2._engine.touched, ckpt["opt"]["touched"]) and o2.param_groups[0]["lr"] == ckpt["opt"]["lr"]
+    for a, b in zip(m2.texture.layers, ckpt["texture"]):
+        assert torch.equal(a.data, b)
     run(m2, o2, s2, 3, start=3)
-    for a, b in zip(m1.texture.layers, m2.texture.layers):
-        assert torch.equal(a.data, b.data)
-    assert torch.equal(m1._engine.arena.m, m2._engine.arena.m) and torch.equal(m1._engine.arena.v, m2._engine.arena.v)
+    # ... and the resumed run follows the uninterrupted one (two runs differ in the last bits of the Gram sums -
+    # atomics - which Adam at lr 1 amplifies: the tolerance of the 5-step Adam goldens)
+    from test_engine_gpu import texture_close
+    for i, (a, b) in enumerate(zip(m1.texture.layers, m2.texture.layers)):
+        texture_close(b.data, a.data.cpu(), 3, f"resumed layer {i}")
+    assert m1._engine.step_count == m2._engine.step_count == 6
+    rel = float((m1._engine.arena.m - m2._engine.arena.m).abs().max() / m1._engine.arena.m.abs().max())
+    assert rel < 2e-2, rel
 
 
 # ------------------------------------------------------------------ the engine with fp32-MFMA kernels everywhere
