@@ -157,9 +157,11 @@ typedef struct {
     const float* gate;
     int H, W;
 } sm_conv_problem;
+/* amax_out (optional, DEVICE float, caller-zeroed): the launch max-es max |output| into it (atomic max on the bit
+ * pattern of a non-negative float) - the operand scale of an sm_conv3x3_grouped_split2 that consumes the output. */
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
-                       size_t ws_floats, void* stream);
+                       size_t ws_floats, float* amax_out, void* stream);
 /* The same grouped convolution on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split into three
  * bf16 parts (x = h + m + l, 24 significand bits) and each product is evaluated as its six partial products of
  * weight >= 2^-16 with fp32 accumulation (stylemesh_amd/csrc/conv_split_kernel.h). Activations / outputs are
@@ -170,7 +172,25 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
 int sm_conv_split_tile_positions(void);
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,
                              const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
-                             float* ws, size_t ws_floats, void* stream);
+                             float* ws, size_t ws_floats, float* amax_out, void* stream);
+/* The same convolution with TWO fp16 parts per fp32 operand and THREE partial products (hh' + hl' + lh', each exact in
+ * fp32, fp32 accumulate; v_mfma_f32_32x32x16_f16): x s = h + l carries 22 significand bits, the dropped ll' is below
+ * 2^-22 of a product. fp16 has 5 exponent bits, so both operands are scaled by powers of two:
+ *   wt2 = the weights times a power of two s_w that puts max |w| into [2^14, 2^15), split by the host into
+ *         [9 taps][Cin/16][2 parts][2][Cout][8] fp16 (runtime/ops.py:pack_conv_split2); w_scale_inv = 1 / s_w;
+ *   amax_in (DEVICE float, required) = an upper bound of max |x| over the input planes of all problems, recorded by
+ *         the kernel that produced them (amax_out of that launch; a max-pool passes its input's bound through): the
+ *         kernel scales x by the power of two that maps amax_in into [2^14, 2^15) while it stages the operand;
+ *   the epilogue multiplies the accumulators by the (exact) inverse scales before bias / add / gate.
+ * Elements more than 2^18 below amax_in lose low bits of l: an absolute error <= 2^-40 amax_in per element.
+ * Same flags / tile_list / ws / amax_out semantics as above. Error against an fp64 convolution: same class as the
+ * fp32-MFMA kernel (tests/test_kernels_gpu.py). */
+int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
+                              const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
+                              float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream);
+/* max |x| over a feature map [C][plane(H,W)], max-ed into *amax_out like the convolutions' amax_out: the operand
+ * bound of sm_conv3x3_grouped_split2 for tensors no convolution produced (the deepest loss layer's gradient). */
+int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream);
 /* tile_list (optional, DEVICE array of n_list entries (problem << 24) | tile): compute only these position
  * tiles; a tile covers sm_conv_tile_positions(Cin_pad, Cout) consecutive positions q starting at row 1 of the
  * problem's plane. Positions of absent tiles are neither read nor written. NULL = every tile. The caller uses

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
+    float vmax = 0.f;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
@@ -210,10 +211,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + a.bias[co], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += P.out[o];
                 if (FLAGS & SM_EPI_RELU_MASK) v = (P.gate[o] > 0.f) ? v : 0.f;
-                P.out[o] = inside ? v : 0.f;
+                v = inside ? v : 0.f;
+                P.out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
             }
         }
     }
+    record_amax(a.amax_out, vmax);
 }
 
 // Tail second pass: one block per tail tile; out = epilogue(sum over its K-splits), 4 positions per thread.
@@ -244,31 +248,45 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
         const int e = blockIdx.y * 256 + threadIdx.x;
         const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
         const int q = q0 + c4;
-        if (q >= q_end) return;   // q_end and q are multiples of 4
-        f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
-        for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
-        const int co = m0 + row;
-        const size_t o = (size_t)co * P.plane + q;
-        f32x4 prev, gate;
-        if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(P.out + o);
-        if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(P.gate + o);
-        const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
+        float m = 0.f;            // max |output| of this thread (all lanes stay active for the wave reduction below)
+        if (q < q_end) {          // q_end and q are multiples of 4
+            f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
+            for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
+            const int co = m0 + row;
+            const size_t o = (size_t)co * P.plane + q;
+            f32x4 prev, gate;
+            if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(P.out + o);
+            if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(P.gate + o);
+            const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = v[j];
-            if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
-            if (FLAGS & SM_EPI_ADD) x += prev[j];
-            if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
-            v[j] = interior(q + j, P.H, P.W, P.Wp) ? x : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                float x = v[j];
+                if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
+                if (FLAGS & SM_EPI_ADD) x += prev[j];
+                if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
+                v[j] = interior(q + j, P.H, P.W, P.Wp) ? x : 0.f;
+                m = fmaxf(m, fabsf(v[j]));
+            }
+            *reinterpret_cast<f32x4*>(P.out + o) = v;
         }
-        *reinterpret_cast<f32x4*>(P.out + o) = v;
+        record_amax(a.amax_out, m);
     }
 }
 
-
+// max |x| over the interior rows of C planes (producers without an amax epilogue: the deepest loss layer's gradient)
+__global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict__ in, int plane, int q_begin, int q_end,
+                                                        float* amax_out) {
+    const float* p = in + (size_t)blockIdx.y * plane;
+    float m = 0.f;
+    for (int q = q_begin + (blockIdx.x * 256 + threadIdx.x) * 4; q < q_end; q += gridDim.x * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + q);     // q_begin, q_end: multiples of 4
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    record_amax(amax_out, m);
+}
 
 // SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false>
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -277,14 +295,18 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + BN - 1) / BN;
     a.n_tiles = a.tile_list ? n_list : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
-    constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN)
+    constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN, NP)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
     // Full rounds of one tile per resident block slot run whole; the tail of `rem` tiles is split along K so that
     // it becomes about one more (short) round of rem * splits small units. Pick the split count that minimises the
     // tail's duration ceil(rem * S / slots) / S, each split keeping >= 2 K-chunks. (The split kernel keeps two
     // blocks resident per CU, but they share the matrix pipes: measured, rounds of 2 x CUs tiles are slower.)
-    constexpr int SLOTS = SM_NUM_CU;
+#ifndef SM_SPLIT2_SLOTS
+#define SM_SPLIT2_SLOTS 1
+#endif
+    // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
+    constexpr int SLOTS = SM_NUM_CU * ((SPLIT && NP == 2) ? SM_SPLIT2_SLOTS : 1);
     a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;
@@ -304,7 +326,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = stamp ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true> : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false>;
+        auto k = (stamp && NP == 3) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true, 3>
+                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -328,6 +351,12 @@ template <int FLAGS>
 static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
     if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true>(a, n_list, ws_floats, s);
+}
+
+template <int FLAGS>
+static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
+    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2>(a, n_list, ws_floats, s);
 }
 
 template <int FLAGS>
@@ -497,7 +526,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 2; }
+int sm_abi_version(void) { return 3; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
@@ -506,6 +535,17 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
         case SM_EPI_RELU_MASK: return sm::dispatch_conv_split<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
         case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
         case SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_ADD>(a, n_list, ws_floats, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
+static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
+    switch (flags) {
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
+        case 0: return sm::dispatch_conv_split2<0>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
+        case SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_ADD>(a, n_list, ws_floats, s);
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -521,12 +561,21 @@ static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws
     }
 }
 
+int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream) {
+    if (C < 1 || amax_out == nullptr) return (int)hipErrorInvalidValue;
+    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W), n = H * Wp;
+    hipLaunchKernelGGL(sm::fmap_amax_kernel, dim3(std::min(8, (n / 4 + 255) / 256), C), dim3(256), 0, (hipStream_t)stream,
+                       planes, plane, Wp, (H + 1) * Wp, amax_out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
 int sm_conv_tile_positions(int Cin_pad, int Cout) { return (Cin_pad == 4 || Cout % 128 != 0) ? 256 : 128; }
 int sm_conv_split_tile_positions(void) { return 128; }
 
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
-                       size_t ws_floats, void* stream) {
+                       size_t ws_floats, float* amax_out, void* stream) {
     if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
     if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
@@ -541,12 +590,36 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
     a.ws = ws;
     a.splits = 1;
     a.tile_list = tile_list;
+    a.amax_out = amax_out;
     return conv_dispatch_flags(a, n_list, flags, ws_floats, (hipStream_t)stream);
+}
+
+int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
+                              const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
+                              float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream) {
+    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
+    if (Cout % 64 != 0 || Cin % 16 != 0 || amax_in == nullptr || !(w_scale_inv > 0.f)) return (int)hipErrorInvalidValue;
+    sm::ConvArgs a{};
+    for (int g = 0; g < n_problems; ++g)
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
+                                 sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    a.n_problems = n_problems;
+    a.wt = reinterpret_cast<const float*>(wt2);
+    a.bias = bias;
+    a.Cin_pad = Cin;
+    a.Cout = Cout;
+    a.ws = ws;
+    a.splits = 1;
+    a.tile_list = tile_list;
+    a.amax_in = amax_in;
+    a.amax_out = amax_out;
+    a.w_scale_inv = w_scale_inv;
+    return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, (hipStream_t)stream);
 }
 
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3, const float* bias,
                              int Cin, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
-                             size_t ws_floats, void* stream) {
+                             size_t ws_floats, float* amax_out, void* stream) {
     if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
     if (Cout % 64 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
@@ -561,13 +634,14 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
     a.ws = ws;
     a.splits = 1;
     a.tile_list = tile_list;
+    a.amax_out = amax_out;
     return conv_dispatch_flags_split(a, n_list, flags, ws_floats, (hipStream_t)stream);
 }
 
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,
                int Cout, int H, int W, int flags, float* ws, size_t ws_floats, void* stream) {
     sm_conv_problem p{in, out, gate, H, W};
-    return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, nullptr, 0, ws, ws_floats, stream);
+    return sm_conv3x3_grouped(&p, 1, wt, bias, Cin_pad, Cout, flags, nullptr, 0, ws, ws_floats, nullptr, stream);
 }
 
 static int make_plane_group(sm::PlaneGroup& g, const sm_plane_problem* p, int n, int kind, const int32_t* tile_list = nullptr) {

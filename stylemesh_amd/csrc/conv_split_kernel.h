@@ -58,14 +58,52 @@
 
 namespace sm {
 
-constexpr size_t conv_split_lds_bytes(int BM, int BN) { return (size_t)(24 * (BN + 2)) * 16; }
+// NP = number of parts an fp32 operand is split into:
+//   NP = 3  bf16 x 3 (above): 6 partial products per fp32 product, no scaling needed (bf16 has the fp32 exponent range);
+//   NP = 2  fp16 x 2: x s = h + l with h = fp16(x s), l = fp16(x s - h): 2 x 11 = 22 significand bits, products
+//           hh' + hl' + lh' (each exact in fp32; the dropped ll' is < 2^-22 of the product) - THREE MFMAs
+//           (v_mfma_f32_32x32x16_f16, same rate as bf16) per fp32 product instead of six. fp16 has 5 exponent bits, so
+//           every operand tensor is scaled by a power of two s that puts its largest magnitude into [2^14, 2^15): the
+//           producer of an activation / gradient tensor records max |x| (ConvArgs::amax_out, one atomic max per wave),
+//           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
+//           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
+//           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
+constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) { return (size_t)(4 * 2 * NP * (BN + 2)) * 16; }
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Live operands are scaled below 2^15. Positions of tiles the active-tile lists skip hold STALE values of earlier
+// views, which the halo of a live tile reads (their products only reach outputs nobody uses): clamped, so that a stale
+// value above the current maximum cannot become an fp16 infinity (and inf - inf a NaN) in a plane that masked sums
+// later multiply by zero.
+#define SM_F16_CLAMP 65000.f
+
+// power-of-two scale that maps a tensor whose largest magnitude is amax into [2^14, 2^15) (1 for amax == 0 / denormal
+// / non-finite), and its inverse
+__device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    const int ex = (int)((bits >> 23) & 0xff);          // amax in [2^(ex-127), 2^(ex-126))
+    if (ex < 16 || ex > 250) { inv = 1.f; return 1.f; }
+    inv = __builtin_bit_cast(float, (unsigned)(ex - 14) << 23);      // 2^(ex - 141)
+    return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);    // 2^(141 - ex)
+}
 
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 // the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false>
+#ifndef SM_SPLIT_BSETS
+#define SM_SPLIT_BSETS 1
+#endif
+#ifndef SM_SPLIT2_AD
+#define SM_SPLIT2_AD 3
+#endif
+#ifndef SM_SPLIT2_WAVES
+#define SM_SPLIT2_WAVES 2      // resident waves per SIMD of the 128-row fp16x2 variant
+#endif
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES, BM == 64 ? SM_SPLIT_WAVES64 : SM_SPLIT_WAVES)))
+__attribute__((amdgpu_waves_per_eu(BM == 64 ? SM_SPLIT_WAVES64 : (NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES),
+                                   BM == 64 ? SM_SPLIT_WAVES64 : (NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES))))
 void conv3x3_split_kernel(ConvArgs a) {
+    static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
@@ -74,7 +112,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     static_assert(BN == 128, "activation staging: one (k-group, position) unit per thread + a 2 x 2 x 8 halo");
     constexpr int KC = 16;
     constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
-    constexpr int SLICE = 6 * BNP;        // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
+    constexpr int SLICE = 2 * NP * BNP;   // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     f32x4* Bs = smem4;                    // [4 slots][SLICE]
 
@@ -139,10 +177,17 @@ void conv3x3_split_kernel(ConvArgs a) {
     // (buffer loads: scalar base in an SGPR resource + one 32-bit lane offset + a scalar stage offset - no 64-bit
     // address arithmetic per load)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.wt), 0, 9 * (a.Cin_pad / KC) * 6 * a.Cout * 16, 0x00020000);
+        const_cast<float*>(a.wt), 0, 9 * (a.Cin_pad / KC) * 2 * NP * a.Cout * 16, 0x00020000);
     const int a_voff = (lhi * a.Cout + m0 + wm + l31) * 16;   // bytes
     const int a_part = 2 * a.Cout * 16;            // bytes between the parts of a stage
-    const int a_stage_bytes = 6 * a.Cout * 16;     // bytes per (tap, chunk) stage
+    const int a_stage_bytes = 2 * NP * a.Cout * 16;   // bytes per (tap, chunk) stage
+    // NP = 2: operand scale from the producer's recorded max |x| (block-uniform scalar loads)
+    float in_scale = 1.f, out_scale = 1.f;
+    if (NP == 2) {
+        float inv;
+        in_scale = pow2_scale_for(a.amax_in ? *a.amax_in : 1.f, inv);
+        out_scale = inv * a.w_scale_inv;
+    }
     // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
     // k-group at stride `plane`; the 2 remaining halo positions x 2 k-groups x 8 channels = 32 single elements are
     // fetched one per lane (every half-wave does the same 32: identical values to identical addresses)
@@ -155,32 +200,37 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int h_kg = l31 >> 4, h_px = 128 + ((l31 >> 3) & 1), h_c = l31 & 7;
     const int h_src = ((h_kg * 8 + h_c) * P.plane + q0 + h_px) * 4;   // bytes, same base
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
-    constexpr int AD = SM_SPLIT_AD;   // weight prefetch distance in stages = ring size; slot of a stage = tap % AD
+    // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
+    // the MFMA time to hide the same fetch latency behind: its ring is deeper
+    constexpr int AD = NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
-    f32x4 ra[AD][MI][3];
-    float rb[8], rh;
+    f32x4 ra[AD][MI][NP];
+    // in-flight activation loads: SM_SPLIT_BSETS = 1: one register set, a slice is loaded two stages before it is
+    // converted and stored; 3: one set per ky slice, re-loaded right after its store - a slice's loads then have a
+    // whole chunk (nine stages) to arrive
+    float rbs[SM_SPLIT_BSETS][8], rhs[SM_SPLIT_BSETS];
 
 #define SM_LOAD_A(tap_, chunk_)                                                                          \
     {                                                                                                    \
         const int so_ = ((tap_) * n_chunks + (chunk_)) * a_stage_bytes;                                  \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                   \
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
                 ra[(tap_) % AD][i][s] = __builtin_bit_cast(                                              \
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_voff, so_ + s * a_part + i * 512, 0)); \
     }
-#define SM_LOAD_B(ky_, chunk_)                                                                           \
+#define SM_LOAD_B(set_, ky_, chunk_)                                                                     \
     {                                                                                                    \
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
         _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                    \
-            rb[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4, 0)); \
-        rh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0));    \
+            rbs[set_][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4, 0)); \
+        rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0)); \
     }
-#define SM_STORE_B(slot_)                                                                                \
-    {                                                                                                    \
+#define SM_STORE_B(set_, slot_)                                                                          \
+    if constexpr (NP == 3) {                                                                             \
         bf16x8 vh, vm, vl;                                                                               \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                  \
             __bf16 h, m, l;                                                                              \
-            split3(rb[c], h, m, l);                                                                      \
+            split3(rbs[set_][c], h, m, l);                                                               \
             vh[c] = h; vm[c] = m; vl[c] = l;                                                             \
         }                                                                                                \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
@@ -188,18 +238,33 @@ void conv3x3_split_kernel(ConvArgs a) {
         d_[b_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                                             \
         d_[b_dst + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                                             \
         __bf16 h, m, l;                                                                                  \
-        split3(rh, h, m, l);                                                                             \
+        split3(rhs[set_], h, m, l);                                                                      \
         __bf16* e_ = reinterpret_cast<__bf16*>(d_);                                                      \
         e_[h_dst] = h;                                                                                   \
         e_[h_dst + 2 * BNP * 8] = m;                                                                     \
         e_[h_dst + 4 * BNP * 8] = l;                                                                     \
+    } else {                                                                                             \
+        f16x8 vh, vl;                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                  \
+            const float xs_ = __builtin_amdgcn_fmed3f(rbs[set_][c] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP); \
+            const _Float16 h_ = (_Float16)xs_;                                                           \
+            vh[c] = h_; vl[c] = (_Float16)(xs_ - (float)h_);                                             \
+        }                                                                                                \
+        f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
+        d_[b_dst] = __builtin_bit_cast(f32x4, vh);                                                       \
+        d_[b_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                             \
+        const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
+        const _Float16 h_ = (_Float16)xs_;                                                               \
+        _Float16* e_ = reinterpret_cast<_Float16*>(d_);                                                  \
+        e_[h_dst] = h_;                                                                                  \
+        e_[h_dst + 2 * BNP * 8] = (_Float16)(xs_ - (float)h_);                                           \
     }
 #define SM_READ_B(dst_, slot_, kx_)                                                                      \
     {                                                                                                    \
         const f32x4* bf_ = b_frag + (slot_) * SLICE + (kx_);                                             \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                   \
             _Pragma("unroll") for (int i = 0; i < NJ; ++i)                                               \
-                dst_[i][s] = __builtin_bit_cast(bf16x8, bf_[s * 2 * BNP + i * 32]);                      \
+                dst_[i][s] = bf_[s * 2 * BNP + i * 32];                                                  \
     }
 
     SM_TS(0)
@@ -210,28 +275,33 @@ void conv3x3_split_kernel(ConvArgs a) {
         float rb3[3][8], rh3[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            SM_LOAD_B(ky, ch_begin);
+            SM_LOAD_B(0, ky, ch_begin);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb3[ky][c] = rb[c];
-            rh3[ky] = rh;
+            for (int c = 0; c < 8; ++c) rb3[ky][c] = rbs[0][c];
+            rh3[ky] = rhs[0];
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb[c] = rb3[ky][c];
-            rh = rh3[ky];
-            SM_STORE_B(ky);
+            for (int c = 0; c < 8; ++c) rbs[0][c] = rb3[ky][c];
+            rhs[0] = rh3[ky];
+            SM_STORE_B(0, ky);
         }
     }
     {
         const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
-        SM_LOAD_B(0, ch1);      // stored at the end of tap 1 of the first chunk
+        if constexpr (SM_SPLIT_BSETS == 1) {
+            SM_LOAD_B(0, 0, ch1);      // stored at the end of tap 1 of the first chunk
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) SM_LOAD_B(ky, ky, ch1);   // stored at the end of taps 1, 4, 7 of the first chunk
+        }
     }
     __syncthreads();
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
     const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
-    bf16x8 fb[NJ][3], fb_next[NJ][3];
+    f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 bf16 / fp16)
 #if SM_SPLIT_PREFETCH_B
     SM_READ_B(fb, 0, 0)
 #endif
@@ -260,25 +330,37 @@ void conv3x3_split_kernel(ConvArgs a) {
             // end of the stage (shorter live ranges) and the next stage's first MFMAs wait out the LDS round trip
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            bf16x8 fa[MI][3];
+            f32x4 fa[MI][NP];
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NP; ++s)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) fa[i][s] = __builtin_bit_cast(bf16x8, ra[tap % AD][i][s]);
-            // six partial products per output tile, smallest first; consecutive MFMAs target different accumulators
+                for (int i = 0; i < MI; ++i) fa[i][s] = ra[tap % AD][i][s];
+            // the partial products per output tile, smallest first; consecutive MFMAs target different accumulators
 #define SM_PRODUCT(pa_, pb_)                                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                   \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa_], fb[j][pb_], acc[i][j], 0, 0, 0);
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                 \
+            if constexpr (NP == 3)                                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][pa_]), \
+                                                                    __builtin_bit_cast(bf16x8, fb[j][pb_]), acc[i][j], 0, 0, 0); \
+            else                                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][pa_]), \
+                                                                   __builtin_bit_cast(f16x8, fb[j][pb_]), acc[i][j], 0, 0, 0); \
+        }
 #if SM_SPLIT_MFMA_PRIO
             __builtin_amdgcn_s_setprio(SM_SPLIT_MFMA_PRIO);
 #endif
-            SM_PRODUCT(2, 0)
-            SM_PRODUCT(0, 2)
-            SM_PRODUCT(1, 1)
-            SM_PRODUCT(1, 0)
-            SM_PRODUCT(0, 1)
-            SM_PRODUCT(0, 0)
+            if constexpr (NP == 3) {
+                SM_PRODUCT(2, 0)
+                SM_PRODUCT(0, 2)
+                SM_PRODUCT(1, 1)
+                SM_PRODUCT(1, 0)
+                SM_PRODUCT(0, 1)
+                SM_PRODUCT(0, 0)
+            } else {
+                SM_PRODUCT(1, 0)
+                SM_PRODUCT(0, 1)
+                SM_PRODUCT(0, 0)
+            }
 #undef SM_PRODUCT
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
@@ -298,21 +380,29 @@ void conv3x3_split_kernel(ConvArgs a) {
             // tap 3 ky - 1. The slice is loaded at the end of tap 3 ky - 1 (for ky = 0: tap 8 of the previous chunk),
             // converted and written at the end of tap 3 ky + 1 - a stage WITHOUT a barrier, so that the conversion does
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
-            if (kx == 1) SM_STORE_B((base + 3 + ky) & 3);
-            if (kx == 2) {
-                if (ky < 2) {
-                    SM_LOAD_B(ky + 1, ch_next);
-                } else {
-                    SM_LOAD_B(0, ch_next2);
+            if constexpr (SM_SPLIT_BSETS == 1) {
+                if (kx == 1) SM_STORE_B(0, (base + 3 + ky) & 3);
+                if (kx == 2) {
+                    if (ky < 2) {
+                        SM_LOAD_B(0, ky + 1, ch_next);
+                    } else {
+                        SM_LOAD_B(0, 0, ch_next2);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
+            } else {
+                if (kx == 1) {   // slice ky of the next chunk out of its register set, the chunk after that into it
+                    SM_STORE_B(ky, (base + 3 + ky) & 3);
+                    SM_LOAD_B(ky, ky, ch_next2);
+                }
+                if (kx == 2) __syncthreads();
             }
 #if SM_SPLIT_TAIL_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
 #if SM_SPLIT_PREFETCH_B
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < NP; ++s)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) fb[i][s] = fb_next[i][s];
 #endif
@@ -336,7 +426,8 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] = acc[mi][nj][r];
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] =
+                        NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r];   // power of two: exact
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
@@ -350,6 +441,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int g = 0; g < 4; ++g)
                 bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
     }
+    float vmax = 0.f;   // max |output| of this lane: the operand scale of the conv that consumes this tensor (NP = 2)
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
@@ -370,13 +462,17 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
                 float v = acc[mi][nj][r];
+                if (NP == 2) v *= out_scale;
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += prev[r];
                 if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
-                P.out[o] = inside ? v : 0.f;
+                v = inside ? v : 0.f;
+                P.out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
             }
         }
     }
+    record_amax(a.amax_out, vmax);
     SM_TS(31)
 #undef SM_TS
 }

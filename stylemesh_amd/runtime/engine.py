@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .fmap import FMap
-from .vgg import PRE_POOL, LevelBuffers, VGGNet, depth_of, layer_hw
+from .vgg import PRE_POOL, AmaxBook, LevelBuffers, VGGNet, depth_of, layer_hw
 
 DEFAULT_STYLE_LAYERS = ['r11', 'r21', 'r31', 'r41', 'r51']        # content_and_style_losses.py:222
 DEFAULT_CONTENT_LAYERS = ['r42']                                  # :223
@@ -132,7 +132,11 @@ class StepEngine:
         self.step_count = 0
         self.epoch = 0
         # device scalars: [content, style] weighted loss accumulators, per-layer sum of squares of the texture
-        self.loss_buf = torch.zeros(2, device=device)
+        # ... and, behind them in the same buffer (one fill zeroes all of it every step), the per-layer max |x| bounds
+        # of the step's activations / gradients over all UV levels (operand scales of the fp16x2 conv kernels)
+        self._step_scalars = torch.zeros(2 + AmaxBook.N, device=device)
+        self.loss_buf = self._step_scalars[0:2]
+        self.amax = AmaxBook(device, self._step_scalars[2:])
         self.sumsq = torch.zeros(n_layers, device=device)
         self._pbuf = {}            # persistent per-view buffers (fixed addresses)
         self._graphs = {}          # view signature -> captured hipGraph of forward_backward
@@ -242,7 +246,7 @@ class StepEngine:
     def _zero_step_accumulators(self):
         """Everything a step accumulates into: the loss pair and - one fill over the arena - the Gram slabs of every
         (level, layer) the previous step added into (instead of two fills per masked-Gram call)."""
-        self.loss_buf.zero_()
+        self._step_scalars.zero_()
         if self._gram_arena is not None and len(self._gram_clean) != len(self._gram):
             self._gram_arena.zero_()
             self._gram_clean = set(self._gram)
@@ -478,15 +482,16 @@ class StepEngine:
             def join(layer):
                 for e2 in done.pop(layer, []):
                     main.wait_event(e2)
-            self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork)
+            self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork, amax=self.amax)
             injected = set(side_layers)
             for lv, b in zip(active, bufs):
                 injected |= self._inject_losses(lv, b, w_style, w_content, only_layers={self.deepest} | set(cfg.content_layers))
-            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, before_layer=join)
+            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, before_layer=join,
+                                    amax=self.amax)
             for layer in list(done):
                 join(layer)
         else:
-            self.vgg.forward_group(bufs, self.view_tiles)
+            self.vgg.forward_group(bufs, self.view_tiles, amax=self.amax)
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
@@ -513,7 +518,7 @@ class StepEngine:
             else:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
-            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles)
+            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax)
         if not accumulate_grad:
             return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:

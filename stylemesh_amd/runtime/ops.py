@@ -87,8 +87,24 @@ def pack_conv_split(wt: torch.Tensor) -> torch.Tensor:
     return torch.stack([h, m, l], dim=2).contiguous().view(torch.int16)      # [9][chunk][3][2][cout][8]
 
 
+def pack_conv_split2(wt: torch.Tensor):
+    """fp32 tap-major pack [9][Cin][Cout] -> (wt2, w_scale_inv) of sm_conv3x3_grouped_split2: the weights times the
+    power of two s_w that puts max |w| into [2^14, 2^15), as [9][Cin/16][2 parts][2 k-groups][Cout][8 ci] fp16 bit
+    patterns (int16) with w s_w = part0 + part1 to 22 significand bits (round-to-nearest); w_scale_inv = 1 / s_w."""
+    import math
+    taps, cin, cout = wt.shape
+    assert taps == 9 and split_eligible(cin, cout)
+    amax = float(wt.abs().max())
+    k = 14 - math.floor(math.log2(amax)) if amax > 0 else 0
+    w = (wt * (2.0 ** k)).view(9, cin // 16, 2, 8, cout).permute(0, 1, 2, 4, 3)     # [9][chunk][kgroup][cout][8]
+    h = w.half()
+    l = (w - h.float()).half()
+    return torch.stack([h, l], dim=2).contiguous().view(torch.int16), 2.0 ** -k    # [9][chunk][2][2][cout][8]
+
+
 # 'f32' = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains); 'split' = bf16x3-split MFMA (6 partial
-# products, fp32 accumulate, same accuracy class) wherever a layer's shape allows and its split pack is given.
+# products, fp32 accumulate, same accuracy class) wherever a layer's shape allows and its split pack is given;
+# 'split2' = fp16x2-split MFMA (3 partial products, operands scaled by powers of two from recorded maxima).
 CONV_MODE = os.environ.get("STYLEMESH_CONV_MODE", "split")
 
 
@@ -235,11 +251,12 @@ def splitk_workspace(device) -> torch.Tensor:
     return _SPLITK_WS[key]
 
 
-def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None, wt3=None):
+def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None, wt3=None, wt2=None,
+            amax_in=None, amax_out=None):
     cin_pad, cout = wt.shape[1], wt.shape[2]
     assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
-    if wt3 is not None and CONV_MODE == "split":
-        return conv3x3_grouped([(inp, out, gate)], wt, bias, flags, None, 1.0, wt3)
+    if (wt3 is not None and CONV_MODE == "split") or (wt2 is not None and CONV_MODE == "split2") or amax_out is not None:
+        return conv3x3_grouped([(inp, out, gate)], wt, bias, flags, None, 1.0, wt3, wt2, amax_in, amax_out)
 
     def run():
         ws = splitk_workspace(wt.device)
@@ -252,17 +269,26 @@ def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap
         CONV_TIMER.launch(run, 2.0 * 9 * cin_true * cout * inp.H * inp.W)
 
 
+def fmap_amax(f: FMap, amax_out: torch.Tensor):
+    """max |x| of ``f`` max-ed into the (caller-zeroed) device float ``amax_out``."""
+    hip.check(lib.sm_fmap_amax(f.ptr, f.C, f.H, f.W, ptr(amax_out), hip.stream()), "sm_fmap_amax")
+
+
 def conv_tile_positions(cin_pad: int, cout: int) -> int:
     """Positions per tile of the kernel that ``conv3x3_grouped`` will pick for this layer shape (``CONV_MODE``)."""
-    if CONV_MODE == "split" and split_eligible(cin_pad, cout):
+    if CONV_MODE in ("split", "split2") and split_eligible(cin_pad, cout):
         return lib.sm_conv_split_tile_positions()
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 
-def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None):
+def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
+                    wt2=None, amax_in=None, amax_out=None):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps).
     ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
-    ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``."""
+    ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
+    ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
+    ``amax_in`` (device float: upper bound of max |input|). ``amax_out`` (device float, caller-zeroed, any mode):
+    receives max |output| of the launch."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
     if tile_list is not None and tile_list.numel() == 0:
         return
@@ -277,19 +303,26 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         streams = cin_true + cout + (cout if flags & hip.EPI_RELU_MASK else 0) + (cout if flags & hip.EPI_ADD else 0)
         nbytes += 4.0 * streams * inp.H * inp.W
 
+    use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
     use_split = wt3 is not None and CONV_MODE == "split"
 
     def run():
         ws = splitk_workspace(wt.device)
+        n_list = 0 if tile_list is None else tile_list.numel()
+        if use_split2:
+            hip.check(lib.sm_conv3x3_grouped_split2(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
+                                                    flags, ptr(tile_list), n_list, ptr(ws), ws.numel(), ptr(amax_in),
+                                                    ptr(amax_out), hip.stream()), "sm_conv3x3_grouped_split2")
+            return
         fn, w = (lib.sm_conv3x3_grouped_split, wt3) if use_split else (lib.sm_conv3x3_grouped, wt)
-        hip.check(fn(arr, len(problems), ptr(w), ptr(bias), cin_pad, cout, flags, ptr(tile_list),
-                     0 if tile_list is None else tile_list.numel(), ptr(ws), ws.numel(), hip.stream()),
-                  "sm_conv3x3_grouped")
+        hip.check(fn(arr, len(problems), ptr(w), ptr(bias), cin_pad, cout, flags, ptr(tile_list), n_list, ptr(ws),
+                     ws.numel(), ptr(amax_out), hip.stream()), "sm_conv3x3_grouped")
     if CONV_TIMER is None:
         run()
     else:   # algorithmic FLOPs of the tiles actually required
-        wbytes = wt3.numel() * 2 if use_split else wt.numel() * 4
-        CONV_TIMER.launch(run, flops * active_fraction, "split" if use_split else "f32", nbytes * active_fraction + wbytes,
+        tag = "split2" if use_split2 else ("split" if use_split else "f32")
+        wbytes = wt2[0].numel() * 2 if use_split2 else (wt3.numel() * 2 if use_split else wt.numel() * 4)
+        CONV_TIMER.launch(run, flops * active_fraction, tag, nbytes * active_fraction + wbytes,
                           f"{cin_pad:3d}->{cout:3d} flags {flags} levels {len(problems)} active {active_fraction:.2f}")
 
 

@@ -44,6 +44,45 @@ def layer_hw(layer: str, H: int, W: int):
     raise ValueError(layer)
 
 
+POOL_INPUT = {out: src for kind, src, out, _, _ in NODES if kind == "pool"}     # p1 -> r12, ...
+POOL_OUTPUT = {src: out for kind, src, out, _, _ in NODES if kind == "pool"}    # r12 -> p1, ...
+
+
+class AmaxBook:
+    """One device float per VGG tensor: an upper bound of max |x| of the activation ('a:<layer>') or gradient
+    ('g:<layer>') planes, recorded by the kernel that writes them (``amax_out``) and read by the fp16x2-split conv that
+    consumes them as its operand scale (``amax_in``; ``ops.CONV_MODE == 'split2'``). Max-pooling passes bounds through:
+    a pooled activation is bounded by the pool's input, a pool-backward gradient by the pooled gradient. Zeroed once per
+    pass (``zero()``), before the first kernel that records into it."""
+
+    N = 2 * len(OUT_NAMES)
+
+    def __init__(self, device, storage=None):
+        names = ["a:" + n for n in OUT_NAMES] + ["g:" + n for n in OUT_NAMES]
+        self.idx = {n: i for i, n in enumerate(names)}
+        self.buf = torch.zeros(len(names), dtype=torch.float32, device=device) if storage is None else storage
+        assert self.buf.numel() == len(names)
+
+    def __getitem__(self, name):
+        i = self.idx[name]
+        return self.buf[i:i + 1]
+
+    def act_bound(self, layer):
+        """bound of the activation planes named ``layer`` (a conv output or a pool output)"""
+        return self["a:" + POOL_INPUT.get(layer, layer)]
+
+    def grad_bound(self, layer):
+        """bound of the gradient planes of ``layer`` (written by a dgrad conv / the loss kernels, or by a pool backward)"""
+        return self["g:" + POOL_OUTPUT.get(layer, layer)]
+
+    def zero(self):
+        self.buf.zero_()
+
+
+def _amax_on():
+    return ops.CONV_MODE == "split2"
+
+
 class LevelBuffers:
     """All activation (and, if ``with_grad``, gradient) feature maps of one VGG pass at one input size.
     Dedicated per size so that the zero borders written at allocation stay valid forever."""
@@ -61,6 +100,7 @@ class LevelBuffers:
             self.act[out] = FMap(cout, h, w, device)
             if with_grad:
                 self.grad[out] = FMap(cout, h, w, device)
+        self.amax = AmaxBook(device)   # bounds of this buffer set's tensors (single-level passes)
 
     def nbytes(self):
         return sum(f.buf.numel() * 4 for f in list(self.act.values()) + list(self.grad.values()))
@@ -71,32 +111,43 @@ class VGGNet:
         self.device = device
         self.wf, self.wd, self.bias = {}, {}, {}
         self.wf3, self.wd3 = {}, {}     # bf16x3-split packs of the layers whose shape the split kernel takes
+        self.wf2, self.wd2 = {}, {}     # fp16x2-split packs (pack, 1 / weight scale) of the same layers
         for kind, _, _, _, _ in NODES:
             if kind == "pool":
                 continue
             w = state_dict[kind + ".weight"].detach().to(device=device, dtype=torch.float32)
             self.wf[kind] = ops.pack_conv_fwd(w)
             self.wd[kind] = ops.pack_conv_dgrad(w)
-            for packs, splits in ((self.wf, self.wf3), (self.wd, self.wd3)):
+            for packs, splits, splits2 in ((self.wf, self.wf3, self.wf2), (self.wd, self.wd3, self.wd2)):
                 p = packs[kind]
-                splits[kind] = ops.pack_conv_split(p) if ops.split_eligible(p.shape[1], p.shape[2]) else None
+                ok = ops.split_eligible(p.shape[1], p.shape[2])
+                splits[kind] = ops.pack_conv_split(p) if ok else None
+                splits2[kind] = ops.pack_conv_split2(p) if ok else None
             self.bias[kind] = state_dict[kind + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
 
     def forward(self, b: LevelBuffers):
         """conv + bias + ReLU / max-pool chain from ``b.act['img']`` through the last layer of ``b``."""
+        am = b.amax if _amax_on() else None
+        if am is not None:
+            am.zero()
         for kind, src, out, _, _ in NODES[:b.last + 1]:
             if kind == "pool":
                 ops.maxpool_fwd(b.act[src], b.act[out])
             else:
                 ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU,
-                            wt3=self.wf3[kind])
+                            wt3=self.wf3[kind], wt2=self.wf2[kind],
+                            amax_in=None if am is None or src == "img" else am.act_bound(src),
+                            amax_out=None if am is None else am["a:" + out])
 
-    def forward_group(self, bufs, tiles=None, on_layer=None):
+    def forward_group(self, bufs, tiles=None, on_layer=None, amax: AmaxBook | None = None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
         weights), which fills the chip where a single small level cannot. ``tiles``: optional active-tile
-        lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed)."""
+        lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed).
+        ``amax``: the group's bounds (one per layer over all levels; zeroed by the caller), fp16x2 mode only."""
         last = bufs[0].last
         assert all(b.last == last for b in bufs)
+        am = amax if _amax_on() else None
+        assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
         for kind, src, out, _, _ in NODES[:last + 1]:
             if kind == "pool":
                 ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
@@ -104,12 +155,21 @@ class VGGNet:
             else:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
-                                    hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind])
+                                    hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind], self.wf2[kind],
+                                    None if am is None or src == "img" else am.act_bound(src),
+                                    None if am is None else am["a:" + out])
                 if on_layer is not None:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
-    def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None):
-        """``backward`` for several levels at once (same injected layers on every level)."""
+    def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None,
+                       amax: AmaxBook | None = None):
+        """``backward`` for several levels at once (same injected layers on every level). ``amax``: as in
+        ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here."""
+        am = amax if _amax_on() else None
+        assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
+        if am is not None:
+            for b in bufs:
+                ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if before_layer is not None and kind != "pool":
                 before_layer(src)      # the injected gradient of ``src`` is about to be consumed
@@ -124,12 +184,14 @@ class VGGNet:
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
-                                    self.wd3[kind])
+                                    self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
+                                    None if am is None else am["g:" + src])
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
                 ops.conv3x3_grouped([(b.grad[out], b.grad[src], b.act[src]) for b in bufs], self.wd[kind], None, flags,
-                                    tl, frac, self.wd3[kind])
+                                    tl, frac, self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
+                                    None if am is None else am["g:" + src])
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
         """Back-propagate to ``b.grad['img']``.
@@ -138,6 +200,11 @@ class VGGNet:
         and for every other layer in ``injected`` the buffer holds the loss gradient w.r.t. its activation;
         it is added to the gradient arriving from above and gated by the layer's ReLU in the data-gradient
         kernel's epilogue."""
+        am = b.amax if _amax_on() else None
+        if am is not None:   # gradient bounds of this pass (the activation bounds of the forward pass stay)
+            n = len(OUT_NAMES)
+            am.buf[n:].zero_()
+            ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if kind == "pool":
                 if src in injected:
@@ -146,7 +213,11 @@ class VGGNet:
             elif src == "img":
                 ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
             elif src.startswith("p"):
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0, wt3=self.wd3[kind])
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0, wt3=self.wd3[kind], wt2=self.wd2[kind],
+                            amax_in=None if am is None else am.grad_bound(out),
+                            amax_out=None if am is None else am["g:" + src])
             else:
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src], wt3=self.wd3[kind])
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src], wt3=self.wd3[kind],
+                            wt2=self.wd2[kind], amax_in=None if am is None else am.grad_bound(out),
+                            amax_out=None if am is None else am["g:" + src])

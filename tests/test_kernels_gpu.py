@@ -194,6 +194,83 @@ def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypa
     assert errs["split"] <= 2.0 * errs["f32"] + 1e-9, errs
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77),
+                                          (64, 64, 17, 21), (128, 64, 33, 47), (128, 128, 120, 300), (256, 512, 54, 72)])
+@pytest.mark.parametrize("in_scale", [1.0, 3e-7, 4e4])
+def test_conv3x3_split2_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, in_scale, monkeypatch):
+    """fp16x2-split conv (3 partial products of fp16 pairs on the matrix cores, power-of-two operand scales from the
+    recorded max |x|) against an fp64 convolution: error class of the fp32-MFMA kernel (<= 2x its rms error, inside the
+    fp32 tolerance) for inputs of very different magnitude (gradients ~1e-7, activations ~1e4); the max |output| the
+    launch records is the true maximum (whole tiles and K-split tail units)."""
+    torch.manual_seed(cin + cout + W)
+    x = F.relu(torch.randn(1, cin, H, W) * 3) * in_scale
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout) * 0.3 * in_scale
+    ref = F.relu(F.conv2d(x.double(), wgt.double(), b.double(), padding=1))[0]
+    xin = rt.FMap(cin, H, W).from_dense(x[0])
+    w = dev(rt.ops.pack_conv_fwd(wgt))
+    w3, w2 = rt.ops.pack_conv_split(w), rt.ops.pack_conv_split2(w)
+    errs = {}
+    for mode in ("f32", "split2"):
+        monkeypatch.setattr(rt.ops, "CONV_MODE", mode)
+        out = rt.FMap(cout, H, W)
+        out.planes.fill_(7.0)
+        out.planes[:, :out.Wp] = 0
+        out.planes[:, (H + 1) * out.Wp:] = 0
+        amax_in = dev(x.abs().max().reshape(1))
+        amax_out = torch.zeros(1).cuda()
+        rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=amax_in, amax_out=amax_out)
+        assert out.border_is_zero()
+        got = out.to_dense()
+        assert float(amax_out) == float(got.abs().max()), mode
+        d = got.double().cpu() - ref
+        errs[mode] = float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+        assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max()), mode
+    assert errs["split2"] <= 2.0 * errs["f32"] + 1e-9, errs
+    # a loose upper bound of the input maximum (a max-pool hands its input's bound through) gives the same class
+    monkeypatch.setattr(rt.ops, "CONV_MODE", "split2")
+    out = rt.FMap(cout, H, W)
+    rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=dev(x.abs().max().reshape(1) * 7.3),
+                   amax_out=torch.zeros(1).cuda())
+    d = out.to_dense().double().cpu() - ref
+    assert float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()) <= 2.0 * errs["f32"] + 1e-9
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 13, 131), (256, 512, 6, 9), (64, 64, 17, 21), (64, 128, 20, 28)])
+def test_conv3x3_split2_dgrad_with_gate_and_add(rt, cin, cout, H, W, monkeypatch):
+    monkeypatch.setattr(rt.ops, "CONV_MODE", "split2")
+    torch.manual_seed(cin * 3 + W)
+    x = F.relu(torch.randn(1, cin, H, W)).requires_grad_(True)
+    wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
+    dy = torch.randn(1, cout, H, W) * 1e-5
+    addend = torch.randn(cin, H, W) * 1e-5
+    F.conv2d(x, wgt, None, padding=1).backward(dy)
+    gate = (x.detach()[0] > 0).float()
+    wd = dev(rt.ops.pack_conv_dgrad(wgt))
+    wd2 = rt.ops.pack_conv_split2(wd)
+    dyf = rt.FMap(cout, H, W).from_dense(dy[0])
+    act = rt.FMap(cin, H, W).from_dense(x.detach()[0])
+    scale = float(x.grad.abs().max())
+    kw = dict(wt2=wd2, amax_in=dev(dy.abs().max().reshape(1)))
+    out = rt.FMap(cin, H, W)
+    rt.ops.conv3x3(dyf, wd, None, out, 0, amax_out=torch.zeros(1).cuda(), **kw)
+    assert_close(out.to_dense(), x.grad[0], 1e-4, 1e-4 * scale, "plain dgrad")
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK, gate=act, amax_out=torch.zeros(1).cuda(), **kw)
+    assert_close(out.to_dense(), x.grad[0] * gate, 1e-4, 1e-4 * scale, "gated dgrad")
+    out.from_dense(addend)
+    am = torch.zeros(1).cuda()
+    rt.ops.conv3x3(dyf, wd, None, out, rt.hip.EPI_RELU_MASK | rt.hip.EPI_ADD, gate=act, amax_out=am, **kw)
+    assert_close(out.to_dense(), (x.grad[0] + addend) * gate, 1e-4, 1e-4 * scale, "gated dgrad + add")
+    assert out.border_is_zero() and float(am) == float(out.to_dense().abs().max())   # the bound covers the addend
+    # stale values far above the recorded bound (a skipped tile of an earlier view) stay finite: clamped, not inf
+    dyf.planes[:, dyf.Wp + 3] = 1e3
+    rt.ops.conv3x3(dyf, wd, None, out, 0, amax_out=torch.zeros(1).cuda(), **kw)
+    assert torch.isfinite(out.to_dense()).all()
+    am = torch.zeros(1).cuda()
+    rt.ops.fmap_amax(dyf, am)
+    assert float(am) == 1e3
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 60, 70), (512, 512, 33, 45), (256, 64, 40, 52)])
 def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, monkeypatch):
     """Fewer tiles than CUs: every tile is a K-split tail reduced by the second pass. Repeated launches must be
