@@ -167,7 +167,7 @@ def main():
                     "per UV level) instead of the sorted gather over the per-view plan")
     ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
                     "with the update of each arena range issued as its sums arrive (default: exchange, then update)")
-    ap.add_argument("--mfma", choices=["split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
+    ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split' (default; bf16 MFMA on bf16x3-split operands, fp32 accuracy) or 'f32' (v_mfma_f32_32x32x2_f32 "
                     "everywhere); same as STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event-time the conv launches of every n-th timed "
@@ -202,7 +202,8 @@ def main():
     from stylemesh_amd.runtime import ops
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
     if args.mfma is not None:
-        ops.CONV_MODE = ops.GRAM_MODE = args.mfma
+        ops.CONV_MODE = args.mfma
+        ops.GRAM_MODE = "f32" if args.mfma == "f32" else "split"
 
     cfg = EngineConfig(tex_w=wl["tex"], tex_h=wl["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                        angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"],
@@ -254,10 +255,11 @@ def main():
         n_timed = len([i for i in range(args.steps) if i % args.timer_every == 0])
         n_all, ms_all, flops_all = timer.summary()
         # the dominant kernel: the bf16x3-split conv when the engine runs in split mode, else the fp32-MFMA conv
-        tag = "split" if ops.CONV_MODE == "split" else "f32"
+        tag = ops.CONV_MODE if ops.CONV_MODE in ("split", "split2") else "f32"
         n, ms, flops = timer.summary(tag)
         ach = flops / (ms * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS / 6 if tag == "split" else PEAK_FP32_MFMA_TFLOPS
+        products = {"split": 6, "split2": 3}.get(tag)
+        peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None   # HBM bytes per conv launch from the committed PMC pass of this workload
         for rnd in ("r02", "r01"):          # (offline: PMC runs cannot be live inside bench.py)
             tf = os.path.join(REPO, "profiles", rnd, f"conv_traffic_{args.workload}_{tag}.json")
@@ -268,10 +270,13 @@ def main():
                     "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_unit": f"HBM bytes per launch (PMC pass, {traffic_src})",
                     "algorithmic_bytes_per_launch": round(timer.bytes.get(tag, 0.0) / max(n, 1)),
-                    "kernel": "conv3x3_split_kernel" if tag == "split" else "conv3x3_mfma_kernel",
-                    "peak_basis": ("bf16 dense MFMA peak 2500 TFLOP/s / 6 bf16 MFMA products per fp32 multiply-add "
-                                   "(operands split into 3 bf16 parts, fp32 accumulate); achieved = algorithmic fp32 "
-                                   "FLOPs / time, i.e. frac = executed bf16 MFMA FLOPs / 2500") if tag == "split" else
+                    "kernel": {"split": "conv3x3_split_kernel<NP=3> (bf16 x 3)", "split2": "conv3x3_split_kernel<NP=2> (fp16 x 2)"}
+                    .get(tag, "conv3x3_mfma_kernel"),
+                    "peak_basis": (f"16-bit dense MFMA peak 2500 TFLOP/s / {products} MFMA partial products per fp32 "
+                                   f"multiply-add (operands split into {'3 bf16' if tag == 'split' else '2 fp16'} parts, fp32 "
+                                   "accumulate); achieved = algorithmic fp32 FLOPs / time, i.e. frac = executed MFMA FLOPs "
+                                   "/ 2500. A pure-MFMA loop on random operands sustains 0.72 of 2500 on this part "
+                                   "(profiles/r02/mfma_rate_operand_sweep.txt)") if products else
                                   "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)",
                     "achieved_vs_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     "launches_timed": n, "timed_steps": n_timed, "avg_launch_us": round(1e3 * ms / n, 2),
@@ -287,11 +292,14 @@ def main():
                f"views/sec (fwd+bwd into {wl['tex']}^2 texture)", "value": round(value, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-               "dtype_note": ("all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the bf16 matrix "
-                              "cores with every fp32 operand split exactly into 3 bf16 parts (6 partial products, fp32 "
-                              "accumulate): error vs an fp64 convolution equals the fp32-MFMA kernel's "
-                              "(tests/test_kernels_gpu.py); STYLEMESH_CONV_MODE=f32 selects the fp32-MFMA kernel")
-               if ops.CONV_MODE == "split" else "fp32 throughout (v_mfma_f32_32x32x2_f32 convolutions)",
+               "dtype_note": {"split": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the bf16 "
+                              "matrix cores with every fp32 operand split into 3 bf16 parts (6 partial products, fp32 accumulate)",
+                              "split2": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the fp16 "
+                              "matrix cores with every fp32 operand (scaled by a power of two from its tensor's recorded "
+                              "max) split into 2 fp16 parts = 22 significand bits (3 partial products, fp32 accumulate)"}
+               .get(ops.CONV_MODE, "fp32 throughout (v_mfma_f32_32x32x2_f32 convolutions)")
+               + ("; error vs an fp64 convolution <= the fp32-MFMA kernel's (tests/test_kernels_gpu.py, tools/bench_conv_split.py); "
+                  "STYLEMESH_CONV_MODE=f32 selects the fp32-MFMA kernel (the f32_mode leg)" if ops.CONV_MODE != "f32" else ""),
                "data": "synthetic",
                "config": {"workload": f"{args.workload}: {wl['desc']}", "texture": f"{wl['tex']}x{wl['tex']} x 4 layers",
                           "active_uv_levels": active_levels, "views_per_step": world,
@@ -315,7 +323,7 @@ def main():
                                         "zero-initialised texture); the fraction grows with the views of the scene"},
                "exchange": None if world == 1 else ("own RCCL communicator (sm_comm_init / sm_allreduce_grad)"
                                                     if type(comm).__name__ == "RcclComm" else "torch.distributed")}
-        if world == 1 and args.f32_steps > 0 and ops.CONV_MODE == "split" and args.mfma is None:
+        if world == 1 and args.f32_steps > 0 and ops.CONV_MODE != "f32" and args.mfma is None:
             out["f32_mode"] = f32_leg(args, wl, cfg, schedule, dev, barrier)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)

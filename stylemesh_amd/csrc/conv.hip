@@ -326,8 +326,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && NP == 3) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true, 3>
-                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP>;
+        auto k = stamp ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true, NP>
+                       : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -316,7 +316,9 @@ void conv3x3_split_kernel(ConvArgs a) {
             const int ky = tap / 3, kx = tap % 3;
             // the next stage's activation fragments are read under this stage's MFMAs (its slice is complete: slices
             // are written a full barrier before their first use)
-#if SM_SPLIT_PREFETCH_B
+#if defined(SM_ABL_NOREAD)
+            if (ch == ch_begin && tap == 0) { SM_READ_B(fb_next, 0, 1) }
+#elif SM_SPLIT_PREFETCH_B
             if (tap < 8) {
                 SM_READ_B(fb_next, (base + (tap + 1) / 3) & 3, (tap + 1) % 3)
             } else {
@@ -349,6 +351,13 @@ void conv3x3_split_kernel(ConvArgs a) {
 #if SM_SPLIT_MFMA_PRIO
             __builtin_amdgcn_s_setprio(SM_SPLIT_MFMA_PRIO);
 #endif
+#ifdef SM_ABL_NOMFMA
+            _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i][s_]));
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(fb[j][s_]));
+            }
+            if constexpr (false)
+#endif
             if constexpr (NP == 3) {
                 SM_PRODUCT(2, 0)
                 SM_PRODUCT(0, 2)
@@ -370,24 +379,30 @@ void conv3x3_split_kernel(ConvArgs a) {
 #elif SM_SPLIT_MFMA_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+#ifndef SM_ABL_NOA   // (ablation builds, timing only: -DSM_ABL_NOA / _NOB / _NOREAD / _NOMFMA drop one ingredient of the loop)
             if (tap + AD < 9) {
                 SM_LOAD_A(tap + AD, ch);
             } else {
                 SM_LOAD_A(tap + AD - 9, ch_next);
             }
+#endif
             // next chunk's slice ky -> slot (base + 3 + ky) & 3: for ky = 0 the spare slot (the previous chunk's
             // ky = 2), for ky = 1, 2 the slot of this chunk's slice ky - 1, whose last readers passed the barrier of
             // tap 3 ky - 1. The slice is loaded at the end of tap 3 ky - 1 (for ky = 0: tap 8 of the previous chunk),
             // converted and written at the end of tap 3 ky + 1 - a stage WITHOUT a barrier, so that the conversion does
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
             if constexpr (SM_SPLIT_BSETS == 1) {
+#ifndef SM_ABL_NOB
                 if (kx == 1) SM_STORE_B(0, (base + 3 + ky) & 3);
+#endif
                 if (kx == 2) {
+#ifndef SM_ABL_NOB
                     if (ky < 2) {
                         SM_LOAD_B(0, ky + 1, ch_next);
                     } else {
                         SM_LOAD_B(0, 0, ch_next2);
                     }
+#endif
                     __syncthreads();
                 }
             } else {

@@ -105,7 +105,7 @@ def pack_conv_split2(wt: torch.Tensor):
 # 'f32' = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains); 'split' = bf16x3-split MFMA (6 partial
 # products, fp32 accumulate, same accuracy class) wherever a layer's shape allows and its split pack is given;
 # 'split2' = fp16x2-split MFMA (3 partial products, operands scaled by powers of two from recorded maxima).
-CONV_MODE = os.environ.get("STYLEMESH_CONV_MODE", "split")
+CONV_MODE = os.environ.get("STYLEMESH_CONV_MODE", "split2")
 
 
 # ---- texture -------------------------------------------------------------------------------------------------

@@ -7,25 +7,20 @@ from stylemesh_amd.runtime.fmap import FMap
 cin, cout, H, W = 512, 512, 98, 130
 x = FMap(cin, H, W); x.planes.normal_()
 w = ops.pack_conv_fwd(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
-w3 = ops.pack_conv_split(w)
+w3, w2 = ops.pack_conv_split(w), ops.pack_conv_split2(w)
 b = torch.zeros(cout, device="cuda")
 out = FMap(cout, H, W)
-ops.CONV_MODE = "split"
+ops.CONV_MODE = sys.argv[1] if len(sys.argv) > 1 else "split2"
+amax_in = x.planes.abs().max().reshape(1).contiguous()
 ws = ops.splitk_workspace(w.device)
 for _ in range(2):
     ws.zero_()
-    ops.conv3x3(x, w, b, out, hip.EPI_BIAS_RELU, wt3=w3)
+    ops.conv3x3(x, w, b, out, hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=amax_in, amax_out=torch.zeros(1, device="cuda"))
 torch.cuda.synchronize()
 ts = ws[15 * 1024 * 1024:].view(torch.int64)[: 256 * 4 * 64].view(256, 4, 64).cpu().numpy()
 for blk in (0, 1, 100, 255):
     t = ts[blk, 0]
     print(f"block {blk} wave0: prologue {t[1]-t[0]}  stages(ch0): {np.diff(t[1:12]).tolist()}  stages(ch1): {np.diff(t[[11]+list(range(14,24))]).tolist()}  loop total {t[30]-t[1]} epilogue {t[31]-t[30]}")
-for blk in (0, 1, 100, 255):
-    for w in range(4):
-        t = ts[blk, w]
-        for c in range(2):
-            b = 2 + c * 12
-            print(f"  block {blk} wave {w} ch{c} tap4: loads-issued {t[40+c*4]-t[b+3]}  frag-reads+mfma-issue {t[41+c*4]-t[40+c*4]}  stores {t[42+c*4]-t[41+c*4]}  barrier {t[b+4]-t[42+c*4]}")
 tot = ts[:, :, 31] - ts[:, :, 0]
 loop = ts[:, :, 30] - ts[:, :, 1]
 print("mean total", tot.mean(), "mean loop", loop.mean(), "per stage", loop.mean() / (32 * 9), " span of whole kernel", ts[:, :, 31].max() - ts[:, :, 0].min())
