@@ -255,15 +255,18 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
  * sm_conv3x3_grouped_split). Same arguments and results class as sm_gram_masked, but the position ranges add into
  * ONE slab with fp32 atomics (no reduction pass): afterwards S_k = the first sm_gram_split_num_slabs() = 1 slab
  * (upper-triangular 64x64 tiles valid; S0 / S1 need room for one [C][C] slab only). Stages whose 16 mask values
- * are all zero are skipped before their data is loaded. */
+ * are all zero are skipped before their data is loaded.
+ * amax_feat (optional, DEVICE float): bound of max |feat| recorded by the producing conv - given, the operand is
+ * split into two fp16 parts scaled by a power of two and three partial products are taken (sm_conv3x3_grouped_split2);
+ * NULL = three bf16 parts, six products. */
 int sm_gram_split_num_slabs(void);
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
-                         int H, int W, void* stream);
+                         int H, int W, const float* amax_feat, void* stream);
 /* Same kernel without the zero fill: the position ranges ADD into S0 / S1, which the caller has zeroed (one fill
  * over the slabs of every level and layer of a step instead of two per call) or which hold a partial sum to
  * continue. */
 int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
-                         int H, int W, void* stream);
+                             int H, int W, const float* amax_feat, void* stream);
 
 /* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
  * S0/S1: the n_slabs partial slabs written by sm_gram_masked (summed here).
@@ -274,11 +277,13 @@ int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float*
  * Writes D0/D1 [C][C] (full symmetric) such that dL/dF = m_0 * (D0 F) + m_1 * (D1 F), and atomically adds
  * the loss value to *loss_out. history (may be NULL): [9][C][C] ring of past normalised mask-0 Grams for
  * gram_mode 'average' (:319-323): the first hist_len entries are averaged with the current Gram, which is
- * then stored in entry hist_slot. targets / term_mask / skip_if_empty are HOST arrays (<= 4 terms). */
+ * then stored in entry hist_slot. targets / term_mask / skip_if_empty are HOST arrays (<= 4 terms).
+ * amax_d_out (optional, DEVICE float, caller-zeroed): receives max(|D0|, |D1|), the operand bound of the fp16x2
+ * sm_gram_backward_split. */
 int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty,
                   float weight, int C, float* D0, float* D1, float* loss_out, float* history, int hist_len,
-                  int hist_slot, int n_slabs, void* stream);
+                  int hist_slot, int n_slabs, float* amax_d_out, void* stream);
 
 /* K5c. dF[c][q] = m0[q] * (D0 F)[c][q] + m1[q] * (D1 F)[c][q], optionally gated by feat > 0
  * (for the top layer r51, whose ReLU gate no later dgrad applies). OVERWRITES dfeat. */
@@ -286,11 +291,14 @@ int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, 
                      const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* stream);
 
 /* K5c on the bf16 matrix cores (same split). ws: DEVICE scratch of sm_gram_backward_split_ws_bytes(C) bytes that
- * receives the bf16x3 image of D0 / D1 (a small pack kernel runs first on the same stream). */
+ * receives the split image of D0 / D1 (a small pack kernel runs first on the same stream).
+ * amax_feat / amax_d (both or neither; DEVICE floats): bounds of max |feat| and max(|D0|, |D1|) - given, the
+ * operands are split into two fp16 parts scaled by powers of two and three partial products are taken (as
+ * sm_conv3x3_grouped_split2); NULL = three bf16 parts, six products. */
 size_t sm_gram_backward_split_ws_bytes(int C);
 int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0,
                            const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* ws,
-                           void* stream);
+                           const float* amax_feat, const float* amax_d, void* stream);
 
 /* K6. Masked content MSE (:343-348): loss += coef * sum m (P-T)^2 / (C N); dP = coef * 2 m (P-T)/(C N),
  * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred.

@@ -36,6 +36,18 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], f32x4& vh, f32x4& 
     vl = __builtin_bit_cast(f32x4, l);
 }
 
+// wave-wide max of a non-negative value -> at most one atomic max (bit patterns of non-negative floats order like
+// uints). Same-address device atomics serialise at ~12 ns each (8 k of them cost a small kernel 100 us), so a wave first
+// reads the current value - it only grows - and skips the atomic unless it would raise it: after the first few
+// hundred waves of a launch almost none does.
+__device__ __forceinline__ void record_amax(float* amax_out, float v) {
+    if (amax_out == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, v));
+}
+
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int row_stride(int W) { return round_up(W + 1, 4); }
 __host__ __device__ inline int plane_size(int H, int W) { return round_up((H + 2) * row_stride(W), 64); }

@@ -41,18 +41,6 @@ struct ConvArgs {
     float w_scale_inv;
 };
 
-// wave-wide max of a non-negative value -> at most one atomic max (bit patterns of non-negative floats order like
-// uints). Same-address device atomics serialise at ~12 ns each (8 k of them cost a small kernel 100 us), so a wave first
-// reads the current value - it only grows - and skips the atomic unless it would raise it: after the first few
-// hundred waves of a launch almost none does.
-__device__ __forceinline__ void record_amax(float* amax_out, float v) {
-    if (amax_out == nullptr) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, v));
-}
-
 constexpr int SM_NUM_CU = 256;
 
 }  // namespace sm

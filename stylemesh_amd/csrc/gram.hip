@@ -166,8 +166,9 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
                                                          const float* __restrict__ factor, StyleTerms terms,
                                                          float weight, int C, float* __restrict__ D0,
                                                          float* __restrict__ D1, float* loss_out, float* history,
-                                                         int hist_len, int hist_slot, int n_slabs) {
+                                                         int hist_len, int hist_slot, int n_slabs, float* amax_d) {
     __shared__ float red[4];
+    float dmax = 0.f;   // max |D0|, |D1|: operand bound of the fp16x2 Gram backward
     const float f = *factor;
     const float inv_c2 = 1.f / ((float)C * (float)C);
     float loss = 0.f;
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     }
     D0[idx] = d[0];
     if (D1) D1[idx] = d[1];
+    dmax = fmaxf(dmax, fmaxf(fabsf(d[0]), fabsf(d[1])));
     }
+    record_amax(amax_d, dmax);
     const float tot = block_sum256(loss, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * weight * f * inv_c2);
 }
@@ -399,7 +402,7 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 int sm_gram_split_num_slabs(void) { return 1; }
 
 static int gram_masked_split_impl(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
-                                  int H, int W, bool zero_fill, void* stream) {
+                                  int H, int W, bool zero_fill, const float* amax_feat, void* stream) {
     if (C % 64 != 0) return (int)hipErrorInvalidValue;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
@@ -414,47 +417,56 @@ static int gram_masked_split_impl(const float* feat, const float* mask0, const f
         if (e == hipSuccess && mask1) e = hipMemsetAsync(S1, 0, cc * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-#define SM_GS(MI_, AT_, T_)                                                                                          \
-    hipLaunchKernelGGL((sm::gram_split_kernel<MI_, AT_>), dim3(p.n_raw, (T_) * ((T_) + 1) / 2, nmask), dim3(256), 0, s, \
-                       feat, mask0, mask1, S0, S1, C, plane, q_begin, q_end, p.qb)
+#define SM_GS(MI_, AT_, T_, NP_)                                                                                     \
+    hipLaunchKernelGGL((sm::gram_split_kernel<MI_, AT_, NP_>), dim3(p.n_raw, (T_) * ((T_) + 1) / 2, nmask), dim3(256), 0, s, \
+                       feat, mask0, mask1, S0, S1, C, plane, q_begin, q_end, p.qb, amax_feat)
+#define SM_GS_NP(MI_, AT_, T_) do { if (amax_feat) SM_GS(MI_, AT_, T_, 2); else SM_GS(MI_, AT_, T_, 3); } while (0)
     if (C % 128 == 0) {
-        if (atomic) SM_GS(2, true, C / 128); else SM_GS(2, false, C / 128);
+        if (atomic) SM_GS_NP(2, true, C / 128); else SM_GS_NP(2, false, C / 128);
     } else {
-        if (atomic) SM_GS(1, true, C / 64); else SM_GS(1, false, C / 64);
+        if (atomic) SM_GS_NP(1, true, C / 64); else SM_GS_NP(1, false, C / 64);
     }
+#undef SM_GS_NP
 #undef SM_GS
     SM_LAUNCH_CHECK();
     return 0;
 }
 
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
-                         int W, void* stream) {
-    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, true, stream);
+                         int W, const float* amax_feat, void* stream) {
+    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, true, amax_feat, stream);
 }
 
 int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
-                             int H, int W, void* stream) {
-    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, false, stream);
+                             int H, int W, const float* amax_feat, void* stream) {
+    return gram_masked_split_impl(feat, mask0, mask1, S0, S1, C, H, W, false, amax_feat, stream);
 }
 
 size_t sm_gram_backward_split_ws_bytes(int C) { return (size_t)2 * 6 * C * C; }
 
 int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0, const float* D1,
-                           float* dfeat, int C, int H, int W, int relu_gate, void* ws, void* stream) {
-    if (C % 64 != 0 || ws == nullptr) return (int)hipErrorInvalidValue;
+                           float* dfeat, int C, int H, int W, int relu_gate, void* ws, const float* amax_feat,
+                           const float* amax_d, void* stream) {
+    if (C % 64 != 0 || ws == nullptr || (amax_feat == nullptr) != (amax_d == nullptr)) return (int)hipErrorInvalidValue;
+    const bool np2 = amax_feat != nullptr;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     hipStream_t s = (hipStream_t)stream;
     const bool two = mask1 && D1;
     sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(ws);
     sm::f32x4* P1 = P0 + (size_t)6 * C * C / 16;
-    hipLaunchKernelGGL(sm::gram_d_pack_kernel, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1, P0, P1,
-                       C);
+    if (np2)
+        hipLaunchKernelGGL(sm::gram_d_pack_kernel<2>, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1,
+                           P0, P1, C, amax_d);
+    else
+        hipLaunchKernelGGL(sm::gram_d_pack_kernel<3>, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1,
+                           P0, P1, C, amax_d);
     SM_LAUNCH_CHECK();
     const float* m1 = two ? mask1 : nullptr;
-#define SM_GBS(MI_, RG)                                                                                               \
-    hipLaunchKernelGGL((sm::gram_backward_split_kernel<MI_, RG>), dim3((q_end - q_begin + 127) / 128, C / (64 * MI_)),  \
-                       dim3(256), 0, s, feat, mask0, m1, P0, P1, dfeat, C, plane, q_begin, q_end)
+#define SM_GBS_(MI_, RG, NP_)                                                                                         \
+    hipLaunchKernelGGL((sm::gram_backward_split_kernel<MI_, RG, NP_>), dim3((q_end - q_begin + 127) / 128, C / (64 * MI_)), \
+                       dim3(256), 0, s, feat, mask0, m1, P0, P1, dfeat, C, plane, q_begin, q_end, amax_feat, amax_d)
+#define SM_GBS(MI_, RG) do { if (np2) SM_GBS_(MI_, RG, 2); else SM_GBS_(MI_, RG, 3); } while (0)
     // 128-row tiles only when they still fill the chip: deep layers of small levels have a handful of position tiles,
     // and a block's K loop (C x live masks) is serial
     if (C % 128 == 0 && (long long)((q_end - q_begin + 127) / 128) * (C / 128) >= 256) {
@@ -463,6 +475,7 @@ int sm_gram_backward_split(const float* feat, const float* mask0, const float* m
         if (relu_gate) SM_GBS(1, true); else SM_GBS(1, false);
     }
 #undef SM_GBS
+#undef SM_GBS_
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -470,7 +483,7 @@ int sm_gram_backward_split(const float* feat, const float* mask0, const float* m
 int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty, float weight,
                   int C, float* D0, float* D1, float* loss_out, float* history, int hist_len, int hist_slot,
-                  int n_slabs, void* stream) {
+                  int n_slabs, float* amax_d_out, void* stream) {
     if (n_terms < 1 || n_terms > 4 || (C * C) % 256 != 0) return (int)hipErrorInvalidValue;
     sm::StyleTerms t;
     t.n = n_terms;
@@ -482,7 +495,7 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
     t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
     t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
     hipLaunchKernelGGL(sm::style_loss_kernel, dim3((C * C + 256 * sm::STYLE_EPT - 1) / (256 * sm::STYLE_EPT)), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
-                       t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs);
+                       t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs, amax_d_out);
     SM_LAUNCH_CHECK();
     return 0;
 }

@@ -11,21 +11,75 @@
 
 namespace sm {
 
-#define SM_MFMA6(ACC, FA, FB)                                                        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2], FB[0], ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[2], ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1], FB[1], ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1], FB[0], ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[1], ACC, 0, 0, 0);       \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0], FB[0], ACC, 0, 0, 0);
+// NP = 3: bf16 x 3 operands, six partial products; NP = 2: fp16 x 2 operands scaled by a power of two from the
+// tensor's recorded max |x| (conv_split_kernel.h), three partial products. Fragments travel as raw 16-byte units.
+typedef _Float16 g_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float gram_pow2_scale(float amax, float& inv) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    const int ex = (int)((bits >> 23) & 0xff);
+    if (ex < 16 || ex > 250) { inv = 1.f; return 1.f; }
+    inv = __builtin_bit_cast(float, (unsigned)(ex - 14) << 23);
+    return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);
+}
+// eight fp32 values (already scaled) -> h, l fp16x8 units
+__device__ __forceinline__ void split2x8(const float (&x)[8], f32x4& vh, f32x4& vl) {
+    g_f16x8 h, l;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float xs = __builtin_amdgcn_fmed3f(x[c], -65000.f, 65000.f);
+        const _Float16 a = (_Float16)xs;
+        h[c] = a;
+        l[c] = (_Float16)(xs - (float)a);
+    }
+    vh = __builtin_bit_cast(f32x4, h);
+    vl = __builtin_bit_cast(f32x4, l);
+}
+template <int NP>
+__device__ __forceinline__ void mfma_parts(f32x16& acc, const f32x4 (&fa)[NP], const f32x4 (&fb)[NP]) {
+    if constexpr (NP == 3) {
+#define SM_B(x_) __builtin_bit_cast(bf16x8, x_)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[2]), SM_B(fb[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[1]), SM_B(fb[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[1]), SM_B(fb[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[0]), acc, 0, 0, 0);
+#undef SM_B
+    } else {
+#define SM_H(x_) __builtin_bit_cast(g_f16x8, x_)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[0]), acc, 0, 0, 0);
+#undef SM_H
+    }
+}
+// eight fp32 values -> NP operand units (NP = 2: scaled by `scale` first)
+template <int NP>
+__device__ __forceinline__ void split_parts(const float (&x)[8], float scale, f32x4 (&v)[NP]) {
+    if constexpr (NP == 3) {
+        split3x8(x, v[0], v[1], v[2]);
+    } else {
+        float y[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y[c] = x[c] * scale;
+        split2x8(y, v[0], v[1]);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // D [C][C] fp32 (symmetric) -> MFMA A-fragment image [C/16 chunks][3 parts][2 k-groups][C rows][8] bf16
 // ---------------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restrict__ D0, const float* __restrict__ D1,
-                                                          f32x4* __restrict__ P0, f32x4* __restrict__ P1, int C) {
+                                                          f32x4* __restrict__ P0, f32x4* __restrict__ P1, int C,
+                                                          const float* __restrict__ amax_d) {
     const float* D = blockIdx.y ? D1 : D0;
     f32x4* P = blockIdx.y ? P1 : P0;
+    float scale = 1.f;
+    if (NP == 2) {   // both matrices share one bound (max |D0|, |D1| of the style-loss kernel)
+        float inv;
+        scale = gram_pow2_scale(*amax_d, inv);
+    }
     const int u = blockIdx.x * 256 + threadIdx.x;   // (row, 8-column group)
     const int groups = C / 8;
     if (u >= C * groups) return;
@@ -35,13 +89,12 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
     const f32x4 b = *reinterpret_cast<const f32x4*>(D + (size_t)row * C + g * 8 + 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { x[c] = a[c]; x[4 + c] = b[c]; }
-    f32x4 vh, vm, vl;
-    split3x8(x, vh, vm, vl);
+    f32x4 v[NP];
+    split_parts<NP>(x, scale, v);
     const int chunk = g >> 1, kg = g & 1;
-    f32x4* d = P + (size_t)(chunk * 6 + kg) * C + row;
-    d[0] = vh;
-    d[2 * (size_t)C] = vm;
-    d[4 * (size_t)C] = vl;
+    f32x4* d = P + (size_t)(chunk * 2 * NP + kg) * C + row;
+#pragma unroll
+    for (int part = 0; part < NP; ++part) d[2 * part * (size_t)C] = v[part];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -53,14 +106,21 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
 // MI = 1: 64-row blocks, waves 2 x 2 with 32 x 64 tiles; MI = 2: 128-row blocks, waves 4 x 1 with 32 x 128 tiles (one
 // 32-row weight fragment set per wave: the loop is sensitive to the number of vector-memory instructions per MFMA,
 // see conv_split_kernel.h)
-template <int MI, bool RELU_GATE>
+template <int MI, bool RELU_GATE, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_backward_split_kernel(
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
     const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
-    int q_end) {
+    int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
     constexpr int BN = 128;
     constexpr int KS = 2;                 // MFMA K-steps (16 channels each) per stage
-    constexpr int SLICE = KS * 6 * BN;    // [kstep][part][kgroup][position] units of 8 channels
+    constexpr int SLICE = KS * 2 * NP * BN;    // [kstep][part][kgroup][position] units of 8 channels
+    float f_scale = 1.f, out_scale = 1.f;
+    if (NP == 2) {
+        float inv_f, inv_d;
+        f_scale = gram_pow2_scale(*amax_feat, inv_f);
+        gram_pow2_scale(*amax_d, inv_d);
+        out_scale = inv_f * inv_d;
+    }
     __shared__ __attribute__((aligned(16))) f32x4 Bs[2][SLICE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     constexpr int NJ = 2 * MI;                       // 32-position MFMA tiles per wave
@@ -88,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int kfix = live0 ? 0 : 1;
         const float* bsrc = feat + (size_t)b_kg * 8 * plane + q0 + b_px;
         const int a_off = lhi * C + m0 + wm + l31;
-        f32x4 ra[2][KS][1][3];
+        f32x4 ra[2][KS][1][NP];
         float rb[2][KS][8];
         // stage s -> (chunk, mask); beyond the last stage the last one is re-read (unconditional loads keep the
         // compiler's vmcnt bookkeeping exact, see conv_split_kernel.h)
@@ -99,10 +159,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define SM_LOAD_A(set_, s_)                                                                 \
     {                                                                                       \
         SM_STAGE_OF(s_, chunk_, k_)                                                         \
-        const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 6 * C + a_off;             \
+        const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 2 * NP * C + a_off;        \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
-            _Pragma("unroll") for (int part = 0; part < 3; ++part)                          \
-                ra[set_][ks][0][part] = p_[(ks * 6 + part * 2) * C];                        \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part)                         \
+                ra[set_][ks][0][part] = p_[(ks * 2 * NP + part * 2) * C];                   \
     }
 #define SM_LOAD_B(set_, s_)                                                                 \
     {                                                                                       \
@@ -120,12 +180,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
             float x_[8];                                                                    \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (mv_ != 0.f) ? rb[set_][ks][c] : 0.f; \
-            f32x4 vh_, vm_, vl_;                                                            \
-            split3x8(x_, vh_, vm_, vl_);                                                    \
-            f32x4* d_ = &Bs[buf_][ks * 6 * BN + b_kg * BN + b_px];                          \
-            d_[0] = vh_;                                                                    \
-            d_[2 * BN] = vm_;                                                               \
-            d_[4 * BN] = vl_;                                                               \
+            f32x4 v_[NP];                                                                   \
+            split_parts<NP>(x_, f_scale, v_);                                               \
+            f32x4* d_ = &Bs[buf_][ks * 2 * NP * BN + b_kg * BN + b_px];                     \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * BN] = v_[part]; \
         }                                                                                   \
     }
 #define SM_STAGE(s_, par_)                                                                  \
@@ -134,13 +192,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         SM_LOAD_B(par_, (s_) + 2)                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
-            bf16x8 fa[1][3], fb[NJ][3];                                                     \
-            const f32x4* bf_ = &Bs[par_][ks * 6 * BN + lhi * BN + wn + l31];                \
-            _Pragma("unroll") for (int part = 0; part < 3; ++part) {                        \
-                fa[0][part] = __builtin_bit_cast(bf16x8, ra[par_][ks][0][part]);            \
-                _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb[j][part] = __builtin_bit_cast(bf16x8, bf_[part * 2 * BN + j * 32]); \
+            f32x4 fa[1][NP], fb[NJ][NP];                                                    \
+            const f32x4* bf_ = &Bs[par_][ks * 2 * NP * BN + lhi * BN + wn + l31];           \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part) {                       \
+                fa[0][part] = ra[par_][ks][0][part];                                        \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb[j][part] = bf_[part * 2 * BN + j * 32]; \
             }                                                                               \
-            _Pragma("unroll") for (int j = 0; j < NJ; ++j) { SM_MFMA6(acc[0][j], fa[0], fb[j]) } \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma_parts<NP>(acc[0][j], fa[0], fb[j]); \
         }                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         SM_LOAD_A(par_, (s_) + 2)                                                           \
@@ -176,6 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[0][nj][r];
+            if (NP == 2) v *= out_scale;
             if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
             dfeat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = v;
         }
@@ -191,12 +250,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ATOMIC: all position ranges accumulate into ONE pre-zeroed slab with fp32 atomics instead of writing a slab each
 // (no reduction pass, C^2 floats of traffic per block instead of written + re-read; summation order - like the
 // texture scatter's - is then not fixed).
-template <int MI, bool ATOMIC>
+template <int MI, bool ATOMIC, int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_split_kernel(
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1, float* S0, float* S1,
-    int C, int plane, int q_begin, int q_end, int qb) {
+    int C, int plane, int q_begin, int q_end, int qb, const float* __restrict__ amax_feat) {
     constexpr int TS = 64 * MI;           // tile size (channels)
-    constexpr int SLICE = 6 * TS;         // [part][kgroup][channel] units of 8 positions
+    constexpr int SLICE = 2 * NP * TS;    // [part][kgroup][channel] units of 8 positions
+    float f_scale = 1.f, out_scale = 1.f;
+    if (NP == 2) {
+        float inv;
+        f_scale = gram_pow2_scale(*amax_feat, inv);
+        out_scale = inv * inv;
+    }
     constexpr int MAX_STAGES = 256;       // qb <= 4096 positions
     __shared__ __attribute__((aligned(16))) f32x4 As[2][SLICE];
     __shared__ __attribute__((aligned(16))) f32x4 Bt[2][SLICE];
@@ -271,16 +336,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define SM_STORE(set_, buf_)                                                                            \
     if (u_on) {                                                                                         \
         float x_[8];                                                                                    \
-        f32x4 vh_, vm_, vl_;                                                                            \
+        f32x4 v_[NP];                                                                                   \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (rM[set_][c] != 0.f) ? rA[set_][c] : 0.f; \
-        split3x8(x_, vh_, vm_, vl_);                                                                    \
+        split_parts<NP>(x_, f_scale, v_);                                                               \
         f32x4* d_ = &As[buf_][u_kg * TS + u_ch];                                                        \
-        d_[0] = vh_; d_[2 * TS] = vm_; d_[4 * TS] = vl_;                                                \
+        _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * TS] = v_[part];           \
         if (!diag) {                                                                                    \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (rM[set_][c] != 0.f) ? rB[set_][c] : 0.f; \
-            split3x8(x_, vh_, vm_, vl_);                                                                \
+            split_parts<NP>(x_, f_scale, v_);                                                           \
             f32x4* e_ = &Bt[buf_][u_kg * TS + u_ch];                                                    \
-            e_[0] = vh_; e_[2 * TS] = vm_; e_[4 * TS] = vl_;                                            \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part) e_[2 * part * TS] = v_[part];       \
         }                                                                                               \
     }
 #define SM_STAGE(i_, par_)                                                                              \
@@ -288,16 +353,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         SM_STORE(1 - (par_), 1 - (par_))                                                                \
         SM_LOAD(par_, (i_) + 2)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        bf16x8 fa[MI][3], fb[MI][3];                                                                    \
+        f32x4 fa[MI][NP], fb[MI][NP];                                                                   \
         const f32x4* af_ = &As[par_][lhi * TS + wm + l31];                                              \
         const f32x4* bf_ = (diag ? &As[par_][0] : &Bt[par_][0]) + lhi * TS + wn + l31;                  \
-        _Pragma("unroll") for (int part = 0; part < 3; ++part)                                          \
+        _Pragma("unroll") for (int part = 0; part < NP; ++part)                                         \
             _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                            \
-                fa[i][part] = __builtin_bit_cast(bf16x8, af_[part * 2 * TS + i * 32]);                  \
-                fb[i][part] = __builtin_bit_cast(bf16x8, bf_[part * 2 * TS + i * 32]);                  \
+                fa[i][part] = af_[part * 2 * TS + i * 32];                                              \
+                fb[i][part] = bf_[part * 2 * TS + i * 32];                                              \
             }                                                                                           \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
-            _Pragma("unroll") for (int j = 0; j < MI; ++j) { SM_MFMA6(acc[i][j], fa[i], fb[j]) }        \
+            _Pragma("unroll") for (int j = 0; j < MI; ++j) mfma_parts<NP>(acc[i][j], fa[i], fb[j]);     \
         __syncthreads();                                                                                \
     }
         SM_LOAD(0, 0)
@@ -320,10 +385,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * TS + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int col = tn * TS + wn + nj * 32 + l31;
+                const float v = NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r];
                 if (ATOMIC) {
-                    if (n_live > 0) atomicAdd(&S[(size_t)row * C + col], acc[mi][nj][r]);
+                    if (n_live > 0) atomicAdd(&S[(size_t)row * C + col], v);
                 } else {
-                    S[(size_t)row * C + col] = acc[mi][nj][r];
+                    S[(size_t)row * C + col] = v;
                 }
             }
 }

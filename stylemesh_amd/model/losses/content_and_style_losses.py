@@ -97,7 +97,9 @@ class _GramFn(torch.autograd.Function):
         f = FMap(c, h, w, feat.device).from_dense(feat[0].detach())
         ones = FMap(1, h, w, feat.device).from_dense(torch.ones(1, h, w))
         S = torch.zeros(ops.gram_workspace_slabs(c, h, w), c, c, device=feat.device)
-        n = ops.gram_masked(f, ones, None, S, None)
+        # fp16x2 mode: the operand bound the producing conv would have recorded (class mirror, not a hot path)
+        ctx.af = feat.detach().abs().max().reshape(1).contiguous() if ops.GRAM_MODE == "split2" else None
+        n = ops.gram_masked(f, ones, None, S, None, amax_feat=ctx.af)
         ctx.f, ctx.ones = f, ones
         from ...runtime.engine import _mirror_tiles
         return (_mirror_tiles(S[:n].sum(0)) / float(h * w))[None]
@@ -107,7 +109,8 @@ class _GramFn(torch.autograd.Function):
         f = ctx.f
         D = ((gG[0] + gG[0].T) / float(f.H * f.W)).contiguous()   # dF = (dG + dG^T) F / (h w)
         df = FMap(f.C, f.H, f.W, f.buf.device)
-        ops.gram_backward(f, ctx.ones, None, D, None, df, relu_gate=False)
+        ad = D.abs().max().reshape(1).contiguous() if ops.GRAM_MODE == "split2" else None
+        ops.gram_backward(f, ctx.ones, None, D, None, df, relu_gate=False, amax_feat=ctx.af, amax_d=ad)
         return df.to_dense()[None]
 
 

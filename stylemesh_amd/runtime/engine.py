@@ -134,9 +134,11 @@ class StepEngine:
         # device scalars: [content, style] weighted loss accumulators, per-layer sum of squares of the texture
         # ... and, behind them in the same buffer (one fill zeroes all of it every step), the per-layer max |x| bounds
         # of the step's activations / gradients over all UV levels (operand scales of the fp16x2 conv kernels)
-        self._step_scalars = torch.zeros(2 + AmaxBook.N, device=device)
+        # ... and one bound per (UV level <= 8, style layer) of the style-loss derivative matrices (fp16x2 Gram backward)
+        self._step_scalars = torch.zeros(2 + AmaxBook.N + 8 * len(cfg.style_layers), device=device)
         self.loss_buf = self._step_scalars[0:2]
-        self.amax = AmaxBook(device, self._step_scalars[2:])
+        self.amax = AmaxBook(device, self._step_scalars[2:2 + AmaxBook.N])
+        self._amax_d = self._step_scalars[2 + AmaxBook.N:]
         self.sumsq = torch.zeros(n_layers, device=device)
         self._pbuf = {}            # persistent per-view buffers (fixed addresses)
         self._graphs = {}          # view signature -> captured hipGraph of forward_backward
@@ -274,7 +276,7 @@ class StepEngine:
                 f = b.act[layer]
                 ones = FMap(1, f.H, f.W, self.device).from_dense(torch.ones(1, f.H, f.W))
                 S = torch.zeros(ops.gram_workspace_slabs(f.C, f.H, f.W), f.C, f.C, device=self.device)
-                n = ops.gram_masked(f, ones, None, S, None)
+                n = ops.gram_masked(f, ones, None, S, None, amax_feat=b.amax["a:" + layer])
                 grams.append(_mirror_tiles(S[:n].sum(0)) / float(f.H * f.W))
             cache[s] = grams
             del b
@@ -530,7 +532,7 @@ class StepEngine:
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
 
-    def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None):
+    def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None, am=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
         layer's gradient already ReLU-gated). ``keep`` (dict) receives clones of the style derivative matrices."""
         cfg = self.cfg
@@ -539,7 +541,7 @@ class StepEngine:
             for li, layer in enumerate(cfg.style_layers):
                 if only_layers is not None and layer not in only_layers:
                     continue
-                D = self._style_terms(lv, b, li, layer, w_style)
+                D = self._style_terms(lv, b, li, layer, w_style, am)
                 if keep is not None:
                     keep[(lv.index, layer)] = tuple(None if d is None else d.clone() for d in D)
                 injected.add(layer)
@@ -563,13 +565,17 @@ class StepEngine:
             return m.channel_ptr(1), m.channel_ptr(2)
         return m.channel_ptr(0), None
 
-    def _style_terms(self, lv, b, li, layer, w_style):
+    def _style_terms(self, lv, b, li, layer, w_style, am=None):
+        """``am``: the AmaxBook that holds the bound of ``b.act[layer]`` (default: the step's group book)."""
         cfg = self.cfg
         f = b.act[layer]
+        two = ops.GRAM_MODE == "split2"
+        af = (self.amax if am is None else am)["a:" + layer] if two else None
+        ad = self._amax_d[lv.index * len(cfg.style_layers) + li:][:1] if two else None
         n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
         key = (f.C, lv.index, layer)
         S0, S1, D0, D1 = self._gram_scratch(key, ops.gram_workspace_slabs(f.C, f.H, f.W))
-        pre = ops.GRAM_MODE == "split" and key in self._gram_clean   # zeroed by _zero_step_accumulators
+        pre = ops.GRAM_MODE in ("split", "split2") and key in self._gram_clean   # zeroed by _zero_step_accumulators
         self._gram_clean.discard(key)
         multi = cfg.style_pyramid_mode == "multi"
         weight = w_style * float(cfg.style_weights[li])
@@ -582,20 +588,20 @@ class StepEngine:
             hist_len, hist_slot = min(cnt, 9), cnt % 9
             self._hist[layer][1] = cnt + 1
         if multi:
-            ops.gram_masked(f, m0, m1, S0, S1, prezeroed=pre)
+            ops.gram_masked(f, m0, m1, S0, S1, prezeroed=pre, amax_feat=af)
             targets = [self.targets[li][2], self.targets[li][2]]
             term_mask = [0, 1]
             if li > 2:   # content_and_style_losses.py:335-338
                 targets.append(self.targets[li][0])
                 term_mask.append(0)
             ops.style_loss(S0, S1, lv.counts[layer][1:3], lv.factor[layer], targets, term_mask, [0, 1], weight, f.C,
-                           D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
+                           D0, D1, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs, amax_d_out=ad)
         else:
             D1 = None
-            ops.gram_masked(f, m0, None, S0, None, prezeroed=pre)
+            ops.gram_masked(f, m0, None, S0, None, prezeroed=pre, amax_feat=af)
             ops.style_loss(S0, None, lv.counts[layer][0:1], lv.factor[layer], [self.targets[li][0]], [0], [0, 0],
-                           weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs)
-        ops.gram_backward(f, m0, m1, D0, D1, b.grad[layer], relu_gate=(layer == self.deepest))
+                           weight, f.C, D0, None, self.loss_buf[1:2], hist, hist_len, hist_slot, n_slabs, amax_d_out=ad)
+        ops.gram_backward(f, m0, m1, D0, D1, b.grad[layer], relu_gate=(layer == self.deepest), amax_feat=af, amax_d=ad)
         return D0, D1
 
     # ------------------------------------------------------------------ explicit-image interface (class mirror)
@@ -620,13 +626,13 @@ class StepEngine:
     def images_forward(self, images, w_style=1.0, w_content=1.0):
         """VGG + losses of explicit images (one per level of ``set_external_levels``). Returns
         ``(loss_buf clone [content, style], kept derivative matrices)``; activations stay in the level buffers."""
-        self.loss_buf.zero_()
+        self._step_scalars.zero_()
         keep = {}
         for lv, img in zip(self.view, images):
             b = self._level_bufs(lv.H, lv.W)
             ops.image_to_fmap(img[0].detach().to(self.device, torch.float32).contiguous(), b.act["img"])
             self.vgg.forward(b)
-            self._inject_losses(lv, b, w_style, w_content, keep)
+            self._inject_losses(lv, b, w_style, w_content, keep, am=b.amax)
         return self.loss_buf.clone(), keep
 
     def images_backward(self, keep, g_style: float, g_content: float):
@@ -640,8 +646,12 @@ class StepEngine:
                 for layer in self.cfg.style_layers:
                     D0, D1 = keep[(lv.index, layer)]
                     m0, m1 = self._style_masks(lv, layer)
-                    ops.gram_backward(b.act[layer], m0, m1, D0 * g_style, None if D1 is None else D1 * g_style,
-                                      b.grad[layer], relu_gate=(layer == self.deepest))
+                    d0, d1 = D0 * g_style, (None if D1 is None else D1 * g_style)
+                    ad = None
+                    if ops.GRAM_MODE == "split2":   # bound of the rescaled derivative matrices (not a hot path)
+                        ad = d0.abs().max().reshape(1) if d1 is None else torch.maximum(d0.abs().max(), d1.abs().max()).reshape(1)
+                    ops.gram_backward(b.act[layer], m0, m1, d0, d1, b.grad[layer], relu_gate=(layer == self.deepest),
+                                      amax_feat=b.amax["a:" + layer], amax_d=ad)
                     injected.add(layer)
             if g_content != 0.0:
                 for li, layer in enumerate(self.cfg.content_layers):

@@ -58,9 +58,9 @@ SIGNATURES = {
     "sm_gram_workspace_slabs": [_i, _i, _i],
     "sm_gram_masked": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_split_num_slabs": [],
-    "sm_gram_masked_split": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sm_gram_masked_split_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sm_gram_masked_split": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "sm_gram_masked_split_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_level_masks": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
@@ -73,7 +73,7 @@ SIGNATURES = {
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
     "sm_gram_backward_split_ws_bytes": [_i],
-    "sm_gram_backward_split": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "sm_gram_backward_split": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sm_reproject_blocks": [_i, _i],
     "sm_reproject": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "sm_raster_maps": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp],

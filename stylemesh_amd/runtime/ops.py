@@ -393,59 +393,67 @@ def maxpool_bwd_relu_grouped(problems, tile_list=None):
 # ---- losses --------------------------------------------------------------------------------------------------
 def gram_num_slabs(C: int, H: int, W: int) -> int:
     """How many leading slabs of the Gram workspace sum to S (mode dependent: the split kernel accumulates into one)."""
-    if GRAM_MODE == "split":
+    if GRAM_MODE in ("split", "split2"):
         return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_num_slabs(C, H, W)
 
 
 def gram_workspace_slabs(C: int, H: int, W: int) -> int:
     """Slabs the workspace must hold in the current mode (split: the one slab every position range adds into)."""
-    if GRAM_MODE == "split":
+    if GRAM_MODE in ("split", "split2"):
         return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_workspace_slabs(C, H, W)
 
 
-# 'split' = the Gram contraction and its backward GEMM on the bf16 matrix cores with bf16x3-split operands (fp32
-# accuracy class, see CONV_MODE); 'f32' = v_mfma_f32_32x32x2_f32 kernels.
-GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", "split")
+# 'split2' = the Gram contraction and its backward GEMM on the fp16 matrix cores with fp16x2-split operands scaled by
+# powers of two from recorded maxima (3 partial products; see CONV_MODE 'split2'); 'split' = bf16x3-split operands
+# (6 partial products); 'f32' = v_mfma_f32_32x32x2_f32 kernels. Default: follows the conv mode.
+GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", {"split2": "split2", "split": "split"}.get(CONV_MODE, "f32"))
 
 
-def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False):
+def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False, amax_feat=None):
     """S0 / S1: [gram_workspace_slabs(C,H,W), C, C]; returns how many leading slabs sum to S. ``prezeroed`` (split
-    mode only): the caller has zeroed the slabs, the kernel adds into them without a fill of its own."""
+    modes only): the caller has zeroed the slabs, the kernel adds into them without a fill of its own.
+    ``amax_feat`` (device float; 'split2' mode): bound of max |feat|."""
     n = gram_num_slabs(feat.C, feat.H, feat.W)
     na = gram_workspace_slabs(feat.C, feat.H, feat.W)
     assert S0.numel() >= na * feat.C * feat.C and (S1 is None or S1.numel() >= na * feat.C * feat.C)
-    if GRAM_MODE == "split":
+    if GRAM_MODE in ("split", "split2"):
+        assert GRAM_MODE == "split" or amax_feat is not None, "GRAM_MODE 'split2' needs the feature map's bound"
         fn = lib.sm_gram_masked_split_acc if prezeroed else lib.sm_gram_masked_split
-    else:
-        fn = lib.sm_gram_masked
-    hip.check(fn(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W, hip.stream()),
-              "sm_gram_masked")
+        hip.check(fn(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
+                     ptr(amax_feat) if GRAM_MODE == "split2" else None, hip.stream()), "sm_gram_masked_split")
+        return n
+    hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
+                                 hip.stream()), "sm_gram_masked")
     return n
 
 
 def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight, C, D0, D1, loss_out,
-               history=None, hist_len=0, hist_slot=0, n_slabs=1):
+               history=None, hist_len=0, hist_slot=0, n_slabs=1, amax_d_out=None):
     hip.check(lib.sm_style_loss(ptr(S0), ptr(S1), ptr(counts), ptr(factor), hip.ptr_array(targets),
                                 hip.int_array(term_mask), len(targets), hip.int_array(skip_if_empty), weight, C,
                                 ptr(D0), ptr(D1), ptr(loss_out), ptr(history), hist_len, hist_slot, n_slabs,
-                                hip.stream()), "sm_style_loss")
+                                ptr(amax_d_out), hip.stream()), "sm_style_loss")
 
 
 _GRAM_BWD_WS = {}   # device -> scratch for the bf16x3 image of D0 / D1 (largest C = 512: 3 MB)
 
 
-def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool):
-    if GRAM_MODE == "split":
+def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool, amax_feat=None, amax_d=None):
+    """``amax_feat`` / ``amax_d`` (device floats; 'split2' mode): bounds of max |feat| and max(|D0|, |D1|)."""
+    if GRAM_MODE in ("split", "split2"):
+        two = GRAM_MODE == "split2"
+        assert not two or (amax_feat is not None and amax_d is not None), "GRAM_MODE 'split2' needs the operand bounds"
         key = (str(D0.device), hip.stream())   # one scratch per launch stream
         need = lib.sm_gram_backward_split_ws_bytes(feat.C)
         if key not in _GRAM_BWD_WS or _GRAM_BWD_WS[key].numel() < need:
             _GRAM_BWD_WS[key] = torch.empty(max(need, lib.sm_gram_backward_split_ws_bytes(512)), dtype=torch.uint8,
                                             device=D0.device)
         hip.check(lib.sm_gram_backward_split(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C,
-                                             feat.H, feat.W, int(relu_gate), ptr(_GRAM_BWD_WS[key]), hip.stream()),
-                  "sm_gram_backward_split")
+                                             feat.H, feat.W, int(relu_gate), ptr(_GRAM_BWD_WS[key]),
+                                             ptr(amax_feat) if two else None, ptr(amax_d) if two else None,
+                                             hip.stream()), "sm_gram_backward_split")
         return
     hip.check(lib.sm_gram_backward(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C, feat.H,
                                    feat.W, int(relu_gate), hip.stream()), "sm_gram_backward")

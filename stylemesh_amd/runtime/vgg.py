@@ -80,7 +80,7 @@ class AmaxBook:
 
 
 def _amax_on():
-    return ops.CONV_MODE == "split2"
+    return ops.CONV_MODE == "split2" or ops.GRAM_MODE == "split2"
 
 
 class LevelBuffers:

@@ -445,7 +445,7 @@ def test_touch_flags_cover_the_scatter(rt):
 
 
 # ------------------------------------------------------------------ K5 / K6
-@pytest.mark.parametrize("gram_mode", ["f32", "split"])
+@pytest.mark.parametrize("gram_mode", ["f32", "split", "split2"])
 @pytest.mark.parametrize("C,H,W,multi", [(64, 20, 28, True), (128, 10, 14, True), (256, 5, 7, False), (64, 50, 70, False),
                                            (64, 150, 200, True), (512, 12, 17, True), (128, 40, 56, True),
                                            (256, 33, 41, True)])
@@ -474,30 +474,33 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi, gram_mode, monkeypatch
     mk = [rt.FMap(1, H, W).from_dense(m[0]) if m is not None else None for m in masks]
     ns, na = rt.ops.gram_num_slabs(C, H, W), rt.ops.gram_workspace_slabs(C, H, W)
     S = [torch.full((na, C, C), 7.0).cuda(), torch.full((na, C, C), 7.0).cuda() if multi else None]   # no pre-zeroing needed
-    assert rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1]) == ns
+    af = dev(feat.detach().abs().max().reshape(1))     # the bound the producing conv records (fp16x2 mode)
+    assert rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1], amax_feat=af) == ns
     n0 = float(masks[0].sum())
     ref_S0 = gp[0] * n0
     T = C // 64
     tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
     assert_close(S[0][:ns].sum(0).cpu()[tile_upper], ref_S0.detach()[tile_upper], 1e-4, 1e-4 * float(ref_S0.abs().max()))
-    if gram_mode == "split":
+    if gram_mode != "f32":
         # accumulate variant: adds into caller-zeroed slabs (the engine zeroes every slab of a step with one fill)
         A = [torch.zeros(na, C, C).cuda(), torch.zeros(na, C, C).cuda() if multi else None]
         for rep in (1, 2):
-            rt.ops.gram_masked(f, mk[0], mk[1], A[0], A[1], prezeroed=True)
+            rt.ops.gram_masked(f, mk[0], mk[1], A[0], A[1], prezeroed=True, amax_feat=af)
             assert_close(A[0][0].cpu()[tile_upper], rep * S[0][:ns].sum(0).cpu()[tile_upper], 1e-5,
                          1e-5 * float(ref_S0.abs().max()))
     counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
     D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
     loss_out = torch.zeros(1).cuda()
+    ad = torch.zeros(1).cuda()
     rt.ops.style_loss(S[0], S[1], counts, dev(torch.tensor([factor])), [dev(t) for t in targets], term_mask, skip,
-                      weight, C, D[0], D[1], loss_out, n_slabs=ns)
+                      weight, C, D[0], D[1], loss_out, n_slabs=ns, amax_d_out=ad)
     assert_close(loss_out, loss.detach().reshape(1), 1e-4, 0)
+    assert float(ad) == max(float(d.abs().max()) for d in D if d is not None)    # bound of the derivative matrices
     df = rt.FMap(C, H, W)
-    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=False)
+    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=False, amax_feat=af, amax_d=ad)
     assert_close(df.to_dense(), feat.grad[0], 1e-4, 2e-5 * float(feat.grad.abs().max()))
     assert df.border_is_zero()
-    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=True)
+    rt.ops.gram_backward(f, mk[0], mk[1], D[0], D[1], df, relu_gate=True, amax_feat=af, amax_d=ad)
     assert_close(df.to_dense(), feat.grad[0] * (feat.detach()[0] > 0), 1e-4, 2e-5 * float(feat.grad.abs().max()))
 
 

@@ -8,7 +8,7 @@ from stylemesh_amd.runtime.fmap import FMap
 LAYERS = [(64, 1), (128, 2), (256, 4), (512, 8), (512, 16)]
 LEVELS = [(256, 341), (432, 576), (608, 811), (784, 1045)]
 sel = [int(a) for a in sys.argv[1:]] or [0, 3]
-tot = {m: [0.0, 0.0] for m in ("f32", "split")}
+tot = {m: [0.0, 0.0] for m in ("f32", "split", "split2")}
 for li in sel:
     H0, W0 = LEVELS[li]
     for C, div in LAYERS:
@@ -26,10 +26,12 @@ for li in sel:
         df = FMap(C, H, W)
         line = f"{H0}x{W0} C={C:3d} {H:4d}x{W:4d}"
         res = {}
-        for mode in ("f32", "split"):
+        af = f.planes.abs().max().reshape(1).contiguous()
+        ad = torch.maximum(D0.abs().max(), D1.abs().max()).reshape(1).contiguous()
+        for mode in ("f32", "split", "split2"):
             ops.GRAM_MODE = mode
-            for which, fn in (("fwd", lambda: ops.gram_masked(f, m0, m1, S0, S1)),
-                              ("bwd", lambda: ops.gram_backward(f, m0, m1, D0, D1, df, relu_gate=False))):
+            for which, fn in (("fwd", lambda: ops.gram_masked(f, m0, m1, S0, S1, amax_feat=af)),
+                              ("bwd", lambda: ops.gram_backward(f, m0, m1, D0, D1, df, relu_gate=False, amax_feat=af, amax_d=ad))):
                 for _ in range(2): fn()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
