@@ -125,7 +125,7 @@ class ScanNetSceneDataset:
         rgb = rgb.resize((w_new, h_new))                                 # PIL default filter, as the reference (:299)
         depth_r = vc.resize_bilinear_np(depth, (h_new, w_new))           # cv2.INTER_LINEAR (:301)
         angle_r = vc.resize_nearest_np(angle, (h_new, w_new))            # cv2.INTER_NEAREST (:308)
-        mask_r = vc.resize_nearest_np(mask_big, (h_new, w_new))          # PIL NEAREST (:311)
+        mask_r = vc.resize_mask_pil(mask_big, (h_new, w_new))            # PIL NEAREST on the mode-"1" image (:311)
         K = np.array(self.intrinsics)
         iw, ih = self.intrinsic_image_size
         if (iw, ih) != (w_new, h_new) and iw > 0 and ih > 0:            # modify_intrinsics_matrix (:257-265)

@@ -53,13 +53,23 @@ def resize_bilinear_np(img: np.ndarray, out_hw) -> np.ndarray:
 
 
 def resize_nearest_np(img: np.ndarray, out_hw) -> np.ndarray:
-    """Legacy nearest resize ``src = floor(dst * in / out)`` (cv2.INTER_NEAREST / PIL NEAREST as used at
-    ``data/abstract_dataset.py:308,311``)."""
+    """Legacy nearest resize ``src = floor(dst * in / out)`` (cv2.INTER_NEAREST as used for the angle map at
+    ``data/abstract_dataset.py:308``; the mask goes through Pillow instead: ``resize_mask_pil``)."""
     h, w = img.shape[:2]
     oh, ow = out_hw
     ys = np.minimum((np.arange(oh) * (h / oh)).astype(np.int64), h - 1)
     xs = np.minimum((np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
     return img[ys][:, xs]
+
+
+def resize_mask_pil(mask: np.ndarray, out_hw) -> np.ndarray:
+    """The reference's mask resize: ``Image.fromarray(bool mask).resize((w, h), Image.NEAREST)``
+    (``data/scannet_dataset.py:325``, ``data/abstract_dataset.py:311``). Pillow's nearest filter samples at pixel
+    CENTRES (source index = floor((dst + 0.5) * in / out), accumulated step by step in double) - not cv2's / torch's
+    legacy ``floor(dst * in / out)`` - so the same Pillow call is made here rather than restated."""
+    from PIL import Image
+    h, w = out_hw
+    return np.asarray(Image.fromarray(np.ascontiguousarray(mask, dtype=bool)).resize((int(w), int(h)), Image.NEAREST)).astype(bool)
 
 
 def calculate_mask(uvmap: np.ndarray, depth: np.ndarray | None = None) -> np.ndarray:
@@ -152,7 +162,7 @@ def assemble_batch(rgb01_chw: torch.Tensor, depth_hw: np.ndarray, uv_levels, ang
     """
     H, W = depth_hw.shape
     mask_big = calculate_mask(uv_levels[-1], depth_hw if use_depth_in_mask else None)
-    mask = resize_nearest_np(mask_big, (H, W))
+    mask = resize_mask_pil(mask_big, (H, W))
     cont, rounded, other, w = calculate_depth_level(depth_hw, levels, min_pyramid_depth)
     angle = torch.from_numpy(np.ascontiguousarray(angle_cos_hw, dtype=np.float32))[None, None]
     eye = torch.eye(4, dtype=torch.float64)[None]

@@ -1,11 +1,12 @@
-"""Condense the FETCH_SIZE / WRITE_SIZE PMC summary (tools/pmc_traffic.sh) into profiles/r01/conv_traffic_<wl>_<tag>.json.
-Usage: traffic_json.py <summary.csv> <workload> <tag: split|f32> <out.json>
+"""Condense the FETCH_SIZE / WRITE_SIZE PMC summary (tools/pmc_traffic.sh) into profiles/rNN/conv_traffic_<wl>_<tag>.json.
+Usage: traffic_json.py <summary.csv> <workload> <tag: split2|split|f32> <out.json>
 FETCH_SIZE on gfx950 under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md); the factor is re-derived from
 the Adam kernel of the same run, whose traffic is known exactly (7 fp32 streams over the texture arena)."""
 import csv, json, sys
 src, wl, tag, out = sys.argv[1:5]
 rows = list(csv.DictReader(open(src)))
-kern = "conv3x3_split_kernel" if tag == "split" else "conv3x3_mfma_kernel"
+kern = "conv3x3_split_kernel" if tag in ("split", "split2") else "conv3x3_mfma_kernel"
+np_arg = {"split": ", 3>", "split2": ", 2>"}.get(tag, "")     # last template argument: parts per operand
 def col(r, name):
     for k, v in r.items():
         if k.startswith(name):
@@ -14,7 +15,7 @@ def col(r, name):
 fetch = write = launches = 0.0
 adam = None
 for r in rows:
-    if kern in r["kernel"]:
+    if kern in r["kernel"] and np_arg in r["kernel"]:
         fetch += r.get("FETCH_SIZE") and float(r["FETCH_SIZE"]) or 0.0
         write += r.get("WRITE_SIZE") and float(r["WRITE_SIZE"]) or 0.0
         launches += col(r, "launches@FETCH")
