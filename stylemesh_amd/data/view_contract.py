@@ -45,11 +45,30 @@ def post(x: torch.Tensor) -> torch.Tensor:
     return x[[2, 1, 0]].clamp(0, 1)
 
 
+def _cv2_linear_taps(n_in: int, n_out: int):
+    """Source index and fraction of cv2's INTER_LINEAR along one axis (imgproc/resize.cpp): the coordinate
+    ``(dst + 0.5) * in / out - 0.5`` is formed in double and rounded to float, the fraction is dropped at both borders."""
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo, hi = s < 0, s >= n_in - 1
+    s = np.clip(s, 0, n_in - 1)
+    f[lo | hi] = 0.0
+    return s, np.minimum(s + 1, n_in - 1), f
+
+
 def resize_bilinear_np(img: np.ndarray, out_hw) -> np.ndarray:
-    """Half-pixel-centre bilinear resize of a 2-D float array (cv2.INTER_LINEAR convention, used by
-    the reference at ``data/abstract_dataset.py:301`` and ``data/scannet_dataset.py:323``)."""
-    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None, None]
-    return F.interpolate(t, size=tuple(out_hw), mode="bilinear", align_corners=False)[0, 0].numpy()
+    """``cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR)`` of a 2-D float32 array, as the reference uses it at
+    ``data/abstract_dataset.py:301`` and ``data/scannet_dataset.py:323``: half-pixel centres, no anti-aliasing, float
+    weights, horizontal pass first (cv2 is absent from the target image; tests/test_reference_conventions.py checks
+    this against a loop restatement and hand-worked samples)."""
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    oh, ow = out_hw
+    x0, x1, fx = _cv2_linear_taps(a.shape[1], int(ow))
+    y0, y1, fy = _cv2_linear_taps(a.shape[0], int(oh))
+    one = np.float32(1.0)
+    rows = a[:, x0] * (one - fx) + a[:, x1] * fx                       # float32 throughout, like cv2's WT = float
+    return (rows[y0] * (one - fy)[:, None] + rows[y1] * fy[:, None]).astype(np.float32)
 
 
 def resize_nearest_np(img: np.ndarray, out_hw) -> np.ndarray:

@@ -35,10 +35,12 @@ class Mesh:
         self._scratch = {}
 
 
-def load_obj(path, device="cuda") -> Mesh:
+def load_obj(path, device="cuda", flip_uvs=True) -> Mesh:
     """Wavefront OBJ with ``v`` / ``vt`` / ``vn`` / ``f a/b/c ...`` records (polygons are fanned); every face corner
     becomes its own vertex, as Assimp hands them to the reference renderer (include/model.h). Missing normals are
-    replaced by the face normal."""
+    replaced by the face normal. ``flip_uvs``: the reference imports with ``aiProcess_FlipUVs``
+    (scripts/scannet/render_uv/include/model.h:57), i.e. the rendered UV maps hold (u, 1 - v) of the file's ``vt``
+    records (the file's v = 0 is the BOTTOM row of the texture image, the UV map's v = 0 the top row)."""
     v, vt, vn, corners, faces = [], [], [], {}, []
     out_v, out_t, out_n = [], [], []
     with open(path) as f:
@@ -66,8 +68,13 @@ def load_obj(path, device="cuda") -> Mesh:
     v = np.asarray(v, dtype=np.float32)
     res = lambda i, n: i - 1 if i > 0 else n + i          # OBJ indices are 1-based, negative = relative
     verts = v[[res(i, len(v)) for i in out_v]]
-    uvs = (np.asarray(vt, dtype=np.float32)[[res(i, len(vt)) for i in out_t]] if vt and all(out_t)
-           else np.zeros((len(out_v), 2), np.float32))
+    if vt and all(out_t):
+        uvs = np.asarray(vt, dtype=np.float64)[[res(i, len(vt)) for i in out_t]]
+        if flip_uvs:
+            uvs = np.stack([uvs[:, 0], 1.0 - uvs[:, 1]], 1)    # in double: exact inverse of save_obj's flip
+        uvs = uvs.astype(np.float32)
+    else:
+        uvs = np.zeros((len(out_v), 2), np.float32)
     faces = np.asarray(faces, dtype=np.int32).reshape(-1, 3)
     if vn and all(out_n):
         normals = np.asarray(vn, dtype=np.float32)[[res(i, len(vn)) for i in out_n]]
@@ -78,6 +85,37 @@ def load_obj(path, device="cuda") -> Mesh:
             np.add.at(normals, faces[:, k], fn)
         normals /= np.maximum(np.linalg.norm(normals, axis=1, keepdims=True), 1e-20)
     return Mesh(verts, normals, uvs, faces, device)
+
+
+def save_obj(mesh: Mesh, path, flip_uvs=True):
+    """Write ``mesh`` as a Wavefront OBJ that ``load_obj`` (same ``flip_uvs``) reads back unchanged: with ``flip_uvs``
+    the file holds (u, 1 - v), the convention of the reference's input meshes."""
+    v, n, t, f = (x.detach().cpu().numpy() for x in (mesh.verts, mesh.normals, mesh.uvs, mesh.faces))
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write(f"v {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n")
+        for p in t:
+            fh.write(f"vt {float(p[0])!r} {(1.0 - float(p[1])) if flip_uvs else float(p[1])!r}\n")
+        for p in n:
+            fh.write(f"vn {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n")
+        for a, b, c in f + 1:
+            fh.write(f"f {a}/{a}/{a} {b}/{b}/{b} {c}/{c}/{c}\n")
+
+
+def project_points(cam2world, intrinsics4, points_world):
+    """The projection ``sm_raster_maps`` implements, on the host (numpy, float64): world points [N,3] -> (x, y, depth)
+    with x = fx X / Z + cx, y = fy Y / Z + cy in the camera frame of the ScanNet pose (x right, y down, z forward) and
+    depth = Z. Pixel (i, j) of the output maps is the sample at (x, y) = (i + 0.5, j + 0.5); row 0 is the TOP row of
+    the image. This equals the reference's OpenGL pipeline - view matrix of scannet_renderer.cpp:19-84, projection of
+    include/util.h:11-35 (intrinsics normalised by the native image size), window transform of the render size,
+    ``glReadPixels`` rows bottom-up with ``flip = 0``, ``LinearizeDepth`` of depth.frag - term by term
+    (tests/test_reference_conventions.py restates that pipeline and compares)."""
+    c2w = np.asarray(cam2world.detach().cpu() if torch.is_tensor(cam2world) else cam2world, dtype=np.float64)
+    w2c = np.linalg.inv(c2w)
+    p = np.asarray(points_world, dtype=np.float64)
+    pc = p @ w2c[:3, :3].T + w2c[:3, 3]
+    fx, fy, cx, cy = [float(v) for v in intrinsics4]
+    return np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy, pc[:, 2]], 1)
 
 
 def box_room_mesh(room, device="cuda", subdiv: int = 1) -> Mesh:
@@ -136,25 +174,29 @@ def render_maps(mesh: Mesh, cam2world, intrinsics4, hw, znear=0.1, zfar=10.0):
     return uv, ang, dep
 
 
-def render_trajectory(mesh: Mesh, poses, names, K, native_wh, out_dir, heights, aspect=None, full_hw=None):
+def render_trajectory(mesh: Mesh, poses, names, K, native_wh, out_dir, heights, aspect=None, full_hw=None, flip=False):
     """Write what scripts/scannet/render_uvs.py produces for one scene: ``uv_<h>/<name>.npy`` (H,W,3 float32) for
     every pyramid height, and in ``uv/`` (at ``full_hw``, default the largest level) ``<name>.npy``,
-    ``<name>.angle.npy`` and ``<name>.rendered_depth.npy`` (3 identical channels, as the reference's read-back)."""
+    ``<name>.angle.npy`` and ``<name>.rendered_depth.npy`` (3 identical channels, as the reference's read-back).
+    ``flip``: the renderer's ``<flip>`` argument (src/main.cpp:39-43, ``Renderer::saveUV``): rows written in reverse
+    order. With ``flip = 0`` row 0 of the file is the top image row (the reference's projection does not negate y, so
+    its bottom-up ``glReadPixels`` rows come out top-down)."""
     aspect = aspect if aspect is not None else native_wh[0] / native_wh[1]
     levels = [(int(h), int(round(h * aspect))) for h in heights]
     full_hw = tuple(full_hw) if full_hw is not None else levels[-1]
     os.makedirs(os.path.join(out_dir, "uv"), exist_ok=True)
+    rows = (lambda a: np.ascontiguousarray(a[::-1])) if flip else (lambda a: a)
     for pose, name in zip(poses, names):
         for (h, w), hh in zip(levels, heights):
             d = os.path.join(out_dir, f"uv_{hh}")
             os.makedirs(d, exist_ok=True)
             uv, _, _ = render_maps(mesh, pose, scaled_intrinsics(K, native_wh, (w, h)), (h, w))
-            np.save(os.path.join(d, f"{name}.npy"), uv.cpu().numpy())
+            np.save(os.path.join(d, f"{name}.npy"), rows(uv.cpu().numpy()))
         uv, ang, dep = render_maps(mesh, pose, scaled_intrinsics(K, native_wh, (full_hw[1], full_hw[0])), full_hw)
-        np.save(os.path.join(out_dir, "uv", f"{name}.npy"), uv.cpu().numpy())
-        np.save(os.path.join(out_dir, "uv", f"{name}.angle.npy"), ang[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
+        np.save(os.path.join(out_dir, "uv", f"{name}.npy"), rows(uv.cpu().numpy()))
+        np.save(os.path.join(out_dir, "uv", f"{name}.angle.npy"), rows(ang[..., None].expand(-1, -1, 3).contiguous().cpu().numpy()))
         np.save(os.path.join(out_dir, "uv", f"{name}.rendered_depth.npy"),
-                dep[..., None].expand(-1, -1, 3).contiguous().cpu().numpy())
+                rows(dep[..., None].expand(-1, -1, 3).contiguous().cpu().numpy()))
 
 
 def build_mipmaps(image: torch.Tensor, min_size: int = 1):

@@ -62,7 +62,8 @@ def texture_close(mine, ref, step, what):
         assert int((err > 1e-5).sum()) <= 3, (what, int((err > 1e-5).sum()))
         return
     f3, f2 = float((err > 2e-3).float().mean()), float((err > 2e-2).float().mean())
-    assert (f3 <= 0.03 or (err > 2e-3).sum() <= 6) and (f2 <= 0.01 or (err > 2e-2).sum() <= 2) and float(err.max()) <= 0.3, \
+    # (the coarsest layer of the test textures has 192 texels: the fractions are floored at a handful of texels)
+    assert (f3 <= 0.03 or (err > 2e-3).sum() <= 8) and (f2 <= 0.01 or (err > 2e-2).sum() <= 2) and float(err.max()) <= 0.3, \
         f"{what}: {f3:.4f} of texels beyond 2e-3, {f2:.4f} beyond 2e-2, max {float(err.max()):.3e} (n = {n})"
 
 

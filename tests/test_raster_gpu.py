@@ -87,14 +87,12 @@ def test_obj_loader_and_scene_writer_feed_the_loader(R, tmp_path):
     """OBJ round trip, and the files written by ``render_trajectory`` are readable by the ScanNet-layout loader."""
     room = S.BoxRoom((6.0, 4.5, 2.8))
     m = R.box_room_mesh(room, subdiv=1)
-    v, n, t, f = (x.cpu().numpy() for x in (m.verts, m.normals, m.uvs, m.faces))
     obj = tmp_path / "room.obj"
-    with open(obj, "w") as fh:
-        for p in v: fh.write(f"v {p[0]} {p[1]} {p[2]}\n")
-        for p in t: fh.write(f"vt {p[0]} {p[1]}\n")
-        for p in n: fh.write(f"vn {p[0]} {p[1]} {p[2]}\n")
-        for a, b, c in f + 1: fh.write(f"f {a}/{a}/{a} {b}/{b}/{b} {c}/{c}/{c}\n")
+    R.save_obj(m, str(obj))                      # (u, 1 - v) in the file: the reference's meshes, model.h:57
     m2 = R.load_obj(str(obj))
+    assert torch.equal(m2.uvs[m2.faces.long()], m.uvs[m.faces.long()])
+    raw = R.load_obj(str(obj), flip_uvs=False)
+    assert torch.allclose(raw.uvs[:, 1], 1.0 - m2.uvs[:, 1], atol=1e-7) and torch.equal(raw.uvs[:, 0], m2.uvs[:, 0])
     hw = (48, 64)
     K, c2w = S.camera_matrices((3.0, 2.0, 1.4), 0.4, 0.0, hw)
     intr = np.array([K[0, 0], K[1, 1], K[0, 2] + 0.5, K[1, 2] + 0.5], dtype=np.float32)
@@ -147,3 +145,49 @@ def test_mipmapped_textured_rerender(R):
     assert float(lod2[hit2].median()) == 0.0
     want2 = f(uv2[..., 0], uv2[..., 1])
     assert float((rgb2 - want2).abs()[:, hit2].mean()) < 2e-3
+
+
+def test_pixel_row_depth_and_uv_conventions_of_the_reference_pipeline(R):
+    """f3 pin on the kernel itself: small camera-facing triangles around known camera-space points, a ScanNet-style pose
+    and off-centre intrinsics at a render size different from the native one. ``project_points`` - shown equal to the
+    reference's OpenGL pipeline (view / projection matrices, window transform, bottom-up read-back with flip = 0,
+    LinearizeDepth) in tests/test_reference_conventions.py - names the pixel each triangle must cover, its depth and,
+    after ``aiProcess_FlipUVs``, its uv."""
+    rng = np.random.default_rng(11)
+    native_wh, hw = (1296, 968), (256, 343)
+    K = np.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 1170.2, 1170.2, 0.52 * 1296, 0.47 * 968
+    intr = R.scaled_intrinsics(K, native_wh, (hw[1], hw[0]))
+    a, b = 0.4, -0.3
+    Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    c2w = np.eye(4)
+    c2w[:3, :3], c2w[:3, 3] = Rm, [0.7, -0.2, 1.1]
+    n = 60
+    px = np.stack([rng.uniform(8, hw[1] - 8, n), rng.uniform(8, hw[0] - 8, n)], 1)          # target (x, y) in pixels
+    Z = rng.uniform(0.5, 6.0, n)
+    cam = np.stack([(px[:, 0] - intr[0 + 2]) / intr[0] * Z, (px[:, 1] - intr[3]) / intr[1] * Z, Z], 1)
+    d = 2.5 * Z / intr[0]                                                                   # ~2.5 px half-size
+    tri = np.stack([cam + np.stack([-d, -d, 0 * d], 1), cam + np.stack([2 * d, -d, 0 * d], 1),
+                    cam + np.stack([-d, 2 * d, 0 * d], 1)], 1)                              # [n,3,3], plane z = Z
+    world = tri.reshape(-1, 3) @ Rm.T + c2w[:3, 3]
+    uv_file = np.repeat(rng.uniform(0.05, 0.95, (n, 2)), 3, 0)
+    obj = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"probe_{os.getpid()}.obj")
+    with open(obj, "w") as fh:
+        for p in world: fh.write(f"v {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n")
+        for t in uv_file: fh.write(f"vt {float(t[0])!r} {float(t[1])!r}\n")
+        for k in range(n): fh.write(f"f {3*k+1}/{3*k+1} {3*k+2}/{3*k+2} {3*k+3}/{3*k+3}\n")
+    mesh = R.load_obj(obj)                                                                   # FlipUVs: (u, 1 - v)
+    os.remove(obj)
+    uv, ang, dep = (t.cpu().numpy() for t in R.render_maps(mesh, c2w, intr, hw))
+    proj = R.project_points(c2w, intr, cam @ Rm.T + c2w[:3, 3])
+    np.testing.assert_allclose(proj[:, :2], px, atol=1e-3)
+    col, row = np.floor(proj[:, 0]).astype(int), np.floor(proj[:, 1]).astype(int)           # row 0 = top image row
+    hit = dep[row, col] > 0
+    assert hit.all()
+    nearest = np.array([Z[(np.abs(px[:, 0] - px[k, 0]) < 9) & (np.abs(px[:, 1] - px[k, 1]) < 9)].min() for k in range(n)])
+    front = nearest == Z                                                                    # not hidden by a closer probe
+    np.testing.assert_allclose(dep[row, col][front], Z[front], rtol=2e-4)
+    want_uv = np.stack([uv_file[::3, 0], 1.0 - uv_file[::3, 1]], 1)
+    np.testing.assert_allclose(uv[row, col][front][:, :2], want_uv[front], atol=2e-5)
+    assert float((dep > 0).mean()) < 0.05                                                    # background stays 0
