@@ -157,8 +157,13 @@ typedef struct {
     const float* gate;
     int H, W;
 } sm_conv_problem;
-/* amax_out (optional, DEVICE float, caller-zeroed): the launch max-es max |output| into it (atomic max on the bit
- * pattern of a non-negative float) - the operand scale of an sm_conv3x3_grouped_split2 that consumes the output. */
+/* "amax" bounds. An amax argument is a DEVICE array of sm_amax_floats() floats (64 slots, 256 bytes apart), zeroed by
+ * the caller before the first launch that records into it; its VALUE is the maximum over the slots. Writers atomically
+ * max max |output| into one slot per block (bit pattern of a non-negative float; spreading the words keeps thousands
+ * of concurrent same-address atomics from serialising), readers take the max of the slots.
+ * amax_out (optional): the launch records max |output| - the operand bound of an sm_conv3x3_grouped_split2 /
+ * sm_gram_*_split that consumes the output. */
+int sm_amax_floats(void);
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
                        size_t ws_floats, float* amax_out, void* stream);
@@ -178,7 +183,7 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
  * 2^-22 of a product. fp16 has 5 exponent bits, so both operands are scaled by powers of two:
  *   wt2 = the weights times a power of two s_w that puts max |w| into [2^14, 2^15), split by the host into
  *         [9 taps][Cin/16][2 parts][2][Cout][8] fp16 (runtime/ops.py:pack_conv_split2); w_scale_inv = 1 / s_w;
- *   amax_in (DEVICE float, required) = an upper bound of max |x| over the input planes of all problems, recorded by
+ *   amax_in (amax array, required) = an upper bound of max |x| over the input planes of all problems, recorded by
  *         the kernel that produced them (amax_out of that launch; a max-pool passes its input's bound through): the
  *         kernel scales x by the power of two that maps amax_in into [2^14, 2^15) while it stages the operand;
  *   the epilogue multiplies the accumulators by the (exact) inverse scales before bias / add / gate.
@@ -188,7 +193,7 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
 int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
                               const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
                               float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream);
-/* max |x| over a feature map [C][plane(H,W)], max-ed into *amax_out like the convolutions' amax_out: the operand
+/* max |x| over a feature map [C][plane(H,W)], max-ed into the amax array like the convolutions' amax_out: the operand
  * bound of sm_conv3x3_grouped_split2 for tensors no convolution produced (the deepest loss layer's gradient). */
 int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream);
 /* tile_list (optional, DEVICE array of n_list entries (problem << 24) | tile): compute only these position
@@ -256,7 +261,7 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
  * ONE slab with fp32 atomics (no reduction pass): afterwards S_k = the first sm_gram_split_num_slabs() = 1 slab
  * (upper-triangular 64x64 tiles valid; S0 / S1 need room for one [C][C] slab only). Stages whose 16 mask values
  * are all zero are skipped before their data is loaded.
- * amax_feat (optional, DEVICE float): bound of max |feat| recorded by the producing conv - given, the operand is
+ * amax_feat (optional, amax array): bound of max |feat| recorded by the producing conv - given, the operand is
  * split into two fp16 parts scaled by a power of two and three partial products are taken (sm_conv3x3_grouped_split2);
  * NULL = three bf16 parts, six products. */
 int sm_gram_split_num_slabs(void);
@@ -278,7 +283,7 @@ int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float*
  * the loss value to *loss_out. history (may be NULL): [9][C][C] ring of past normalised mask-0 Grams for
  * gram_mode 'average' (:319-323): the first hist_len entries are averaged with the current Gram, which is
  * then stored in entry hist_slot. targets / term_mask / skip_if_empty are HOST arrays (<= 4 terms).
- * amax_d_out (optional, DEVICE float, caller-zeroed): receives max(|D0|, |D1|), the operand bound of the fp16x2
+ * amax_d_out (optional, amax array, caller-zeroed): receives max(|D0|, |D1|), the operand bound of the fp16x2
  * sm_gram_backward_split. */
 int sm_style_loss(const float* S0, const float* S1, const float* counts, const float* factor,
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty,
@@ -292,7 +297,7 @@ int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, 
 
 /* K5c on the bf16 matrix cores (same split). ws: DEVICE scratch of sm_gram_backward_split_ws_bytes(C) bytes that
  * receives the split image of D0 / D1 (a small pack kernel runs first on the same stream).
- * amax_feat / amax_d (both or neither; DEVICE floats): bounds of max |feat| and max(|D0|, |D1|) - given, the
+ * amax_feat / amax_d (both or neither; amax arrays): bounds of max |feat| and max(|D0|, |D1|) - given, the
  * operands are split into two fp16 parts scaled by powers of two and three partial products are taken (as
  * sm_conv3x3_grouped_split2); NULL = three bf16 parts, six products. */
 size_t sm_gram_backward_split_ws_bytes(int C);

@@ -36,16 +36,40 @@ __device__ __forceinline__ void split3x8(const float (&x)[8], f32x4& vh, f32x4& 
     vl = __builtin_bit_cast(f32x4, l);
 }
 
-// wave-wide max of a non-negative value -> at most one atomic max (bit patterns of non-negative floats order like
-// uints). Same-address device atomics serialise at ~12 ns each (8 k of them cost a small kernel 100 us), so a wave first
-// reads the current value - it only grows - and skips the atomic unless it would raise it: after the first few
-// hundred waves of a launch almost none does.
-__device__ __forceinline__ void record_amax(float* amax_out, float v) {
+// ---- "amax" bounds: max |x| of what a launch writes = the operand bound of the fp16x2 kernels that read it ----------
+// A bound is SM_AMAX_SLOTS words spaced SM_AMAX_STRIDE floats (256 bytes) apart; its value is the maximum over the
+// slots. Writers: a wave-wide max, then at most one atomic max on the bit pattern (non-negative floats order like
+// uints) into the slot of the wave's BLOCK (block id mod 64). Why slots: EVERY same-address access that reaches the L2 /
+// fabric serialises there - an atomic costs ~12 ns, a coherent load ~2.5 ns - and a launch whose 16 k waves start
+// together all see the same stale value: one word made a 6.5 us second-pass kernel take 47 us. Spread over 64 cache
+// lines the same traffic is 64 short queues. A wave also peeks at its slot with a PLAIN vector load (served by the CU's
+// L1; possibly stale, which only costs a redundant atomic - a bound only grows) beside the kernel's first loads and
+// skips the atomic unless it would raise the slot. Readers (`amax_read`): lane l loads slot l, wave max - one vector
+// load + six cross-lane steps per wave at kernel start.
+#define SM_AMAX_SLOTS 64
+#define SM_AMAX_STRIDE 64
+__device__ __forceinline__ int amax_slot_offset() {
+    return (int)((blockIdx.x + blockIdx.y * gridDim.x) & (SM_AMAX_SLOTS - 1)) * SM_AMAX_STRIDE;
+}
+__device__ __forceinline__ float amax_peek(const float* amax_out) {
+    if (amax_out == nullptr) return 0.f;
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));   // opaque index: a vector (L1) load, not a scalar one
+    return amax_out[amax_slot_offset() + zero];
+}
+__device__ __forceinline__ void record_amax(float* amax_out, float v, float seen) {
     if (amax_out == nullptr) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, v));
+    if ((threadIdx.x & 63) == 0 && v > seen)
+        atomicMax(reinterpret_cast<unsigned*>(amax_out + amax_slot_offset()), __builtin_bit_cast(unsigned, v));
+}
+// the bound's value, uniform over the wave (every lane returns the max over the slots)
+__device__ __forceinline__ float amax_read(const float* amax) {
+    float v = amax[(threadIdx.x & (SM_AMAX_SLOTS - 1)) * SM_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

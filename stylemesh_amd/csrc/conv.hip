@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int m0 = m_tile * BM;
     const int q0 = P.Wp + n_tile * BN;  // first computed position = start of row 1
 
+    const float amax_seen = split < 0 ? amax_peek(a.amax_out) : 0.f;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     }
-    record_amax(a.amax_out, vmax);
+    record_amax(a.amax_out, vmax, amax_seen);
 }
 
 // Tail second pass: one block per tail tile; out = epilogue(sum over its K-splits), 4 positions per thread.
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     }
     const int m0 = m_tile * BM, q0 = P.Wp + n_tile * BN, q_end = (P.H + 1) * P.Wp;
     const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
+    const float amax_seen = amax_peek(a.amax_out);   // beside the slab loads, not behind the stores
     {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
         const int e = blockIdx.y * 256 + threadIdx.x;
         const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
             }
             *reinterpret_cast<f32x4*>(P.out + o) = v;
         }
-        record_amax(a.amax_out, m);
+        record_amax(a.amax_out, m, amax_seen);
     }
 }
 
@@ -277,12 +279,13 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
 __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict__ in, int plane, int q_begin, int q_end,
                                                         float* amax_out) {
     const float* p = in + (size_t)blockIdx.y * plane;
+    const float seen = amax_peek(amax_out);
     float m = 0.f;
     for (int q = q_begin + (blockIdx.x * 256 + threadIdx.x) * 4; q < q_end; q += gridDim.x * 1024) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(p + q);     // q_begin, q_end: multiples of 4
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    record_amax(amax_out, m);
+    record_amax(amax_out, m, seen);
 }
 
 // SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
@@ -560,6 +563,8 @@ static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws
         default: return (int)hipErrorInvalidValue;
     }
 }
+
+int sm_amax_floats(void) { return SM_AMAX_SLOTS * SM_AMAX_STRIDE; }
 
 int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream) {
     if (C < 1 || amax_out == nullptr) return (int)hipErrorInvalidValue;

@@ -162,6 +162,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int m0 = m_tile * BM;
     const int q0 = P.Wp + n_tile * BN;
 
+    const float amax_seen = split < 0 ? amax_peek(a.amax_out) : 0.f;   // whole tiles record their output's bound
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -181,11 +182,11 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int a_voff = (lhi * a.Cout + m0 + wm + l31) * 16;   // bytes
     const int a_part = 2 * a.Cout * 16;            // bytes between the parts of a stage
     const int a_stage_bytes = 2 * NP * a.Cout * 16;   // bytes per (tap, chunk) stage
-    // NP = 2: operand scale from the producer's recorded max |x| (block-uniform scalar loads)
+    // NP = 2: operand scale from the producer's recorded max |x| (one vector load of the bound's slots per wave)
     float in_scale = 1.f, out_scale = 1.f;
     if (NP == 2) {
         float inv;
-        in_scale = pow2_scale_for(a.amax_in ? *a.amax_in : 1.f, inv);
+        in_scale = pow2_scale_for(a.amax_in ? amax_read(a.amax_in) : 1.f, inv);
         out_scale = inv * a.w_scale_inv;
     }
     // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
@@ -487,7 +488,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             }
         }
     }
-    record_amax(a.amax_out, vmax);
+    record_amax(a.amax_out, vmax, amax_seen);
     SM_TS(31)
 #undef SM_TS
 }

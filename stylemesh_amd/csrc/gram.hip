@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
                                                          int hist_len, int hist_slot, int n_slabs, float* amax_d) {
     __shared__ float red[4];
     float dmax = 0.f;   // max |D0|, |D1|: operand bound of the fp16x2 Gram backward
+    const float dseen = amax_peek(amax_d);
     const float f = *factor;
     const float inv_c2 = 1.f / ((float)C * (float)C);
     float loss = 0.f;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     if (D1) D1[idx] = d[1];
     dmax = fmaxf(dmax, fmaxf(fabsf(d[0]), fabsf(d[1])));
     }
-    record_amax(amax_d, dmax);
+    record_amax(amax_d, dmax, dseen);
     const float tot = block_sum256(loss, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * weight * f * inv_c2);
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
     float scale = 1.f;
     if (NP == 2) {   // both matrices share one bound (max |D0|, |D1| of the style-loss kernel)
         float inv;
-        scale = gram_pow2_scale(*amax_d, inv);
+        scale = gram_pow2_scale(amax_read(amax_d), inv);
     }
     const int u = blockIdx.x * 256 + threadIdx.x;   // (row, 8-column group)
     const int groups = C / 8;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float f_scale = 1.f, out_scale = 1.f;
     if (NP == 2) {
         float inv_f, inv_d;
-        f_scale = gram_pow2_scale(*amax_feat, inv_f);
-        gram_pow2_scale(*amax_d, inv_d);
+        f_scale = gram_pow2_scale(amax_read(amax_feat), inv_f);
+        gram_pow2_scale(amax_read(amax_d), inv_d);
         out_scale = inv_f * inv_d;
     }
     __shared__ __attribute__((aligned(16))) f32x4 Bs[2][SLICE];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float f_scale = 1.f, out_scale = 1.f;
     if (NP == 2) {
         float inv;
-        f_scale = gram_pow2_scale(*amax_feat, inv);
+        f_scale = gram_pow2_scale(amax_read(amax_feat), inv);
         out_scale = inv * inv;
     }
     constexpr int MAX_STAGES = 256;       // qb <= 4096 positions

@@ -98,7 +98,10 @@ class _GramFn(torch.autograd.Function):
         ones = FMap(1, h, w, feat.device).from_dense(torch.ones(1, h, w))
         S = torch.zeros(ops.gram_workspace_slabs(c, h, w), c, c, device=feat.device)
         # fp16x2 mode: the operand bound the producing conv would have recorded (class mirror, not a hot path)
-        ctx.af = feat.detach().abs().max().reshape(1).contiguous() if ops.GRAM_MODE == "split2" else None
+        ctx.af = None
+        if ops.GRAM_MODE == "split2":
+            ctx.af = ops.new_amax(feat.device)
+            ctx.af[0] = feat.detach().abs().max()
         n = ops.gram_masked(f, ones, None, S, None, amax_feat=ctx.af)
         ctx.f, ctx.ones = f, ones
         from ...runtime.engine import _mirror_tiles
@@ -109,7 +112,10 @@ class _GramFn(torch.autograd.Function):
         f = ctx.f
         D = ((gG[0] + gG[0].T) / float(f.H * f.W)).contiguous()   # dF = (dG + dG^T) F / (h w)
         df = FMap(f.C, f.H, f.W, f.buf.device)
-        ad = D.abs().max().reshape(1).contiguous() if ops.GRAM_MODE == "split2" else None
+        ad = None
+        if ops.GRAM_MODE == "split2":
+            ad = ops.new_amax(D.device)
+            ad[0] = D.abs().max()
         ops.gram_backward(f, ctx.ones, None, D, None, df, relu_gate=False, amax_feat=ctx.af, amax_d=ad)
         return df.to_dense()[None]
 

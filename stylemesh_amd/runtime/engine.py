@@ -135,10 +135,11 @@ class StepEngine:
         # ... and, behind them in the same buffer (one fill zeroes all of it every step), the per-layer max |x| bounds
         # of the step's activations / gradients over all UV levels (operand scales of the fp16x2 conv kernels)
         # ... and one bound per (UV level <= 8, style layer) of the style-loss derivative matrices (fp16x2 Gram backward)
-        self._step_scalars = torch.zeros(2 + AmaxBook.N + 8 * len(cfg.style_layers), device=device)
+        AW = ops.AMAX_FLOATS   # a bound is 64 slots spaced 256 bytes apart: 16 KB (1.3 MB for all of them)
+        self._step_scalars = torch.zeros(AW + (AmaxBook.N + 8 * len(cfg.style_layers)) * AW, device=device)
         self.loss_buf = self._step_scalars[0:2]
-        self.amax = AmaxBook(device, self._step_scalars[2:2 + AmaxBook.N])
-        self._amax_d = self._step_scalars[2 + AmaxBook.N:]
+        self.amax = AmaxBook(device, self._step_scalars[AW:AW + AmaxBook.N * AW])
+        self._amax_d = self._step_scalars[AW + AmaxBook.N * AW:]
         self.sumsq = torch.zeros(n_layers, device=device)
         self._pbuf = {}            # persistent per-view buffers (fixed addresses)
         self._graphs = {}          # view signature -> captured hipGraph of forward_backward
@@ -571,7 +572,8 @@ class StepEngine:
         f = b.act[layer]
         two = ops.GRAM_MODE == "split2"
         af = (self.amax if am is None else am)["a:" + layer] if two else None
-        ad = self._amax_d[lv.index * len(cfg.style_layers) + li:][:1] if two else None
+        k = (lv.index * len(cfg.style_layers) + li) * ops.AMAX_FLOATS
+        ad = self._amax_d[k:k + ops.AMAX_FLOATS] if two else None
         n_slabs = ops.gram_num_slabs(f.C, f.H, f.W)
         key = (f.C, lv.index, layer)
         S0, S1, D0, D1 = self._gram_scratch(key, ops.gram_workspace_slabs(f.C, f.H, f.W))
@@ -649,7 +651,8 @@ class StepEngine:
                     d0, d1 = D0 * g_style, (None if D1 is None else D1 * g_style)
                     ad = None
                     if ops.GRAM_MODE == "split2":   # bound of the rescaled derivative matrices (not a hot path)
-                        ad = d0.abs().max().reshape(1) if d1 is None else torch.maximum(d0.abs().max(), d1.abs().max()).reshape(1)
+                        ad = ops.new_amax(self.device)
+                        ad[0] = d0.abs().max() if d1 is None else torch.maximum(d0.abs().max(), d1.abs().max())
                     ops.gram_backward(b.act[layer], m0, m1, d0, d1, b.grad[layer], relu_gate=(layer == self.deepest),
                                       amax_feat=b.amax["a:" + layer], amax_d=ad)
                     injected.add(layer)

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sm_conv3x3_grouped": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp],
     "sm_conv3x3_grouped_split": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp],
     "sm_conv3x3_grouped_split2": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp],
+    "sm_amax_floats": [],
     "sm_fmap_amax": [_vp, _i, _i, _i, _vp, _vp],
     "sm_conv_tile_positions": [_i, _i],
     "sm_conv_split_tile_positions": [],

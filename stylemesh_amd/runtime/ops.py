@@ -269,8 +269,20 @@ def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap
         CONV_TIMER.launch(run, 2.0 * 9 * cin_true * cout * inp.H * inp.W)
 
 
+AMAX_FLOATS = lib.sm_amax_floats()   # floats of one "amax" bound (64 slots, 256 bytes apart; value = max over them)
+
+
+def new_amax(device, value: float = 0.0) -> torch.Tensor:
+    """A zeroed amax bound (``sm_amax_floats`` floats), optionally preset to ``value`` (tests / one-off callers)."""
+    t = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=device)
+    if value:
+        t[0] = float(value)
+    return t
+
+
 def fmap_amax(f: FMap, amax_out: torch.Tensor):
-    """max |x| of ``f`` max-ed into the (caller-zeroed) device float ``amax_out``."""
+    """max |x| of ``f`` max-ed into the (caller-zeroed) amax bound ``amax_out``."""
+    assert amax_out.numel() == AMAX_FLOATS
     hip.check(lib.sm_fmap_amax(f.ptr, f.C, f.H, f.W, ptr(amax_out), hip.stream()), "sm_fmap_amax")
 
 

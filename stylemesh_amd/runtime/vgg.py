@@ -56,16 +56,17 @@ class AmaxBook:
     pass (``zero()``), before the first kernel that records into it."""
 
     N = 2 * len(OUT_NAMES)
+    W = ops.AMAX_FLOATS          # floats per bound (64 slots, 256 bytes apart: include/stylemesh_hip.h)
 
     def __init__(self, device, storage=None):
         names = ["a:" + n for n in OUT_NAMES] + ["g:" + n for n in OUT_NAMES]
         self.idx = {n: i for i, n in enumerate(names)}
-        self.buf = torch.zeros(len(names), dtype=torch.float32, device=device) if storage is None else storage
-        assert self.buf.numel() == len(names)
+        self.buf = torch.zeros(len(names) * self.W, dtype=torch.float32, device=device) if storage is None else storage
+        assert self.buf.numel() == len(names) * self.W
 
     def __getitem__(self, name):
         i = self.idx[name]
-        return self.buf[i:i + 1]
+        return self.buf[i * self.W:(i + 1) * self.W]
 
     def act_bound(self, layer):
         """bound of the activation planes named ``layer`` (a conv output or a pool output)"""
@@ -202,8 +203,7 @@ class VGGNet:
         kernel's epilogue."""
         am = b.amax if _amax_on() else None
         if am is not None:   # gradient bounds of this pass (the activation bounds of the forward pass stay)
-            n = len(OUT_NAMES)
-            am.buf[n:].zero_()
+            am.buf[len(OUT_NAMES) * am.W:].zero_()
             ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if kind == "pool":

@@ -22,7 +22,7 @@ for li in sel:
         x = FMap(cin, H, W).from_dense(xd)
         w = ops.pack_conv_fwd(wgt)
         w3, w2 = ops.pack_conv_split(w), ops.pack_conv_split2(w)
-        amax_in, amax_out = xd.abs().max().reshape(1).contiguous(), torch.zeros(1, device="cuda")
+        amax_in, amax_out = ops.new_amax("cuda", float(xd.abs().max())), ops.new_amax("cuda")
         out = FMap(cout, H, W)
         line = f"{H0}x{W0} {cin:3d}->{cout:3d} {H:4d}x{W:4d}"
         for mode in modes:

@@ -23,8 +23,8 @@ for li in sel:
         w = ops.pack_conv_fwd(wgt)
         w3 = ops.pack_conv_split(w)
         w2 = ops.pack_conv_split2(w)
-        amax_in = xd.abs().max().reshape(1).contiguous()
-        amax_out = torch.zeros(1, device="cuda")
+        amax_in = ops.new_amax("cuda", float(xd.abs().max()))
+        amax_out = ops.new_amax("cuda")
         out = FMap(cout, H, W)
         ref = F.relu(F.conv2d(xd[None].double(), wgt.double(), b.double(), padding=1))[0]
         line = f"{H0}x{W0} {cin:3d}->{cout:3d} {H:4d}x{W:4d}"

@@ -26,8 +26,8 @@ for li in sel:
         df = FMap(C, H, W)
         line = f"{H0}x{W0} C={C:3d} {H:4d}x{W:4d}"
         res = {}
-        af = f.planes.abs().max().reshape(1).contiguous()
-        ad = torch.maximum(D0.abs().max(), D1.abs().max()).reshape(1).contiguous()
+        af = ops.new_amax("cuda", float(f.planes.abs().max()))
+        ad = ops.new_amax("cuda", float(torch.maximum(D0.abs().max(), D1.abs().max())))
         for mode in ("f32", "split", "split2"):
             ops.GRAM_MODE = mode
             for which, fn in (("fwd", lambda: ops.gram_masked(f, m0, m1, S0, S1, amax_feat=af)),

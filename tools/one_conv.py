@@ -13,8 +13,8 @@ b = torch.randn(cout, device="cuda") * 0.3
 x = FMap(cin, H, W).from_dense(xd)
 w = ops.pack_conv_fwd(wgt)
 w3, w2 = ops.pack_conv_split(w), ops.pack_conv_split2(w)
-amax_in = xd.abs().max().reshape(1).contiguous()
-amax_out = torch.zeros(1, device="cuda")
+amax_in = ops.new_amax("cuda", float(xd.abs().max()))
+amax_out = ops.new_amax("cuda")
 out = FMap(cout, H, W)
 ops.CONV_MODE = mode
 kw = dict(wt3=w3, wt2=w2, amax_in=amax_in, amax_out=amax_out) if mode == "split2" else dict(wt3=w3)

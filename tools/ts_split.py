@@ -11,11 +11,11 @@ w3, w2 = ops.pack_conv_split(w), ops.pack_conv_split2(w)
 b = torch.zeros(cout, device="cuda")
 out = FMap(cout, H, W)
 ops.CONV_MODE = sys.argv[1] if len(sys.argv) > 1 else "split2"
-amax_in = x.planes.abs().max().reshape(1).contiguous()
+amax_in = ops.new_amax("cuda", float(x.planes.abs().max()))
 ws = ops.splitk_workspace(w.device)
 for _ in range(2):
     ws.zero_()
-    ops.conv3x3(x, w, b, out, hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=amax_in, amax_out=torch.zeros(1, device="cuda"))
+    ops.conv3x3(x, w, b, out, hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=amax_in, amax_out=ops.new_amax("cuda"))
 torch.cuda.synchronize()
 ts = ws[15 * 1024 * 1024:].view(torch.int64)[: 256 * 4 * 64].view(256, 4, 64).cpu().numpy()
 for blk in (0, 1, 100, 255):
