@@ -375,6 +375,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
             __builtin_amdgcn_sched_barrier(0);
+            if (STAMP && ch - ch_begin == 1) SM_TS(32 + tap)      // this stage's MFMAs are issued
 #if SM_SPLIT_TAIL_PRIO
             __builtin_amdgcn_s_setprio(SM_SPLIT_TAIL_PRIO);   // the load / convert / store tail outranks the partner's MFMAs
 #elif SM_SPLIT_MFMA_PRIO
@@ -404,6 +405,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         SM_LOAD_B(0, 0, ch_next2);
                     }
 #endif
+                    if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
                     __syncthreads();
                 }
             } else {
