@@ -188,8 +188,10 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
  *         kernel scales x by the power of two that maps amax_in into [2^14, 2^15) while it stages the operand;
  *   the epilogue multiplies the accumulators by the (exact) inverse scales before bias / add / gate.
  * Elements more than 2^18 below amax_in lose low bits of l: an absolute error <= 2^-40 amax_in per element.
- * Same flags / tile_list / ws / amax_out semantics as above. Error against an fp64 convolution: same class as the
- * fp32-MFMA kernel (tests/test_kernels_gpu.py). */
+ * Same flags / tile_list / ws / amax_out semantics as above; a tile covers sm_conv_split2_tile_positions(Cout)
+ * positions (128; 256 for the 64-channel layers, whose 64 x 256 tiles keep four 64 x 64 wave tiles busy). Error against
+ * an fp64 convolution: same class as the fp32-MFMA kernel (tests/test_kernels_gpu.py). */
+int sm_conv_split2_tile_positions(int Cout);
 int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
                               const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
                               float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream);

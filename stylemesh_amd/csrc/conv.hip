@@ -18,6 +18,12 @@
 #include "conv_common.h"
 #include "conv_split_kernel.h"
 
+#ifndef SM_SPLIT2_BN256
+#define SM_SPLIT2_BN256 1   // fp16x2, Cout % 128 != 0: 64 x 256 tiles instead of 64 x 128
+#endif
+#ifndef SM_SPLIT2_BM256
+#define SM_SPLIT2_BM256 0
+#endif
 #ifndef SM_SPLIT_WGM
 #define SM_SPLIT_WGM 4   // waves along the channel dimension of the 128 x 128 split tile: 4 (32x128 wave tiles: half the
                          // weight-fragment loads per MFMA, +2.5 %) or 2 (64x64)
@@ -358,7 +364,16 @@ static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, 
 
 template <int FLAGS>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
+#if SM_SPLIT2_BN256
+    // 64 output channels: 64 x 256 tiles, four waves of 64 x 64 (the same MFMAs per stage and wave as the 128-row tile)
+    if (a.Cout % 128 != 0) return launch_conv<64, 256, 16, 1, 4, FLAGS, true, 2>(a, n_list, ws_floats, s);
+#else
     if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2>(a, n_list, ws_floats, s);
+#endif
+#if SM_SPLIT2_BM256
+    // one wave per SIMD with a 64 x 128 wave tile (128 accumulator registers): 24 MFMAs per stage and wave
+    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2>(a, n_list, ws_floats, s);
+#endif
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2>(a, n_list, ws_floats, s);
 }
 
@@ -529,7 +544,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 3; }
+int sm_abi_version(void) { return 4; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
@@ -577,6 +592,7 @@ int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void
 
 int sm_conv_tile_positions(int Cin_pad, int Cout) { return (Cin_pad == 4 || Cout % 128 != 0) ? 256 : 128; }
 int sm_conv_split_tile_positions(void) { return 128; }
+int sm_conv_split2_tile_positions(int Cout) { return (SM_SPLIT2_BN256 && Cout % 128 != 0) ? 256 : 128; }
 
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,

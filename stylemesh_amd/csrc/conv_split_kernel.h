@@ -68,7 +68,13 @@ namespace sm {
 //           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
 //           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
 //           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
-constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) { return (size_t)(4 * 2 * NP * (BN + 2)) * 16; }
+#ifndef SM_SPLIT2_RING6
+#define SM_SPLIT2_RING6 0      // fp16x2: six LDS slots (two whole chunks), ONE barrier per chunk instead of three
+#endif
+constexpr int conv_split_slots(int NP) { return (NP == 2 && SM_SPLIT2_RING6) ? 6 : 4; }
+constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) {
+    return (size_t)(conv_split_slots(NP) * 2 * NP * (BN + 2)) * 16;
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // Live operands are scaled below 2^15. Positions of tiles the active-tile lists skip hold STALE values of earlier
@@ -98,10 +104,13 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
 #ifndef SM_SPLIT2_WAVES
 #define SM_SPLIT2_WAVES 2      // resident waves per SIMD of the 128-row fp16x2 variant
 #endif
+// resident waves per SIMD the register budget of a variant is set for
+constexpr int conv_split_waves(int BM, int BN, int NP) {
+    return BM == 256 ? 1 : (BM == 64 && BN == 128) ? SM_SPLIT_WAVES64 : NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES;
+}
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(BM == 64 ? SM_SPLIT_WAVES64 : (NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES),
-                                   BM == 64 ? SM_SPLIT_WAVES64 : (NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES))))
+__attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
 void conv3x3_split_kernel(ConvArgs a) {
     static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
@@ -109,7 +118,8 @@ void conv3x3_split_kernel(ConvArgs a) {
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
                       WGM * WGN == 4,
                   "wave tile is (32 MI) x (32 NJ)");
-    static_assert(BN == 128, "activation staging: one (k-group, position) unit per thread + a 2 x 2 x 8 halo");
+    static_assert(BN == 128 || BN == 256, "activation staging: BN / 128 (k-group, position) units per thread + a 2 x 2 x 8 halo");
+    constexpr int NU = BN / 128;          // staging units per thread and slice
     constexpr int KC = 16;
     constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
     constexpr int SLICE = 2 * NP * BNP;   // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
@@ -198,7 +208,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         const_cast<float*>(P.in) - P.Wp - 1, 0, 0x7ffffff0, 0x00020000);
     const int b_src = (b_kg * 8 * P.plane + q0 + b_px) * 4;   // bytes, relative to the shifted base, row ky = 0
     const int b_dst = b_kg * BNP + b_px;                      // + part * 2 * BNP (+ slot * SLICE)
-    const int h_kg = l31 >> 4, h_px = 128 + ((l31 >> 3) & 1), h_c = l31 & 7;
+    const int h_kg = l31 >> 4, h_px = BN + ((l31 >> 3) & 1), h_c = l31 & 7;
     const int h_src = ((h_kg * 8 + h_c) * P.plane + q0 + h_px) * 4;   // bytes, same base
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
     // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
@@ -209,7 +219,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     // in-flight activation loads: SM_SPLIT_BSETS = 1: one register set, a slice is loaded two stages before it is
     // converted and stored; 3: one set per ky slice, re-loaded right after its store - a slice's loads then have a
     // whole chunk (nine stages) to arrive
-    float rbs[SM_SPLIT_BSETS][8], rhs[SM_SPLIT_BSETS];
+    float rbs[SM_SPLIT_BSETS][NU][8], rhs[SM_SPLIT_BSETS];
 
 #define SM_LOAD_A(tap_, chunk_)                                                                          \
     {                                                                                                    \
@@ -222,22 +232,25 @@ void conv3x3_split_kernel(ConvArgs a) {
 #define SM_LOAD_B(set_, ky_, chunk_)                                                                     \
     {                                                                                                    \
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                    \
-            rbs[set_][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4, 0)); \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                   \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
+                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4 + u * 512, 0)); \
         rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0)); \
     }
 #define SM_STORE_B(set_, slot_)                                                                          \
     if constexpr (NP == 3) {                                                                             \
-        bf16x8 vh, vm, vl;                                                                               \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                  \
-            __bf16 h, m, l;                                                                              \
-            split3(rbs[set_][c], h, m, l);                                                               \
-            vh[c] = h; vm[c] = m; vl[c] = l;                                                             \
-        }                                                                                                \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
-        d_[b_dst] = __builtin_bit_cast(f32x4, vh);                                                       \
-        d_[b_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                                             \
-        d_[b_dst + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                                             \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
+            bf16x8 vh, vm, vl;                                                                           \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
+                __bf16 h, m, l;                                                                          \
+                split3(rbs[set_][u][c], h, m, l);                                                        \
+                vh[c] = h; vm[c] = m; vl[c] = l;                                                         \
+            }                                                                                            \
+            d_[b_dst + u * 128] = __builtin_bit_cast(f32x4, vh);                                         \
+            d_[b_dst + u * 128 + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                               \
+            d_[b_dst + u * 128 + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                               \
+        }                                                                                                \
         __bf16 h, m, l;                                                                                  \
         split3(rhs[set_], h, m, l);                                                                      \
         __bf16* e_ = reinterpret_cast<__bf16*>(d_);                                                      \
@@ -245,15 +258,17 @@ void conv3x3_split_kernel(ConvArgs a) {
         e_[h_dst + 2 * BNP * 8] = m;                                                                     \
         e_[h_dst + 4 * BNP * 8] = l;                                                                     \
     } else {                                                                                             \
-        f16x8 vh, vl;                                                                                    \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                  \
-            const float xs_ = __builtin_amdgcn_fmed3f(rbs[set_][c] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP); \
-            const _Float16 h_ = (_Float16)xs_;                                                           \
-            vh[c] = h_; vl[c] = (_Float16)(xs_ - (float)h_);                                             \
-        }                                                                                                \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
-        d_[b_dst] = __builtin_bit_cast(f32x4, vh);                                                       \
-        d_[b_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                             \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
+            f16x8 vh, vl;                                                                                \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
+                const float xs_ = __builtin_amdgcn_fmed3f(rbs[set_][u][c] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP); \
+                const _Float16 h_ = (_Float16)xs_;                                                       \
+                vh[c] = h_; vl[c] = (_Float16)(xs_ - (float)h_);                                         \
+            }                                                                                            \
+            d_[b_dst + u * 128] = __builtin_bit_cast(f32x4, vh);                                         \
+            d_[b_dst + u * 128 + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                               \
+        }                                                                                                \
         const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
         const _Float16 h_ = (_Float16)xs_;                                                               \
         _Float16* e_ = reinterpret_cast<_Float16*>(d_);                                                  \
@@ -273,18 +288,22 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < AD; ++t) SM_LOAD_A(t, ch_begin);
     {   // all three slices' loads in flight together (one memory round trip instead of three)
-        float rb3[3][8], rh3[3];
+        float rb3[3][NU][8], rh3[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             SM_LOAD_B(0, ky, ch_begin);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb3[ky][c] = rbs[0][c];
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rb3[ky][u][c] = rbs[0][u][c];
             rh3[ky] = rhs[0];
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rbs[0][c] = rb3[ky][c];
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rbs[0][u][c] = rb3[ky][u][c];
             rhs[0] = rh3[ky];
             SM_STORE_B(0, ky);
         }
@@ -301,6 +320,10 @@ void conv3x3_split_kernel(ConvArgs a) {
     __syncthreads();
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
+    constexpr bool RING6 = conv_split_slots(NP) == 6;
+    // slot of slice ky of the current / of the next chunk
+#define SM_CUR_SLOT(ky_) (RING6 ? base + (ky_) : (base + (ky_)) & 3)
+#define SM_NEXT_SLOT(ky_) (RING6 ? (3 - base) + (ky_) : (base + 3 + (ky_)) & 3)
     const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
     f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 bf16 / fp16)
 #if SM_SPLIT_PREFETCH_B
@@ -321,12 +344,12 @@ void conv3x3_split_kernel(ConvArgs a) {
             if (ch == ch_begin && tap == 0) { SM_READ_B(fb_next, 0, 1) }
 #elif SM_SPLIT_PREFETCH_B
             if (tap < 8) {
-                SM_READ_B(fb_next, (base + (tap + 1) / 3) & 3, (tap + 1) % 3)
+                SM_READ_B(fb_next, SM_CUR_SLOT((tap + 1) / 3), (tap + 1) % 3)
             } else {
-                SM_READ_B(fb_next, (base + 3) & 3, 0)
+                SM_READ_B(fb_next, SM_NEXT_SLOT(0), 0)
             }
 #else
-            SM_READ_B(fb, (base + ky) & 3, kx)
+            SM_READ_B(fb, SM_CUR_SLOT(ky), kx)
 #endif
 #if SM_SPLIT_PIN_READS
             // keep the fragment reads HERE, a full stage ahead of their use: left alone, the scheduler sinks them to the
@@ -395,8 +418,12 @@ void conv3x3_split_kernel(ConvArgs a) {
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
             if constexpr (SM_SPLIT_BSETS == 1) {
 #ifndef SM_ABL_NOB
-                if (kx == 1) SM_STORE_B(0, (base + 3 + ky) & 3);
+                if (kx == 1) SM_STORE_B(0, SM_NEXT_SLOT(ky));
 #endif
+                // six slots: the next chunk is written into the other half of the ring, which nobody reads after the
+                // barrier at the end of tap 7 of the previous chunk (tap 8 already prefetches from the new half): that
+                // one barrier per chunk both publishes the three new slices and releases the old half
+                if (RING6 && tap == 7) __syncthreads();
                 if (kx == 2) {
 #ifndef SM_ABL_NOB
                     if (ky < 2) {
@@ -406,14 +433,14 @@ void conv3x3_split_kernel(ConvArgs a) {
                     }
 #endif
                     if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
-                    __syncthreads();
+                    if (!RING6) __syncthreads();
                 }
             } else {
                 if (kx == 1) {   // slice ky of the next chunk out of its register set, the chunk after that into it
-                    SM_STORE_B(ky, (base + 3 + ky) & 3);
+                    SM_STORE_B(ky, SM_NEXT_SLOT(ky));
                     SM_LOAD_B(ky, ky, ch_next2);
                 }
-                if (kx == 2) __syncthreads();
+                if (RING6 ? tap == 7 : kx == 2) __syncthreads();
             }
 #if SM_SPLIT_TAIL_PRIO
             __builtin_amdgcn_s_setprio(0);
@@ -426,9 +453,11 @@ void conv3x3_split_kernel(ConvArgs a) {
 #endif
             if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
         }
-        base = (base + 3) & 3;
+        base = RING6 ? 3 - base : (base + 3) & 3;
     }
     SM_TS(30)
+#undef SM_CUR_SLOT
+#undef SM_NEXT_SLOT
 #undef SM_LOAD_A
 #undef SM_LOAD_B
 #undef SM_STORE_B

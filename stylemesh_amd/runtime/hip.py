@@ -45,6 +45,7 @@ SIGNATURES = {
     "sm_fmap_amax": [_vp, _i, _i, _i, _vp, _vp],
     "sm_conv_tile_positions": [_i, _i],
     "sm_conv_split_tile_positions": [],
+    "sm_conv_split2_tile_positions": [_i],
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_conv3x3_dgrad_c3_grouped": [_vp, _i, _vp, _i, _vp],
     "sm_maxpool2x2_fwd_grouped": [_vp, _i, _i, _vp],

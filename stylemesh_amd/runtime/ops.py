@@ -289,7 +289,7 @@ def fmap_amax(f: FMap, amax_out: torch.Tensor):
 def conv_tile_positions(cin_pad: int, cout: int) -> int:
     """Positions per tile of the kernel that ``conv3x3_grouped`` will pick for this layer shape (``CONV_MODE``)."""
     if CONV_MODE in ("split", "split2") and split_eligible(cin_pad, cout):
-        return lib.sm_conv_split_tile_positions()
+        return lib.sm_conv_split2_tile_positions(cout) if CONV_MODE == "split2" else lib.sm_conv_split_tile_positions()
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 

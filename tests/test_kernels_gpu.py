@@ -195,7 +195,8 @@ def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypa
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77),
-                                          (64, 64, 17, 21), (128, 64, 33, 47), (128, 128, 120, 300), (256, 512, 54, 72)])
+                                          (64, 64, 17, 21), (128, 64, 33, 47), (128, 128, 120, 300), (256, 512, 54, 72),
+                                          (64, 64, 250, 301)])
 @pytest.mark.parametrize("in_scale", [1.0, 3e-7, 4e4])
 def test_conv3x3_split2_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, in_scale, monkeypatch):
     """fp16x2-split conv (3 partial products of fp16 pairs on the matrix cores, power-of-two operand scales from the
