@@ -274,6 +274,21 @@ int sm_gram_masked_split(const float* feat, const float* mask0, const float* mas
  * continue. */
 int sm_gram_masked_split_acc(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                              int H, int W, const float* amax_feat, void* stream);
+/* The same Gram forward for MANY (level, layer) problems in at most two launches (one per tile class: 64-channel tiles
+ * for C % 128 != 0, 128-channel tiles otherwise) - the loss phase of a step is ~20 small problems whose separate
+ * launches are latency-bound. fp16x2 operands (amax_feat required, see sm_conv3x3_grouped_split2). S0 / S1 must be
+ * ZERO on entry (every position range adds into them atomically); mask1 / S1 may be NULL. problems: HOST array. */
+typedef struct {
+    const float* feat;      /* [C][plane(H,W)] */
+    const float* mask0;     /* [plane(H,W)] 0/1 */
+    const float* mask1;
+    float* S0;              /* [C][C]; upper-triangular 64x64 tiles valid */
+    float* S1;
+    const float* amax_feat; /* amax array: bound of max |feat| */
+    int C, H, W;
+} sm_gram_problem;
+int sm_gram_masked_split2_grouped(const sm_gram_problem* problems, int n_problems, void* stream);
+
 
 /* K5b. Style-loss value and its derivative matrices for one (level, layer) (:301-340).
  * S0/S1: the n_slabs partial slabs written by sm_gram_masked (summed here).
@@ -306,6 +321,43 @@ size_t sm_gram_backward_split_ws_bytes(int C);
 int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0,
                            const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* ws,
                            const float* amax_feat, const float* amax_d, void* stream);
+
+/* The loss phase of a step in a handful of launches. sm_style_loss_grouped = sm_style_loss for many (level, layer)
+ * problems (same field meanings as its arguments), all adding into ONE loss value; sm_gram_backward_split2_grouped =
+ * sm_gram_backward_split (fp16x2: amax_feat / amax_d required) for many problems: one launch packs every derivative
+ * matrix, then one launch per row-tile class (64 / 128 channels) runs the GEMMs. ws: per-problem DEVICE scratch of
+ * sm_gram_backward_split_ws_bytes(C) bytes (distinct for every problem of a call). problems: HOST arrays. */
+typedef struct {
+    const float* S0;
+    const float* S1;
+    const float* counts;
+    const float* factor;
+    const float* targets[4];
+    int term_mask[4];
+    int n_terms;
+    int skip_if_empty[2];
+    float weight;
+    int C;
+    float* D0;
+    float* D1;
+    float* history;
+    int hist_len, hist_slot, n_slabs;
+    float* amax_d_out;
+} sm_style_problem;
+int sm_style_loss_grouped(const sm_style_problem* problems, int n_problems, float* loss_out, void* stream);
+typedef struct {
+    const float* feat;
+    const float* mask0;
+    const float* mask1;
+    const float* D0;
+    const float* D1;
+    float* dfeat;
+    void* ws;
+    const float* amax_feat;
+    const float* amax_d;
+    int C, H, W, relu_gate;
+} sm_gram_bwd_problem;
+int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream);
 
 /* K6. Masked content MSE (:343-348): loss += coef * sum m (P-T)^2 / (C N); dP = coef * 2 m (P-T)/(C N),
  * coef = content_weight * loss_weight * (*factor), N = *count (0 -> nothing). OVERWRITES dpred.

@@ -8,6 +8,8 @@
 #include <algorithm>
 
 #include "common.h"
+#include <cstdlib>
+
 #include "gram_split_kernels.h"
 
 namespace sm {
@@ -161,12 +163,11 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 #define SM_STYLE_EPT 4
 #endif
 constexpr int STYLE_EPT = SM_STYLE_EPT;   // elements per thread
-__global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
-                                                         const float* __restrict__ counts,
-                                                         const float* __restrict__ factor, StyleTerms terms,
-                                                         float weight, int C, float* __restrict__ D0,
-                                                         float* __restrict__ D1, float* loss_out, float* history,
-                                                         int hist_len, int hist_slot, int n_slabs, float* amax_d) {
+__device__ __forceinline__ void style_loss_body(const float* __restrict__ S0, const float* __restrict__ S1,
+                                                const float* __restrict__ counts, const float* __restrict__ factor,
+                                                const StyleTerms& terms, float weight, int C, float* __restrict__ D0,
+                                                float* __restrict__ D1, float* loss_out, float* history, int hist_len,
+                                                int hist_slot, int n_slabs, float* amax_d, int block_x) {
     __shared__ float red[4];
     float dmax = 0.f;   // max |D0|, |D1|: operand bound of the fp16x2 Gram backward
     const float dseen = amax_peek(amax_d);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     float loss = 0.f;
     // STYLE_EPT elements per thread: one atomic on the (single) loss address per 1024 elements
     for (int it = 0; it < STYLE_EPT; ++it) {
-    const int idx = (blockIdx.x * STYLE_EPT + it) * 256 + threadIdx.x;
+    const int idx = (block_x * STYLE_EPT + it) * 256 + threadIdx.x;
     if (idx >= C * C) break;
     const int i = idx / C, j = idx - i * C;
     float G[2], invN[2], d[2] = {0.f, 0.f};
@@ -213,6 +214,44 @@ __global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict
     record_amax(amax_d, dmax, dseen);
     const float tot = block_sum256(loss, red);
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(loss_out, tot * weight * f * inv_c2);
+}
+__global__ __launch_bounds__(256) void style_loss_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
+                                                         const float* __restrict__ counts,
+                                                         const float* __restrict__ factor, StyleTerms terms,
+                                                         float weight, int C, float* __restrict__ D0,
+                                                         float* __restrict__ D1, float* loss_out, float* history,
+                                                         int hist_len, int hist_slot, int n_slabs, float* amax_d) {
+    style_loss_body(S0, S1, counts, factor, terms, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs,
+                    amax_d, blockIdx.x);
+}
+// GROUPED: the terms of many (level, layer) problems in one launch, all adding into one loss value
+struct StyleProb {
+    const float* S0;
+    const float* S1;
+    const float* counts;
+    const float* factor;
+    StyleTerms terms;
+    float weight;
+    int C;
+    float* D0;
+    float* D1;
+    float* history;
+    int hist_len, hist_slot, n_slabs;
+    float* amax_d;
+};
+constexpr int STYLE_MAX_GROUP = 20;
+struct StyleGroup {
+    StyleProb p[STYLE_MAX_GROUP];
+    int first_block[STYLE_MAX_GROUP + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void style_loss_group_kernel(StyleGroup G, float* loss_out) {
+    int g = 0;
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_block[i]) g = i;
+    const StyleProb& P = G.p[g];
+    style_loss_body(P.S0, P.S1, P.counts, P.factor, P.terms, P.weight, P.C, P.D0, P.D1, loss_out, P.history, P.hist_len,
+                    P.hist_slot, P.n_slabs, P.amax_d, blockIdx.x - G.first_block[g]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -362,6 +401,110 @@ __global__ __launch_bounds__(256) void mse_masked_kernel(const float* __restrict
 
 }  // namespace sm
 
+// positions per block of the grouped Gram forward: equal K ranges for every problem of a launch (equal block work);
+// long enough to amortise the block's C^2-float atomic epilogue, short enough that the launch has >= ~4 blocks per CU
+static int gram_group_qb(int MI, long long total_block_positions) {
+    // total_block_positions = sum over problems of positions x tile pairs x masks
+    const int sp = MI == 1 ? 64 : 32;
+    static const int target = getenv("SM_GRAM_TARGET_BLOCKS") ? atoi(getenv("SM_GRAM_TARGET_BLOCKS")) : 1024;
+    long long qb = total_block_positions / target;
+    qb = (qb + sp - 1) / sp * sp;
+    return (int)std::max<long long>(8 * sp, std::min<long long>(qb, MI == 1 ? 4096 : 2048));
+}
+
+template <int MI, int NP>
+static int launch_gram_group(const sm_gram_problem* problems, const int* idx, int n, hipStream_t s) {
+    if (n == 0) return 0;
+    constexpr int TS = 64 * MI;
+    long long tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const sm_gram_problem& q = problems[idx[i]];
+        const int T = q.C / TS;
+        tot += (long long)q.H * sm::row_stride(q.W) * (T * (T + 1) / 2) * (q.mask1 ? 2 : 1);
+    }
+    const int qb = gram_group_qb(MI, tot);
+    for (int i0 = 0; i0 < n; i0 += sm::GRAM_MAX_GROUP) {
+        sm::GramGroup G{};
+        G.n = std::min(n - i0, sm::GRAM_MAX_GROUP);
+        G.first_block[0] = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const sm_gram_problem& q = problems[idx[i0 + i]];
+            const int Wp = sm::row_stride(q.W), T = q.C / TS;
+            sm::GramProb& P = G.p[i];
+            P = sm::GramProb{q.feat, q.mask0, q.mask1, q.S0, q.S1, q.amax_feat, q.C, sm::plane_size(q.H, q.W), Wp,
+                             (q.H + 1) * Wp, qb, (q.H * Wp + qb - 1) / qb};
+            G.first_block[i + 1] = G.first_block[i] + P.n_ranges * (T * (T + 1) / 2) * (q.mask1 ? 2 : 1);
+        }
+        bool diag_only = true;
+        for (int i = 0; i < G.n; ++i) diag_only &= G.p[i].C == TS;
+        const size_t lds = sm::gram_group_lds_bytes(MI, NP, diag_only), lds_max = sm::gram_group_lds_bytes(MI, NP);
+        auto k = sm::gram_group_kernel<MI, NP>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k, dim3(G.first_block[G.n]), dim3(256), lds, s, G);
+        SM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// All problems in at most two launches (64-channel tiles for C % 128 != 0, 128-channel tiles otherwise). S0 / S1 must
+// be zero on entry.
+static int gram_masked_grouped_impl(const sm_gram_problem* problems, int n, bool np2, hipStream_t s) {
+    if (n < 1 || n > 256) return (int)hipErrorInvalidValue;
+    int idx1[256], idx2[256], n1 = 0, n2 = 0;
+    for (int i = 0; i < n; ++i) {
+        const sm_gram_problem& q = problems[i];
+        if (q.C % 64 != 0 || q.feat == nullptr || q.mask0 == nullptr || q.S0 == nullptr || (q.mask1 && !q.S1) ||
+            (np2 && q.amax_feat == nullptr))
+            return (int)hipErrorInvalidValue;
+        if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
+    }
+    int rc = np2 ? launch_gram_group<2, 2>(problems, idx2, n2, s) : launch_gram_group<2, 3>(problems, idx2, n2, s);
+    if (rc) return rc;
+    return np2 ? launch_gram_group<1, 2>(problems, idx1, n1, s) : launch_gram_group<1, 3>(problems, idx1, n1, s);
+}
+
+
+static int fill_style_terms(sm::StyleTerms& t, const float* const* targets, const int* term_mask, int n_terms,
+                            const int* skip_if_empty, bool have1) {
+    if (n_terms < 1 || n_terms > 4) return (int)hipErrorInvalidValue;
+    t.n = n_terms;
+    for (int i = 0; i < n_terms; ++i) {
+        t.target[i] = targets[i];
+        t.mask[i] = term_mask[i];
+        if (term_mask[i] == 1 && !have1) return (int)hipErrorInvalidValue;
+    }
+    t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
+    t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
+    return 0;
+}
+
+template <int MI>
+static int launch_gram_bwd_group(const sm_gram_bwd_problem* problems, const int* idx, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += sm::GRAM_MAX_GROUP) {
+        sm::GramBwdGroup G{};
+        G.n = std::min(n - i0, sm::GRAM_MAX_GROUP);
+        G.first_block[0] = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const sm_gram_bwd_problem& q = problems[idx[i0 + i]];
+            const int Wp = sm::row_stride(q.W), np = (q.H * Wp + 127) / 128;
+            const bool two = q.mask1 && q.D1;
+            sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(q.ws);
+            G.p[i] = sm::GramBwdProb{q.feat, q.mask0, two ? q.mask1 : nullptr, P0, P0 + (size_t)6 * q.C * q.C / 16, q.dfeat,
+                                     q.amax_feat, q.amax_d, q.C, sm::plane_size(q.H, q.W), Wp, (q.H + 1) * Wp,
+                                     q.relu_gate, np};
+            G.first_block[i + 1] = G.first_block[i] + np * (q.C / (64 * MI));
+        }
+        hipLaunchKernelGGL((sm::gram_backward_group_kernel<MI, 2>), dim3(G.first_block[G.n]), dim3(256), 0, s, G);
+        SM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" {
 
 int sm_gram_num_slabs(int C, int H, int W) { return sm::gram_plan(C, H * sm::row_stride(W)).n_red; }
@@ -402,35 +545,22 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 
 int sm_gram_split_num_slabs(void) { return 1; }
 
+int sm_gram_masked_split2_grouped(const sm_gram_problem* problems, int n_problems, void* stream) {
+    return gram_masked_grouped_impl(problems, n_problems, true, (hipStream_t)stream);
+}
+
 static int gram_masked_split_impl(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                                   int H, int W, bool zero_fill, const float* amax_feat, void* stream) {
     if (C % 64 != 0) return (int)hipErrorInvalidValue;
-    const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
-    const int q_begin = Wp, q_end = (H + 1) * Wp;
-    const sm::GramPlan p = sm::gram_plan(C, q_end - q_begin);
-    const size_t cc = (size_t)C * C;
     hipStream_t s = (hipStream_t)stream;
-    const int nmask = mask1 ? 2 : 1;
-    // several position ranges -> they all add into slab 0 (zeroed here); a single range stores it directly
-    const bool atomic = p.n_raw > 1 || !zero_fill;
-    if (atomic && zero_fill) {
+    if (zero_fill) {   // the position ranges add into the slab
+        const size_t cc = (size_t)C * C;
         hipError_t e = hipMemsetAsync(S0, 0, cc * sizeof(float), s);
         if (e == hipSuccess && mask1) e = hipMemsetAsync(S1, 0, cc * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-#define SM_GS(MI_, AT_, T_, NP_)                                                                                     \
-    hipLaunchKernelGGL((sm::gram_split_kernel<MI_, AT_, NP_>), dim3(p.n_raw, (T_) * ((T_) + 1) / 2, nmask), dim3(256), 0, s, \
-                       feat, mask0, mask1, S0, S1, C, plane, q_begin, q_end, p.qb, amax_feat)
-#define SM_GS_NP(MI_, AT_, T_) do { if (amax_feat) SM_GS(MI_, AT_, T_, 2); else SM_GS(MI_, AT_, T_, 3); } while (0)
-    if (C % 128 == 0) {
-        if (atomic) SM_GS_NP(2, true, C / 128); else SM_GS_NP(2, false, C / 128);
-    } else {
-        if (atomic) SM_GS_NP(1, true, C / 64); else SM_GS_NP(1, false, C / 64);
-    }
-#undef SM_GS_NP
-#undef SM_GS
-    SM_LAUNCH_CHECK();
-    return 0;
+    const sm_gram_problem q{feat, mask0, mask1, S0, S1, amax_feat, C, H, W};
+    return gram_masked_grouped_impl(&q, 1, amax_feat != nullptr, s);
 }
 
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
@@ -485,16 +615,10 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
                   const float* const* targets, const int* term_mask, int n_terms, const int* skip_if_empty, float weight,
                   int C, float* D0, float* D1, float* loss_out, float* history, int hist_len, int hist_slot,
                   int n_slabs, float* amax_d_out, void* stream) {
-    if (n_terms < 1 || n_terms > 4 || (C * C) % 256 != 0) return (int)hipErrorInvalidValue;
+    if ((C * C) % 256 != 0) return (int)hipErrorInvalidValue;
     sm::StyleTerms t;
-    t.n = n_terms;
-    for (int i = 0; i < n_terms; ++i) {
-        t.target[i] = targets[i];
-        t.mask[i] = term_mask[i];
-        if (term_mask[i] == 1 && (S1 == nullptr || D1 == nullptr)) return (int)hipErrorInvalidValue;
-    }
-    t.skip_if_empty[0] = skip_if_empty ? skip_if_empty[0] : 0;
-    t.skip_if_empty[1] = skip_if_empty ? skip_if_empty[1] : 0;
+    const int rc = fill_style_terms(t, targets, term_mask, n_terms, skip_if_empty, S1 != nullptr && D1 != nullptr);
+    if (rc) return rc;
     hipLaunchKernelGGL(sm::style_loss_kernel, dim3((C * C + 256 * sm::STYLE_EPT - 1) / (256 * sm::STYLE_EPT)), dim3(256), 0, (hipStream_t)stream, S0, S1, counts, factor,
                        t, weight, C, D0, D1, loss_out, history, hist_len, hist_slot, n_slabs, amax_d_out);
     SM_LAUNCH_CHECK();
@@ -530,6 +654,61 @@ int sm_mse_masked(const float* pred, const float* target, const float* mask, con
                        weight, dpred, loss_out, C, plane, q_begin, q_end, relu_gate);
     SM_LAUNCH_CHECK();
     return 0;
+}
+
+
+int sm_style_loss_grouped(const sm_style_problem* problems, int n_problems, float* loss_out, void* stream) {
+    if (n_problems < 1 || loss_out == nullptr) return (int)hipErrorInvalidValue;
+    for (int i0 = 0; i0 < n_problems; i0 += sm::STYLE_MAX_GROUP) {
+        sm::StyleGroup G{};
+        G.n = std::min(n_problems - i0, sm::STYLE_MAX_GROUP);
+        G.first_block[0] = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const sm_style_problem& q = problems[i0 + i];
+            if ((q.C * q.C) % 256 != 0 || q.S0 == nullptr || q.D0 == nullptr) return (int)hipErrorInvalidValue;
+            sm::StyleProb& P = G.p[i];
+            const int rc = fill_style_terms(P.terms, q.targets, q.term_mask, q.n_terms, q.skip_if_empty, q.S1 && q.D1);
+            if (rc) return rc;
+            P.S0 = q.S0; P.S1 = q.S1; P.counts = q.counts; P.factor = q.factor; P.weight = q.weight; P.C = q.C;
+            P.D0 = q.D0; P.D1 = q.D1; P.history = q.history; P.hist_len = q.hist_len; P.hist_slot = q.hist_slot;
+            P.n_slabs = q.n_slabs; P.amax_d = q.amax_d_out;
+            G.first_block[i + 1] = G.first_block[i] + (q.C * q.C + 256 * sm::STYLE_EPT - 1) / (256 * sm::STYLE_EPT);
+        }
+        hipLaunchKernelGGL(sm::style_loss_group_kernel, dim3(G.first_block[G.n]), dim3(256), 0, (hipStream_t)stream, G, loss_out);
+        SM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream) {
+    if (n_problems < 1 || n_problems > 256) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int idx1[256], idx2[256], n1 = 0, n2 = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const sm_gram_bwd_problem& q = problems[i];
+        if (q.C % 64 != 0 || q.ws == nullptr || q.amax_feat == nullptr || q.amax_d == nullptr || q.D0 == nullptr)
+            return (int)hipErrorInvalidValue;
+        if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
+    }
+    // operand images of all derivative matrices in one launch
+    for (int i0 = 0; i0 < n_problems; i0 += sm::GRAM_MAX_GROUP) {
+        sm::GramPackGroup G{};
+        G.n = std::min(n_problems - i0, sm::GRAM_MAX_GROUP);
+        G.first_block[0] = 0;
+        for (int i = 0; i < G.n; ++i) {
+            const sm_gram_bwd_problem& q = problems[i0 + i];
+            const bool two = q.mask1 && q.D1;
+            sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(q.ws);
+            const int blocks = (q.C * (q.C / 8) + 255) / 256;
+            G.p[i] = sm::GramPackProb{q.D0, two ? q.D1 : nullptr, P0, P0 + (size_t)6 * q.C * q.C / 16, q.amax_d, q.C, blocks};
+            G.first_block[i + 1] = G.first_block[i] + blocks * (two ? 2 : 1);
+        }
+        hipLaunchKernelGGL(sm::gram_d_pack_group_kernel<2>, dim3(G.first_block[G.n]), dim3(256), 0, s, G);
+        SM_LAUNCH_CHECK();
+    }
+    int rc = launch_gram_bwd_group<2>(problems, idx2, n2, s);
+    if (rc) return rc;
+    return launch_gram_bwd_group<1>(problems, idx1, n1, s);
 }
 
 }  // extern "C"

@@ -3,13 +3,32 @@
 // per fp32 product, fp32 accumulate). Replace the same reference operators as gram_masked_kernel /
 // gram_backward_kernel (bool-mask gather + torch.bmm and its backward, content_and_style_losses.py:74-80,136-143).
 //
-// Both kernels run the same pipeline per 16-deep K stage: global loads two stages ahead into one of two register
-// sets, fp32 -> 3 x bf16x8 conversion while storing into one of two LDS buffers one stage ahead, fragment reads +
-// 6 MFMAs per output tile on the current buffer, one barrier per stage.
+// Both kernels run the same pipeline per K stage: global loads into one of two register sets - re-issued straight
+// after the set's previous contents were converted and stored, i.e. two stages ahead of their own conversion -,
+// fp32 -> operand-part conversion while storing into one of two LDS buffers one stage ahead, fragment reads + MFMAs on
+// the current buffer, one barrier per stage.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
+// resident waves per SIMD the register budgets are set for (A/B: tools/build_variant.sh -f gram -DSM_GRAM_FWD_W1=4 ...)
+#ifndef SM_GRAM_FWD_W1
+#define SM_GRAM_FWD_W1 2
+#endif
+#ifndef SM_GRAM_FWD_W2
+#define SM_GRAM_FWD_W2 2
+#endif
+#ifndef SM_GRAM_BWD_W1
+#define SM_GRAM_BWD_W1 2
+#endif
+#ifndef SM_GRAM_BWD_W2
+#define SM_GRAM_BWD_W2 2
+#endif
+
 namespace sm {
+
+constexpr int GRAM_MAX_GROUP = 24;   // problems per grouped launch (kernel-argument tables)
 
 // NP = 3: bf16 x 3 operands, six partial products; NP = 2: fp16 x 2 operands scaled by a power of two from the
 // tensor's recorded max |x| (conv_split_kernel.h), three partial products. Fragments travel as raw 16-byte units.
@@ -53,6 +72,21 @@ __device__ __forceinline__ void mfma_parts(f32x16& acc, const f32x4 (&fa)[NP], c
 #undef SM_H
     }
 }
+// eight fp32 values times eight per-position factors (the operand scale where the 0/1 mask is set, 0 elsewhere) -> h, l
+// fp16x8 units. No clamp: every position with a non-zero factor is live data below the recorded bound, and a masked-out
+// (possibly stale, always finite) value times 0 is 0.
+__device__ __forceinline__ void split2x8_scaled(const float (&x)[8], const float (&sm)[8], f32x4& vh, f32x4& vl) {
+    g_f16x8 h, l;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float xs = x[c] * sm[c];
+        const _Float16 a = (_Float16)xs;
+        h[c] = a;
+        l[c] = (_Float16)(xs - (float)a);
+    }
+    vh = __builtin_bit_cast(f32x4, h);
+    vl = __builtin_bit_cast(f32x4, l);
+}
 // eight fp32 values -> NP operand units (NP = 2: scaled by `scale` first)
 template <int NP>
 __device__ __forceinline__ void split_parts(const float (&x)[8], float scale, f32x4 (&v)[NP]) {
@@ -66,21 +100,31 @@ __device__ __forceinline__ void split_parts(const float (&x)[8], float scale, f3
     }
 }
 
+// eight fp32 values x eight per-position factors (NP = 2: operand scale or 0; NP = 3: 1 or 0) -> NP operand units
+template <int NP>
+__device__ __forceinline__ void masked_parts(const float (&x)[8], const float (&sm)[8], f32x4 (&v)[NP]) {
+    if constexpr (NP == 3) {
+        float y[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y[c] = (sm[c] != 0.f) ? x[c] : 0.f;
+        split3x8(y, v[0], v[1], v[2]);
+    } else {
+        split2x8_scaled(x, sm, v[0], v[1]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // D [C][C] fp32 (symmetric) -> MFMA A-fragment image [C/16 chunks][3 parts][2 k-groups][C rows][8] bf16
 // ---------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restrict__ D0, const float* __restrict__ D1,
-                                                          f32x4* __restrict__ P0, f32x4* __restrict__ P1, int C,
-                                                          const float* __restrict__ amax_d) {
-    const float* D = blockIdx.y ? D1 : D0;
-    f32x4* P = blockIdx.y ? P1 : P0;
+__device__ __forceinline__ void gram_d_pack_body(const float* __restrict__ D, f32x4* __restrict__ P, int C,
+                                                 const float* __restrict__ amax_d, int block_x) {
     float scale = 1.f;
     if (NP == 2) {   // both matrices share one bound (max |D0|, |D1| of the style-loss kernel)
         float inv;
         scale = gram_pow2_scale(amax_read(amax_d), inv);
     }
-    const int u = blockIdx.x * 256 + threadIdx.x;   // (row, 8-column group)
+    const int u = block_x * 256 + threadIdx.x;   // (row, 8-column group)
     const int groups = C / 8;
     if (u >= C * groups) return;
     const int row = u / groups, g = u - row * groups;
@@ -96,6 +140,36 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
 #pragma unroll
     for (int part = 0; part < NP; ++part) d[2 * part * (size_t)C] = v[part];
 }
+template <int NP>
+__global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restrict__ D0, const float* __restrict__ D1,
+                                                          f32x4* __restrict__ P0, f32x4* __restrict__ P1, int C,
+                                                          const float* __restrict__ amax_d) {
+    gram_d_pack_body<NP>(blockIdx.y ? D1 : D0, blockIdx.y ? P1 : P0, C, amax_d, blockIdx.x);
+}
+// GROUPED: the derivative matrices of many (level, layer) problems in one launch
+struct GramPackProb {
+    const float* D0;
+    const float* D1;          // nullptr: one matrix
+    f32x4* P0;
+    f32x4* P1;
+    const float* amax_d;
+    int C, blocks;            // blocks per matrix
+};
+struct GramPackGroup {
+    GramPackProb p[GRAM_MAX_GROUP];
+    int first_block[GRAM_MAX_GROUP + 1];
+    int n;
+};
+template <int NP>
+__global__ __launch_bounds__(256) void gram_d_pack_group_kernel(GramPackGroup G) {
+    int g = 0;
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_block[i]) g = i;
+    const GramPackProb P = G.p[g];
+    const int local = blockIdx.x - G.first_block[g];
+    const int which = local / P.blocks;
+    gram_d_pack_body<NP>(which ? P.D1 : P.D0, which ? P.P1 : P.P0, P.C, P.amax_d, local - which * P.blocks);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // K5c-s: dF[c][q] = m0[q] (D0 F)[c][q] + m1[q] (D1 F)[c][q]; GEMM M = C, N = positions, K = C per live mask.
@@ -106,11 +180,35 @@ __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restric
 // MI = 1: 64-row blocks, waves 2 x 2 with 32 x 64 tiles; MI = 2: 128-row blocks, waves 4 x 1 with 32 x 128 tiles (one
 // 32-row weight fragment set per wave: the loop is sensitive to the number of vector-memory instructions per MFMA,
 // see conv_split_kernel.h)
-template <int MI, bool RELU_GATE, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_backward_split_kernel(
-    const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
-    const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
-    int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
+struct GramBwdProb {
+    const float* feat;
+    const float* mask0;
+    const float* mask1;       // nullptr: one mask
+    const f32x4* P0;          // operand images of D0 / D1 (gram_d_pack_kernel)
+    const f32x4* P1;
+    float* dfeat;
+    const float* amax_feat;   // NP = 2 only
+    const float* amax_d;
+    int C, plane, q_begin, q_end, relu_gate, n_ptiles;
+};
+struct GramBwdGroup {
+    GramBwdProb p[GRAM_MAX_GROUP];
+    int first_block[GRAM_MAX_GROUP + 1];
+    int n;
+};
+
+template <int MI, int NP>
+__device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const int block_x, const int block_y) {
+    const float* __restrict__ feat = G.feat;
+    const float* __restrict__ mask0 = G.mask0;
+    const float* __restrict__ mask1 = G.mask1;
+    const f32x4* __restrict__ P0 = G.P0;
+    const f32x4* __restrict__ P1 = G.P1;
+    float* __restrict__ dfeat = G.dfeat;
+    const float* __restrict__ amax_feat = G.amax_feat;
+    const float* __restrict__ amax_d = G.amax_d;
+    const int C = G.C, plane = G.plane, q_begin = G.q_begin, q_end = G.q_end;
+    const bool RELU_GATE = G.relu_gate != 0;
     constexpr int BN = 128;
     constexpr int KS = 2;                 // MFMA K-steps (16 channels each) per stage
     constexpr int SLICE = KS * 2 * NP * BN;    // [kstep][part][kgroup][position] units of 8 channels
@@ -125,8 +223,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     constexpr int NJ = 2 * MI;                       // 32-position MFMA tiles per wave
     const int wm = (MI == 2 ? wave : (wave >> 1)) * 32, wn = (MI == 2 ? 0 : (wave & 1)) * 64;
-    const int m0 = blockIdx.y * (64 * MI);
-    const int q0 = q_begin + blockIdx.x * BN;
+    const int m0 = block_y * (64 * MI);
+    const int q0 = q_begin + block_x * BN;
 
     // staging units of this thread: k-group b_kg of every K-step, position b_px; its two mask values
     const int b_kg = tid >> 7, b_px = tid & 127;
@@ -177,11 +275,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         SM_STAGE_OF(s_, chunk_, k_)                                                         \
         (void)chunk_;                                                                       \
         const float mv_ = k_ ? mv1 : mv0;                                                   \
+        float sm_[8];   /* the operand scale where this position's mask is set, 0 elsewhere */ \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) sm_[c] = (mv_ != 0.f) ? f_scale : 0.f; \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
-            float x_[8];                                                                    \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (mv_ != 0.f) ? rb[set_][ks][c] : 0.f; \
             f32x4 v_[NP];                                                                   \
-            split_parts<NP>(x_, f_scale, v_);                                               \
+            masked_parts<NP>(rb[set_][ks], sm_, v_);                                        \
             f32x4* d_ = &Bs[buf_][ks * 2 * NP * BN + b_kg * BN + b_px];                     \
             _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * BN] = v_[part]; \
         }                                                                                   \
@@ -189,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define SM_STAGE(s_, par_)                                                                  \
     {                                                                                       \
         SM_STORE_B(1 - (par_), (s_) + 1, 1 - (par_))                                        \
-        SM_LOAD_B(par_, (s_) + 2)                                                           \
+        SM_LOAD_B(1 - (par_), (s_) + 3)   /* back into the set just stored: two stages of lead */ \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
             f32x4 fa[1][NP], fb[NJ][NP];                                                    \
@@ -209,6 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         SM_LOAD_A(0, 0)
         SM_LOAD_A(1, 1)
         SM_STORE_B(0, 0, 0)
+        SM_LOAD_B(0, 2)
         __syncthreads();
         for (int s = 0; s < n_stages; s += 2) {
             SM_STAGE(s, 0)
@@ -241,67 +340,137 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+template <int MI, bool RELU_GATE_, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2, MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2))) void gram_backward_split_kernel(
+    const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
+    const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
+    int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
+    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0};
+    gram_backward_body<MI, NP>(G, blockIdx.x, blockIdx.y);
+}
+
+// GROUPED: one launch over the (level, layer) problems of one row-tile class; block -> (problem, position tile, row tile)
+template <int MI, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2, MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2))) void gram_backward_group_kernel(GramBwdGroup G) {
+    int g = 0;
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_block[i]) g = i;
+    const GramBwdProb P = G.p[g];
+    const int local = blockIdx.x - G.first_block[g];
+    gram_backward_body<MI, NP>(P, local % P.n_ptiles, local / P.n_ptiles);
+}
+
 // ---------------------------------------------------------------------------------------------------
-// K5a-s: S_k[i][j] = sum_q m_k[q] F[i][q] F[j][q] = (m_k F)(m_k F)^T for 0/1 masks. grid = (position ranges, tile
-// pairs tm <= tn of (64 MI)^2, masks). K runs over positions in stages of 16; a stage whose 16 mask values are all
-// zero is skipped before anything is loaded (the masks of a level are sparse and disjoint). Partial sums of the
-// range go to slab blockIdx.x, exactly like gram_masked_kernel.
+// K5a-s: S_k[i][j] = sum_q m_k[q] F[i][q] F[j][q] = (m_k F)(m_k F)^T for 0/1 masks, GROUPED: one launch covers the
+// (level, layer) problems of one tile class (TS = 64 MI channels per tile). A block = (problem, position range, tile
+// pair tm <= tn, mask); its partial sums are added into the problem's PRE-ZEROED S_k with fp32 atomics (C^2 floats of
+// traffic per block, no slab reduction; summation order - like the texture scatter's - is not fixed).
+// K runs over positions in stages of SP = 16 KS positions (KS MFMA K-steps per barrier); a stage whose mask values are
+// all zero is skipped before anything is loaded (the masks of a level are sparse and disjoint). The loop is bound by
+// the latency of the feature-map loads: two stages are in flight per block (MI = 1: 2 x 64 channels x 64 positions =
+// 32 KB, MI = 2 off-diagonal: 2 x 256 x 32 = 64 KB), which is what one CU needs outstanding to draw its share of the
+// HBM bandwidth (the 16-position stages of the first version kept 8 KB in flight and ran at 1.9 TB/s).
+// LDS operand image per buffer: [K-step][part][k-group][channel] 16-byte units (8 positions), strides padded so that
+// the eight lanes of a ds_write_b128 group land on eight different bank groups.
 // ---------------------------------------------------------------------------------------------------
-// ATOMIC: all position ranges accumulate into ONE pre-zeroed slab with fp32 atomics instead of writing a slab each
-// (no reduction pass, C^2 floats of traffic per block instead of written + re-read; summation order - like the
-// texture scatter's - is then not fixed).
-template <int MI, bool ATOMIC, int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_split_kernel(
-    const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1, float* S0, float* S1,
-    int C, int plane, int q_begin, int q_end, int qb, const float* __restrict__ amax_feat) {
-    constexpr int TS = 64 * MI;           // tile size (channels)
-    constexpr int SLICE = 2 * NP * TS;    // [part][kgroup][channel] units of 8 positions
-    float f_scale = 1.f, out_scale = 1.f;
-    if (NP == 2) {
-        float inv;
-        f_scale = gram_pow2_scale(amax_read(amax_feat), inv);
-        out_scale = inv * inv;
-    }
-    constexpr int MAX_STAGES = 256;       // qb <= 4096 positions
-    __shared__ __attribute__((aligned(16))) f32x4 As[2][SLICE];
-    __shared__ __attribute__((aligned(16))) f32x4 Bt[2][SLICE];
-    __shared__ int live_list[MAX_STAGES];
+struct GramProb {
+    const float* feat;
+    const float* mask0;
+    const float* mask1;       // nullptr: one mask
+    float* S0;
+    float* S1;
+    const float* amax_feat;   // NP = 2 only
+    int C, plane, q_begin, q_end, qb, n_ranges;
+};
+struct GramGroup {
+    GramProb p[GRAM_MAX_GROUP];
+    int first_block[GRAM_MAX_GROUP + 1];
+    int n;
+};
+constexpr int gram_ks(int MI) { return MI == 1 ? 4 : 2; }
+constexpr int gram_kg_stride(int MI) { return MI == 1 ? 64 + 1 : 128 + 2; }
+constexpr int gram_ks_stride(int MI, int NP) {
+    int v = 2 * NP * gram_kg_stride(MI);
+    while (v % 8 != (MI == 1 ? 2 : 4)) ++v;
+    return v;
+}
+constexpr size_t gram_group_lds_bytes(int MI, int NP, bool diag_only = false) {
+    return (size_t)(diag_only ? 2 : 4) * gram_ks(MI) * gram_ks_stride(MI, NP) * 16;
+}
+
+// MI = 1 (126 VGPRs): four blocks per CU when every problem of the launch is a single diagonal tile (C = 64: the Bt
+// half of the LDS image is not allocated then) - a block keeps ~one 16 KB stage in flight, a CU needs ~50 KB
+template <int MI, int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4 : 2, MI == 1 ? 4 : 2))) void gram_group_kernel(GramGroup G) {
+    constexpr int TS = 64 * MI;                 // tile size (channels)
+    constexpr int KS = gram_ks(MI);             // MFMA K-steps per stage
+    constexpr int SP = 16 * KS;                 // positions per stage
+    constexpr int NG = 2 * KS;                  // 8-position k-groups per stage
+    constexpr int CP = 256 / NG;                // channels per staging pass
+    constexpr int R = TS / CP;                  // staging passes
+    static_assert(R == 2, "two staging units per thread and operand");
+    constexpr int KG = gram_kg_stride(MI), PART = 2 * KG, KSS = gram_ks_stride(MI, NP), BUF = KS * KSS;
+    extern __shared__ __attribute__((aligned(16))) f32x4 gsm[];
+    f32x4* As = gsm;                            // [2][BUF]
+    f32x4* Bt = gsm + 2 * BUF;                  // [2][BUF]
+    __shared__ int live_list[64];               // qb <= 64 SP positions
     __shared__ int wave_count[4];
-    const int T = C / TS;
-    int tm = 0, rem = blockIdx.y;
+
+    int g = 0;
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_block[i]) g = i;
+    const GramProb P = G.p[g];
+    int local = blockIdx.x - G.first_block[g];
+    const int T = P.C / TS, pairs = T * (T + 1) / 2;
+    const int range = local % P.n_ranges;
+    local /= P.n_ranges;
+    int rem = local % pairs;
+    const int which = local / pairs;
+    int tm = 0;
     while (rem >= T - tm) { rem -= T - tm; ++tm; }
     const int tn = tm + rem;
     const bool diag = tm == tn;
-    const float* mask = blockIdx.z ? mask1 : mask0;
-    float* S = (blockIdx.z ? S1 : S0) + (ATOMIC ? (size_t)0 : (size_t)blockIdx.x * C * C);
+    const float* mask = which ? P.mask1 : P.mask0;
+    float* S = which ? P.S1 : P.S0;
+    const int C = P.C, plane = P.plane;
+
+    float f_scale = 1.f, out_scale = 1.f;
+    if (NP == 2) {
+        float inv;
+        f_scale = gram_pow2_scale(amax_read(P.amax_feat), inv);
+        out_scale = inv * inv;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * MI);
-    const int qs = q_begin + blockIdx.x * qb;
-    const int qe = min(qs + qb, q_end);
-    const int n_st = (qe - qs + 15) / 16;
+    const int qs = P.q_begin + range * P.qb;
+    const int qe = min(qs + P.qb, P.q_end);
+    const int n_st = (qe - qs + SP - 1) / SP;
 
     // ---- compact list of the stages with any non-zero mask value (order preserved)
     {
-        bool lv = false;
-        if (tid < n_st) {
-            const int q = qs + tid * 16;
+        // four threads per stage (n_st <= 64), SP / 16 float4 each, all loads in flight together (unconditional,
+        // addresses clamped into the range)
+        const int st = tid >> 2;
+        const int q = qs + min(st, max(n_st - 1, 0)) * SP + (tid & 3) * (SP / 4);
+        f32x4 m[SP / 16];
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) {
-                if (q + e < qe) {   // qe, q are multiples of 4
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(mask + q + e);
-                    lv |= (m[0] != 0.f) | (m[1] != 0.f) | (m[2] != 0.f) | (m[3] != 0.f);
-                }
-            }
-        }
-        const unsigned long long b = __ballot(lv);
+        for (int e = 0; e < SP / 16; ++e) m[e] = *reinterpret_cast<const f32x4*>(mask + min(q + 4 * e, qe - 4));   // qe, q: multiples of 4
+        bool lv = false;
+#pragma unroll
+        for (int e = 0; e < SP / 16; ++e)
+            lv |= (q + 4 * e < qe) & ((m[e][0] != 0.f) | (m[e][1] != 0.f) | (m[e][2] != 0.f) | (m[e][3] != 0.f));
+        const unsigned long long b4 = __ballot(lv && st < n_st);
+        const bool leader = (lane & 3) == 0 && ((b4 >> lane) & 0xFull) != 0ull;   // first thread of a live stage
+        const unsigned long long b = __ballot(leader);
         if (lane == 0) wave_count[wave] = __popcll(b);
         __syncthreads();
         int off = 0;
         for (int w = 0; w < wave; ++w) off += wave_count[w];
-        if (lv) live_list[off + __popcll(b & ((1ull << lane) - 1ull))] = tid;
+        if (leader) live_list[off + __popcll(b & ((1ull << lane) - 1ull))] = st;
         __syncthreads();
     }
     const int n_live = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    if (n_live == 0) return;   // nothing to add
 
     f32x16 acc[MI][MI];
 #pragma unroll
@@ -311,72 +480,106 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (n_live > 0) {
-        // staging unit of this thread: channel u_ch of the tile, k-group u_kg (8 consecutive positions)
-        const int u_ch = (tid >> 1) % TS, u_kg = tid & 1;
-        const bool u_on = tid < 2 * TS;   // 64-channel tiles use half the block for staging
-        const float* a_src = feat + (size_t)(tm * TS + u_ch) * plane + u_kg * 8;
-        const float* b_src = feat + (size_t)(tn * TS + u_ch) * plane + u_kg * 8;
-        float rA[2][8], rB[2][8], rM[2][8];
+    // staging units of this thread: k-group u_kg (8 consecutive positions) of channels u_ch, u_ch + CP
+    const int u_kg = tid % NG, u_ch = tid / NG;
+    const float* a_src = P.feat + (size_t)(tm * TS + u_ch) * plane + u_kg * 8;
+    const float* b_src = P.feat + (size_t)(tn * TS + u_ch) * plane + u_kg * 8;
+    const int u_dst = (u_kg >> 1) * KSS + (u_kg & 1) * KG + u_ch;
+// (ablation builds, timing only: -DSM_ABL_GRAM_NOMFMA / _NOLOAD / _NOSTORE drop one ingredient of the loop)
+#ifdef SM_ABL_GRAM_NOMFMA
+#define SM_GRAM_MFMA(acc_, fa_, fb_) asm volatile("" :: "v"(fa_[0]), "v"(fb_[0]), "v"(fa_[1]), "v"(fb_[1]))
+#else
+#define SM_GRAM_MFMA(acc_, fa_, fb_) mfma_parts<NP>(acc_, fa_, fb_)
+#endif
+#ifdef SM_ABL_GRAM_NOLOAD
+#define SM_ABL_LOAD_COND(i_) if ((i_) < 2)
+#else
+#define SM_ABL_LOAD_COND(i_)
+#endif
 #define SM_LOAD(set_, i_)                                                                               \
+    SM_ABL_LOAD_COND(i_)                                                                                \
     {                                                                                                   \
-        const int q_ = qs + live_list[min((i_), n_live - 1)] * 16;                                      \
-        const f32x4 a0_ = *reinterpret_cast<const f32x4*>(a_src + q_), a1_ = *reinterpret_cast<const f32x4*>(a_src + q_ + 4); \
+        const int q_ = qs + live_list[min((i_), n_live - 1)] * SP;                                      \
         const f32x4 m0_ = *reinterpret_cast<const f32x4*>(mask + q_ + u_kg * 8), m1_ = *reinterpret_cast<const f32x4*>(mask + q_ + u_kg * 8 + 4); \
+        const int qe_ = (i_) < n_live ? qe : 0;   /* stages past the list (odd counts are padded) add zeros */ \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                 \
-            rA[set_][c] = a0_[c]; rA[set_][4 + c] = a1_[c];                                             \
-            rM[set_][c] = (q_ + u_kg * 8 + c < qe) ? m0_[c] : 0.f;                                      \
-            rM[set_][4 + c] = (q_ + u_kg * 8 + 4 + c < qe) ? m1_[c] : 0.f;                              \
+            rM[set_][c] = (q_ + u_kg * 8 + c < qe_ && m0_[c] != 0.f) ? f_scale : 0.f;                   \
+            rM[set_][4 + c] = (q_ + u_kg * 8 + 4 + c < qe_ && m1_[c] != 0.f) ? f_scale : 0.f;           \
         }                                                                                               \
-        if (!diag) {                                                                                    \
-            const f32x4 b0_ = *reinterpret_cast<const f32x4*>(b_src + q_), b1_ = *reinterpret_cast<const f32x4*>(b_src + q_ + 4); \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) { rB[set_][c] = b0_[c]; rB[set_][4 + c] = b1_[c]; } \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
+            const float* pa_ = a_src + (size_t)r * CP * plane + q_;                                     \
+            const f32x4 a0_ = *reinterpret_cast<const f32x4*>(pa_), a1_ = *reinterpret_cast<const f32x4*>(pa_ + 4); \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) { rA[set_][r][c] = a0_[c]; rA[set_][r][4 + c] = a1_[c]; } \
+            if constexpr (!DIAG) {                                                                                \
+                const float* pb_ = b_src + (size_t)r * CP * plane + q_;                                 \
+                const f32x4 b0_ = *reinterpret_cast<const f32x4*>(pb_), b1_ = *reinterpret_cast<const f32x4*>(pb_ + 4); \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) { rB[set_][r][c] = b0_[c]; rB[set_][r][4 + c] = b1_[c]; } \
+            }                                                                                           \
         }                                                                                               \
     }
+#ifdef SM_ABL_GRAM_NOSTORE
+#define SM_ABL_STORE_COND if (n_live < 0)
+#else
+#define SM_ABL_STORE_COND
+#endif
 #define SM_STORE(set_, buf_)                                                                            \
-    if (u_on) {                                                                                         \
-        float x_[8];                                                                                    \
-        f32x4 v_[NP];                                                                                   \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (rM[set_][c] != 0.f) ? rA[set_][c] : 0.f; \
-        split_parts<NP>(x_, f_scale, v_);                                                               \
-        f32x4* d_ = &As[buf_][u_kg * TS + u_ch];                                                        \
-        _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * TS] = v_[part];           \
-        if (!diag) {                                                                                    \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) x_[c] = (rM[set_][c] != 0.f) ? rB[set_][c] : 0.f; \
-            split_parts<NP>(x_, f_scale, v_);                                                           \
-            f32x4* e_ = &Bt[buf_][u_kg * TS + u_ch];                                                    \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part) e_[2 * part * TS] = v_[part];       \
+    SM_ABL_STORE_COND                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
+            f32x4 v_[NP];                                                                               \
+            masked_parts<NP>(rA[set_][r], rM[set_], v_);                                                \
+            f32x4* d_ = As + (buf_) * BUF + u_dst + r * CP;                                             \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[part * PART] = v_[part];         \
+            if constexpr (!DIAG) {                                                                                \
+                masked_parts<NP>(rB[set_][r], rM[set_], v_);                                            \
+                f32x4* e_ = Bt + (buf_) * BUF + u_dst + r * CP;                                         \
+                _Pragma("unroll") for (int part = 0; part < NP; ++part) e_[part * PART] = v_[part];     \
+            }                                                                                           \
         }                                                                                               \
     }
 #define SM_STAGE(i_, par_)                                                                              \
     {                                                                                                   \
         SM_STORE(1 - (par_), 1 - (par_))                                                                \
-        SM_LOAD(par_, (i_) + 2)                                                                         \
+        SM_LOAD(1 - (par_), (i_) + 3)   /* straight back into the set just stored: two stages of lead */ \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        f32x4 fa[MI][NP], fb[MI][NP];                                                                   \
-        const f32x4* af_ = &As[par_][lhi * TS + wm + l31];                                              \
-        const f32x4* bf_ = (diag ? &As[par_][0] : &Bt[par_][0]) + lhi * TS + wn + l31;                  \
-        _Pragma("unroll") for (int part = 0; part < NP; ++part)                                         \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                            \
-                fa[i][part] = af_[part * 2 * TS + i * 32];                                              \
-                fb[i][part] = bf_[part * 2 * TS + i * 32];                                              \
-            }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                  \
-            _Pragma("unroll") for (int j = 0; j < MI; ++j) mfma_parts<NP>(acc[i][j], fa[i], fb[j]);     \
+        const f32x4* af_ = As + (par_) * BUF + lhi * KG + wm + l31;                                     \
+        const f32x4* bf_ = (DIAG ? As : Bt) + (par_) * BUF + lhi * KG + wn + l31;                       \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                             \
+            f32x4 fa[MI][NP], fb[MI][NP];                                                               \
+            _Pragma("unroll") for (int part = 0; part < NP; ++part)                                     \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                        \
+                    fa[i][part] = af_[ks * KSS + part * PART + i * 32];                                 \
+                    fb[i][part] = bf_[ks * KSS + part * PART + i * 32];                                 \
+                }                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                              \
+                _Pragma("unroll") for (int j = 0; j < MI; ++j) SM_GRAM_MFMA(acc[i][j], fa[i], fb[j]);   \
+        }                                                                                               \
         __syncthreads();                                                                                \
     }
-        SM_LOAD(0, 0)
-        SM_LOAD(1, 1)
-        SM_STORE(0, 0)
-        __syncthreads();
-        for (int i = 0; i < n_live; i += 2) {
-            SM_STAGE(i, 0)
-            if (i + 1 < n_live) SM_STAGE(i + 1, 1)
-        }
+    // the pipeline, compiled once per tile kind: a load under a runtime `if (!diag)` would make the compiler's waitcnt
+    // pass drain the whole load queue at every later wait (conv_split_kernel.h)
+    auto pipeline = [&](auto diag_c) {
+    constexpr bool DIAG = decltype(diag_c)::value;
+    float rA[2][R][8], rB[2][R][8], rM[2][8];
+    SM_LOAD(0, 0)
+    SM_LOAD(1, 1)
+    SM_STORE(0, 0)
+    SM_LOAD(0, 2)
+    __syncthreads();
+    // stages in unconditional pairs (a load under a condition makes the compiler's waitcnt pass drain the whole queue
+    // at every later wait, see conv_split_kernel.h): an odd count runs one padding stage of zeros
+    for (int i = 0; i < n_live; i += 2) {
+        SM_STAGE(i, 0)
+        SM_STAGE(i + 1, 1)
+    }
+    };
+    if (diag) pipeline(std::true_type{}); else pipeline(std::false_type{});
 #undef SM_LOAD
 #undef SM_STORE
 #undef SM_STAGE
-    }
+#undef SM_GRAM_MFMA
+#undef SM_ABL_LOAD_COND
+#undef SM_ABL_STORE_COND
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -385,12 +588,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * TS + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int col = tn * TS + wn + nj * 32 + l31;
-                const float v = NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r];
-                if (ATOMIC) {
-                    if (n_live > 0) atomicAdd(&S[(size_t)row * C + col], v);
-                } else {
-                    S[(size_t)row * C + col] = v;
-                }
+#ifdef SM_ABL_GRAM_NOATOMIC   // (ablation build, timing only)
+                if (acc[mi][nj][r] == 12345.f) S[(size_t)row * C + col] = 1.f;
+#else
+                atomicAdd(&S[(size_t)row * C + col], NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r]);
+#endif
             }
 }
 

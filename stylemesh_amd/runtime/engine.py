@@ -151,6 +151,9 @@ class StepEngine:
         # filling idle CUs at the tails of the conv launches. Measured +1.7 % on c3 only (the conv grids leave few
         # idle CUs and no LDS for co-resident blocks), so it is off by default.
         self.overlap_style = False
+        self.group_losses = True       # fp16x2 mode: the loss phase as grouped launches over all levels and layers
+        self._loss_tables = None       # (signature, Gram / style-loss / Gram-backward problem tables, slab keys)
+        self._gram_bwd_ws = {}         # (C, level, layer) -> scratch of the derivative matrices' operand images
         self._side = None
         # the loss branches of the UV levels (5 x [Gram -> loss -> Gram backward] + content MSE each, ~25 small
         # launches per level) are independent: one HIP stream per level lets the small levels' latency-bound kernels
@@ -498,7 +501,9 @@ class StepEngine:
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
-            if concurrent:
+            if self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average":
+                injected = self._inject_losses_grouped(active, bufs, w_style, w_content)
+            elif concurrent:
                 main = torch.cuda.current_stream()
                 while len(self._lv_streams) < len(active) - 1:
                     self._lv_streams.append(torch.cuda.Stream(device=self.device))
@@ -532,6 +537,66 @@ class StepEngine:
             for lv, b in zip(active, bufs):
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
+
+    def _inject_losses_grouped(self, active, bufs, w_style, w_content):
+        """The loss phase of a step over ALL active levels and style layers in a handful of launches (fp16x2 mode):
+        masked Grams (one launch per tile class), loss values + derivative matrices (one launch), operand images of
+        the derivative matrices (one launch), Gram backward into ``grad[layer]`` (one launch per tile class); then the
+        content terms. The problem tables hold raw pointers: they are rebuilt whenever the view (masks, counts), the
+        level buffers or the weights change (the per-view masks and counts
+        live in persistent buffers, so consecutive views of the same level set reuse the tables)."""
+        cfg = self.cfg
+        l0 = cfg.style_layers[0]
+        sig = (tuple((lv.index, id(b), lv.masks[l0].ptr, lv.counts[l0].data_ptr()) for lv, b in zip(active, bufs)),
+               w_style, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
+        if self._loss_tables is None or self._loss_tables[0] != sig:
+            multi = cfg.style_pyramid_mode == "multi"
+            fwd, sty, bwd, keys = [], [], [], []
+            for lv, b in zip(active, bufs):
+                for li, layer in enumerate(cfg.style_layers):
+                    f = b.act[layer]
+                    key = (f.C, lv.index, layer)
+                    S0, S1, D0, D1 = self._gram_scratch(key, ops.gram_workspace_slabs(f.C, f.H, f.W))
+                    k = (lv.index * len(cfg.style_layers) + li) * ops.AMAX_FLOATS
+                    ad = self._amax_d[k:k + ops.AMAX_FLOATS]
+                    af = self.amax["a:" + layer]
+                    m0, m1 = self._style_masks(lv, layer)
+                    weight = w_style * float(cfg.style_weights[li])
+                    if multi:
+                        targets, term_mask = [self.targets[li][2], self.targets[li][2]], [0, 1]
+                        if li > 2:   # content_and_style_losses.py:335-338
+                            targets.append(self.targets[li][0])
+                            term_mask.append(0)
+                        counts, skip = lv.counts[layer][1:3], [0, 1]
+                    else:
+                        S1 = D1 = None
+                        targets, term_mask, counts, skip = [self.targets[li][0]], [0], lv.counts[layer][0:1], [0, 0]
+                    ws = self._gram_bwd_ws.get(key)
+                    if ws is None:
+                        ws = self._gram_bwd_ws[key] = torch.empty(ops.gram_backward_ws_bytes(f.C), dtype=torch.uint8,
+                                                                  device=self.device)
+                    fwd.append(ops.gram_problem(f, m0, m1, S0, S1, af))
+                    sty.append(ops.style_problem(S0, S1, counts, lv.factor[layer], targets, term_mask, skip, weight, f.C,
+                                                 D0, D1, ad))
+                    bwd.append(ops.gram_bwd_problem(f, m0, m1, D0, D1, b.grad[layer], ws, af, ad,
+                                                    relu_gate=(layer == self.deepest)))
+                    keys.append(key)
+            from . import hip
+            self._loss_tables = (sig, ops.struct_array(hip.GramProblem, fwd), ops.struct_array(hip.StyleProblem, sty),
+                                 ops.struct_array(hip.GramBwdProblem, bwd), keys)
+        _, fwd, sty, bwd, keys = self._loss_tables
+        assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
+        ops.gram_masked_grouped(fwd)
+        self._gram_clean.difference_update(keys)
+        ops.style_loss_grouped(sty, self.loss_buf[1:2])
+        ops.gram_backward_grouped(bwd)
+        injected = set(cfg.style_layers)
+        if w_content != 0.0:
+            for lv, b in zip(active, bufs):
+                for li, layer in enumerate(cfg.content_layers):
+                    self._content_term(lv, b, li, layer, w_content)
+                    injected.add(layer)
+        return injected
 
     def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None, am=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest

@@ -62,6 +62,9 @@ SIGNATURES = {
     "sm_gram_split_num_slabs": [],
     "sm_gram_masked_split": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "sm_gram_masked_split_acc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "sm_gram_masked_split2_grouped": [_vp, _i, _vp],
+    "sm_style_loss_grouped": [_vp, _i, _vp, _vp],
+    "sm_gram_backward_split2_grouped": [_vp, _i, _vp],
     "sm_style_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "sm_gram_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sm_mse_masked": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -93,6 +96,28 @@ SIGNATURES = {
 class ConvProblem(C.Structure):
     """sm_conv_problem of include/stylemesh_hip.h"""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int)]
+
+
+class GramProblem(C.Structure):
+    """sm_gram_problem of include/stylemesh_hip.h"""
+    _fields_ = [("feat", C.c_void_p), ("mask0", C.c_void_p), ("mask1", C.c_void_p), ("S0", C.c_void_p),
+                ("S1", C.c_void_p), ("amax_feat", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
+class StyleProblem(C.Structure):
+    """sm_style_problem of include/stylemesh_hip.h"""
+    _fields_ = [("S0", C.c_void_p), ("S1", C.c_void_p), ("counts", C.c_void_p), ("factor", C.c_void_p),
+                ("targets", C.c_void_p * 4), ("term_mask", C.c_int * 4), ("n_terms", C.c_int),
+                ("skip_if_empty", C.c_int * 2), ("weight", C.c_float), ("C", C.c_int), ("D0", C.c_void_p),
+                ("D1", C.c_void_p), ("history", C.c_void_p), ("hist_len", C.c_int), ("hist_slot", C.c_int),
+                ("n_slabs", C.c_int), ("amax_d_out", C.c_void_p)]
+
+
+class GramBwdProblem(C.Structure):
+    """sm_gram_bwd_problem of include/stylemesh_hip.h"""
+    _fields_ = [("feat", C.c_void_p), ("mask0", C.c_void_p), ("mask1", C.c_void_p), ("D0", C.c_void_p),
+                ("D1", C.c_void_p), ("dfeat", C.c_void_p), ("ws", C.c_void_p), ("amax_feat", C.c_void_p),
+                ("amax_d", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("relu_gate", C.c_int)]
 
 
 class PlaneProblem(C.Structure):

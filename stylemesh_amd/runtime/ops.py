@@ -441,6 +441,67 @@ def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False, amax_feat=Non
     return n
 
 
+def gram_problem(feat: FMap, mask0, mask1, S0, S1, amax_feat) -> "hip.GramProblem":
+    """One entry of ``gram_masked_grouped`` (pointers only: valid while the tensors live)."""
+    return hip.GramProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), ptr(amax_feat), feat.C, feat.H, feat.W)
+
+
+def gram_problem_array(problems):
+    arr = (hip.GramProblem * len(problems))()
+    for i, p in enumerate(problems):
+        arr[i] = p
+    return arr
+
+
+def gram_masked_grouped(arr):
+    """fp16x2 Gram forward of many (level, layer) problems (``gram_problem_array``) in at most two launches; every
+    S0 / S1 must be zero on entry (the position ranges add into them)."""
+    hip.check(lib.sm_gram_masked_split2_grouped(arr, len(arr), hip.stream()), "sm_gram_masked_split2_grouped")
+
+
+def style_problem(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight, C, D0, D1, amax_d_out,
+                  n_slabs=1) -> "hip.StyleProblem":
+    """One entry of ``style_loss_grouped`` (same meanings as the arguments of ``style_loss``; no Gram history)."""
+    p = hip.StyleProblem()
+    p.S0, p.S1, p.counts, p.factor = ptr(S0), ptr(S1), ptr(counts), ptr(factor)
+    for i, t in enumerate(targets):
+        p.targets[i] = ptr(t)
+        p.term_mask[i] = int(term_mask[i])
+    p.n_terms = len(targets)
+    p.skip_if_empty[0], p.skip_if_empty[1] = int(skip_if_empty[0]), int(skip_if_empty[1])
+    p.weight, p.C, p.D0, p.D1 = float(weight), int(C), ptr(D0), ptr(D1)
+    p.history, p.hist_len, p.hist_slot, p.n_slabs, p.amax_d_out = None, 0, 0, int(n_slabs), ptr(amax_d_out)
+    return p
+
+
+def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate) -> "hip.GramBwdProblem":
+    """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own."""
+    assert ws.numel() >= lib.sm_gram_backward_split_ws_bytes(feat.C)
+    return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, ptr(ws), ptr(amax_feat),
+                              ptr(amax_d), feat.C, feat.H, feat.W, int(relu_gate))
+
+
+def gram_backward_ws_bytes(C: int) -> int:
+    return lib.sm_gram_backward_split_ws_bytes(C)
+
+
+def struct_array(kind, problems):
+    arr = (kind * len(problems))()
+    for i, p in enumerate(problems):
+        arr[i] = p
+    return arr
+
+
+def style_loss_grouped(arr, loss_out):
+    """Loss value (added into ``loss_out``) and derivative matrices of many (level, layer) problems in one launch."""
+    hip.check(lib.sm_style_loss_grouped(arr, len(arr), ptr(loss_out), hip.stream()), "sm_style_loss_grouped")
+
+
+def gram_backward_grouped(arr):
+    """fp16x2 Gram backward of many (level, layer) problems: one packing launch + one GEMM launch per tile class."""
+    hip.check(lib.sm_gram_backward_split2_grouped(arr, len(arr), hip.stream()), "sm_gram_backward_split2_grouped")
+
+
 def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight, C, D0, D1, loss_out,
                history=None, hist_len=0, hist_slot=0, n_slabs=1, amax_d_out=None):
     hip.check(lib.sm_style_loss(ptr(S0), ptr(S1), ptr(counts), ptr(factor), hip.ptr_array(targets),

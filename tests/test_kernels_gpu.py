@@ -505,6 +505,93 @@ def test_gram_style_loss_and_backward(rt, C, H, W, multi, gram_mode, monkeypatch
     assert_close(df.to_dense(), feat.grad[0] * (feat.detach()[0] > 0), 1e-4, 2e-5 * float(feat.grad.abs().max()))
 
 
+def test_gram_grouped_matches_fp64(rt):
+    """All (level, layer) Gram problems of a step in one grouped call (two launches: 64- and 128-channel tile classes)
+    against fp64 masked Grams; one of the problems has a single mask, one an empty mask."""
+    shapes = [(64, 150, 200), (64, 37, 50), (128, 75, 100), (256, 37, 50), (512, 18, 25), (512, 9, 12), (128, 20, 28)]
+    probs, keep, refs = [], [], []
+    for n, (C, H, W) in enumerate(shapes):
+        torch.manual_seed(C + H)
+        feat = F.relu(torch.randn(C, H, W)) * (10.0 ** (n - 3))          # very different magnitudes per problem
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        m_all = ((yy > 0.1 * H) & (xx < 0.8 * W) & (torch.rand(H, W) > 0.05)).float()
+        passed = (xx < 0.4 * W).float()
+        m0, m1 = m_all * passed, m_all * (1 - passed)
+        if n == 3: m1 = None
+        if n == 4: m1 = torch.zeros(H, W)
+        f = rt.FMap(C, H, W).from_dense(feat)
+        mk = [rt.FMap(1, H, W).from_dense(m[None]) if m is not None else None for m in (m0, m1)]
+        S = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda() if m1 is not None else None]
+        af = rt.ops.new_amax("cuda", float(feat.abs().max()))
+        keep.append((f, mk, S, af))
+        probs.append(rt.ops.gram_problem(f, mk[0], mk[1], S[0], S[1], af))
+        fd = feat.double().reshape(C, -1)
+        refs.append([(fd * m.double().reshape(1, -1)) @ fd.T if m is not None else None for m in (m0, m1)])
+    rt.ops.gram_masked_grouped(rt.ops.gram_problem_array(probs))
+    for (C, H, W), (f, mk, S, af), ref in zip(shapes, keep, refs):
+        T = C // 64
+        tile_upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
+        for k in range(2):
+            if ref[k] is None: continue
+            scale = max(float(ref[0].abs().max()), 1e-30)
+            assert_close(S[k].cpu().double()[tile_upper], ref[k][tile_upper], 1e-5, 2e-6 * scale, f"C={C} {H}x{W} mask {k}")
+
+
+def test_loss_phase_grouped_matches_per_problem_calls(rt, monkeypatch):
+    """sm_style_loss_grouped / sm_gram_backward_split2_grouped over several (level, layer) problems against the
+    per-problem entry points on the same inputs: loss value, derivative matrices, their recorded bound, dF."""
+    monkeypatch.setattr(rt.ops, "GRAM_MODE", "split2")
+    shapes = [(64, 60, 80, True), (128, 30, 40, True), (256, 15, 20, False), (512, 9, 12, True), (64, 21, 30, True)]
+    keep, fwd, sty, bwd = [], [], [], []
+    loss_ref = torch.zeros(1).cuda()
+    for n, (C, H, W, multi) in enumerate(shapes):
+        torch.manual_seed(C + H)
+        feat = F.relu(torch.randn(C, H, W)) * (3.0 ** n)
+        m_all = (torch.rand(H, W) > 0.3).float()
+        passed = (torch.rand(H, W) > 0.5).float()
+        masks = (m_all * passed, m_all * (1 - passed)) if multi else (m_all, None)
+        f = rt.FMap(C, H, W).from_dense(feat)
+        mk = [rt.FMap(1, H, W).from_dense(m[None]) if m is not None else None for m in masks]
+        Y = [dev((lambda t: (t + t.T) / 2)(torch.randn(C, C))) for _ in range(2)]
+        targets, term_mask, skip = ([Y[0], Y[0], Y[1]], [0, 1, 0], [0, 1]) if multi else ([Y[0]], [0], [0, 0])
+        counts = dev(torch.tensor([float(m.sum()) if m is not None else 0.0 for m in masks]))
+        factor = dev(torch.tensor([0.3 + 0.1 * n]))
+        weight = 0.1 * (n + 1)
+        af = rt.ops.new_amax("cuda", float(feat.abs().max()))
+        # per-problem reference
+        S = [torch.zeros(1, C, C).cuda(), torch.zeros(1, C, C).cuda() if multi else None]
+        rt.ops.gram_masked(f, mk[0], mk[1], S[0], S[1], amax_feat=af)
+        Dr = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
+        adr = rt.ops.new_amax("cuda")
+        rt.ops.style_loss(S[0], S[1], counts, factor, targets, term_mask, skip, weight, C, Dr[0], Dr[1], loss_ref, amax_d_out=adr)
+        dfr = rt.FMap(C, H, W)
+        gate = n == 3
+        rt.ops.gram_backward(f, mk[0], mk[1], Dr[0], Dr[1], dfr, relu_gate=gate, amax_feat=af, amax_d=adr)
+        # grouped problem entries (own outputs)
+        G = [torch.zeros(C, C).cuda(), torch.zeros(C, C).cuda() if multi else None]
+        D = [torch.empty(C, C).cuda(), torch.empty(C, C).cuda() if multi else None]
+        ad = rt.ops.new_amax("cuda")
+        df = rt.FMap(C, H, W)
+        ws = torch.empty(rt.ops.gram_backward_ws_bytes(C), dtype=torch.uint8, device="cuda")
+        fwd.append(rt.ops.gram_problem(f, mk[0], mk[1], G[0], G[1], af))
+        sty.append(rt.ops.style_problem(G[0], G[1], counts, factor, targets, term_mask, skip, weight, C, D[0], D[1], ad))
+        bwd.append(rt.ops.gram_bwd_problem(f, mk[0], mk[1], D[0], D[1], df, ws, af, ad, relu_gate=gate))
+        keep.append((f, mk, Y, counts, factor, af, S, Dr, adr, dfr, G, D, ad, df, ws))
+    loss = torch.zeros(1).cuda()
+    rt.ops.gram_masked_grouped(rt.ops.struct_array(rt.hip.GramProblem, fwd))
+    rt.ops.style_loss_grouped(rt.ops.struct_array(rt.hip.StyleProblem, sty), loss)
+    rt.ops.gram_backward_grouped(rt.ops.struct_array(rt.hip.GramBwdProblem, bwd))
+    assert_close(loss, loss_ref, 1e-5, 0)
+    for (C, H, W, multi), k in zip(shapes, keep):
+        f, mk, Y, counts, factor, af, S, Dr, adr, dfr, G, D, ad, df, ws = k
+        for a, b in zip(D, Dr):
+            if a is not None:
+                assert_close(a, b, 1e-4, 1e-5 * float(b.abs().max()), f"D C={C}")
+        assert abs(float(ad.max()) - float(adr.max())) <= 1e-4 * float(adr.max())
+        assert_close(df.to_dense(), dfr.to_dense(), 1e-4, 2e-5 * float(dfr.to_dense().abs().max()), f"dF C={C}")
+        assert df.border_is_zero()
+
+
 @pytest.mark.parametrize("gram_mode", ["f32", "split"])
 def test_style_loss_empty_masks(rt, gram_mode, monkeypatch):
     """N_pass == 0 -> Gram of zeros still compared with the target; N_fail == 0 -> term dropped (:332)."""

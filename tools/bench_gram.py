@@ -9,6 +9,7 @@ LAYERS = [(64, 1), (128, 2), (256, 4), (512, 8), (512, 16)]
 LEVELS = [(256, 341), (432, 576), (608, 811), (784, 1045)]
 sel = [int(a) for a in sys.argv[1:]] or [0, 3]
 tot = {m: [0.0, 0.0] for m in ("f32", "split", "split2")}
+group, keep = [], []
 for li in sel:
     H0, W0 = LEVELS[li]
     for C, div in LAYERS:
@@ -43,5 +44,14 @@ for li in sel:
                 tot[mode][0 if which == "fwd" else 1] += us
             line += f" | {mode}: fwd {res[(mode,'fwd')]:7.1f} us  bwd {res[(mode,'bwd')]:7.1f} us"
         print(line, flush=True)
+        group.append(ops.gram_problem(f, m0, m1, S0, S1, af)); keep.append((f, m0, m1, S0, S1, af))
 for m, (a, b) in tot.items():
     print(f"{m}: fwd {a/1e3:.3f} ms  bwd {b/1e3:.3f} ms")
+arr = ops.gram_problem_array(group)
+for _ in range(2): ops.gram_masked_grouped(arr)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): ops.gram_masked_grouped(arr)
+e1.record(); torch.cuda.synchronize()
+print(f"split2 grouped fwd over the {len(group)} problems above: {e0.elapsed_time(e1) / 5:.3f} ms")
