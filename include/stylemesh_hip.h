@@ -355,6 +355,7 @@ typedef struct {
     void* ws;
     const float* amax_feat;
     const float* amax_d;
+    float* amax_out;        /* optional amax array: records max |dfeat| (see sm_conv3x3_grouped: amax_out) */
     int C, H, W, relu_gate;
 } sm_gram_bwd_problem;
 int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream);

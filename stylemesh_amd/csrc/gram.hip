@@ -160,7 +160,7 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 }
 
 #ifndef SM_STYLE_EPT
-#define SM_STYLE_EPT 4
+#define SM_STYLE_EPT 16
 #endif
 constexpr int STYLE_EPT = SM_STYLE_EPT;   // elements per thread
 __device__ __forceinline__ void style_loss_body(const float* __restrict__ S0, const float* __restrict__ S1,
@@ -495,7 +495,7 @@ static int launch_gram_bwd_group(const sm_gram_bwd_problem* problems, const int*
             const bool two = q.mask1 && q.D1;
             sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(q.ws);
             G.p[i] = sm::GramBwdProb{q.feat, q.mask0, two ? q.mask1 : nullptr, P0, P0 + (size_t)6 * q.C * q.C / 16, q.dfeat,
-                                     q.amax_feat, q.amax_d, q.C, sm::plane_size(q.H, q.W), Wp, (q.H + 1) * Wp,
+                                     q.amax_feat, q.amax_d, q.amax_out, q.C, sm::plane_size(q.H, q.W), Wp, (q.H + 1) * Wp,
                                      q.relu_gate, np};
             G.first_block[i + 1] = G.first_block[i] + np * (q.C / (64 * MI));
         }

@@ -189,6 +189,7 @@ struct GramBwdProb {
     float* dfeat;
     const float* amax_feat;   // NP = 2 only
     const float* amax_d;
+    float* amax_out;          // optional: records max |dF| (the operand bound of the conv that consumes dfeat)
     int C, plane, q_begin, q_end, relu_gate, n_ptiles;
 };
 struct GramBwdGroup {
@@ -209,6 +210,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
     const float* __restrict__ amax_d = G.amax_d;
     const int C = G.C, plane = G.plane, q_begin = G.q_begin, q_end = G.q_end;
     const bool RELU_GATE = G.relu_gate != 0;
+    const float amax_seen = amax_peek(G.amax_out);
     constexpr int BN = 128;
     constexpr int KS = 2;                 // MFMA K-steps (16 channels each) per stage
     constexpr int SLICE = KS * 2 * NP * BN;    // [kstep][part][kgroup][position] units of 8 channels
@@ -320,6 +322,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
 #undef SM_STAGE
     }
     // epilogue: 32x32 C/D layout, column (position) = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float vmax = 0.f;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         const int q = q0 + wn + nj * 32 + l31;
@@ -336,8 +339,10 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
             if (NP == 2) v *= out_scale;
             if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
             dfeat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
     }
+    record_amax(G.amax_out, vmax, amax_seen);
 }
 
 template <int MI, bool RELU_GATE_, int NP>
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
     const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
     int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
-    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0};
+    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, nullptr, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0};
     gram_backward_body<MI, NP>(G, blockIdx.x, blockIdx.y);
 }
 

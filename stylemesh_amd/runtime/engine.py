@@ -501,8 +501,11 @@ class StepEngine:
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
+            start_bound = False
             if self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average":
                 injected = self._inject_losses_grouped(active, bufs, w_style, w_content)
+                start_bound = (self.deepest in cfg.style_layers and self.deepest not in cfg.content_layers
+                               and ops.CONV_MODE == "split2")
             elif concurrent:
                 main = torch.cuda.current_stream()
                 while len(self._lv_streams) < len(active) - 1:
@@ -526,7 +529,8 @@ class StepEngine:
             else:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
-            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax)
+            self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax,
+                                    start_bound_recorded=start_bound)
         if not accumulate_grad:
             return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
@@ -548,7 +552,7 @@ class StepEngine:
         cfg = self.cfg
         l0 = cfg.style_layers[0]
         sig = (tuple((lv.index, id(b), lv.masks[l0].ptr, lv.counts[l0].data_ptr()) for lv, b in zip(active, bufs)),
-               w_style, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
+               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
         if self._loss_tables is None or self._loss_tables[0] != sig:
             multi = cfg.style_pyramid_mode == "multi"
             fwd, sty, bwd, keys = [], [], [], []
@@ -578,8 +582,12 @@ class StepEngine:
                     fwd.append(ops.gram_problem(f, m0, m1, S0, S1, af))
                     sty.append(ops.style_problem(S0, S1, counts, lv.factor[layer], targets, term_mask, skip, weight, f.C,
                                                  D0, D1, ad))
+                    # the deepest layer's gradient starts the backward pass: its bound is recorded here (unless a
+                    # content term also writes that buffer)
+                    rec = layer == self.deepest and layer not in cfg.content_layers and ops.CONV_MODE == "split2"
                     bwd.append(ops.gram_bwd_problem(f, m0, m1, D0, D1, b.grad[layer], ws, af, ad,
-                                                    relu_gate=(layer == self.deepest)))
+                                                    relu_gate=(layer == self.deepest),
+                                                    amax_out=self.amax["g:" + layer] if rec else None))
                     keys.append(key)
             from . import hip
             self._loss_tables = (sig, ops.struct_array(hip.GramProblem, fwd), ops.struct_array(hip.StyleProblem, sty),

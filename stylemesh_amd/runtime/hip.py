@@ -117,7 +117,8 @@ class GramBwdProblem(C.Structure):
     """sm_gram_bwd_problem of include/stylemesh_hip.h"""
     _fields_ = [("feat", C.c_void_p), ("mask0", C.c_void_p), ("mask1", C.c_void_p), ("D0", C.c_void_p),
                 ("D1", C.c_void_p), ("dfeat", C.c_void_p), ("ws", C.c_void_p), ("amax_feat", C.c_void_p),
-                ("amax_d", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("relu_gate", C.c_int)]
+                ("amax_d", C.c_void_p), ("amax_out", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("relu_gate", C.c_int)]
 
 
 class PlaneProblem(C.Structure):

@@ -474,11 +474,13 @@ def style_problem(S0, S1, counts, factor, targets, term_mask, skip_if_empty, wei
     return p
 
 
-def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate) -> "hip.GramBwdProblem":
-    """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own."""
+def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate,
+                     amax_out=None) -> "hip.GramBwdProblem":
+    """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own;
+    ``amax_out`` (optional amax bound): max |dfeat| is max-ed into it."""
     assert ws.numel() >= lib.sm_gram_backward_split_ws_bytes(feat.C)
     return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, ptr(ws), ptr(amax_feat),
-                              ptr(amax_d), feat.C, feat.H, feat.W, int(relu_gate))
+                              ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate))
 
 
 def gram_backward_ws_bytes(C: int) -> int:

@@ -163,12 +163,13 @@ class VGGNet:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
     def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None,
-                       amax: AmaxBook | None = None):
+                       amax: AmaxBook | None = None, start_bound_recorded=False):
         """``backward`` for several levels at once (same injected layers on every level). ``amax``: as in
-        ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here."""
+        ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here unless
+        the loss kernels recorded it themselves (``start_bound_recorded``)."""
         am = amax if _amax_on() else None
         assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
-        if am is not None:
+        if am is not None and not start_bound_recorded:
             for b in bufs:
                 ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
