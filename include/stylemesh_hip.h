@@ -156,6 +156,14 @@ typedef struct {
     float* out;
     const float* gate;
     int H, W;
+    /* sm_conv3x3_grouped_split2 only (NULL elsewhere), flags SM_EPI_RELU_MASK [| SM_EPI_ADD], all problems of a launch
+     * or none: the conv's input is the backward of a 2x2 max-pool (+ the ReLU before it), taken on the fly. `in` is
+     * then the gradient of the POOLED map [Cin][plane(H/2, W/2)] and unpool_code the code image
+     * sm_maxpool2x2_fwd_codes_tiles wrote beside the pooled map ([Cin / 8][plane(H/2, W/2)] dwords, nibble c of
+     * [g][q] = code of channel 8 g + c: 0..3 = the window element dy * 2 + dx holding the first maximum, 4 = maximum
+     * <= 0): operand(y, x) = in(y/2, x/2) if code(y/2, x/2) == (y & 1) * 2 + (x & 1) else 0. Replaces the
+     * sm_maxpool2x2_bwd_relu pass (2.75 plane-sizes of traffic) and the re-read of its output. */
+    const uint32_t* unpool_code;
 } sm_conv_problem;
 /* "amax" bounds. An amax argument is a DEVICE array of sm_amax_floats() floats (64 slots, 256 bytes apart), zeroed by
  * the caller before the first launch that records into it; its VALUE is the maximum over the slots. Writers atomically
@@ -244,6 +252,13 @@ int sm_maxpool2x2_fwd_tiles(const sm_plane_problem* problems, int n, int C, cons
                             void* stream);
 int sm_maxpool2x2_bwd_relu_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
                                  void* stream);
+/* Pool forward that also records, per pooled element, WHERE its maximum came from: codes[i] = DEVICE code image of
+ * problem i, [C / 8][plane(H/2, W/2)] dwords (C % 8 == 0; codes: HOST array of n pointers, or NULL = plain forward):
+ * nibble c of [g][q] belongs to channel 8 g + c: 0..3 = window element dy * 2 + dx holding the first maximum in
+ * row-major order (the rule of sm_maxpool2x2_bwd_relu), 4 = maximum <= 0 (no gradient passes the ReLU) or padding.
+ * sm_conv3x3_grouped_split2 takes the pool's backward from these codes on the fly (sm_conv_problem::unpool_code). */
+int sm_maxpool2x2_fwd_codes_tiles(const sm_plane_problem* problems, uint32_t* const* codes, int n, int C,
+                                  const int32_t* tile_list, int n_list, void* stream);
 
 /* ---- Gram / style / content losses: content_and_style_losses.py:74-80,136-143,288-350 --------------- */
 

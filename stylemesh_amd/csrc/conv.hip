@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict_
 }
 
 // SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3>
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -335,8 +335,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = stamp ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, true, NP>
-                       : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP>;
+        auto k = (stamp && !UNPOOL) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL, NP, UNPOOL>
+                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -362,19 +362,19 @@ static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, 
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true>(a, n_list, ws_floats, s);
 }
 
-template <int FLAGS>
+template <int FLAGS, bool UNPOOL = false>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
 #if SM_SPLIT2_BN256
     // 64 output channels: 64 x 256 tiles, four waves of 64 x 64 (the same MFMAs per stage and wave as the 128-row tile)
-    if (a.Cout % 128 != 0) return launch_conv<64, 256, 16, 1, 4, FLAGS, true, 2>(a, n_list, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 256, 16, 1, 4, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 #else
-    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2>(a, n_list, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 #endif
 #if SM_SPLIT2_BM256
     // one wave per SIMD with a 64 x 128 wave tile (128 accumulator registers): 24 MFMAs per stage and wave
-    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2>(a, n_list, ws_floats, s);
+    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 #endif
-    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 }
 
 template <int FLAGS>
@@ -443,6 +443,36 @@ __device__ __forceinline__ void maxpool_fwd_body(const float* __restrict__ in, f
         v = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[Wp], p[Wp + 1]));
     }
     out[(size_t)c * plane_o + q] = v;
+}
+// The same with argmax codes: a thread pools EIGHT channels of its position (blockIdx.y = 8-channel group) and writes,
+// beside the pooled values, one dword code[g][q] whose nibble c says which window element of channel 8 g + c holds the
+// FIRST maximum in row-major order (0..3 = dy * 2 + dx; the rule of maxpool_bwd_relu_body / ATen), or 4 when the
+// maximum is <= 0 (every ReLU gate of the window is closed) or the position is padding - what the data-gradient
+// convolution below the pool needs to take the pool's backward on the fly (ConvProblem::code).
+__device__ __forceinline__ void maxpool_fwd_codes_body(const float* __restrict__ in, float* __restrict__ out,
+                                                       uint32_t* __restrict__ code, int H, int W, int Wp, int plane,
+                                                       int Ho, int Wo, int Wpo, int plane_o, int block_x) {
+    const int g = blockIdx.y;
+    const int q = Wpo + block_x * 256 + threadIdx.x;  // output position, rows 1..Ho
+    if (q >= (Ho + 1) * Wpo) return;
+    const int r = q / Wpo, x = q - r * Wpo;
+    const bool inside = x >= 1 && x <= Wo;
+    const float* p = in + (size_t)g * 8 * plane + (2 * (r - 1) + 1) * Wp + 2 * (x - 1) + 1;
+    float v00[8], v01[8], v10[8], v11[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {   // all loads of the eight windows in flight together
+        const float* pc = inside ? p + (size_t)c * plane : in;
+        v00[c] = pc[0]; v01[c] = pc[1]; v10[c] = pc[Wp]; v11[c] = pc[Wp + 1];
+    }
+    uint32_t codes = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = inside ? fmaxf(fmaxf(v00[c], v01[c]), fmaxf(v10[c], v11[c])) : 0.f;
+        const uint32_t k = (!inside || !(v > 0.f)) ? 4u : (v00[c] == v ? 0u : (v01[c] == v ? 1u : (v10[c] == v ? 2u : 3u)));
+        codes |= k << (4 * c);
+        out[(size_t)(g * 8 + c) * plane_o + q] = v;
+    }
+    code[(size_t)g * plane_o + q] = codes;
 }
 
 __device__ __forceinline__ void maxpool_bwd_relu_body(const float* __restrict__ act, const float* __restrict__ pooled,
@@ -530,6 +560,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
                      plane_size(Ho, Wo), bx);
 }
 
+__global__ __launch_bounds__(256) void maxpool_fwd_codes_kernel(PlaneGroup g) {
+    int bx;
+    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
+    const int Ho = P.H / 2, Wo = P.W / 2;
+    // (the code image travels in the problem's otherwise unused `c` slot)
+    maxpool_fwd_codes_body(P.a, P.out, reinterpret_cast<uint32_t*>(const_cast<float*>(P.c)), P.H, P.W, row_stride(P.W),
+                           plane_size(P.H, P.W), Ho, Wo, row_stride(Wo), plane_size(Ho, Wo), bx);
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_relu_kernel(PlaneGroup g) {
     int bx;
     const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
@@ -557,7 +596,14 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
     }
 }
 
-static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
+static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
+    if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
+        switch (flags) {
+            case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, ws_floats, s);
+            default: return (int)hipErrorInvalidValue;
+        }
+    }
     switch (flags) {
         case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
         case 0: return sm::dispatch_conv_split2<0>(a, n_list, ws_floats, s);
@@ -601,8 +647,11 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
     if (Cout % 64 != 0 || Cin_pad % 4 != 0 || (Cin_pad > 4 && Cin_pad % 8 != 0)) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
     for (int g = 0; g < n_problems; ++g)
-        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
+    {
+        if (problems[g].unpool_code != nullptr) return (int)hipErrorInvalidValue;   // fp16x2 kernel only
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, nullptr, problems[g].H, problems[g].W,
                                  sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    }
     a.n_problems = n_problems;
     a.wt = wt;
     a.bias = bias;
@@ -621,9 +670,14 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
     if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
     if (Cout % 64 != 0 || Cin % 16 != 0 || amax_in == nullptr || !(w_scale_inv > 0.f)) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
+    int unpool = 0;   // problems whose input is a pooled gradient + argmax codes: all of a launch or none
     for (int g = 0; g < n_problems; ++g)
-        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
-                                 sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    {
+        unpool += problems[g].unpool_code != nullptr;
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].unpool_code,
+                                 problems[g].H, problems[g].W, sm::row_stride(problems[g].W),
+                                 sm::plane_size(problems[g].H, problems[g].W)};
+    }
     a.n_problems = n_problems;
     a.wt = reinterpret_cast<const float*>(wt2);
     a.bias = bias;
@@ -635,7 +689,8 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
     a.amax_in = amax_in;
     a.amax_out = amax_out;
     a.w_scale_inv = w_scale_inv;
-    return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, (hipStream_t)stream);
+    if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
+    return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
 }
 
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3, const float* bias,
@@ -645,8 +700,11 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
     if (Cout % 64 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
     sm::ConvArgs a{};
     for (int g = 0; g < n_problems; ++g)
-        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].H, problems[g].W,
+    {
+        if (problems[g].unpool_code != nullptr) return (int)hipErrorInvalidValue;   // fp16x2 kernel only
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, nullptr, problems[g].H, problems[g].W,
                                  sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
+    }
     a.n_problems = n_problems;
     a.wt = reinterpret_cast<const float*>(wt3);
     a.bias = bias;
@@ -708,8 +766,25 @@ int sm_conv3x3_dgrad_c3_tiles(const sm_plane_problem* problems, int n, const flo
 
 int sm_maxpool2x2_fwd_tiles(const sm_plane_problem* problems, int n, int C, const int32_t* tile_list, int n_list,
                             void* stream) {
+    return sm_maxpool2x2_fwd_codes_tiles(problems, nullptr, n, C, tile_list, n_list, stream);
+}
+
+int sm_maxpool2x2_fwd_codes_tiles(const sm_plane_problem* problems, uint32_t* const* codes, int n, int C,
+                                  const int32_t* tile_list, int n_list, void* stream) {
     sm::PlaneGroup g;
     if (int e = make_plane_group(g, problems, n, 1, tile_list)) return e;
+    if (codes != nullptr) {
+        if (C % 8 != 0) return (int)hipErrorInvalidValue;
+        for (int i = 0; i < n; ++i) {
+            if (codes[i] == nullptr) return (int)hipErrorInvalidValue;
+            g.p[i].c = reinterpret_cast<const float*>(codes[i]);
+        }
+        const int blocks = tile_list ? n_list : g.block_begin[n];
+        if (blocks == 0) return 0;
+        hipLaunchKernelGGL(sm::maxpool_fwd_codes_kernel, dim3(blocks, C / 8), dim3(256), 0, (hipStream_t)stream, g);
+        SM_LAUNCH_CHECK();
+        return 0;
+    }
     const int blocks = tile_list ? n_list : g.block_begin[n];
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(sm::maxpool_fwd_kernel, dim3(blocks, C), dim3(256), 0, (hipStream_t)stream, g);

@@ -11,6 +11,12 @@ struct ConvProblem {
     const float* in;
     float* out;
     const float* gate;
+    // fp16x2 kernel, optional ("unpool" input): `in` is then the gradient of the 2x2 max-pooled map [Cin][plane(H/2,
+    // W/2)] and `code` the pool's argmax codes [Cin / 8][plane(H/2, W/2)], one dword per position and 8-channel group,
+    // nibble c = code of channel 8 g + c (0..3 = window element dy * 2 + dx that holds the first maximum, 4 = maximum
+    // <= 0: no gradient through the ReLU); the operand the kernel stages is the gradient w.r.t. the pool's PRE-ReLU
+    // input, computed on the fly: in[q/2] where code[q/2] == parity(q), else 0.
+    const uint32_t* code;
     int H, W, Wp, plane;
 };
 

@@ -108,11 +108,12 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
 constexpr int conv_split_waves(int BM, int BN, int NP) {
     return BM == 256 ? 1 : (BM == 64 && BN == 128) ? SM_SPLIT_WAVES64 : NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES;
 }
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3>
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
 void conv3x3_split_kernel(ConvArgs a) {
     static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
+    static_assert(!UNPOOL || (NP == 2 && SM_SPLIT_BSETS == 1), "the unpool input exists for the fp16x2 kernel");
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
@@ -210,6 +211,32 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int b_dst = b_kg * BNP + b_px;                      // + part * 2 * BNP (+ slot * SLICE)
     const int h_kg = l31 >> 4, h_px = BN + ((l31 >> 3) & 1), h_c = l31 & 7;
     const int h_src = ((h_kg * 8 + h_c) * P.plane + q0 + h_px) * 4;   // bytes, same base
+    // UNPOOL: the operand is the max-pool backward of the pooled gradient `in`, taken on the fly. Geometry of the pooled
+    // planes, and row / column (in the un-pooled image) of the CENTRE-row position of every staging unit of this thread
+    // (slice ky reads row + ky - 1); -1 marks the padding column left of the image.
+    const int up_Ho = P.H >> 1, up_Wo = P.W >> 1, up_Wp = row_stride(up_Wo), up_plane = plane_size(up_Ho, up_Wo);
+    __amdgpu_buffer_rsrc_t gp_rsrc, code_rsrc;
+    int up_y[NU], up_x[NU], up_hy = 0, up_hx = 0;
+    if constexpr (UNPOOL) {
+        gp_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7ffffff0, 0x00020000);
+        code_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P.code), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int qc = q0 + b_px + u * 128 - 1;
+            up_y[u] = qc / P.Wp - 1;
+            up_x[u] = qc - (up_y[u] + 1) * P.Wp - 1;
+        }
+        const int qh = q0 + h_px - 1;
+        up_hy = qh / P.Wp - 1;
+        up_hx = qh - (up_hy + 1) * P.Wp - 1;
+    }
+    // pooled offset (elements) and window parity of un-pooled (y, x); parity -1: outside every pooling window
+#define SM_UP_MAP(y_, x_, off_, par_)                                                                    \
+    {                                                                                                    \
+        const bool ok_ = (unsigned)(y_) < (unsigned)(2 * up_Ho) && (unsigned)(x_) < (unsigned)(2 * up_Wo); \
+        off_ = ok_ ? (((y_) >> 1) + 1) * up_Wp + ((x_) >> 1) + 1 : 0;                                    \
+        par_ = ok_ ? ((((y_) & 1) << 1) | ((x_) & 1)) : -1;                                              \
+    }
     const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
     // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
     // the MFMA time to hide the same fetch latency behind: its ring is deeper
@@ -219,7 +246,11 @@ void conv3x3_split_kernel(ConvArgs a) {
     // in-flight activation loads: SM_SPLIT_BSETS = 1: one register set, a slice is loaded two stages before it is
     // converted and stored; 3: one set per ky slice, re-loaded right after its store - a slice's loads then have a
     // whole chunk (nine stages) to arrive
-    float rbs[SM_SPLIT_BSETS][NU][8], rhs[SM_SPLIT_BSETS];
+    // (register sets 1 and 2 of the one-set variant only carry the prologue's three slices)
+    constexpr int NSET = 3;
+    float rbs[NSET][NU][8], rhs[NSET];
+    unsigned rcs[UNPOOL ? NSET : 1][NU], rhc[UNPOOL ? NSET : 1];   // UNPOOL: argmax codes of the loaded gradients (one
+    int rps[UNPOOL ? NSET : 1][NU], rhp[UNPOOL ? NSET : 1];        // nibble per channel) and each unit's window parity
 
 #define SM_LOAD_A(tap_, chunk_)                                                                          \
     {                                                                                                    \
@@ -230,7 +261,22 @@ void conv3x3_split_kernel(ConvArgs a) {
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_voff, so_ + s * a_part + i * 512, 0)); \
     }
 #define SM_LOAD_B(set_, ky_, chunk_)                                                                     \
-    {                                                                                                    \
+    if constexpr (UNPOOL) {                                                                              \
+        const int sc_ = ((chunk_) * KC + b_kg * 8) * up_plane;   /* elements */                         \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
+            int off_;                                                                                    \
+            SM_UP_MAP(up_y[u] + (ky_) - 1, up_x[u], off_, rps[set_][u])                                  \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
+                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, off_ * 4, (sc_ + c * up_plane) * 4, 0)); \
+            /* the eight channels' codes: one dword of the [Cin / 8][plane] code image */               \
+            rcs[set_][u] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, off_ * 4, ((chunk_) * 2 + b_kg) * up_plane * 4, 0); \
+        }                                                                                                \
+        int off_;                                                                                        \
+        SM_UP_MAP(up_hy + (ky_) - 1, up_hx, off_, rhp[set_])                                             \
+        const int sh_ = ((chunk_) * KC + h_kg * 8 + h_c) * up_plane;                                     \
+        rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, off_ * 4, sh_ * 4, 0)); \
+        rhc[set_] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, off_ * 4, ((chunk_) * 2 + h_kg) * up_plane * 4, 0); \
+    } else {                                                                                             \
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
         _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                   \
             _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
@@ -259,6 +305,12 @@ void conv3x3_split_kernel(ConvArgs a) {
         e_[h_dst + 4 * BNP * 8] = l;                                                                     \
     } else {                                                                                             \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
+        if constexpr (UNPOOL) {   /* gradient only at the window element that held the maximum */       \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u)                                               \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c)                                            \
+                    rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
+            rhs[set_] = ((int)((rhc[set_] >> (4 * h_c)) & 15u) == rhp[set_]) ? rhs[set_] : 0.f;          \
+        }                                                                                                \
         _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
             f16x8 vh, vl;                                                                                \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
@@ -288,25 +340,10 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < AD; ++t) SM_LOAD_A(t, ch_begin);
     {   // all three slices' loads in flight together (one memory round trip instead of three)
-        float rb3[3][NU][8], rh3[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            SM_LOAD_B(0, ky, ch_begin);
+        for (int ky = 0; ky < 3; ++ky) SM_LOAD_B(ky, ky, ch_begin);
 #pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rb3[ky][u][c] = rbs[0][u][c];
-            rh3[ky] = rhs[0];
-        }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rbs[0][u][c] = rb3[ky][u][c];
-            rhs[0] = rh3[ky];
-            SM_STORE_B(0, ky);
-        }
+        for (int ky = 0; ky < 3; ++ky) SM_STORE_B(ky, ky);
     }
     {
         const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
@@ -418,7 +455,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
             if constexpr (SM_SPLIT_BSETS == 1) {
 #ifndef SM_ABL_NOB
-                if (kx == 1) SM_STORE_B(0, SM_NEXT_SLOT(ky));
+                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky)); }
 #endif
                 // six slots: the next chunk is written into the other half of the ring, which nobody reads after the
                 // barrier at the end of tap 7 of the previous chunk (tap 8 already prefetches from the new half): that
@@ -458,6 +495,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     SM_TS(30)
 #undef SM_CUR_SLOT
 #undef SM_NEXT_SLOT
+#undef SM_UP_MAP
 #undef SM_LOAD_A
 #undef SM_LOAD_B
 #undef SM_STORE_B

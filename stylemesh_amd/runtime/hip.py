@@ -54,6 +54,7 @@ SIGNATURES = {
     "sm_conv3x3_dgrad_c3_tiles": [_vp, _i, _vp, _i, _vp, _i, _vp],
     "sm_maxpool2x2_fwd_tiles": [_vp, _i, _i, _vp, _i, _vp],
     "sm_maxpool2x2_bwd_relu_tiles": [_vp, _i, _i, _vp, _i, _vp],
+    "sm_maxpool2x2_fwd_codes_tiles": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "sm_maxpool2x2_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "sm_maxpool2x2_bwd_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_gram_num_slabs": [_i, _i, _i],
@@ -95,7 +96,8 @@ SIGNATURES = {
 
 class ConvProblem(C.Structure):
     """sm_conv_problem of include/stylemesh_hip.h"""
-    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int)]
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int),
+                ("unpool_code", C.c_void_p)]
 
 
 class GramProblem(C.Structure):

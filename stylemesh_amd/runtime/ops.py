@@ -295,7 +295,9 @@ def conv_tile_positions(cin_pad: int, cout: int) -> int:
 
 def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
                     wt2=None, amax_in=None, amax_out=None):
-    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None), ...] (FMaps).
+    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code]), ...] (FMaps; with a
+    ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel takes the pool's
+    backward on the fly, see ``maxpool_fwd_grouped``).
     ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
     ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
     ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
@@ -306,14 +308,21 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         return
     arr = (hip.ConvProblem * len(problems))()
     flops = nbytes = 0.0
-    for i, (inp, out, gate) in enumerate(problems):
-        assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
-        arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), inp.H, inp.W)
+    for i, prob in enumerate(problems):
+        inp, out, gate = prob[:3]
+        code = prob[3] if len(prob) > 3 else None   # "unpool" input: inp = pooled gradient, code = the pool's argmax codes
+        if code is None:
+            assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
+        else:
+            assert CONV_MODE == "split2" and inp.C >= cin_pad and out.C == cout
+            assert (inp.H, inp.W) == (out.H // 2, out.W // 2) and code.dtype == torch.int32
+            assert code.numel() >= inp.C // 8 * inp.plane
+        arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code))
         cin_true = 3 if cin_pad == 4 else cin_pad
-        flops += 2.0 * 9 * cin_true * cout * inp.H * inp.W
+        flops += 2.0 * 9 * cin_true * cout * out.H * out.W
         # algorithmic HBM bytes: input read once, output written once, + the epilogue's gate / addend reads
-        streams = cin_true + cout + (cout if flags & hip.EPI_RELU_MASK else 0) + (cout if flags & hip.EPI_ADD else 0)
-        nbytes += 4.0 * streams * inp.H * inp.W
+        streams = cout + (cout if flags & hip.EPI_RELU_MASK else 0) + (cout if flags & hip.EPI_ADD else 0)
+        nbytes += 4.0 * streams * out.H * out.W + (4.0 if code is None else 4.5) * cin_true * inp.H * inp.W
 
     use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
     use_split = wt3 is not None and CONV_MODE == "split"
@@ -380,16 +389,20 @@ def conv3x3_dgrad_c3_grouped(problems, wd: torch.Tensor, tile_list=None):
                                             hip.stream()), "sm_conv3x3_dgrad_c3_tiles")
 
 
-def maxpool_fwd_grouped(problems, tile_list=None):
+def maxpool_fwd_grouped(problems, tile_list=None, codes=None):
     """``problems``: [(inp, out), ...] with equal channel counts - one launch. ``tile_list``: active blocks of 256
-    positions of the pooled planes."""
+    positions of the pooled planes. ``codes``: optional int32 tensors [C / 8 * plane(out)], one per problem, that
+    receive the argmax codes (a nibble per channel: which window element held the maximum; 4: none > 0) for
+    ``conv3x3_grouped``'s unpool input."""
     C = problems[0][0].C
     assert all((o.H, o.W, o.C) == (i.H // 2, i.W // 2, C) and i.C == C for i, o in problems)
     if tile_list is not None and tile_list.numel() == 0:
         return
     arr = _plane_problems([(i, None, None, o) for i, o in problems])
-    hip.check(lib.sm_maxpool2x2_fwd_tiles(arr, len(problems), C, *_tile_args(tile_list), hip.stream()),
-              "sm_maxpool2x2_fwd_tiles")
+    if codes is not None:
+        assert all(c.dtype == torch.int32 and c.numel() >= C // 8 * o.plane for c, (_, o) in zip(codes, problems))
+    hip.check(lib.sm_maxpool2x2_fwd_codes_tiles(arr, None if codes is None else hip.ptr_array(codes), len(problems), C,
+                                                *_tile_args(tile_list), hip.stream()), "sm_maxpool2x2_fwd_codes_tiles")
 
 
 def maxpool_bwd_relu_grouped(problems, tile_list=None):

@@ -7,6 +7,8 @@ conv5_2..5_4).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip, ops
@@ -46,6 +48,11 @@ def layer_hw(layer: str, H: int, W: int):
 
 POOL_INPUT = {out: src for kind, src, out, _, _ in NODES if kind == "pool"}     # p1 -> r12, ...
 POOL_OUTPUT = {src: out for kind, src, out, _, _ in NODES if kind == "pool"}    # r12 -> p1, ...
+NODE_BELOW = {out: (kind, src) for kind, src, out, _, _ in NODES}                # r12 -> ("conv1_2", "r11"), ...
+# fp16x2 mode, grouped passes: the pool forward records argmax codes and the data-gradient conv below a pool takes the
+# pool's backward from them while it stages its operand - no pool-backward pass (2.75 plane sizes of HBM traffic per
+# pool) and a quarter-size operand read
+FUSE_POOL_BWD = os.environ.get("STYLEMESH_FUSE_POOL_BWD", "1") != "0"
 
 
 class AmaxBook:
@@ -92,6 +99,7 @@ class LevelBuffers:
         self.H, self.W, self.last = H, W, depth_of(last_layer)
         self.act = {"img": FMap(4, H, W, device)}  # 3 channels + 1 zero plane (K-chunk of 4)
         self.grad = {"img": FMap(3, H, W, device)} if with_grad else {}
+        self.code = {}
         h, w = H, W
         for kind, _, out, _, cout in NODES[:self.last + 1]:
             if kind == "pool":
@@ -101,6 +109,8 @@ class LevelBuffers:
             self.act[out] = FMap(cout, h, w, device)
             if with_grad:
                 self.grad[out] = FMap(cout, h, w, device)
+                if kind == "pool":   # argmax codes of the pool (fused pool backward of the fp16x2 data-gradient convs)
+                    self.code[out] = torch.zeros(cout // 8 * self.act[out].plane, dtype=torch.int32, device=device)
         self.amax = AmaxBook(device)   # bounds of this buffer set's tensors (single-level passes)
 
     def nbytes(self):
@@ -151,8 +161,10 @@ class VGGNet:
         assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
         for kind, src, out, _, _ in NODES[:last + 1]:
             if kind == "pool":
+                fused = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(out in b.code for b in bufs)
                 ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
-                                        tiles[("pool", out)][0] if tiles else None)
+                                        tiles[("pool", out)][0] if tiles else None,
+                                        [b.code[out] for b in bufs] if fused else None)
             else:
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
@@ -172,12 +184,17 @@ class VGGNet:
         if am is not None and not start_bound_recorded:
             for b in bufs:
                 ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
+        fuse = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(b.code for b in bufs)
+        unpool = None   # fused pool backward: name of the pooled map whose gradient the next conv un-pools on the fly
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if before_layer is not None and kind != "pool":
                 before_layer(src)      # the injected gradient of ``src`` is about to be consumed
             if kind == "pool":
                 if src in injected:
                     raise ValueError(f"style/content layer {src} directly below a pool is not supported")
+                if fuse and src != "img" and not NODE_BELOW[src][1].startswith("p") and NODE_BELOW[src][1] != "img":
+                    unpool = out       # the conv that produced ``src`` reads grad[out] + code[out] instead of grad[src]
+                    continue
                 ops.maxpool_bwd_relu_grouped([(b.act[src], b.act[out], b.grad[out], b.grad[src]) for b in bufs],
                                              tiles[("pool", out)][0] if tiles else None)
             elif src == "img":
@@ -191,9 +208,15 @@ class VGGNet:
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
-                ops.conv3x3_grouped([(b.grad[out], b.grad[src], b.act[src]) for b in bufs], self.wd[kind], None, flags,
+                if unpool is not None:
+                    probs = [(b.grad[unpool], b.grad[src], b.act[src], b.code[unpool]) for b in bufs]
+                    unpool = None
+                else:
+                    probs = [(b.grad[out], b.grad[src], b.act[src]) for b in bufs]
+                ops.conv3x3_grouped(probs, self.wd[kind], None, flags,
                                     tl, frac, self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
                                     None if am is None else am["g:" + src])
+            assert unpool is None or kind == "pool", "a fused pool backward must be consumed by the conv below it"
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
         """Back-propagate to ``b.grad['img']``.

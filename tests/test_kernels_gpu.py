@@ -272,6 +272,47 @@ def test_conv3x3_split2_dgrad_with_gate_and_add(rt, cin, cout, H, W, monkeypatch
     assert float(am.max()) == 1e3
 
 
+@pytest.mark.parametrize("C,cout,H,W", [(64, 64, 37, 50), (128, 128, 40, 53), (256, 256, 21, 30), (64, 64, 150, 201)])
+def test_conv3x3_split2_fused_pool_backward(rt, C, cout, H, W, monkeypatch):
+    """The data-gradient conv below a max-pool with the pool's backward taken on the fly from the forward's argmax codes
+    (sm_conv_problem::unpool_code) against the two-pass form (sm_maxpool2x2_bwd_relu, then the conv): identical results -
+    including exact ties (constant regions: the first maximum wins), closed ReLU gates and odd sizes."""
+    monkeypatch.setattr(rt.ops, "CONV_MODE", "split2")
+    torch.manual_seed(C + W)
+    act = F.relu(torch.randn(C, H, W))
+    act[:, 4:12, 6:20] = 0.75                      # exact 4-way ties
+    act[:, 14:18, :] = 0.0                         # windows whose maximum is 0: no gradient
+    below = F.relu(torch.randn(cout, H, W))        # forward activation of the conv's input layer (its ReLU gate)
+    dpooled = torch.randn(C, H // 2, W // 2) * 1e-4
+    wgt = torch.randn(C, cout, 3, 3) * (2.0 / (9 * C)) ** 0.5     # conv below the pool: cout -> C channels
+    wd = dev(rt.ops.pack_conv_dgrad(wgt))
+    wd2 = rt.ops.pack_conv_split2(wd)
+    a = rt.FMap(C, H, W).from_dense(act)
+    gate = rt.FMap(cout, H, W).from_dense(below)
+    pooled, dp = rt.FMap(C, H // 2, W // 2), rt.FMap(C, H // 2, W // 2).from_dense(dpooled)
+    code = torch.zeros(C // 8 * pooled.plane, dtype=torch.int32, device="cuda")
+    rt.ops.maxpool_fwd_grouped([(a, pooled)], None, [code])
+    assert_close(pooled.to_dense(), F.max_pool2d(act[None], 2)[0], 0, 0)
+    amax_in = rt.ops.new_amax("cuda", float(dpooled.abs().max()))
+    # two passes
+    da = rt.FMap(C, H, W)
+    rt.ops.maxpool_bwd_relu(a, pooled, dp, da)
+    ref = rt.FMap(cout, H, W)
+    addend = torch.randn(cout, H, W) * 1e-4
+    for flags, name in ((rt.hip.EPI_RELU_MASK, "gated"), (rt.hip.EPI_RELU_MASK | rt.hip.EPI_ADD, "gated + add")):
+        ref.from_dense(addend)
+        out = rt.FMap(cout, H, W).from_dense(addend)
+        am_ref, am = rt.ops.new_amax("cuda"), rt.ops.new_amax("cuda")
+        rt.ops.conv3x3_grouped([(da, ref, gate)], wd, None, flags, wt2=wd2, amax_in=amax_in, amax_out=am_ref)
+        rt.ops.conv3x3_grouped([(dp, out, gate, code)], wd, None, flags, wt2=wd2, amax_in=amax_in, amax_out=am)
+        assert torch.equal(out.to_dense(), ref.to_dense()), name
+        assert out.border_is_zero() and float(am.max()) == float(am_ref.max())
+    # and the two-pass form is the reference's max_pool2d backward through the ReLU
+    x = act.clone().requires_grad_(True)
+    F.max_pool2d(F.relu(x)[None], 2).backward(dpooled[None])
+    assert_close(da.to_dense(), x.grad, 0, 0)
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 60, 70), (512, 512, 33, 45), (256, 64, 40, 52)])
 def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, monkeypatch):
     """Fewer tiles than CUs: every tile is a K-split tail reduced by the second pass. Repeated launches must be
