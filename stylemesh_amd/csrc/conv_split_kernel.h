@@ -262,20 +262,21 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
 #define SM_LOAD_B(set_, ky_, chunk_)                                                                     \
     if constexpr (UNPOOL) {                                                                              \
-        const int sc_ = ((chunk_) * KC + b_kg * 8) * up_plane;   /* elements */                         \
+        /* (everything that varies inside a wave - k-group, halo channel - goes into the VECTOR offset: a scalar  \
+           offset the compiler cannot prove wave-uniform turns every load into a waterfall loop) */     \
+        const int sc_ = (chunk_) * KC * up_plane * 4;   /* bytes, wave-uniform */                        \
         _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
             int off_;                                                                                    \
             SM_UP_MAP(up_y[u] + (ky_) - 1, up_x[u], off_, rps[set_][u])                                  \
             _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
-                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, off_ * 4, (sc_ + c * up_plane) * 4, 0)); \
+                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, (off_ + b_kg * 8 * up_plane) * 4, sc_ + c * up_plane * 4, 0)); \
             /* the eight channels' codes: one dword of the [Cin / 8][plane] code image */               \
-            rcs[set_][u] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, off_ * 4, ((chunk_) * 2 + b_kg) * up_plane * 4, 0); \
+            rcs[set_][u] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, (off_ + b_kg * up_plane) * 4, (chunk_) * 2 * up_plane * 4, 0); \
         }                                                                                                \
         int off_;                                                                                        \
         SM_UP_MAP(up_hy + (ky_) - 1, up_hx, off_, rhp[set_])                                             \
-        const int sh_ = ((chunk_) * KC + h_kg * 8 + h_c) * up_plane;                                     \
-        rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, off_ * 4, sh_ * 4, 0)); \
-        rhc[set_] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, off_ * 4, ((chunk_) * 2 + h_kg) * up_plane * 4, 0); \
+        rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, (off_ + (h_kg * 8 + h_c) * up_plane) * 4, sc_, 0)); \
+        rhc[set_] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, (off_ + h_kg * up_plane) * 4, (chunk_) * 2 * up_plane * 4, 0); \
     } else {                                                                                             \
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
         _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                   \
