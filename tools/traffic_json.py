@@ -6,7 +6,7 @@ import csv, json, sys
 src, wl, tag, out = sys.argv[1:5]
 rows = list(csv.DictReader(open(src)))
 kern = "conv3x3_split_kernel" if tag in ("split", "split2") else "conv3x3_mfma_kernel"
-np_arg = {"split": ", 3>", "split2": ", 2>"}.get(tag, "")     # last template argument: parts per operand
+np_arg = {"split": ", 3, ", "split2": ", 2, "}.get(tag, "")   # template argument NP (parts per operand), before UNPOOL
 def col(r, name):
     for k, v in r.items():
         if k.startswith(name):
