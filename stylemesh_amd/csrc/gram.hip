@@ -174,45 +174,64 @@ __device__ __forceinline__ void style_loss_body(const float* __restrict__ S0, co
     const float f = *factor;
     const float inv_c2 = 1.f / ((float)C * (float)C);
     float loss = 0.f;
-    // STYLE_EPT elements per thread (one atomic on the single loss address per block), fully unrolled and predicated:
-    // with a `break` the iterations' loads are issued one memory round trip after the other
-#pragma unroll
-    for (int it = 0; it < STYLE_EPT; ++it) {
-    const int idx = (block_x * STYLE_EPT + it) * 256 + threadIdx.x;
-    if (idx < C * C) {
-    const int i = idx / C, j = idx - i * C;
-    float G[2], invN[2], d[2] = {0.f, 0.f};
+    // STYLE_EPT elements per thread (one atomic on the single loss address per block). Two phases: every load of all
+    // elements first (predicated, no stores in between - a store to D / history may alias a later element's loads, which
+    // would put one memory round trip per element on the critical path: 44 us for the step's 20 problems), then the math
+    // and the stores.
+    float N[2], invN[2];
     bool empty[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float* S = k == 0 ? S0 : S1;
-        const float N = (S != nullptr) ? counts[k] : 0.f;
-        empty[k] = !(N > 0.f);
-        invN[k] = empty[k] ? 0.f : 1.f / N;
-        G[k] = (S != nullptr && !empty[k]) ? sym_read(S, C, i, j, n_slabs) / N : 0.f;  // N == 0: masked_features -> zeros
+        N[k] = (S != nullptr) ? counts[k] : 0.f;
+        empty[k] = !(N[k] > 0.f);
+        invN[k] = empty[k] ? 0.f : 1.f / N[k];
     }
-    float navg = 1.f;
-    float Gavg0 = G[0];
-    if (history) {  // gram_mode 'average': mean over the current and up to 9 detached previous Grams (:319-323)
-        const size_t cc = (size_t)C * C;
-        for (int h = 0; h < hist_len; ++h) Gavg0 += history[h * cc + idx];
-        navg = (float)(hist_len + 1);
-        Gavg0 /= navg;
-        history[(size_t)hist_slot * cc + idx] = G[0];
+    const int cc = C * C;
+    float Gs[STYLE_EPT][2], Y[STYLE_EPT][4], Hs[STYLE_EPT];
+#pragma unroll
+    for (int it = 0; it < STYLE_EPT; ++it) {
+        const int idx = min((block_x * STYLE_EPT + it) * 256 + (int)threadIdx.x, cc - 1);
+        const int i = idx / C, j = idx - i * C;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float* S = k == 0 ? S0 : S1;
+            Gs[it][k] = (S != nullptr && !empty[k]) ? sym_read(S, C, i, j, n_slabs) : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Y[it][t] = t < terms.n ? terms.target[t][idx] : 0.f;
+        Hs[it] = 0.f;
+        if (history)
+            for (int h = 0; h < hist_len; ++h) Hs[it] += history[(size_t)h * cc + idx];
     }
-    for (int t = 0; t < terms.n; ++t) {
-        const int k = terms.mask[t];
-        if (empty[k] && terms.skip_if_empty[k]) continue;
-        const float g = (k == 0) ? Gavg0 : G[k];
-        const float diff = g - terms.target[t][idx];
-        loss += diff * diff;
-        // dL/dF = 2 dL/dS F (S symmetric), dL/dS = dL/dG / N, dL/dG = weight f (2/C^2) (G - Y) [/ navg]
-        d[k] += diff * (4.f * weight * f * inv_c2 * invN[k] / ((k == 0) ? navg : 1.f));
-    }
-    D0[idx] = d[0];
-    if (D1) D1[idx] = d[1];
-    dmax = fmaxf(dmax, fmaxf(fabsf(d[0]), fabsf(d[1])));
-    }
+#pragma unroll
+    for (int it = 0; it < STYLE_EPT; ++it) {
+        const int idx = (block_x * STYLE_EPT + it) * 256 + threadIdx.x;
+        if (idx >= cc) continue;
+        float G[2], d[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) G[k] = empty[k] ? 0.f : Gs[it][k] / N[k];   // N == 0: masked_features -> zeros
+        float navg = 1.f;
+        float Gavg0 = G[0];
+        if (history) {  // gram_mode 'average': mean over the current and up to 9 detached previous Grams (:319-323)
+            navg = (float)(hist_len + 1);
+            Gavg0 = (G[0] + Hs[it]) / navg;
+            history[(size_t)hist_slot * cc + idx] = G[0];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= terms.n) continue;
+            const int k = terms.mask[t];
+            if (empty[k] && terms.skip_if_empty[k]) continue;
+            const float g = (k == 0) ? Gavg0 : G[k];
+            const float diff = g - Y[it][t];
+            loss += diff * diff;
+            // dL/dF = 2 dL/dS F (S symmetric), dL/dS = dL/dG / N, dL/dG = weight f (2/C^2) (G - Y) [/ navg]
+            d[k] += diff * (4.f * weight * f * inv_c2 * invN[k] / ((k == 0) ? navg : 1.f));
+        }
+        D0[idx] = d[0];
+        if (D1) D1[idx] = d[1];
+        dmax = fmaxf(dmax, fmaxf(fabsf(d[0]), fabsf(d[1])));
     }
     record_amax(amax_d, dmax, dseen);
     const float tot = block_sum256(loss, red);

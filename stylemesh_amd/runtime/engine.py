@@ -423,7 +423,11 @@ class StepEngine:
             if dsts:
                 torch._foreach_copy_(dsts, srcs)
             # gradient planes must be zero outside this view's active tiles: the previous view wrote elsewhere
-            torch._foreach_zero_([g.buf for lv in active for g in self._level_bufs(lv.H, lv.W).grad.values()])
+            # (with the fused pool backward the gradients of the pools' input layers are never materialised)
+            from . import vgg as _vgg
+            skip = set(_vgg.POOL_OUTPUT) if (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2") else set()
+            torch._foreach_zero_([g.buf for lv in active
+                                  for name, g in self._level_bufs(lv.H, lv.W).grad.items() if name not in skip])
         # identifies the step's launch sequence (grid sizes depend on the tile lists)
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
                          None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))
