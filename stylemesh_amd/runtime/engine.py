@@ -14,6 +14,7 @@ reused for the 20-100 consecutive steps the reference's RepeatingSampler spends 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -152,6 +153,8 @@ class StepEngine:
         # idle CUs and no LDS for co-resident blocks), so it is off by default.
         self.overlap_style = False
         self.group_losses = True       # fp16x2 mode: the loss phase as grouped launches over all levels and layers
+        # style layers whose branch runs on a side stream beside the conv trunk (grouped loss phase only)
+        self.side_style_layers = tuple(x for x in os.environ.get("STYLEMESH_SIDE_STYLE", "r11").split(",") if x)
         self._loss_tables = None       # (signature, Gram / style-loss / Gram-backward problem tables, slab keys)
         self._gram_bwd_ws = {}         # (C, level, layer) -> scratch of the derivative matrices' operand images
         self._side = None
@@ -501,13 +504,44 @@ class StepEngine:
             for layer in list(done):
                 join(layer)
         else:
-            self.vgg.forward_group(bufs, self.view_tiles, amax=self.amax)
+            # Grouped loss phase: the branches of the EARLY style layers (HBM-bound Gram kernels over the largest planes)
+            # run on a side stream beside the power-limited conv trunk - forked right after the layer's forward conv,
+            # joined right before the data-gradient conv that adds its gradient plane
+            grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
+            side = tuple(l for l in self.side_style_layers if l in cfg.style_layers and l != self.deepest
+                         and l not in cfg.content_layers) if (grouped and not torch.cuda.is_current_stream_capturing()) else ()
+            side_done = None
+            if side:
+                main = torch.cuda.current_stream()
+                if not self._lv_streams:
+                    self._lv_streams.append(torch.cuda.Stream(device=self.device))
+                last_side = max(side, key=depth_of)
+
+                def fork(layer):
+                    nonlocal side_done
+                    if layer != last_side:
+                        return
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    st = self._lv_streams[0]
+                    st.wait_event(ev)
+                    with torch.cuda.stream(st):
+                        self._inject_losses_grouped(active, bufs, w_style, w_content, "side", side)
+                        side_done = torch.cuda.Event()
+                        side_done.record(st)
+
+                def join(layer):
+                    nonlocal side_done
+                    if side_done is not None and layer in side:
+                        main.wait_event(side_done)
+                        side_done = None
+            self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork if side else None, amax=self.amax)
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
             start_bound = False
             if self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average":
-                injected = self._inject_losses_grouped(active, bufs, w_style, w_content)
+                injected = self._inject_losses_grouped(active, bufs, w_style, w_content, "main", side)
                 start_bound = (self.deepest in cfg.style_layers and self.deepest not in cfg.content_layers
                                and ops.CONV_MODE == "split2")
             elif concurrent:
@@ -534,7 +568,9 @@ class StepEngine:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax,
-                                    start_bound_recorded=start_bound)
+                                    start_bound_recorded=start_bound, before_layer=join if side else None)
+            if side_done is not None:
+                torch.cuda.current_stream().wait_event(side_done)
         if not accumulate_grad:
             return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
@@ -546,20 +582,23 @@ class StepEngine:
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
 
-    def _inject_losses_grouped(self, active, bufs, w_style, w_content):
+    def _inject_losses_grouped(self, active, bufs, w_style, w_content, part="main", side_layers=()):
         """The loss phase of a step over ALL active levels and style layers in a handful of launches (fp16x2 mode):
         masked Grams (one launch per tile class), loss values + derivative matrices (one launch), operand images of
         the derivative matrices (one launch), Gram backward into ``grad[layer]`` (one launch per tile class); then the
         content terms. The problem tables hold raw pointers: they are rebuilt whenever the view (masks, counts), the
         level buffers or the weights change (the per-view masks and counts
-        live in persistent buffers, so consecutive views of the same level set reuse the tables)."""
+        live in persistent buffers, so consecutive views of the same level set reuse the tables).
+        ``side_layers``: style layers whose whole branch runs apart from the rest (``part='side'``: only them - the caller
+        has forked a side stream after their forward conv; ``part='main'``: the others + the content terms)."""
         cfg = self.cfg
         l0 = cfg.style_layers[0]
         sig = (tuple((lv.index, id(b), lv.masks[l0].ptr, lv.counts[l0].data_ptr()) for lv, b in zip(active, bufs)),
-               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
+               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode,
+               tuple(side_layers))
         if self._loss_tables is None or self._loss_tables[0] != sig:
             multi = cfg.style_pyramid_mode == "multi"
-            fwd, sty, bwd, keys = [], [], [], []
+            fwd, sty, bwd, keys, names = [], [], [], [], []
             for lv, b in zip(active, bufs):
                 for li, layer in enumerate(cfg.style_layers):
                     f = b.act[layer]
@@ -593,15 +632,26 @@ class StepEngine:
                                                     relu_gate=(layer == self.deepest),
                                                     amax_out=self.amax["g:" + layer] if rec else None))
                     keys.append(key)
+                    names.append(layer)
             from . import hip
-            self._loss_tables = (sig, ops.struct_array(hip.GramProblem, fwd), ops.struct_array(hip.StyleProblem, sty),
-                                 ops.struct_array(hip.GramBwdProblem, bwd), keys)
-        _, fwd, sty, bwd, keys = self._loss_tables
-        assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
-        ops.gram_masked_grouped(fwd)
-        self._gram_clean.difference_update(keys)
-        ops.style_loss_grouped(sty, self.loss_buf[1:2])
-        ops.gram_backward_grouped(bwd)
+            tables = {}
+            for which, pick in (("side", lambda n: n in side_layers), ("main", lambda n: n not in side_layers)):
+                sel = [i for i, n in enumerate(names) if pick(n)]
+                tables[which] = None if not sel else (
+                    ops.struct_array(hip.GramProblem, [fwd[i] for i in sel]),
+                    ops.struct_array(hip.StyleProblem, [sty[i] for i in sel]),
+                    ops.struct_array(hip.GramBwdProblem, [bwd[i] for i in sel]), [keys[i] for i in sel])
+            self._loss_tables = (sig, tables)
+        tab = self._loss_tables[1][part]
+        if tab is not None:
+            fwd, sty, bwd, keys = tab
+            assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
+            ops.gram_masked_grouped(fwd)
+            self._gram_clean.difference_update(keys)
+            ops.style_loss_grouped(sty, self.loss_buf[1:2])
+            ops.gram_backward_grouped(bwd)
+        if part == "side":
+            return set(side_layers)
         injected = set(cfg.style_layers)
         if w_content != 0.0:
             for lv, b in zip(active, bufs):
