@@ -510,7 +510,9 @@ class StepEngine:
             grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
             side = tuple(l for l in self.side_style_layers if l in cfg.style_layers and l != self.deepest
                          and l not in cfg.content_layers) if (grouped and not torch.cuda.is_current_stream_capturing()) else ()
-            side_done = None
+            # ... and so do the content terms of the layers above which the forward pass still has convs to run
+            side_content = tuple(l for l in cfg.content_layers if l != self.deepest) if (side and w_content != 0.0) else ()
+            side_done = {}   # layer -> event: its gradient plane is complete
             if side:
                 main = torch.cuda.current_stream()
                 if not self._lv_streams:
@@ -518,30 +520,36 @@ class StepEngine:
                 last_side = max(side, key=depth_of)
 
                 def fork(layer):
-                    nonlocal side_done
-                    if layer != last_side:
+                    if layer != last_side and layer not in side_content:
                         return
                     ev = torch.cuda.Event()
                     ev.record(main)
                     st = self._lv_streams[0]
                     st.wait_event(ev)
                     with torch.cuda.stream(st):
-                        self._inject_losses_grouped(active, bufs, w_style, w_content, "side", side)
-                        side_done = torch.cuda.Event()
-                        side_done.record(st)
+                        if layer == last_side:
+                            self._inject_losses_grouped(active, bufs, w_style, w_content, "side", side)
+                            done_layers = side
+                        else:
+                            for lv, b in zip(active, bufs):
+                                self._content_term(lv, b, cfg.content_layers.index(layer), layer, w_content)
+                            done_layers = (layer,)
+                        done = torch.cuda.Event()
+                        done.record(st)
+                        for l in done_layers:
+                            side_done[l] = done
 
                 def join(layer):
-                    nonlocal side_done
-                    if side_done is not None and layer in side:
-                        main.wait_event(side_done)
-                        side_done = None
+                    done = side_done.pop(layer, None)
+                    if done is not None:
+                        main.wait_event(done)
             self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork if side else None, amax=self.amax)
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
             start_bound = False
             if self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average":
-                injected = self._inject_losses_grouped(active, bufs, w_style, w_content, "main", side)
+                injected = self._inject_losses_grouped(active, bufs, w_style, w_content, "main", side, side_content)
                 start_bound = (self.deepest in cfg.style_layers and self.deepest not in cfg.content_layers
                                and ops.CONV_MODE == "split2")
             elif concurrent:
@@ -569,8 +577,8 @@ class StepEngine:
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax,
                                     start_bound_recorded=start_bound, before_layer=join if side else None)
-            if side_done is not None:
-                torch.cuda.current_stream().wait_event(side_done)
+            for done in side_done.values():
+                torch.cuda.current_stream().wait_event(done)
         if not accumulate_grad:
             return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
@@ -582,7 +590,7 @@ class StepEngine:
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
 
-    def _inject_losses_grouped(self, active, bufs, w_style, w_content, part="main", side_layers=()):
+    def _inject_losses_grouped(self, active, bufs, w_style, w_content, part="main", side_layers=(), content_done=()):
         """The loss phase of a step over ALL active levels and style layers in a handful of launches (fp16x2 mode):
         masked Grams (one launch per tile class), loss values + derivative matrices (one launch), operand images of
         the derivative matrices (one launch), Gram backward into ``grad[layer]`` (one launch per tile class); then the
@@ -656,7 +664,8 @@ class StepEngine:
         if w_content != 0.0:
             for lv, b in zip(active, bufs):
                 for li, layer in enumerate(cfg.content_layers):
-                    self._content_term(lv, b, li, layer, w_content)
+                    if layer not in content_done:   # (the caller ran those on the side stream)
+                        self._content_term(lv, b, li, layer, w_content)
                     injected.add(layer)
         return injected
 
