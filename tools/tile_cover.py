@@ -42,6 +42,8 @@ for seed in (0, 2, 6):
                 n_t = (flat.numel() + bn - 1) // bn
                 flat = torch.nn.functional.pad(flat, (0, n_t * bn - flat.numel()))
                 tot["1d"] += fl * bn * float((flat.view(n_t, bn).sum(1) > 0).sum())
+                for sub in (64, 32, 16):   # dead sub-ranges inside live tiles skipped
+                    tot[f"1d/{sub}"] = tot.get(f"1d/{sub}", 0.0) + fl * sub * float((flat.view(-1, sub).sum(1) > 0).sum())
                 for name, (th, tw) in (("8x16", (8, 16)), ("16x16", (16, 16)), ("4x32", (4, 32))):
                     hh, ww = -(-h // th) * th, -(-w // tw) * tw
                     p2 = torch.zeros(hh, ww, device=dev); p2[:h, :w] = nd
