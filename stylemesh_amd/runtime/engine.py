@@ -155,6 +155,7 @@ class StepEngine:
         self.group_losses = True       # fp16x2 mode: the loss phase as grouped launches over all levels and layers
         # style layers whose branch runs on a side stream beside the conv trunk (grouped loss phase only)
         self.side_style_layers = tuple(x for x in os.environ.get("STYLEMESH_SIDE_STYLE", "r11").split(",") if x)
+        self.side_streams = os.environ.get("STYLEMESH_SIDE_STREAMS", "1") != "0"
         self._loss_tables = None       # (signature, Gram / style-loss / Gram-backward problem tables, slab keys)
         self._gram_bwd_ws = {}         # (C, level, layer) -> scratch of the derivative matrices' operand images
         self._side = None
@@ -504,40 +505,48 @@ class StepEngine:
             for layer in list(done):
                 join(layer)
         else:
-            # Grouped loss phase: the branches of the EARLY style layers (HBM-bound Gram kernels over the largest planes)
-            # run on a side stream beside the power-limited conv trunk - forked right after the layer's forward conv,
-            # joined right before the data-gradient conv that adds its gradient plane
+            # Grouped loss phase (fp16x2 mode). Only the deepest layer's branch sits between the forward and the backward
+            # pass; every other branch runs on a side stream beside the power-limited conv trunk and is joined right
+            # before the data-gradient conv that consumes its gradient plane:
+            #   * ``side_style_layers`` (relu1_1: HBM-bound Gram kernels over the largest planes) and the content terms fork
+            #     right after their layer's forward conv;
+            #   * the other style layers fork when the forward pass is done, deepest first - the order the backward pass
+            #     needs them in.
             grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
-            side = tuple(l for l in self.side_style_layers if l in cfg.style_layers and l != self.deepest
-                         and l not in cfg.content_layers) if (grouped and not torch.cuda.is_current_stream_capturing()) else ()
-            # ... and so do the content terms of the layers above which the forward pass still has convs to run
-            side_content = tuple(l for l in cfg.content_layers if l != self.deepest) if (side and w_content != 0.0) else ()
+            use_side = grouped and self.side_streams and not torch.cuda.is_current_stream_capturing()
+            early = tuple(l for l in self.side_style_layers if l in cfg.style_layers and l != self.deepest) if use_side else ()
+            late = tuple(sorted((l for l in cfg.style_layers if l not in early and l != self.deepest),
+                                key=depth_of, reverse=True)) if use_side else ()
+            side_content = tuple(l for l in cfg.content_layers if l != self.deepest) if (use_side and w_content != 0.0) else ()
             side_done = {}   # layer -> event: its gradient plane is complete
+            side = bool(early or late or side_content)
             if side:
                 main = torch.cuda.current_stream()
                 if not self._lv_streams:
                     self._lv_streams.append(torch.cuda.Stream(device=self.device))
-                last_side = max(side, key=depth_of)
+                st = self._lv_streams[0]
+                last_early = max(early, key=depth_of) if early else None
 
-                def fork(layer):
-                    if layer != last_side and layer not in side_content:
-                        return
+                def on_side(work, done_layers):
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    st = self._lv_streams[0]
                     st.wait_event(ev)
                     with torch.cuda.stream(st):
-                        if layer == last_side:
-                            self._inject_losses_grouped(active, bufs, w_style, w_content, "side", side)
-                            done_layers = side
-                        else:
-                            for lv, b in zip(active, bufs):
-                                self._content_term(lv, b, cfg.content_layers.index(layer), layer, w_content)
-                            done_layers = (layer,)
+                        work()
                         done = torch.cuda.Event()
                         done.record(st)
-                        for l in done_layers:
-                            side_done[l] = done
+                    for l in done_layers:
+                        side_done[l] = done
+
+                def content_terms(layer):
+                    for lv, b in zip(active, bufs):
+                        self._content_term(lv, b, cfg.content_layers.index(layer), layer, w_content)
+
+                def fork(layer):
+                    if layer == last_early:
+                        on_side(lambda: self._style_group(active, bufs, w_style, early), early)
+                    elif layer in side_content:
+                        on_side(lambda: content_terms(layer), (layer,))
 
                 def join(layer):
                     done = side_done.pop(layer, None)
@@ -548,9 +557,19 @@ class StepEngine:
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
             start_bound = False
-            if self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average":
-                injected = self._inject_losses_grouped(active, bufs, w_style, w_content, "main", side, side_content)
-                start_bound = (self.deepest in cfg.style_layers and self.deepest not in cfg.content_layers
+            if grouped:
+                for l in late:   # deepest first: each branch has its own event
+                    on_side(lambda l=l: self._style_group(active, bufs, w_style, (l,)), (l,))
+                on_main = [l for l in cfg.style_layers if l not in early and l not in late]
+                self._style_group(active, bufs, w_style, on_main)
+                injected = set(cfg.style_layers)
+                if w_content != 0.0:
+                    for layer in cfg.content_layers:
+                        if layer not in side_content:
+                            for lv, b in zip(active, bufs):
+                                self._content_term(lv, b, cfg.content_layers.index(layer), layer, w_content)
+                        injected.add(layer)
+                start_bound = (self.deepest in on_main and self.deepest not in cfg.content_layers
                                and ops.CONV_MODE == "split2")
             elif concurrent:
                 main = torch.cuda.current_stream()
@@ -590,25 +609,30 @@ class StepEngine:
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
 
-    def _inject_losses_grouped(self, active, bufs, w_style, w_content, part="main", side_layers=(), content_done=()):
-        """The loss phase of a step over ALL active levels and style layers in a handful of launches (fp16x2 mode):
-        masked Grams (one launch per tile class), loss values + derivative matrices (one launch), operand images of
-        the derivative matrices (one launch), Gram backward into ``grad[layer]`` (one launch per tile class); then the
-        content terms. The problem tables hold raw pointers: they are rebuilt whenever the view (masks, counts), the
-        level buffers or the weights change (the per-view masks and counts
-        live in persistent buffers, so consecutive views of the same level set reuse the tables).
-        ``side_layers``: style layers whose whole branch runs apart from the rest (``part='side'``: only them - the caller
-        has forked a side stream after their forward conv; ``part='main'``: the others + the content terms)."""
+    def _style_group(self, active, bufs, w_style, layers):
+        """The style branches (masked Gram -> loss value + derivative matrices -> Gram backward into ``grad[layer]``) of
+        the given style ``layers`` over ALL active levels, as grouped launches on the current stream (fp16x2 mode): masked
+        Grams (one launch per tile class), loss + derivative matrices (one), their operand images (one), Gram backward
+        (one per tile class). The problem tables hold raw pointers: they are rebuilt whenever the level buffers, the
+        per-view mask / count buffers or the weights change (those buffers are persistent, so consecutive views of the
+        same level set reuse the tables)."""
         cfg = self.cfg
+        layers = tuple(layers)
+        if not layers:
+            return
         l0 = cfg.style_layers[0]
         sig = (tuple((lv.index, id(b), lv.masks[l0].ptr, lv.counts[l0].data_ptr()) for lv, b in zip(active, bufs)),
-               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode,
-               tuple(side_layers))
+               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
         if self._loss_tables is None or self._loss_tables[0] != sig:
+            self._loss_tables = (sig, {})
+        tab = self._loss_tables[1].get(layers)
+        if tab is None:
+            from . import hip
             multi = cfg.style_pyramid_mode == "multi"
-            fwd, sty, bwd, keys, names = [], [], [], [], []
+            fwd, sty, bwd, keys = [], [], [], []
             for lv, b in zip(active, bufs):
-                for li, layer in enumerate(cfg.style_layers):
+                for layer in layers:
+                    li = cfg.style_layers.index(layer)
                     f = b.act[layer]
                     key = (f.C, lv.index, layer)
                     S0, S1, D0, D1 = self._gram_scratch(key, ops.gram_workspace_slabs(f.C, f.H, f.W))
@@ -640,34 +664,15 @@ class StepEngine:
                                                     relu_gate=(layer == self.deepest),
                                                     amax_out=self.amax["g:" + layer] if rec else None))
                     keys.append(key)
-                    names.append(layer)
-            from . import hip
-            tables = {}
-            for which, pick in (("side", lambda n: n in side_layers), ("main", lambda n: n not in side_layers)):
-                sel = [i for i, n in enumerate(names) if pick(n)]
-                tables[which] = None if not sel else (
-                    ops.struct_array(hip.GramProblem, [fwd[i] for i in sel]),
-                    ops.struct_array(hip.StyleProblem, [sty[i] for i in sel]),
-                    ops.struct_array(hip.GramBwdProblem, [bwd[i] for i in sel]), [keys[i] for i in sel])
-            self._loss_tables = (sig, tables)
-        tab = self._loss_tables[1][part]
-        if tab is not None:
-            fwd, sty, bwd, keys = tab
-            assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
-            ops.gram_masked_grouped(fwd)
-            self._gram_clean.difference_update(keys)
-            ops.style_loss_grouped(sty, self.loss_buf[1:2])
-            ops.gram_backward_grouped(bwd)
-        if part == "side":
-            return set(side_layers)
-        injected = set(cfg.style_layers)
-        if w_content != 0.0:
-            for lv, b in zip(active, bufs):
-                for li, layer in enumerate(cfg.content_layers):
-                    if layer not in content_done:   # (the caller ran those on the side stream)
-                        self._content_term(lv, b, li, layer, w_content)
-                    injected.add(layer)
-        return injected
+            tab = self._loss_tables[1][layers] = (ops.struct_array(hip.GramProblem, fwd),
+                                                  ops.struct_array(hip.StyleProblem, sty),
+                                                  ops.struct_array(hip.GramBwdProblem, bwd), keys)
+        fwd, sty, bwd, keys = tab
+        assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
+        ops.gram_masked_grouped(fwd)
+        self._gram_clean.difference_update(keys)
+        ops.style_loss_grouped(sty, self.loss_buf[1:2])
+        ops.gram_backward_grouped(bwd)
 
     def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None, am=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
