@@ -377,9 +377,103 @@ static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats,
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// First layer forward (3 -> C_out channels, bias + ReLU): 27 multiply-adds per output are far too thin for the matrix
+// cores - the MFMA tile kernel spends its time in the epilogue (64 x 256 tiles: 165 us for 7.6 GFLOP, 2 TB/s of stores).
+// A streaming VALU kernel instead: a thread holds the 3 x 3 x 6 input window of FOUR consecutive positions in registers
+// and walks the output channels, weights through the scalar cache (wave-uniform), one 16-byte store per channel
+// (1 KB contiguous per wave): bound by the HBM write of the output planes. A block = 1024 positions (the tile unit of
+// this layer's active-tile list, sm_conv_tile_positions(4, .)).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(ConvArgs a) {
+    const int n_glob = blockIdx.x;
+    ConvProblem P = a.p[0];
+    int n_tile = n_glob;
+    if (a.tile_list) {
+        const int e = a.tile_list[n_glob];
+        const int gsel = e >> 24;
+        n_tile = e & 0xFFFFFF;
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g == gsel) P = a.p[g];
+    } else {
+#pragma unroll
+        for (int g = 1; g < SM_MAX_GROUP; ++g)
+            if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+                P = a.p[g];
+                n_tile = n_glob - a.tile_begin[g];
+            }
+    }
+    const float seen = amax_peek(a.amax_out);
+    const int q = P.Wp + (n_tile * 256 + threadIdx.x) * 4;   // Wp % 4 == 0: 16-byte aligned
+    float vmax = 0.f;
+    if (q < (P.H + 1) * P.Wp) {
+        float x[3][3][6];
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* r = P.in + (size_t)ci * P.plane + q + (ky - 1) * P.Wp;
+                const f32x4 m = *reinterpret_cast<const f32x4*>(r);
+                x[ci][ky][0] = r[-1]; x[ci][ky][1] = m[0]; x[ci][ky][2] = m[1]; x[ci][ky][3] = m[2]; x[ci][ky][4] = m[3];
+                x[ci][ky][5] = r[4];
+            }
+        bool in4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in4[j] = interior(q + j, P.H, P.W, P.Wp);
+        const int Cout = a.Cout;
+        for (int co = 0; co < Cout; co += 4) {   // four output channels per pass: their 27 weights each as scalar float4s
+            float acc[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[c][j] = a.bias[co + c];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(a.wt + ((ky * 3 + kx) * 4 + ci) * Cout + co);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w[c], x[ci][ky][j + kx], acc[c][j]);
+                    }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = in4[j] ? fmaxf(acc[c][j], 0.f) : 0.f;
+                    vmax = fmaxf(vmax, v[j]);
+                }
+                *reinterpret_cast<f32x4*>(P.out + (size_t)(co + c) * P.plane + q) = v;
+            }
+        }
+    }
+    record_amax(a.amax_out, vmax, seen);
+}
+
+static int launch_conv_c3_fwd(const ConvArgs& a0, int n_list, hipStream_t s) {
+    ConvArgs a = a0;
+    a.tile_begin[0] = 0;
+    for (int g = 0; g < a.n_problems; ++g)
+        a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + 1023) / 1024;
+    const int n = a.tile_list ? n_list : a.tile_begin[a.n_problems];
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(n), dim3(256), 0, s, a);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int FLAGS>
 static int dispatch_conv(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
-    if (a.Cin_pad == 4) return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, n_list, ws_floats, s);
+    if (a.Cin_pad == 4 && FLAGS == SM_EPI_BIAS_RELU && a.Cout % 4 == 0) return launch_conv_c3_fwd(a, n_list, s);
+    if (a.Cin_pad == 4) {   // (other epilogues: the MFMA tile kernel; its tiles are not the 1024-position list units)
+        if (a.tile_list != nullptr) return (int)hipErrorInvalidValue;
+        return launch_conv<64, 256, 4, 1, 4, FLAGS>(a, n_list, ws_floats, s);
+    }
     if (a.Cout % 128 != 0) return launch_conv<64, 256, 8, 1, 4, FLAGS>(a, n_list, ws_floats, s);
     return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, n_list, ws_floats, s);
 }
@@ -636,7 +730,7 @@ int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void
     return 0;
 }
 
-int sm_conv_tile_positions(int Cin_pad, int Cout) { return (Cin_pad == 4 || Cout % 128 != 0) ? 256 : 128; }
+int sm_conv_tile_positions(int Cin_pad, int Cout) { return Cin_pad == 4 ? 1024 : (Cout % 128 != 0 ? 256 : 128); }
 int sm_conv_split_tile_positions(void) { return 128; }
 int sm_conv_split2_tile_positions(int Cout) { return (SM_SPLIT2_BN256 && Cout % 128 != 0) ? 256 : 128; }
 
