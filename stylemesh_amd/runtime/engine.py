@@ -194,6 +194,10 @@ class StepEngine:
         # non-zero: random_init, load_texture / from_tensor, a loaded optimizer state).
         self.touched_log2 = 6
         self.touched = None if random_init else torch.zeros(-(-self.arena.n // 64), dtype=torch.int32, device=device)
+        self._view_flags = None        # the current view's chunks (same granularity)
+        self._other_flags = None       # touched & ~view
+        self._adam_early_done = None   # event: the update of the other chunks (issued at the head of the step) is done
+        self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
     # ------------------------------------------------------------------ texture access
@@ -360,9 +364,17 @@ class StepEngine:
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
         self._last_batch = batch
         if self.touched is not None:
+            # chunks this view's scatter (and its texture sampling) can reach: OR-ed into the ever-touched flags; the
+            # split update (``_adam_early``) treats them apart from the rest
+            if self._view_flags is None:
+                self._view_flags = torch.zeros_like(self.touched)
+            else:
+                self._view_flags.zero_()
             for lv in self.view:
                 if lv.active:
-                    ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, self.touched, self.touched_log2)
+                    ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, self._view_flags, self.touched_log2)
+            ops.flags_or(self.touched, self._view_flags)
+            self._other_flags = None   # ever-touched and not in this view: built on first use
 
     def _finish_view(self, levels, rgb_dev, msums=None):
         """Layer-resolution masks + counts + level factors (calculate_pyramid, losses :146-217) and the content
@@ -847,8 +859,41 @@ class StepEngine:
     def _touched_arg(self):
         return (self.touched, self.touched_log2) if (self.sparse_update and self.touched is not None) else (None, 0)
 
+    def _adam_early(self):
+        """Split update, first half, at the HEAD of a step: the ever-touched chunks the current view (all ranks' views)
+        cannot reach have a zero gradient whatever this step computes, and the step neither samples nor scatters there -
+        their update (step count of the update that closes this step) runs on a side stream beside the forward pass;
+        ``_optimizer_launch`` then only walks the view's own chunks. Call after ``loss_tensors()`` (which reads the
+        sum of squares this zeroes)."""
+        if not (self.split_update and self.sparse_update and self.touched is not None and self._view_flags is not None
+                and not self._can_graph() and not torch.cuda.is_current_stream_capturing()):
+            return
+        if self._other_flags is None or self._other_flags[0] is not self.touched:   # (a loaded state replaces `touched`)
+            self._other_flags = (self.touched, ((self.touched != 0) & (self._view_flags == 0)).to(torch.int32))
+        main = torch.cuda.current_stream()
+        while len(self._lv_streams) < 2:
+            self._lv_streams.append(torch.cuda.Stream(device=self.device))
+        st = self._lv_streams[1]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            self.sumsq.zero_()
+            ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
+                           self.lr, self.step_count + 1, grad_scale=1.0, sumsq_out=self.sumsq, dev_hyper=None,
+                           touched=self._other_flags[1], touched_log2=self.touched_log2)
+            self._adam_early_done = torch.cuda.Event()
+            self._adam_early_done.record(st)
+
     def _optimizer_launch(self, world_size, dev_hyper):
         self._grad_dirty = False   # the fused update zeroes the gradient arena
+        if self._adam_early_done is not None:   # second half of the split update: the view's own chunks
+            torch.cuda.current_stream().wait_event(self._adam_early_done)
+            self._adam_early_done = None
+            ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
+                           self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
+                           dev_hyper=dev_hyper, touched=self._view_flags, touched_log2=self.touched_log2)
+            return
         self.sumsq.zero_()
         if dev_hyper is not None:
             ops.adam_hyper_step(self._hyper_state, dev_hyper)
@@ -903,6 +948,8 @@ class StepEngine:
         ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
         self.begin_step(batch, reducer, new_view)
         losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
+        if not (reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined")):
+            self._adam_early()
         self.step_forward_backward()
         # content / style of loss_tensors() are views of the accumulators the NEXT step zeroes: hand out this step's
         # values (one 2-float copy), so that a caller may read them any number of steps later
@@ -940,6 +987,9 @@ class StepEngine:
             if self.touched is not None:
                 if reducer.chunk_log2 == self.touched_log2:
                     ops.flags_or(self.touched, flags)   # the other ranks' gradients arrive with the exchange
+                    if self._view_flags is not None:
+                        ops.flags_or(self._view_flags, flags)
+                        self._other_flags = None
                 else:
                     self.touched = None
 

@@ -102,6 +102,41 @@ def test_sparse_update_equals_dense_and_touched_texels_keep_decaying():
     assert float(mB[never].abs().max()) == 0.0 and float(vB[never].abs().max()) == 0.0
 
 
+def test_split_update_equals_dense():
+    """The split update (chunks the view cannot reach updated at the HEAD of the step on a side stream, the view's own
+    chunks after the scatter) leaves exactly the state of one dense update with the same gradient - over two views, so
+    that 'ever touched but not in this view' is a non-empty set."""
+    views = small_views((3, 4))
+    eng = make_engine(FLAGSETS["with_angle_and_depth"], None)
+    assert eng.touched is not None and eng.split_update
+    a = eng.arena
+    n_other = 0
+    for v in views:
+        for _ in range(3):
+            eng.begin_step(v)
+            before = [t.clone() for t in (a.p, a.m, a.v)]
+            count = eng.step_count
+            eng._adam_early()                      # first half: beside the forward pass
+            assert eng._adam_early_done is not None
+            n_other += int(eng._other_flags[1].sum())
+            eng.forward_backward()
+            g = a.g.clone()
+            eng.optimizer_step()                   # second half
+            split = [t.clone() for t in (a.p, a.g, a.m, a.v)]
+            ssq = eng.sumsq.clone()
+            for dst, src in zip((a.p, a.m, a.v), before):
+                dst.copy_(src)
+            a.g.copy_(g)
+            eng.step_count = count
+            eng.sparse_update = False
+            eng.optimizer_step()                   # one dense update of the same state and gradient
+            eng.sparse_update = True
+            for got, want in zip(split, (a.p, a.g, a.m, a.v)):
+                assert torch.equal(got, want)
+            assert_close(ssq, eng.sumsq, 1e-6, 0)
+    assert n_other > 0                             # the second view left chunks of the first one to the early half
+
+
 def test_load_texture_switches_to_dense_update():
     g5 = load_golden("g5_with_angle_and_depth")
     eng = make_engine(FLAGSETS["with_angle_and_depth"], [T(g5[f"init{i}"]) for i in range(4)])
