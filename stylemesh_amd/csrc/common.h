@@ -12,6 +12,7 @@ namespace sm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // bf16x3 split of an fp32 number: x -> (h, m, l) bf16 with h + m + l == x to 24 significand bits; round-to-nearest

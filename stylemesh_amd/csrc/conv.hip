@@ -385,7 +385,10 @@ static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats,
 // (1 KB contiguous per wave): bound by the HBM write of the output planes. A block = 1024 positions (the tile unit of
 // this layer's active-tile list, sm_conv_tile_positions(4, .)).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(ConvArgs a) {
+// (wt / bias arrive as separate __restrict__ parameters: read through the pointers inside ConvArgs the compiler cannot
+// rule out that the output stores alias them, and re-loads the weights with VECTOR loads after the first store)
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(ConvArgs a, const float* __restrict__ wt,
+                                                             const float* __restrict__ bias) {
     const int n_glob = blockIdx.x;
     ConvProblem P = a.p[0];
     int n_tile = n_glob;
@@ -423,29 +426,34 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(ConvArgs a) {
         for (int j = 0; j < 4; ++j) in4[j] = interior(q + j, P.H, P.W, P.Wp);
         const int Cout = a.Cout;
         for (int co = 0; co < Cout; co += 4) {   // four output channels per pass: their 27 weights each as scalar float4s
-            float acc[4][4];
+            // accumulators as pairs of output channels: the multiply-adds issue as v_pk_fma_f32 (two per instruction)
+            f32x2 acc[2][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[c][j] = a.bias[co + c];
+                for (int j = 0; j < 4; ++j) acc[cp][j] = f32x2{bias[co + 2 * cp], bias[co + 2 * cp + 1]};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                     for (int ci = 0; ci < 3; ++ci) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(a.wt + ((ky * 3 + kx) * 4 + ci) * Cout + co);
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wt + ((ky * 3 + kx) * 4 + ci) * Cout + co);
+                        const f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w[c], x[ci][ky][j + kx], acc[c][j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const float xv = x[ci][ky][j + kx];
+                            const f32x2 x2 = {xv, xv};
+                            acc[0][j] = __builtin_elementwise_fma(w01, x2, acc[0][j]);
+                            acc[1][j] = __builtin_elementwise_fma(w23, x2, acc[1][j]);
+                        }
                     }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[j] = in4[j] ? fmaxf(acc[c][j], 0.f) : 0.f;
+                    v[j] = in4[j] ? fmaxf(acc[c >> 1][j][c & 1], 0.f) : 0.f;
                     vmax = fmaxf(vmax, v[j]);
                 }
                 *reinterpret_cast<f32x4*>(P.out + (size_t)(co + c) * P.plane + q) = v;
@@ -462,7 +470,7 @@ static int launch_conv_c3_fwd(const ConvArgs& a0, int n_list, hipStream_t s) {
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + 1023) / 1024;
     const int n = a.tile_list ? n_list : a.tile_begin[a.n_problems];
     if (n == 0) return 0;
-    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(n), dim3(256), 0, s, a, a.wt, a.bias);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -493,13 +501,31 @@ __device__ __forceinline__ void dgrad_c3_body(const float* __restrict__ dz, cons
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+    // the next channel's three rows are requested before this channel's 108 multiply-adds (the compiler does not
+    // pipeline the loop by itself: every iteration would wait out a full memory round trip)
+    f32x4 nm[3];
+    float nl[3], nr[3];
+#define SM_DG_LOAD(ci_)                                                                 \
+    {                                                                                   \
+        const float* p_ = dz + (size_t)min((ci_), Cin - 1) * plane + q;                 \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                              \
+            const float* r_ = p_ + (ky - 1) * Wp;                                       \
+            nm[ky] = *reinterpret_cast<const f32x4*>(r_);                               \
+            nl[ky] = r_[-1];                                                            \
+            nr[ky] = r_[4];                                                             \
+        }                                                                               \
+    }
+    SM_DG_LOAD(0)
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* p = dz + (size_t)ci * plane + q;
+        f32x4 cm[3];
+        float cl[3], cr[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { cm[ky] = nm[ky]; cl[ky] = nl[ky]; cr[ky] = nr[ky]; }
+        SM_DG_LOAD(ci + 1)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const float* r = p + (ky - 1) * Wp;
-            const f32x4 m = *reinterpret_cast<const f32x4*>(r);
-            const float x[6] = {r[-1], m[0], m[1], m[2], m[3], r[4]};
+            const f32x4 m = cm[ky];
+            const float x[6] = {cl[ky], m[0], m[1], m[2], m[3], cr[ky]};
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const float* w = wd + ((ky * 3 + kx) * Cin + ci) * 4;
@@ -513,6 +539,7 @@ __device__ __forceinline__ void dgrad_c3_body(const float* __restrict__ dz, cons
             }
         }
     }
+#undef SM_DG_LOAD
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         f32x4 v;

@@ -198,6 +198,7 @@ class StepEngine:
         self._other_flags = None       # touched & ~view
         self._adam_early_done = None   # event: the update of the other chunks (issued at the head of the step) is done
         self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
+        self.overlap_min_pixels = int(os.environ.get("STYLEMESH_OVERLAP_MIN_PIXELS", "400000"))
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
     # ------------------------------------------------------------------ texture access
@@ -525,7 +526,10 @@ class StepEngine:
             #   * the other style layers fork when the forward pass is done, deepest first - the order the backward pass
             #     needs them in.
             grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
-            use_side = grouped and self.side_streams and not torch.cuda.is_current_stream_capturing()
+            # (only for steps long enough to pay for the extra events and stream switches on the host: a single
+            # 256 x 341 level is host-bound, its step 3 % slower with them)
+            use_side = (grouped and self.side_streams and self._overlap_pays(active)
+                        and not torch.cuda.is_current_stream_capturing())
             early = tuple(l for l in self.side_style_layers if l in cfg.style_layers and l != self.deepest) if use_side else ()
             late = tuple(sorted((l for l in cfg.style_layers if l not in early and l != self.deepest),
                                 key=depth_of, reverse=True)) if use_side else ()
@@ -859,6 +863,11 @@ class StepEngine:
     def _touched_arg(self):
         return (self.touched, self.touched_log2) if (self.sparse_update and self.touched is not None) else (None, 0)
 
+    def _overlap_pays(self, active) -> bool:
+        """Side-stream overlap costs the host a few events and stream switches per step: worth it when the GPU step is
+        several milliseconds (c3 / c5: 1.6 M pixels over the levels), not for a single small level (c2: 87 k)."""
+        return sum(lv.H * lv.W for lv in active) >= self.overlap_min_pixels
+
     def _adam_early(self):
         """Split update, first half, at the HEAD of a step: the ever-touched chunks the current view (all ranks' views)
         cannot reach have a zero gradient whatever this step computes, and the step neither samples nor scatters there -
@@ -866,7 +875,8 @@ class StepEngine:
         ``_optimizer_launch`` then only walks the view's own chunks. Call after ``loss_tensors()`` (which reads the
         sum of squares this zeroes)."""
         if not (self.split_update and self.sparse_update and self.touched is not None and self._view_flags is not None
-                and not self._can_graph() and not torch.cuda.is_current_stream_capturing()):
+                and not self._can_graph() and not torch.cuda.is_current_stream_capturing()
+                and self.view is not None and self._overlap_pays([lv for lv in self.view if lv.active])):
             return
         if self._other_flags is None or self._other_flags[0] is not self.touched:   # (a loaded state replaces `touched`)
             self._other_flags = (self.touched, ((self.touched != 0) & (self._view_flags == 0)).to(torch.int32))
