@@ -49,6 +49,11 @@ int sm_abi_version(void);
  * out: padded planar fmap with out_channels >= 3 planes (planes >= 3 are left untouched = zero). */
 int sm_tex_sample_fwd(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
                       const float* grid, int h, int w, float* out, void* stream);
+/* The same for up to 8 images (the UV levels of a view) in ONE launch: grids / hs / ws / outs are HOST arrays of n
+ * entries (device grid [h][w][2], sizes, device output planes). */
+int sm_tex_sample_fwd_grouped(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
+                              const float* const* grids, const int* hs, const int* ws, float* const* outs, int n,
+                              void* stream);
 
 /* K2. Backward of K1 (ATen grid_sampler_2d_backward + RepeatBackward + the zero-filled dense gradient,
  * texture.py:49-53) fused with the two tensor hooks of model/model.py:195-202,245-251:

@@ -45,9 +45,9 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int W, int H) {
 
 struct __attribute__((aligned(4))) pair4 { float x, y; };   // two adjacent floats at 4-byte alignment
 
-__global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
-                                                             float* __restrict__ out, int Wp, int plane) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void tex_sample_fwd_body(const TexLayers& L, const float2* __restrict__ grid, int h, int w,
+                                                    float* __restrict__ out, int Wp, int plane, int block_x) {
+    const int i = block_x * 256 + threadIdx.x;
     if (i >= h * w) return;
     const int y = i / w, x = i - y * w;
     const float2 g = grid[i];
@@ -89,6 +89,34 @@ __global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const 
     out[q] = acc0;
     out[plane + q] = acc1;
     out[2 * (size_t)plane + q] = acc2;
+}
+
+__global__ __launch_bounds__(256) void tex_sample_fwd_kernel(TexLayers L, const float2* __restrict__ grid, int h, int w,
+                                                             float* __restrict__ out, int Wp, int plane) {
+    tex_sample_fwd_body(L, grid, h, w, out, Wp, plane, blockIdx.x);
+}
+
+// The UV levels of a view in ONE launch (four gather-bound launches of 11-22 us each otherwise)
+constexpr int TEX_MAX_GROUP = 8;
+struct TexSampleGroup {
+    const float2* grid[TEX_MAX_GROUP];
+    float* out[TEX_MAX_GROUP];
+    int h[TEX_MAX_GROUP], w[TEX_MAX_GROUP];
+    int block_begin[TEX_MAX_GROUP + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void tex_sample_fwd_group_kernel(TexLayers L, TexSampleGroup G) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < TEX_MAX_GROUP; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.block_begin[i]) g = i;
+    const float2* grid = G.grid[0];
+    float* out = G.out[0];
+    int h = G.h[0], w = G.w[0];
+#pragma unroll
+    for (int i = 1; i < TEX_MAX_GROUP; ++i)
+        if (i == g) { grid = G.grid[i]; out = G.out[i]; h = G.h[i]; w = G.w[i]; }
+    tex_sample_fwd_body(L, grid, h, w, out, row_stride(w), plane_size(h, w), blockIdx.x - G.block_begin[g]);
 }
 
 // K2, tiled: one block = a 16x16 pixel tile of the view. Neighbouring pixels hit neighbouring (coarse layers: the
@@ -386,6 +414,26 @@ static TexLayers make_layers(float* const* layers, const int* lw, const int* lh,
 }  // namespace sm
 
 extern "C" {
+
+int sm_tex_sample_fwd_grouped(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
+                              const float* const* grids, const int* hs, const int* ws, float* const* outs, int n,
+                              void* stream) {
+    if (n_layers < 1 || n_layers > SM_MAX_TEX_LAYERS || n < 1 || n > sm::TEX_MAX_GROUP) return (int)hipErrorInvalidValue;
+    sm::TexLayers L = sm::make_layers(const_cast<float* const*>(layers), layer_w, layer_h, n_layers);
+    sm::TexSampleGroup G{};
+    G.n = n;
+    for (int i = 0; i < n; ++i) {
+        G.grid[i] = reinterpret_cast<const float2*>(grids[i]);
+        G.out[i] = outs[i];
+        G.h[i] = hs[i];
+        G.w[i] = ws[i];
+        G.block_begin[i + 1] = G.block_begin[i] + (hs[i] * ws[i] + 255) / 256;
+    }
+    if (G.block_begin[n] == 0) return 0;
+    hipLaunchKernelGGL(sm::tex_sample_fwd_group_kernel, dim3(G.block_begin[n]), dim3(256), 0, (hipStream_t)stream, L, G);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
 
 int sm_tex_sample_fwd(const float* const* layers, const int* layer_w, const int* layer_h, int n_layers,
                       const float* grid, int h, int w, float* out, void* stream) {

@@ -478,8 +478,11 @@ class StepEngine:
         self._zero_step_accumulators()
         if len({(lv.H, lv.W) for lv in active}) != len(active):
             raise ValueError("two UV levels of the same resolution are not supported")
-        for lv, b in zip(active, bufs):
-            ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
+        if len(active) <= 8:
+            ops.tex_sample_fwd_grouped(self.layers, [lv.grid for lv in active], [b.act["img"] for b in bufs])
+        else:
+            for lv, b in zip(active, bufs):
+                ops.tex_sample_fwd(self.layers, lv.grid, b.act["img"])
         style_on = w_style != 0.0
         side_layers = [l for l in cfg.style_layers if l != self.deepest] if (style_on and self.overlap_style) else []
         if side_layers:

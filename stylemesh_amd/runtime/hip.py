@@ -27,6 +27,7 @@ SIGNATURES = {
     "sm_fmap_plane": [_i, _i],
     "sm_abi_version": [],
     "sm_tex_sample_fwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "sm_tex_sample_fwd_grouped": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sm_tex_sample_bwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "sm_tex_touch_flags": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     "sm_tex_scatter_plan_temp_bytes": [_sz, _i],

@@ -117,6 +117,17 @@ def tex_sample_fwd(layers, grid: torch.Tensor, out: FMap):
                                     out.ptr, hip.stream()), "sm_tex_sample_fwd")
 
 
+def tex_sample_fwd_grouped(layers, grids, outs):
+    """``tex_sample_fwd`` for the UV levels of a view in one launch: ``grids`` [h,w,2] tensors, ``outs`` FMaps."""
+    hs, ws = [g.shape[-3] for g in grids], [g.shape[-2] for g in grids]
+    assert all(o.H == h and o.W == w and o.C >= 3 for o, h, w in zip(outs, hs, ws))
+    out_ptrs = (hip.C.c_void_p * len(outs))(*[o.ptr for o in outs])
+    hip.check(lib.sm_tex_sample_fwd_grouped(hip.ptr_array(layers), hip.int_array([l.shape[2] for l in layers]),
+                                            hip.int_array([l.shape[1] for l in layers]), len(layers),
+                                            hip.ptr_array(grids), hip.int_array(hs), hip.int_array(ws), out_ptrs,
+                                            len(grids), hip.stream()), "sm_tex_sample_fwd_grouped")
+
+
 def tex_sample_bwd(grad_layers, grid: torch.Tensor, grad_img: FMap, pixel_weight=None):
     h, w = grid.shape[-3], grid.shape[-2]
     assert grad_img.H == h and grad_img.W == w
