@@ -131,6 +131,13 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
  * step-dependent value crossing from the host. */
 int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream);
 
+/* Head of a training step in ONE launch: *reg_out = sum_l coef[l] * sumsq[l] (the regulariser loss `tex_reg` of the
+ * current texture from the per-layer sums of squares the previous sm_adam_fused left; model/model.py:387-395), and a
+ * zero fill of the two float ranges a step accumulates into (loss values + operand bounds; Gram slabs). n_a, n_b:
+ * multiples of 4 (16-byte aligned ranges); either may be 0; reg_out may be NULL. */
+int sm_step_begin(const float* sumsq, const float* coef, int n_seg, float* reg_out, float* zero_a, size_t n_a,
+                  float* zero_b, size_t n_b, void* stream);
+
 /* dst[i] = 1 wherever src[i] != 0 (int32 flag arrays of n entries): accumulates a view's sm_tex_touch_flags (after
  * the ranks' max-all-reduce, if any) into the ever-touched flags sm_adam_fused takes. */
 int sm_flags_or(int32_t* dst, const int32_t* src, size_t n, void* stream);

@@ -411,6 +411,24 @@ static TexLayers make_layers(float* const* layers, const int* lw, const int* lh,
     return L;
 }
 
+// Head of a step in one launch: the regulariser loss of the current texture (sum_l coef_l * sum p^2 of layer l, the
+// sums left by the previous update) and the zero fill of everything the step accumulates into (loss values + operand
+// bounds, Gram slabs) - instead of a multiply, a reduction and two fills.
+__global__ __launch_bounds__(256) void step_begin_kernel(const float* __restrict__ sumsq, const float* __restrict__ coef,
+                                                         int n_seg, float* __restrict__ reg_out, f32x4* __restrict__ za,
+                                                         size_t na4, f32x4* __restrict__ zb, size_t nb4) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && reg_out != nullptr) {
+        float r = 0.f;
+        for (int l = 0; l < n_seg; ++l) r += sumsq[l] * coef[l];
+        *reg_out = r;
+    }
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += stride) {
+        if (i < na4) za[i] = z; else zb[i - na4] = z;
+    }
+}
+
 }  // namespace sm
 
 extern "C" {
@@ -502,6 +520,17 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
 
 int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream) {
     hipLaunchKernelGGL(sm::adam_hyper_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2, dev_hyper);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_step_begin(const float* sumsq, const float* coef, int n_seg, float* reg_out, float* zero_a, size_t n_a,
+                  float* zero_b, size_t n_b, void* stream) {
+    if (n_seg < 0 || n_a % 4 != 0 || n_b % 4 != 0) return (int)hipErrorInvalidValue;
+    const size_t work = (n_a + n_b) / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (work + 255) / 256));
+    hipLaunchKernelGGL(sm::step_begin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sumsq, coef, n_seg, reg_out,
+                       reinterpret_cast<sm::f32x4*>(zero_a), n_a / 4, reinterpret_cast<sm::f32x4*>(zero_b), n_b / 4);
     SM_LAUNCH_CHECK();
     return 0;
 }

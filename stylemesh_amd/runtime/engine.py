@@ -156,6 +156,7 @@ class StepEngine:
         # style layers whose branch runs on a side stream beside the conv trunk (grouped loss phase only)
         self.side_style_layers = tuple(x for x in os.environ.get("STYLEMESH_SIDE_STYLE", "r11").split(",") if x)
         self.side_streams = os.environ.get("STYLEMESH_SIDE_STREAMS", "1") != "0"
+        self._step_zeroed = False      # the step's accumulators were zeroed by _step_begin
         self._loss_tables = None       # (signature, Gram / style-loss / Gram-backward problem tables, slab keys)
         self._gram_bwd_ws = {}         # (C, level, layer) -> scratch of the derivative matrices' operand images
         self._side = None
@@ -258,9 +259,28 @@ class StepEngine:
                 f = b.act[layer]
                 self._gram_scratch((f.C, lv.index, layer), ops.gram_workspace_slabs(f.C, f.H, f.W))
 
+    def _step_begin(self):
+        """Head of a training step, ONE launch: the regulariser loss of the current texture (from the sums of squares the
+        previous update left, before this step's update overwrites them) and the zero fill of everything the step
+        accumulates into. Returns ``loss_tensors()`` with this step's ``tex_reg``."""
+        reg = torch.empty(1, device=self.device)
+        if self._can_graph():   # the captured step carries its own fills
+            ops.step_begin(self.sumsq, self._reg_loss_coef_dev, reg, None, None)
+            return {"content": self.loss_buf[0:1], "style": self.loss_buf[1:2], "tex_reg": reg}
+        dirty = self._gram_arena is not None and len(self._gram_clean) != len(self._gram)
+        ops.step_begin(self.sumsq, self._reg_loss_coef_dev, reg, self._step_scalars, self._gram_arena if dirty else None)
+        if dirty:
+            self._gram_clean = set(self._gram)
+        self._step_zeroed = True
+        return {"content": self.loss_buf[0:1], "style": self.loss_buf[1:2], "tex_reg": reg}
+
     def _zero_step_accumulators(self):
         """Everything a step accumulates into: the loss pair and - one fill over the arena - the Gram slabs of every
         (level, layer) the previous step added into (instead of two fills per masked-Gram call)."""
+        if self._step_zeroed:      # ``_step_begin`` has just done it (the arena may have been created since: zeros)
+            self._step_zeroed = False
+            if self._gram_arena is None or len(self._gram_clean) == len(self._gram):
+                return
         self._step_scalars.zero_()
         if self._gram_arena is not None and len(self._gram_clean) != len(self._gram):
             self._gram_arena.zero_()
@@ -960,7 +980,7 @@ class StepEngine:
         """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.
         ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
         self.begin_step(batch, reducer, new_view)
-        losses = self.loss_tensors()   # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
+        losses = self._step_begin()    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         if not (reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined")):
             self._adam_early()
         self.step_forward_backward()

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sm_tex_scatter_planned": [_vp, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp],
     "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp],
     "sm_adam_hyper_step": [_vp, _d, _d, _vp, _vp],
+    "sm_step_begin": [_vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp],
     "sm_flags_or": [_vp, _vp, _sz, _vp],
     "sm_clamp_sumsq": [_vp, _sz, _vp, _i, _f, _f, _vp, _vp],
     "sm_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],

@@ -240,6 +240,14 @@ def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999):
     hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), hip.stream()), "sm_adam_hyper_step")
 
 
+def step_begin(sumsq, coef, reg_out, zero_a, zero_b=None):
+    """Regulariser loss of the current texture into ``reg_out`` + zero fill of the step's accumulators, one launch."""
+    assert (zero_a is None or zero_a.numel() % 4 == 0) and (zero_b is None or zero_b.numel() % 4 == 0)
+    hip.check(lib.sm_step_begin(ptr(sumsq), ptr(coef), sumsq.numel(), ptr(reg_out), ptr(zero_a),
+                                0 if zero_a is None else zero_a.numel(), ptr(zero_b),
+                                0 if zero_b is None else zero_b.numel(), hip.stream()), "sm_step_begin")
+
+
 def flags_or(dst, src):
     assert dst.dtype == src.dtype == torch.int32 and dst.numel() == src.numel()
     hip.check(lib.sm_flags_or(ptr(dst), ptr(src), dst.numel(), hip.stream()), "sm_flags_or")
