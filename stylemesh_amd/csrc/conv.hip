@@ -366,7 +366,11 @@ template <int FLAGS, bool UNPOOL = false>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
 #if SM_SPLIT2_BN256
     // 64 output channels: 64 x 256 tiles, four waves of 64 x 64 (the same MFMAs per stage and wave as the 128-row tile)
-    if (a.Cout % 128 != 0) return launch_conv<64, 256, 16, 1, 4, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
+#ifndef SM_SPLIT2_W64GM
+#define SM_SPLIT2_W64GM 2   // waves along the channel dimension of the 64 x 256 tile: 2 (32 x 128 wave tiles, +3-5 % on the 64-channel layers) or 1 (64 x 64)
+#endif
+    if (a.Cout % 128 != 0)
+        return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 #else
     if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
 #endif
