@@ -365,9 +365,11 @@ static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, 
 template <int FLAGS, bool UNPOOL = false>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
 #if SM_SPLIT2_BN256
-    // 64 output channels: 64 x 256 tiles, four waves of 64 x 64 (the same MFMAs per stage and wave as the 128-row tile)
+    // 64 output channels: 64 x 256 tiles (the same 12 MFMAs per stage and wave as the 128-row tile), waves 2 x 2 with
+    // 32 x 128 wave tiles: half the weight-fragment loads of the 1 x 4 layout (64 x 64 wave tiles, all four waves
+    // fetching the same 64 rows), +3-5 % on the 64-channel layers
 #ifndef SM_SPLIT2_W64GM
-#define SM_SPLIT2_W64GM 2   // waves along the channel dimension of the 64 x 256 tile: 2 (32 x 128 wave tiles, +3-5 % on the 64-channel layers) or 1 (64 x 64)
+#define SM_SPLIT2_W64GM 2
 #endif
     if (a.Cout % 128 != 0)
         return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
