@@ -4,10 +4,14 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-# a step starts with tex_sample_fwd launches following an adam kernel
-adam = [i for i, e in enumerate(ev) if "adam_kernel<true>" in e[2]]
-a0, a1 = adam[-k - 1], adam[-k]
-step = ev[a0 + 1:a1 + 1]
+# a step starts with the step-head kernel (older traces: with the launches following the update kernel)
+head = [i for i, e in enumerate(ev) if "step_begin_kernel" in e[2]]
+if len(head) > k + 1:
+    step = ev[head[-k - 1]:head[-k]]
+else:
+    adam = [i for i, e in enumerate(ev) if "adam_kernel<true>" in e[2]]
+    a0, a1 = adam[-k - 1], adam[-k]
+    step = ev[a0 + 1:a1 + 1]
 t0 = step[0][0]
 def short(n):
     n = n.replace("void ", "").replace("sm::", "")
