@@ -49,6 +49,36 @@ def test_tex_sample_forward_backward_golden(rt):
     assert_close(out.to_dense()[0, 0], [0, 11, 5.5, 3], 1e-6, 1e-6)
 
 
+def test_tex_sample_grouped_equals_per_level_and_step_begin(rt):
+    """sm_tex_sample_fwd_grouped over several images = sm_tex_sample_fwd per image, bit for bit; sm_step_begin computes
+    sum_l coef_l * sumsq_l and zeroes both ranges (and only them)."""
+    d = load_golden("g1_texture")
+    layers = [dev(torch.from_numpy(d[f"layer{i}"]).clamp(O.CLAMP_LO, O.CLAMP_HI)) for i in range(4)]
+    torch.manual_seed(5)
+    grids = [dev(torch.rand(1, h, w, 2) * 2.4 - 1.2) for h, w in ((17, 23), (40, 31), (9, 64), (33, 33))]
+    outs = [rt.FMap(4, g.shape[1], g.shape[2]) for g in grids]
+    refs = [rt.FMap(4, g.shape[1], g.shape[2]) for g in grids]
+    rt.ops.tex_sample_fwd_grouped(layers, grids, outs)
+    for g, r in zip(grids, refs):
+        rt.ops.tex_sample_fwd(layers, g, r)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o.to_dense(3), r.to_dense(3)) and o.border_is_zero()
+    sumsq = dev(torch.tensor([1.5, 2.25, 4.0, 0.125]))
+    coef = dev(torch.tensor([2.0, 0.5, 0.25, 8.0]))
+    reg = torch.full((1,), -1.0).cuda()
+    buf = torch.full((4096 + 8 + 1024 + 8,), 3.0).cuda()
+    a, b = buf[4:4 + 4096], buf[4 + 4096 + 4:4 + 4096 + 4 + 1024]
+    rt.ops.step_begin(sumsq, coef, reg, a, b)
+    assert float(reg) == 1.5 * 2.0 + 2.25 * 0.5 + 4.0 * 0.25 + 0.125 * 8.0
+    assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+    keep = torch.ones_like(buf, dtype=torch.bool)
+    keep[4:4 + 4096] = False
+    keep[4 + 4096 + 4:4 + 4096 + 4 + 1024] = False
+    assert bool((buf[keep] == 3.0).all())
+    rt.ops.step_begin(sumsq, coef, reg, None, None)      # regulariser only (graph mode)
+    assert float(reg) == 6.125
+
+
 def test_tex_sample_backward_pixel_weight_and_accumulate(rt):
     torch.manual_seed(0)
     H, W, h, w = 33, 47, 40, 56
