@@ -40,6 +40,10 @@ extern "C" {
 int sm_fmap_row_stride(int W);        /* Wp */
 int sm_fmap_plane(int H, int W);      /* floats per channel plane (multiple of 64) */
 int sm_abi_version(void);
+/* sizeof of the problem structs of this header as the library was compiled (which: 0 sm_conv_problem, 1
+ * sm_plane_problem, 2 sm_gram_problem, 3 sm_style_problem, 4 sm_gram_bwd_problem; anything else: -1) - a binding checks
+ * its own struct layouts against it. */
+int sm_sizeof_problem(int which);
 
 /* ---- texture: model/texture/texture.py ------------------------------------------------------------ */
 

@@ -733,4 +733,15 @@ int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_p
     return launch_gram_bwd_group<1>(problems, idx1, n1, s);
 }
 
+int sm_sizeof_problem(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(sm_conv_problem);
+        case 1: return (int)sizeof(sm_plane_problem);
+        case 2: return (int)sizeof(sm_gram_problem);
+        case 3: return (int)sizeof(sm_style_problem);
+        case 4: return (int)sizeof(sm_gram_bwd_problem);
+        default: return -1;
+    }
+}
+
 }  // extern "C"

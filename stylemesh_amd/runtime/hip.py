@@ -26,6 +26,7 @@ SIGNATURES = {
     "sm_fmap_row_stride": [_i],
     "sm_fmap_plane": [_i, _i],
     "sm_abi_version": [],
+    "sm_sizeof_problem": [_i],
     "sm_tex_sample_fwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "sm_tex_sample_fwd_grouped": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "sm_tex_sample_bwd": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],

@@ -32,6 +32,14 @@ def test_layout_helpers_are_pure_host_functions():
     assert hip.plane(256, 341) % 64 == 0 and hip.plane(256, 341) >= 258 * 344
 
 
+def test_problem_struct_layouts_match_the_library():
+    """The ctypes mirrors of the header's problem structs have the sizes the library was compiled with."""
+    from stylemesh_amd.runtime import hip
+    for which, kind in enumerate((hip.ConvProblem, hip.PlaneProblem, hip.GramProblem, hip.StyleProblem, hip.GramBwdProblem)):
+        assert hip.lib.sm_sizeof_problem(which) == ctypes.sizeof(kind), kind.__name__
+    assert hip.lib.sm_sizeof_problem(99) == -1
+
+
 def test_weight_packing_layouts():
     import torch
     from stylemesh_amd.runtime import ops
