@@ -71,9 +71,10 @@ namespace sm {
 #ifndef SM_SPLIT2_RING6
 #define SM_SPLIT2_RING6 0      // fp16x2: six LDS slots (two whole chunks), ONE barrier per chunk instead of three
 #endif
-constexpr int conv_split_slots(int NP) { return (NP == 2 && SM_SPLIT2_RING6) ? 6 : 4; }
+// (128-row tiles only: six slots of the 64 x 256 tile would be 99 KB per block - one block per CU)
+constexpr int conv_split_slots(int NP, int BM = 128) { return (NP == 2 && BM == 128 && SM_SPLIT2_RING6) ? 6 : 4; }
 constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) {
-    return (size_t)(conv_split_slots(NP) * 2 * NP * (BN + 2)) * 16;
+    return (size_t)(conv_split_slots(NP, BM) * 2 * NP * (BN + 2)) * 16;
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -358,7 +359,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     __syncthreads();
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
-    constexpr bool RING6 = conv_split_slots(NP) == 6;
+    constexpr bool RING6 = conv_split_slots(NP, BM) == 6;
     // slot of slice ky of the current / of the next chunk
 #define SM_CUR_SLOT(ky_) (RING6 ? base + (ky_) : (base + (ky_)) & 3)
 #define SM_NEXT_SLOT(ky_) (RING6 ? (3 - base) + (ky_) : (base + 3 + (ky_)) & 3)
