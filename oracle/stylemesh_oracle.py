@@ -237,7 +237,13 @@ def image_pyramid(img: torch.Tensor, levels, minimum_size=256):
 def style_targets(state, style_image, style_layers, num_levels=5):
     """``set_style_image`` (:273-286): ``targets[layer_index][level]`` = Gram of VGG(style pyramid[level])."""
     pyr = image_pyramid(style_image, list(range(num_levels)))
-    enc = [vgg_forward(state, p, style_layers) for p in pyr]
+    by_size = {}   # the padded entries repeat the original image (:126-131): same input, same features - encoded once
+    enc = []
+    for p in pyr:
+        key = tuple(p.shape[2:])
+        if key not in by_size:
+            by_size[key] = vgg_forward(state, p, style_layers)
+        enc.append(by_size[key])
     return [{lvl: gram_matrix(enc[lvl][layer]).detach() for lvl in range(num_levels)} for layer in style_layers]
 
 
@@ -434,7 +440,7 @@ class OraclePipeline:
     """The reference training loop for one scene on CPU: clamp -> sample -> VGG -> losses -> backward ->
     Adam (+ StepLR per epoch), Lightning's automatic-optimisation order."""
 
-    def __init__(self, vgg_state, style_image, cfg: OracleConfig, tex_wh, n_layers=4, init_layers=None):
+    def __init__(self, vgg_state, style_image, cfg: OracleConfig, tex_wh, n_layers=4, init_layers=None, targets=None):
         self.state, self.cfg = vgg_state, cfg
         W, H = tex_wh
         n = n_layers if cfg.hierarchical else 1
@@ -443,8 +449,9 @@ class OraclePipeline:
             self.layers = [t.clone().float() for t in init_layers[:n]]
         for l in self.layers:
             l.requires_grad_(True)
-        self.targets = style_targets(vgg_state, style_image[None] if style_image.dim() == 3 else style_image,
-                                     cfg.style_layers)
+        # ``targets``: a previous ``style_targets`` result for the same style image / layers (tests share it)
+        self.targets = targets if targets is not None else style_targets(
+            vgg_state, style_image[None] if style_image.dim() == 3 else style_image, cfg.style_layers)
         self.gram_cache = GramCache(cfg.style_layers)
         self.m = [torch.zeros_like(l) for l in self.layers]
         self.v = [torch.zeros_like(l) for l in self.layers]

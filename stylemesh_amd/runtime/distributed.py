@@ -99,23 +99,46 @@ class RcclComm:
     ReduceOp = _ReduceOp
 
     def __init__(self, dist_module, rank: int, world_size: int, device):
+        """COLLECTIVE over ``dist_module``: every rank runs the same sequence of ``torch.distributed`` calls whether or
+        not its own part succeeds (the id broadcast carries an empty payload when rank 0 could not make one; the
+        outcome of ``ncclCommInitRank`` is agreed on with a MIN all-reduce), so that a failure on SOME ranks ends in
+        the same exception on ALL of them instead of mismatched collectives."""
         import ctypes
         import torch
         from . import hip
         self._hip, self._torch = hip, torch
         self.rank, self.world_size, self.device = rank, world_size, device
+        self.handle, self._side = None, None
         nbytes = hip.lib.sm_comm_unique_id_bytes()
         buf = ctypes.create_string_buffer(nbytes)
+        err = None
         if rank == 0:
-            hip.check(hip.lib.sm_comm_get_unique_id(buf), "sm_comm_get_unique_id")
-        box = [bytes(buf.raw)]
+            rc = hip.lib.sm_comm_get_unique_id(buf)
+            if rc != 0:
+                err = f"sm_comm_get_unique_id failed ({rc})"
+        box = [bytes(buf.raw) if err is None else b""]
         if world_size > 1:
             dist_module.broadcast_object_list(box, src=0)
+        if err is None and len(box[0]) != nbytes:
+            err = "rank 0 could not create the RCCL unique id"
         handle = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            hip.check(hip.lib.sm_comm_init(ctypes.byref(handle), world_size, box[0], rank), "sm_comm_init")
+        if err is None:
+            import contextlib
+            with (torch.cuda.device(device) if device is not None else contextlib.nullcontext()):
+                rc = hip.lib.sm_comm_init(ctypes.byref(handle), world_size, box[0], rank)
+            if rc != 0:
+                err, handle = f"sm_comm_init (ncclCommInitRank) failed ({rc})", ctypes.c_void_p()
+        if world_size > 1:   # agree on the outcome
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32,
+                              device=device if str(dist_module.get_backend()) == "nccl" else "cpu")
+            dist_module.all_reduce(ok, op=dist_module.ReduceOp.MIN)
+            if int(ok) == 0 and err is None:
+                err = "another rank could not join the RCCL communicator"
+        if err is not None:
+            if handle:
+                hip.lib.sm_comm_destroy(handle)
+            raise RuntimeError(err)
         self.handle = handle
-        self._side = None
 
     def _launch(self, tensor, op):
         hip, torch = self._hip, self._torch
@@ -155,20 +178,27 @@ class RcclComm:
 def make_comm(dist_module, rank: int, world_size: int, device, kind=None):
     """The collective provider of the gradient exchange. ``kind`` (default: env STYLEMESH_COMM, else 'rccl' when the
     process group's backend is nccl = RCCL): 'rccl' = the product's own communicator (``RcclComm``); 'torch' = the
-    ``torch.distributed`` module itself (the only choice over gloo: CPU tests, two ranks sharing one GPU). If the RCCL
-    communicator cannot be created the reason is printed and the torch path is used - a multi-GPU job never dies on it."""
+    ``torch.distributed`` module itself (the only choice over gloo: CPU tests, two ranks sharing one GPU).
+    The decision is COLLECTIVE: ``RcclComm`` either comes up on every rank or raises on every rank. When 'rccl' was
+    asked for explicitly (argument or STYLEMESH_COMM=rccl) that exception propagates - the job fails loudly; when it
+    was only the default, every rank prints the reason and uses ``torch.distributed`` (same interface)."""
     if world_size <= 1:
         return None
-    kind = kind or os.environ.get("STYLEMESH_COMM")
+    explicit = kind or os.environ.get("STYLEMESH_COMM")
+    kind = explicit
     if kind is None:
         kind = "rccl" if str(dist_module.get_backend()) == "nccl" else "torch"
+    if kind not in ("rccl", "torch"):
+        raise ValueError(f"STYLEMESH_COMM / kind must be 'rccl' or 'torch', not {kind!r}")
     if kind == "rccl":
         try:
             return RcclComm(dist_module, rank, world_size, device)
-        except Exception as e:   # noqa: BLE001 - any failure falls back to the torch path
+        except RuntimeError as e:
+            if explicit == "rccl":
+                raise
             import sys
-            print(f"[stylemesh_amd] rank {rank}: own RCCL communicator unavailable ({e}); using torch.distributed",
-                  file=sys.stderr)
+            print(f"[stylemesh_amd] rank {rank}: own RCCL communicator unavailable on some rank ({e}); every rank uses "
+                  "torch.distributed", file=sys.stderr)
     return dist_module
 
 

@@ -107,6 +107,8 @@ class _ViewLevel:
 
 
 class StepEngine:
+    MAX_UV_LEVELS = 8   # per-(level, style layer) bounds of the derivative matrices are laid out for this many levels
+
     def __init__(self, cfg: EngineConfig, vgg_state: dict, device="cuda", random_init=False):
         cfg.validate()
         self.cfg, self.device = cfg, device
@@ -137,7 +139,7 @@ class StepEngine:
         # of the step's activations / gradients over all UV levels (operand scales of the fp16x2 conv kernels)
         # ... and one bound per (UV level <= 8, style layer) of the style-loss derivative matrices (fp16x2 Gram backward)
         AW = ops.AMAX_FLOATS   # a bound is 64 slots spaced 256 bytes apart: 16 KB (1.3 MB for all of them)
-        self._step_scalars = torch.zeros(AW + (AmaxBook.N + 8 * len(cfg.style_layers)) * AW, device=device)
+        self._step_scalars = torch.zeros(AW + (AmaxBook.N + self.MAX_UV_LEVELS * len(cfg.style_layers)) * AW, device=device)
         self.loss_buf = self._step_scalars[0:2]
         self.amax = AmaxBook(device, self._step_scalars[AW:AW + AmaxBook.N * AW])
         self._amax_d = self._step_scalars[AW + AmaxBook.N * AW:]
@@ -332,6 +334,8 @@ class StepEngine:
             raise ValueError("batch size 1 only (the reference's masked_features indexing requires it too)")
         h, w = rgb.shape[2:]
         n_levels = len(uv_map)
+        if n_levels > self.MAX_UV_LEVELS:
+            raise ValueError(f"{n_levels} UV levels: at most {self.MAX_UV_LEVELS} are supported (per-level operand bounds)")
 
         def stage(name, src, dt=torch.float32):
             dst = self._persist((name, tuple(src.shape), dt), lambda: torch.empty(src.shape, dtype=dt, device=dev))
@@ -391,9 +395,12 @@ class StepEngine:
                 self._view_flags = torch.zeros_like(self.touched)
             else:
                 self._view_flags.zero_()
+            # (the SAMPLED footprint - no pixel weights: the forward pass samples every pixel of an active level, also
+            # the ones whose backward weight is zero, so the early half of the split update must not rewrite p there
+            # while the sampling kernel reads it; the weighted flags - ``touch_flags`` - only size the exchange)
             for lv in self.view:
                 if lv.active:
-                    ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, self._view_flags, self.touched_log2)
+                    ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, None, self._view_flags, self.touched_log2)
             ops.flags_or(self.touched, self._view_flags)
             self._other_flags = None   # ever-touched and not in this view: built on first use
 
@@ -660,8 +667,11 @@ class StepEngine:
         if not layers:
             return
         l0 = cfg.style_layers[0]
-        sig = (tuple((lv.index, id(b), lv.masks[l0].ptr, lv.counts[l0].data_ptr()) for lv, b in zip(active, bufs)),
-               w_style, ops.CONV_MODE, tuple(cfg.style_weights), id(self.targets), id(self._gram_arena), cfg.style_pyramid_mode)
+        sig = (tuple((lv.index, b.act[l0].ptr, b.grad[l0].ptr, lv.masks[l0].ptr, lv.counts[l0].data_ptr())
+                     for lv, b in zip(active, bufs)),
+               w_style, ops.CONV_MODE, tuple(cfg.style_weights),
+               tuple(t.data_ptr() for tl in self.targets for t in tl.values()),
+               None if self._gram_arena is None else self._gram_arena.data_ptr(), cfg.style_pyramid_mode)
         if self._loss_tables is None or self._loss_tables[0] != sig:
             self._loss_tables = (sig, {})
         tab = self._loss_tables[1].get(layers)
@@ -869,7 +879,9 @@ class StepEngine:
             if self._hyper_step != self.step_count - 1:
                 self._hyper_state[1:2].fill_(float(self.step_count - 1))
             self._hyper_step = self.step_count
-            key = world_size
+            # the capture bakes in the flags pointer and the sparse-vs-dense choice: part of the key
+            touched, tl2 = self._touched_arg()
+            key = (world_size, None if touched is None else touched.data_ptr(), tl2)
             if self._opt_graph is None or self._opt_graph[0] != key:
                 if getattr(self, "_opt_warm", 0) < 1:      # one eager run before capturing
                     self._opt_warm = 1
@@ -1014,6 +1026,12 @@ class StepEngine:
             self.set_view(batch)
         if new_view is None:
             new_view = getattr(batch, "new_view", None)
+        if reducer is not None and not hasattr(reducer, "new_view") and self.touched is not None:
+            # A reducer that cannot union the ranks' footprints (the plain dense all-reduce, any callable): the other
+            # ranks' gradients arrive in chunks this rank's views never flagged, which the sparse update would skip
+            # without updating or zeroing them - every texel takes part in the update from now on
+            self.touched = None
+            self._other_flags = None
         if reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view):
             flags = self.touch_flags(reducer.chunk_log2)
             reducer.new_view(flags)   # in place: now the union over the ranks' views

@@ -189,3 +189,95 @@ def test_two_rank_odd_view_count_keeps_collectives_matched(tmp_path):
     r0, r1 = (torch.load(tmp_path / f"sched{r}.pt") for r in (0, 1))
     assert [k for _, k in r0["log"]] == [0, 2, 4] and [k for _, k in r1["log"]] == [1, 3]   # rank 1: no 3rd set_view
     assert r0["sums"] == r1["sums"] and len(r0["sums"]) == 6
+
+
+def _comm_worker(rank, world, port, out_dir):
+    """``RcclComm`` / ``make_comm`` with the library's communicator entry points stubbed so that ``sm_comm_init`` fails
+    on rank 1 ONLY: both ranks must come out the same way (a per-rank fallback left the ranks in different
+    collectives)."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stylemesh_amd.runtime import hip
+    destroyed = []
+
+    class Lib:
+        def __init__(self, fail_init_on, fail_id=False):
+            self.fail_init_on, self.fail_id = fail_init_on, fail_id
+
+        def sm_comm_unique_id_bytes(self):
+            return 128
+
+        def sm_comm_get_unique_id(self, buf):
+            return 1 if self.fail_id else 0
+
+        def sm_comm_init(self, handle_ref, world_size, uid, r):
+            if r in self.fail_init_on:
+                return 1
+            handle_ref._obj.value = 1234
+            return 0
+
+        def sm_comm_destroy(self, handle):
+            destroyed.append(rank)
+            return 0
+    real = hip.lib
+    out = {}
+    try:
+        for name, lib in (("one_rank_fails", Lib({1})), ("id_fails", Lib(set(), fail_id=True)), ("all_fine", Lib(set()))):
+            hip.lib = lib
+            destroyed.clear()
+            res = {}
+            try:
+                os.environ.pop("STYLEMESH_COMM", None)
+                c = D.make_comm(dist, rank, world, None, kind="rccl")
+                res["explicit"] = type(c).__name__
+            except RuntimeError as e:
+                res["explicit"] = "raised: " + str(e)
+            res["destroyed_after_explicit"] = list(destroyed)
+            # the non-explicit path: pretend the backend is nccl so that 'rccl' is only the default
+            class FakeNccl:
+                ReduceOp = dist.ReduceOp
+                broadcast_object_list = staticmethod(dist.broadcast_object_list)
+                all_reduce = staticmethod(dist.all_reduce)
+
+                @staticmethod
+                def get_backend():
+                    return "gloo"   # tensors of the agreement stay on the CPU
+            try:
+                # default selection: backend string "nccl" -> rccl; emulate by calling RcclComm through make_comm's
+                # default branch with a module whose get_backend() says nccl for the SELECTION only
+                class Sel(FakeNccl):
+                    calls = [0]
+
+                    @staticmethod
+                    def get_backend():
+                        Sel.calls[0] += 1
+                        return "nccl" if Sel.calls[0] == 1 else "gloo"
+                c = D.make_comm(Sel, rank, world, None)
+                res["default"] = "RcclComm" if type(c).__name__ == "RcclComm" else "torch"
+            except RuntimeError as e:
+                res["default"] = "raised: " + str(e)
+            # whatever was chosen, the next collective must line up on both ranks
+            t = torch.tensor([rank + 1.0])
+            dist.all_reduce(t)
+            res["sum"] = float(t)
+            out[name] = res
+    finally:
+        hip.lib = real
+    torch.save(out, os.path.join(out_dir, f"comm{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_comm_creation_failure_is_decided_collectively(tmp_path):
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_comm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"comm{r}.pt") for r in (0, 1))
+    for name in ("one_rank_fails", "id_fails"):
+        assert r0[name]["explicit"].startswith("raised") and r1[name]["explicit"].startswith("raised"), (r0, r1)
+        assert r0[name]["default"] == r1[name]["default"] == "torch"
+        assert r0[name]["sum"] == r1[name]["sum"] == 3.0
+    # the rank whose ncclCommInitRank succeeded gives its communicator back
+    assert r0["one_rank_fails"]["destroyed_after_explicit"] == [0] and r1["one_rank_fails"]["destroyed_after_explicit"] == []
+    assert r0["all_fine"]["explicit"] == r1["all_fine"]["explicit"] == "RcclComm"
+    assert r0["all_fine"]["default"] == r1["all_fine"]["default"] == "RcclComm"

@@ -1,5 +1,5 @@
-"""ONE step of the HIP engine against ONE step of the oracle at BASELINE.json's full sizes, on the same seeded,
-non-constant texture and the same synthetic view:
+"""The HIP engine against the oracle at BASELINE.json's full sizes, on the same seeded, non-constant texture and the same
+synthetic views (VERDICT r2 task 1):
 
 * c3 - ScanNet with_angle_and_depth: 4096^2 hier-4 texture, UV levels 256x341 .. 784x1045, multi, angle 30
   (reference model/model.py:178-327, scripts/train/optimize_texture_scannet_with_angle_and_depth.sh);
@@ -7,13 +7,23 @@ non-constant texture and the same synthetic view:
 * c5 - Matterport with_angle_and_depth: 4096^2, UV levels 256x320 .. 784x980, angle 40, min_pyramid_depth 0.2
   (scripts/train/optimize_texture_matterport_with_angle_and_depth.sh:11-15).
 
-Stated fp32 tolerances: losses rtol 2e-4; texture gradient by the ``grad_close`` rule of test_engine_gpu.py
-(|err| <= 1e-3 |ref| + 2e-4 max|ref| on >= 97 % of the TOUCHED texels - counted over the texels some view pixel maps
-to; on the others the data term must be exactly zero here and the oracle's gradient the regulariser's alone - and
-<= 2e-2 max|ref| everywhere). The measured fraction of
-texels beyond the tight bound (max-pool argmax flips) is printed and written to
-gpurun_out/fullsize_parity.json (copied to profiles/ by the builder).
+Two kinds of test, both in the default fp16x2-split arithmetic AND with v_mfma_f32_32x32x2_f32 everywhere
+(STYLEMESH_CONV_MODE / GRAM_MODE = f32), on three view seeds per config and the full-size 1528 x 1200 style image:
 
+1. ``test_one_step_matches_oracle_at_full_size``: ONE step's losses and texture gradient. Stated fp32 tolerances: losses
+   rtol 2e-4; gradient ``|err| <= 1e-3 |ref| + 2e-4 max|ref|`` on >= 99.5 % of the TOUCHED texels (the texels some view
+   pixel maps to; on the others the data term must be exactly zero and the oracle's gradient the regulariser's alone),
+   everywhere ``<= MAX_ERR[config] max|ref|`` (twice the largest value measured over seeds and modes). The texels
+   beyond the tight bound are max-pool argmax flips: the fp32-MFMA mode shows the same fractions,
+   and ``test_split_arithmetic_adds_no_flips_over_all_cases`` asserts that the split arithmetic adds nothing to them
+   (mean split2 fraction <= 1.5 x mean f32 fraction + 2e-4 over the nine cases).
+2. ``test_k_steps_texture_values_match_oracle_at_full_size``: FIVE training steps (3 on one view, 2 on the next: a view
+   change inside) of the engine against five of the oracle - reference model/model.py:178-327 + Adam :387-395 - and the
+   texture VALUES compared after every step: in lock-step (every step from the oracle's state) by DESIGN.md section 2's
+   rule, free-running against a measured control - the oracle's distance from ITSELF under another fp32 summation
+   order (see the test's docstring).
+
+Everything measured is printed and written to gpurun_out/fullsize_parity.json (copied to profiles/ by the builder).
 The oracle runs on the host cores (a few seconds per step at these sizes)."""
 import json
 import os
@@ -32,16 +42,20 @@ pytestmark = pytest.mark.gpu
 
 LOSS_WEIGHTS = {"content": 7e1, "style": 1e-4, "tex_reg": 5e3}
 STYLE_WEIGHTS = [1000., 1000., 10., 10., 1000.]
-STYLE_HW = (764, 600)   # half of "The Scream" (1528 x 1200): the style image only sets constants (Gram targets)
+STYLE_HW = (1528, 1200)   # "The Scream" (styles/120styles/17.jpg) is 1200 x 1528 px: the bench's style image
 ROOM = (12.0, 9.0, 3.0)
 CASES = {
     "c3": dict(tex=4096, level_hw=S.SCANNET_LEVEL_HW, view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0, angle=True,
-               depth=True, min_depth=0.25, seed=2, active=[0, 1, 2, 3]),
+               depth=True, min_depth=0.25, seeds=(2, 6, 9), active=[0, 1, 2, 3]),
     "c2": dict(tex=2048, level_hw=[S.SCANNET_VIEW_HW], view_hw=S.SCANNET_VIEW_HW, mode="single", thr=3000.0, angle=False,
-               depth=False, min_depth=0.25, seed=2, active=[0]),
+               depth=False, min_depth=0.25, seeds=(2, 6, 9), active=[0]),
     "c5": dict(tex=4096, level_hw=S.MATTERPORT_LEVEL_HW, view_hw=S.MATTERPORT_VIEW_HW, mode="multi", thr=40.0, angle=True,
-               depth=True, min_depth=0.2, seed=2, active=None),
+               depth=True, min_depth=0.2, seeds=(2, 6, 9), active=None),
 }
+MODES = ("split2", "f32")
+# one step, gradient: fraction of the touched texels beyond the tight bound, and max |err| / max |ref| (= 2 x measured)
+FLIP_FRAC_MAX = 0.005
+MAX_ERR = {"c3": 5e-2, "c2": 1e-2, "c5": 2.5e-2}
 
 
 def seeded_texture(tex, n_layers=4, amp=60.0):
@@ -60,36 +74,56 @@ def _record(name, entry):
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_one_step_matches_oracle_at_full_size(name):
-    require_gpu()
-    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
-    c = CASES[name]
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    vgg = S.seeded_vgg_state(0)
-    style = S.style_image(1, *STYLE_HW)
-    view = S.make_view(c["seed"], view_hw=c["view_hw"], level_hw=c["level_hw"], level_heights=[h for h, _ in c["level_hw"]],
-                       min_pyramid_depth=c["min_depth"], room=S.BoxRoom(ROOM))
-    tex0 = seeded_texture(c["tex"])
+_CACHE = {}
 
+
+def _shared(key, make):
+    if key not in _CACHE:
+        _CACHE[key] = make()
+    return _CACHE[key]
+
+
+def _vgg():
+    return _shared("vgg", lambda: S.seeded_vgg_state(0))
+
+
+def _style():
+    return _shared("style", lambda: S.style_image(1, *STYLE_HW))
+
+
+def _oracle_targets():
+    """Gram targets of the full-size style image on the oracle side: once per test session (a few seconds)."""
+    return _shared("oracle_targets", lambda: O.style_targets(_vgg(), _style()[None], list(O.OracleConfig().style_layers)))
+
+
+def _view(c, seed):
+    return S.make_view(seed, view_hw=c["view_hw"], level_hw=c["level_hw"], level_heights=[h for h, _ in c["level_hw"]],
+                       min_pyramid_depth=c["min_depth"], room=S.BoxRoom(ROOM))
+
+
+def _oracle(c, tex0):
+    ocfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=c["thr"],
+                          style_pyramid_mode=c["mode"], use_angle_weight=c["angle"], use_depth_scaling=c["depth"],
+                          loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
+    return O.OraclePipeline(_vgg(), _style(), ocfg, (c["tex"], c["tex"]), init_layers=tex0, targets=_oracle_targets())
+
+
+def _engine(c, mode, tex0, monkeypatch):
+    from stylemesh_amd.runtime import ops
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    monkeypatch.setattr(ops, "CONV_MODE", mode)
+    monkeypatch.setattr(ops, "GRAM_MODE", mode)
     cfg = EngineConfig(tex_w=c["tex"], tex_h=c["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                        angle_threshold=c["thr"], style_pyramid_mode=c["mode"], use_angle_weight=c["angle"],
                        use_depth_scaling=c["depth"], loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
-    eng = StepEngine(cfg, vgg)
+    eng = StepEngine(cfg, _vgg())
     eng.load_texture(tex0)
-    eng.set_style_image(style)
-    eng.set_view(view)
-    active = [lv.index for lv in eng.view if lv.active]
-    if c["active"] is not None:
-        assert active == c["active"]
-    assert len(active) >= 1
-    eng.arena.g.zero_()
-    lt = eng.loss_tensors()
-    eng.forward_backward()
-    mine = eng.losses(lt)
-    g_mine = torch.cat([(g + k * p).reshape(-1) for g, k, p in zip(eng.grads, eng.reg_coef, eng.layers)]).cpu()
-    g_data = eng.arena.g.cpu()
-    # coverage: scatter gradient images of ones (no pixel weights) -> exactly the texels some pixel maps to are non-zero
+    eng.set_style_image(_style())
+    return eng
+
+
+def _coverage(eng):
+    """bool per arena element: does some pixel of the current view map to this texel? (scatter of ones, no weights)"""
     from stylemesh_amd.runtime import ops
     cover = torch.zeros_like(eng.arena.g)
     for lv in eng.view:
@@ -97,37 +131,198 @@ def test_one_step_matches_oracle_at_full_size(name):
             b = eng._level_bufs(lv.H, lv.W)
             ones = type(b.grad["img"])(3, lv.H, lv.W).from_dense(torch.ones(3, lv.H, lv.W))
             ops.tex_sample_bwd(eng.arena.views(cover), lv.grid, ones, None)
-    touched = (cover != 0).cpu()
+    return (cover != 0).cpu()
 
-    ocfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=c["thr"],
-                          style_pyramid_mode=c["mode"], use_angle_weight=c["angle"], use_depth_scaling=c["depth"],
-                          loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
-    pipe = O.OraclePipeline(vgg, style, ocfg, (c["tex"], c["tex"]), init_layers=tex0)
+
+@pytest.mark.parametrize("seed_index", [0, 1, 2])
+@pytest.mark.parametrize("name", list(CASES))
+def test_one_step_matches_oracle_at_full_size(name, seed_index, monkeypatch):
+    require_gpu()
+    c = CASES[name]
+    seed = c["seeds"][seed_index]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    view = _view(c, seed)
+    tex0 = _shared(("tex", c["tex"]), lambda: seeded_texture(c["tex"]))
+
+    pipe = _oracle(c, tex0)
     rec = {}
     t0 = time.time()
     ref_losses, ref_grads = pipe.grads(view, rec)
     oracle_s = time.time() - t0
-    assert rec["active"] == active
-    for k in ("content", "style", "tex_reg", "total"):
-        np.testing.assert_allclose(mine[k], float(ref_losses[k]), rtol=2e-4, err_msg=f"{name} loss {k}")
-
     g_ref = torch.cat([g.reshape(-1) for g in ref_grads])
-    reg = torch.cat([(k * p).reshape(-1) for k, p in zip(eng.reg_coef, tex0)])
-    # texels no pixel of the view maps to: an exactly-zero data term here, the regulariser's gradient alone there
-    assert (~touched).any() and float(g_data[~touched].abs().max()) == 0.0
-    assert float((g_ref - reg)[~touched].abs().max()) <= 1e-6 * float(reg.abs().max()) + 1e-12
-    frac_touched = float(touched.float().mean())
-    assert 0.0 < frac_touched < 0.6
     mx = float(g_ref.abs().max())
-    err = (g_mine - g_ref).abs()
-    bad = (err > 1e-3 * g_ref.abs() + 2e-4 * mx) & touched
-    flip_frac = float(bad.sum()) / float(touched.sum())
-    entry = {"texels": int(g_ref.numel()), "touched_fraction": round(frac_touched, 5),
-             "fraction_of_touched_texels_beyond_tight_bound": flip_frac, "max_err_over_max_ref": float(err.max()) / mx,
-             "max_ref": mx, "active_levels": active, "oracle_seconds": round(oracle_s, 1),
-             "loss_rel_err": {k: abs(mine[k] - float(ref_losses[k])) / max(abs(float(ref_losses[k])), 1e-30)
-                              for k in ("content", "style", "tex_reg", "total")}}
-    print(f"\n[{name}] {json.dumps(entry)}")
-    _record(name, entry)
-    assert flip_frac <= 0.03, f"{name}: {flip_frac:.4f} of the touched texels beyond 1e-3|ref| + 2e-4 max|ref|"
-    assert float(err.max()) <= 2e-2 * mx, f"{name}: max err {float(err.max()):.3e} vs max|ref| {mx:.3e}"
+    del pipe
+
+    entry = {"seed": seed, "texels": int(g_ref.numel()), "max_ref": mx, "oracle_seconds": round(oracle_s, 1),
+             "style_image": f"{STYLE_HW[1]}x{STYLE_HW[0]}"}
+    fracs = {}
+    for mode in MODES:
+        eng = _engine(c, mode, tex0, monkeypatch)
+        eng.set_view(view)
+        active = [lv.index for lv in eng.view if lv.active]
+        if c["active"] is not None:
+            assert active == c["active"]
+        assert len(active) >= 1 and rec["active"] == active
+        eng.arena.g.zero_()
+        lt = eng.loss_tensors()
+        eng.forward_backward()
+        mine = eng.losses(lt)
+        g_mine = torch.cat([(g + k * p).reshape(-1) for g, k, p in zip(eng.grads, eng.reg_coef, eng.layers)]).cpu()
+        g_data = eng.arena.g.cpu()
+        touched = _coverage(eng)
+        for k in ("content", "style", "tex_reg", "total"):
+            np.testing.assert_allclose(mine[k], float(ref_losses[k]), rtol=2e-4, err_msg=f"{name} {mode} loss {k}")
+        reg = torch.cat([(k * p).reshape(-1) for k, p in zip(eng.reg_coef, tex0)])
+        # texels no pixel of the view maps to: an exactly-zero data term here, the regulariser's gradient alone there
+        assert (~touched).any() and float(g_data[~touched].abs().max()) == 0.0
+        assert float((g_ref - reg)[~touched].abs().max()) <= 1e-6 * float(reg.abs().max()) + 1e-12
+        frac_touched = float(touched.float().mean())
+        assert 0.0 < frac_touched < 0.6
+        err = (g_mine - g_ref).abs()
+        bad = (err > 1e-3 * g_ref.abs() + 2e-4 * mx) & touched
+        flip_frac = float(bad.sum()) / float(touched.sum())
+        fracs[mode] = flip_frac
+        entry[mode] = {"touched_fraction": round(frac_touched, 5), "fraction_of_touched_texels_beyond_tight_bound": flip_frac,
+                       "max_err_over_max_ref": float(err.max()) / mx, "active_levels": active,
+                       "loss_rel_err": {k: abs(mine[k] - float(ref_losses[k])) / max(abs(float(ref_losses[k])), 1e-30)
+                                        for k in ("content", "style", "tex_reg", "total")}}
+        del eng, g_mine, g_data, err, bad
+        torch.cuda.empty_cache()
+    print(f"\n[{name} seed {seed}] {json.dumps(entry)}")
+    _record(f"{name}_seed{seed}", entry)
+    for mode in MODES:
+        e = entry[mode]
+        assert e["fraction_of_touched_texels_beyond_tight_bound"] <= FLIP_FRAC_MAX, \
+            f"{name} {mode}: {fracs[mode]:.5f} of the touched texels beyond 1e-3|ref| + 2e-4 max|ref|"
+        assert e["max_err_over_max_ref"] <= MAX_ERR[name], f"{name} {mode}: max err {e['max_err_over_max_ref']:.3e} of max|ref|"
+
+
+def test_split_arithmetic_adds_no_flips_over_all_cases():
+    """Flips are discrete events (a case can show 0 in one mode and 0.1 % in the other): the comparison between the
+    fp16x2-split and the fp32-MFMA arithmetic is made over ALL the cases of the test above."""
+    path = os.path.join(REPO, "gpurun_out", "fullsize_parity.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    cases = [v for k, v in data.items() if "_seed" in k and all(m in v for m in MODES)]
+    if len(cases) < 6:
+        pytest.skip("needs the one-step cases of this session")
+    key = "fraction_of_touched_texels_beyond_tight_bound"
+    mean = {m: float(np.mean([v[m][key] for v in cases])) for m in MODES}
+    worst = {m: float(np.max([v[m]["max_err_over_max_ref"] for v in cases])) for m in MODES}
+    print(f"\n[flip fractions over {len(cases)} cases] mean {mean}, worst max-err {worst}")
+    _record("summary_one_step", {"cases": len(cases), "mean_flip_fraction": mean, "worst_max_err_over_max_ref": worst})
+    assert mean["split2"] <= 1.5 * mean["f32"] + 2e-4, mean
+
+
+K_STEPS, SWITCH_AT = 5, 3
+
+
+class _Mode:
+    """Run a block under one arithmetic mode (the mode is a module global read at launch time)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from stylemesh_amd.runtime import ops
+        self.saved = ops.CONV_MODE, ops.GRAM_MODE
+        ops.CONV_MODE = ops.GRAM_MODE = self.mode
+
+    def __exit__(self, *exc):
+        from stylemesh_amd.runtime import ops
+        ops.CONV_MODE, ops.GRAM_MODE = self.saved
+
+
+def _tex_stats(err):
+    return {"beyond_1e-5": float((err > 1e-5).float().mean()), "beyond_2e-3": float((err > 2e-3).float().mean()),
+            "beyond_2e-2": float((err > 2e-2).float().mean()), "beyond_0.3": float((err > 0.3).float().mean()),
+            "max": float(err.max())}
+
+
+def _flat(tensors):
+    return torch.cat([t.detach().reshape(-1) for t in tensors])
+
+
+# lock-step (the engine starts every step from the oracle's texture and Adam moments): DESIGN.md section 2's rule
+LOCK_TIGHT_FRAC, LOCK_LOOSE_FRAC = 0.01, 0.001   # (measured: <= 0.31 % / <= 0.032 %)
+
+
+@pytest.mark.parametrize("name", ["c3", "c2"])
+def test_k_steps_texture_values_match_oracle_at_full_size(name, monkeypatch):
+    """Texture VALUES over five training steps with a view change inside (north_star: 'outputs match the reference
+    PyTorch path's texture values'; reference model/model.py:178-327 + Adam :387-395), two ways, both modes:
+
+    * LOCK-STEP: before every step the engine is given the oracle's texture and Adam moments, so that each step's own
+      contribution is compared: |err| <= 2e-3 on >= 99 %, <= 2e-2 on >= 99.9 % of the texels (step 1: 1e-5 except
+      sign-flip texels - the first update is -lr sign(g)).
+    * FREE-RUNNING: five engine steps against five oracle steps. Adam at lr 1 normalises every texel's update to O(1)
+      whatever its gradient's magnitude, so texels whose gradient is at the level of the fp32 summation-order noise take
+      a different path after a few steps in ANY two fp32 implementations. The test measures exactly that as its
+      CONTROL - the same oracle run with oneDNN switched off (ATen's im2col + GEMM convolutions instead: the reference
+      op for op, another summation order) - and requires the engine's distance from the oracle to stay within 2 x the
+      oracle's distance from itself (+ 0.5 % of the texels)."""
+    require_gpu()
+    c = CASES[name]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    views = [_view(c, c["seeds"][0]), _view(c, c["seeds"][1])]
+    tex0 = _shared(("tex", c["tex"]), lambda: seeded_texture(c["tex"]))
+    schedule = [views[0] if k < SWITCH_AT else views[1] for k in range(K_STEPS)]
+
+    pipe, ctrl = _oracle(c, tex0), _oracle(c, tex0)
+    free, lock = {}, {}
+    for mode in MODES:
+        free[mode] = _engine(c, mode, tex0, monkeypatch)
+        lock[mode] = _engine(c, mode, tex0, monkeypatch)
+    entry = {"steps": K_STEPS, "view_change_before_step": SWITCH_AT + 1, "texels": int(free["split2"].arena.n),
+             "control": [], "free": {m: [] for m in MODES}, "lock_step": {m: [] for m in MODES}}
+    clamp = lambda t: t.clamp(O.CLAMP_LO, O.CLAMP_HI)
+    t_oracle = 0.0
+    for k, batch in enumerate(schedule):
+        # lock-step engines start from the oracle's state before this step
+        state = [_flat(pipe.layers), _flat(pipe.m), _flat(pipe.v)]
+        for mode in MODES:
+            e = lock[mode]
+            for dst, src in zip((e.arena.p, e.arena.m, e.arena.v), state):
+                dst.copy_(src)
+            e.step_count = pipe.step_count
+            e.sumsq.zero_()
+            from stylemesh_amd.runtime import ops
+            ops.clamp_sumsq(e.arena.p, e.arena.seg_end, e.sumsq)
+        t0 = time.time()
+        ref_loss = pipe.training_step(batch)
+        t_oracle += time.time() - t0
+        with torch.backends.mkldnn.flags(enabled=False):
+            ctrl.training_step(batch)
+        ref = clamp(_flat(pipe.layers))
+        entry["control"].append(_tex_stats((clamp(_flat(ctrl.layers)) - ref).abs()))
+        for mode in MODES:
+            with _Mode(mode):
+                lt = free[mode].training_step(batch)
+                mine = free[mode].losses(lt)
+                ll = lock[mode].training_step(batch)
+                lock_loss = lock[mode].losses(ll)
+            np.testing.assert_allclose(lock_loss["total"], ref_loss["total"], rtol=2e-4, err_msg=f"{name} {mode} step {k + 1}")
+            st = _tex_stats((free[mode].arena.p.cpu() - ref).abs())
+            st["loss_total_rel_err"] = abs(mine["total"] - ref_loss["total"]) / abs(ref_loss["total"])
+            entry["free"][mode].append(st)
+            entry["lock_step"][mode].append(_tex_stats((lock[mode].arena.p.cpu() - ref).abs()))
+    entry["oracle_seconds"] = round(t_oracle, 1)
+    for mode in MODES:
+        assert float(free[mode].arena.g.abs().max()) == 0.0   # the fused update leaves a zeroed gradient
+    del free, lock, pipe, ctrl
+    torch.cuda.empty_cache()
+    print(f"\n[{name} k-step] {json.dumps(entry)}")
+    _record(f"{name}_ksteps", entry)
+    for mode in MODES:
+        for k in range(K_STEPS):
+            m = entry["lock_step"][mode][k]
+            what = f"{name} {mode} lock-step, step {k + 1}: {m}"
+            if k == 0:
+                assert m["beyond_1e-5"] <= 2e-4, what
+            assert m["beyond_2e-3"] <= LOCK_TIGHT_FRAC and m["beyond_2e-2"] <= LOCK_LOOSE_FRAC, what
+            f, ctl = entry["free"][mode][k], entry["control"][k]
+            what = f"{name} {mode} free-running, step {k + 1}: {f} vs the oracle's own {ctl}"
+            for key in ("beyond_2e-3", "beyond_2e-2", "beyond_0.3"):
+                assert f[key] <= 2.0 * ctl[key] + 5e-3, what
+    # the split arithmetic adds nothing: after the last step its fractions are those of the fp32-MFMA mode
+    a, b = entry["free"]["split2"][-1], entry["free"]["f32"][-1]
+    assert a["beyond_2e-3"] <= 1.5 * b["beyond_2e-3"] + 5e-3 and a["beyond_2e-2"] <= 1.5 * b["beyond_2e-2"] + 5e-3, (a, b)

@@ -839,3 +839,110 @@ def test_resizes_and_factors(rt):
     factors = [torch.zeros(1).cuda() for _ in range(3)]
     rt.ops.level_factors(counts, [60.0, 40.0, 20.0], factors)
     assert_close(torch.cat(factors), [0.5 / 0.75, 0.25 / 0.75, 0.0], 1e-6, 0)
+
+
+# ------------------------------------------------------------------ dynamic-range stress of the fp16x2-split kernels
+# (task 1). The split represents an operand x of a tensor with maximum A = max |x| as
+#     x s = h + l,   h = fp16(x s),  l = fp16(x s - h),   s = the power of two with A s in [2^14, 2^15)
+# so  |x - (h + l) / s| <= 2^-22 |x|  while l is a normal fp16 number, and <= 2^-25 / s <= 2^-39 A below that (l in the
+# subnormal range: elements more than ~2^18 below the tensor's maximum). A product drops ll' (< 2^-22 of it), and the
+# partial products are summed in fp32 (16 exact products per MFMA, n_acc = 3 K / 16 sequential accumulations). The bound
+# the tests assert ELEMENTWISE against an fp64 result, with a factor 2 of margin on each term:
+#     |err| <= (2^-21 + 4 sqrt(n_acc) 2^-24) sum |x||w|  +  2^-38 (A_x sum |w| + A_w sum |x|)
+# i.e. fp32-class relative accuracy for the terms within 2^18 of the tensor maximum and an ABSOLUTE floor of 2^-38
+# max|x| per unit weight below that - a single 10^6 x outlier lowers the accuracy of the ordinary elements to ~2^-18
+# relative, it cannot produce garbage. The fp32-MFMA kernel is run on the same inputs for comparison (recorded).
+def _stress_input(kind, shape, gen):
+    if kind == "loguniform":    # magnitudes log-uniform over 2^-30 .. 1 of the maximum, random signs
+        mag = torch.exp2(-30.0 * torch.rand(shape, generator=gen)) * 50.0
+        sign = torch.where(torch.rand(shape, generator=gen) < 0.5, -1.0, 1.0)
+        x = mag * sign
+        x.view(-1)[int(torch.randint(0, x.numel(), (1,), generator=gen))] = 50.0
+        return x
+    assert kind == "outlier"    # ReLU'd normal values with ONE element 10^6 times the rest's maximum
+    x = F.relu(torch.randn(shape, generator=gen))
+    x.view(-1)[int(torch.randint(0, x.numel(), (1,), generator=gen))] = float(x.max()) * 1e6
+    return x
+
+
+def _split2_bound(abs_prod, amax_x, sum_w, amax_w, sum_x, K):
+    n_acc = 3.0 * K / 16.0
+    return (2.0 ** -21 + 4.0 * n_acc ** 0.5 * 2.0 ** -24) * abs_prod + 2.0 ** -38 * (amax_x * sum_w + amax_w * sum_x)
+
+
+@pytest.mark.parametrize("kind", ["loguniform", "outlier"])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 40, 52), (128, 256, 33, 47), (512, 512, 12, 17)])
+def test_conv3x3_split2_dynamic_range_stress(rt, cin, cout, H, W, kind, monkeypatch):
+    gen = torch.Generator().manual_seed(cin + cout + H + len(kind))
+    x = _stress_input(kind, (1, cin, H, W), gen)
+    wgt = torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+    xd, wd_ = x.double(), wgt.double()
+    ref = F.conv2d(xd, wd_, None, padding=1)[0]
+    abs_prod = F.conv2d(xd.abs(), wd_.abs(), None, padding=1)[0]
+    sum_w = wd_.abs().sum((1, 2, 3)).view(-1, 1, 1)
+    sum_x = F.conv2d(xd.abs().sum(1, keepdim=True), torch.ones(1, 1, 3, 3, dtype=torch.float64), None, padding=1)[0]
+    amax_x, amax_w = float(x.abs().max()), float(wgt.abs().max())
+    bound = _split2_bound(abs_prod, amax_x, sum_w, amax_w, sum_x, 9 * cin)
+    xin = rt.FMap(cin, H, W).from_dense(x[0])
+    w = dev(rt.ops.pack_conv_fwd(wgt))
+    w2 = rt.ops.pack_conv_split2(w)
+    worst = {}
+    for mode in ("f32", "split2"):
+        monkeypatch.setattr(rt.ops, "CONV_MODE", mode)
+        out = rt.FMap(cout, H, W)
+        rt.ops.conv3x3(xin, w, None, out, 0, wt2=w2, amax_in=rt.ops.new_amax("cuda", amax_x), amax_out=rt.ops.new_amax("cuda"))
+        got = out.to_dense().double().cpu()
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs()
+        worst[mode] = float((err / bound).max())
+        worst[mode + "_vs_amax"] = float(err.max()) / (amax_x * float(sum_w.max()))
+    print(f"\n[conv stress {kind} {cin}->{cout}] max err / bound: {worst}")
+    assert worst["split2"] <= 1.0, worst
+    # relative to the tensor maximum (the statement of DESIGN.md section 2): |err| <= 2^-21 A sum|w| always
+    assert worst["split2_vs_amax"] <= 2.0 ** -21, worst
+
+
+@pytest.mark.parametrize("kind", ["loguniform", "outlier"])
+@pytest.mark.parametrize("C,H,W", [(64, 60, 81), (128, 40, 56), (512, 12, 17)])
+def test_gram_split2_dynamic_range_stress(rt, C, H, W, kind, monkeypatch):
+    """The masked Gram contraction and its backward GEMM (fp16x2 operands: the feature map for both sides of the
+    forward; the derivative matrix and the feature map for the backward) on heavy-tailed feature maps, against fp64."""
+    monkeypatch.setattr(rt.ops, "GRAM_MODE", "split2")
+    gen = torch.Generator().manual_seed(C + H + len(kind))
+    feat = _stress_input(kind, (C, H, W), gen)
+    m0 = (torch.rand(H, W, generator=gen) > 0.3).float()
+    fd = feat.double().reshape(C, -1)
+    md = m0.double().reshape(1, -1)
+    A = float(feat.abs().max())
+    f = rt.FMap(C, H, W).from_dense(feat)
+    mk = rt.FMap(1, H, W).from_dense(m0[None])
+    af = rt.ops.new_amax("cuda", A)
+    # forward: S = (F m) F^T
+    S = torch.zeros(rt.ops.gram_workspace_slabs(C, H, W), C, C).cuda()
+    n = rt.ops.gram_masked(f, mk, None, S, None, amax_feat=af)
+    got = S[:n].sum(0).double().cpu()
+    ref = (fd * md) @ fd.T
+    abs_prod = (fd.abs() * md) @ fd.abs().T
+    row = (fd.abs() * md).sum(1)
+    bound = _split2_bound(abs_prod, A, row.view(-1, 1), A, row.view(1, -1), H * W)
+    T = C // 64
+    upper = torch.ones(T, T).triu().repeat_interleave(64, 0).repeat_interleave(64, 1).bool()
+    assert torch.isfinite(got[upper]).all()
+    worst_f = float(((got - ref).abs() / bound)[upper].max())
+    # backward: dF = m (D F), D symmetric with its own recorded bound
+    D = torch.randn(C, C, generator=gen) * 1e-3
+    D = (D + D.T) / 2
+    ad = rt.ops.new_amax("cuda", float(D.abs().max()))
+    df = rt.FMap(C, H, W)
+    rt.ops.gram_backward(f, mk, None, dev(D), None, df, relu_gate=False, amax_feat=af, amax_d=ad)
+    gotb = df.to_dense().double().cpu().reshape(C, -1)
+    refb = (D.double() @ fd) * md
+    abs_b = (D.double().abs() @ fd.abs()) * md
+    boundb = _split2_bound(abs_b, A, D.double().abs().sum(1).view(-1, 1) * md, float(D.abs().max()),
+                           fd.abs().sum(0).view(1, -1) * md, C)
+    assert torch.isfinite(gotb).all()
+    live = (md > 0).expand_as(gotb)
+    worst_b = float(((gotb - refb).abs()[live] / boundb[live].clamp_min(1e-300)).max())
+    assert float(gotb[~live].abs().max()) == 0.0
+    print(f"\n[gram stress {kind} C={C}] max err / bound: forward {worst_f:.3f}, backward {worst_b:.3f}")
+    assert worst_f <= 1.0 and worst_b <= 1.0, (worst_f, worst_b)

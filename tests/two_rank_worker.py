@@ -2,6 +2,7 @@
 
     two_rank_worker.py g8 <out_dir>        mean-gradient step of golden G8 with the HIP gradients
     two_rank_worker.py trainer <out_dir>   MiniTrainer epoch over 5 train views (odd) with index_repeat 2
+    two_rank_worker.py dense_vs_sparse <out_dir>   zero-initialised texture, 6 steps, dense and sparse reducer
 
 STYLEMESH_TEST_BACKEND=nccl: one GPU per rank, exchange over the product's own RCCL communicator;
 gloo: both ranks on cuda:0, exchange through torch.distributed's gloo backend (1-GPU boxes)."""
@@ -90,6 +91,28 @@ def main():
         torch.cuda.synchronize()
         torch.save({"layers": [l.data.detach().cpu().clone() for l in model.texture.layers], "steps": tr.global_step},
                    os.path.join(out_dir, f"rank{rank}.pt"))
+    elif mode == "dense_vs_sparse":
+        # a ZERO-initialised texture (sparse ever-touched update) with the plain dense reducer. Each
+        # rank optimises its own views; the other rank's gradients arrive in chunks this rank's views never flagged.
+        from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+        out = {}
+        for kind in ("dense", "sparse"):
+            cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
+                               angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
+                               use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
+                               learning_rate=1, decay_gamma=0.1, decay_step_size=1)
+            eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
+            eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
+            assert eng.touched is not None
+            red = D.make_grad_reducer(comm, world) if kind == "dense" else D.make_sparse_grad_reducer(comm, world)
+            get = lambda i: S.make_view(MULTIVIEW_SEEDS[i], view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW,
+                                        level_heights=[40, 64], min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+            for batch in D.scheduled_batches(get, range(len(MULTIVIEW_SEEDS)), rank, world, index_repeat=3):
+                eng.training_step(batch, world_size=world, reducer=red)
+            torch.cuda.synchronize()
+            out[kind] = {"p": eng.arena.p.cpu().clone(), "g": eng.arena.g.cpu().clone(), "m": eng.arena.m.cpu().clone(),
+                         "dense_update": eng.touched is None}
+        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     else:
         raise SystemExit(f"unknown mode {mode}")
     if hasattr(comm, "destroy"):
