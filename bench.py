@@ -5,8 +5,8 @@ Adam) on synthetic ScanNet-shaped input. One process per GPU; for N > 1 launch w
 texture gradient is all-reduced over RCCL before the update: SURVEY.md section 8 e).
 
 Prints ONE JSON line on rank 0 (contract in the task description): whole-job views/s, the roofline of the
-dominant kernel (fp32-MFMA implicit-GEMM conv, timed with HIP events on its launch stream inside the timed
-region) and, at N = 1, the CPU baseline (the oracle, timed on this host's cores on a bounded sample).
+dominant kernel (the fp16x2-split MFMA implicit-GEMM conv - fp32 operands split into two fp16 parts, fp32 accumulate -
+timed with HIP events on its launch stream inside the timed region; the fp32-MFMA conv in the f32_mode leg) and, at N = 1, the CPU baseline (the oracle, timed on this host's cores on a bounded sample).
 """
 import argparse
 import json
@@ -168,8 +168,9 @@ def main():
     ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
                     "with the update of each arena range issued as its sums arrive (default: exchange, then update)")
     ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
-                    "'split' (default; bf16 MFMA on bf16x3-split operands, fp32 accuracy) or 'f32' (v_mfma_f32_32x32x2_f32 "
-                    "everywhere); same as STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
+                    "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate), 'split' "
+                    "(bf16x3-split operands, 6 partial products) or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
+                    "STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
                     "of the throughput, so the roofline is sampled; 7 -> 3 timed steps of --steps 20, 6 of 40)")
@@ -203,7 +204,7 @@ def main():
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
     if args.mfma is not None:
         ops.CONV_MODE = args.mfma
-        ops.GRAM_MODE = "f32" if args.mfma == "f32" else "split"
+        ops.GRAM_MODE = args.mfma   # the Gram kernels follow the conv mode
 
     cfg = EngineConfig(tex_w=wl["tex"], tex_h=wl["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                        angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"],
@@ -291,7 +292,9 @@ def main():
         out = {"metric": "views/sec (fwd+bwd into 4096^2 texture)" if wl["tex"] == 4096 else
                f"views/sec (fwd+bwd into {wl['tex']}^2 texture)", "value": round(value, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": {"split2": "f32 (fp16x2 split multiply, fp32 accumulate)",
+                         "split": "f32 (bf16x3 split multiply, fp32 accumulate)"}.get(ops.CONV_MODE, "f32"),
                "dtype_note": {"split": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the bf16 "
                               "matrix cores with every fp32 operand split into 3 bf16 parts (6 partial products, fp32 accumulate)",
                               "split2": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the fp16 "

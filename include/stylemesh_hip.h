@@ -8,7 +8,11 @@
  *
  * Conventions
  *  - extern "C", plain pointers and sizes, no torch types. All pointers are DEVICE pointers unless a
- *    parameter is documented as host. fp32 everywhere (the reference computes in fp32).
+ *    parameter is documented as host. Every tensor, sum, loss and optimizer state is fp32 (the reference computes
+ *    in fp32). The matrix-core kernels come in three arithmetic flavours with fp32 accumulation: exact fp32 MFMA
+ *    (sm_conv3x3*, sm_gram_masked, sm_gram_backward), bf16x3-split operands (*_split: 6 partial products) and
+ *    fp16x2-split operands scaled by recorded power-of-two bounds (*_split2: 3 partial products; the default of the
+ *    Python host: |err| <= 2^-21 sum|x||w| + 2^-38 (max|x| sum|w| + max|w| sum|x|) elementwise).
  *  - Every call is asynchronous on the caller's hipStream_t (passed as void*), allocates nothing and
  *    keeps no state: the caller owns every buffer. Return value: 0 (hipSuccess) or a hipError_t.
  *  - Feature maps use the "padded planar" layout: [C][plane] floats; a plane holds (H+2) rows of Wp

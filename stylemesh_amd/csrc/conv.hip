@@ -47,16 +47,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int wm = (wave / WGN) * 64;
     const int wn = (wave % WGN) * 64;
 
-    // unit -> (tile, split). Whole tiles: XCD-aware order (neighbours in an XCD's share use the same weight slab
-    // and adjacent positions); tail units keep the dispatcher's round-robin so every XCD gets its share of them.
-    int tile, split = -1;
-    if ((int)blockIdx.x < a.n_whole) {
-        tile = xcd_linear(blockIdx.x, a.n_whole);
-    } else {
-        const int v = blockIdx.x - a.n_whole;
-        tile = a.n_whole + v / a.splits;
-        split = v - (tile - a.n_whole) * a.splits;
-    }
+    int tile, split;
+    conv_unit(a, blockIdx.x, tile, split);   // XCD-aware order of whole tiles and of the tail's (tile, K-split) units
     const int m_tile = tile / a.n_tiles;
     const int n_glob = tile - m_tile * a.n_tiles;
     // which problem of the group does this position tile belong to (block-uniform scalar selects)
@@ -328,6 +320,16 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
             const int cps = (chunks + S - 1) / S, S_eff = (chunks + cps - 1) / cps;
             const float cost = (float)((rem * S_eff + SLOTS - 1) / SLOTS) * (cps + 1.f) / chunks;
             if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
+        }
+    }
+    {   // experiments (tools/bench_c2_layers.py): SM_CONV_FORCE_SPLITS=<S> forces the tail's split count
+        static const int force_s = getenv("SM_CONV_FORCE_SPLITS") ? atoi(getenv("SM_CONV_FORCE_SPLITS")) : 0;
+        if (force_s > 0 && a.ws != nullptr && tiles - tiles / SLOTS * SLOTS > 0) {
+            a.n_whole = tiles / SLOTS * SLOTS;
+            rem = tiles - a.n_whole;
+            const int S = std::max(1, std::min({force_s, chunks, (int)(ws_floats / ((size_t)rem * BM * BN))}));
+            a.chunks_per_split = (chunks + S - 1) / S;
+            a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
         }
     }
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }

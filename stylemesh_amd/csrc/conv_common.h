@@ -49,4 +49,34 @@ struct ConvArgs {
 
 constexpr int SM_NUM_CU = 256;
 
+// Block id -> (tile, split) of a conv launch. Whole tiles: XCD-aware order (neighbours in an XCD's share use the same
+// weight slab and adjacent positions). Tail units (tile, K-split) are ordered (row of M-tiles, split, position tile)
+// and dealt to the XCDs in contiguous runs of that order: the units that read the SAME slice of the weight image - an
+// M-tile's rows of one K-range - run on one XCD (two at a run boundary), so a slice crosses the fabric into one L2
+// instead of into all eight. (Round 2 dealt the splits of a tile round-robin: every XCD pulled the whole 9-19 MB image
+// of a deep layer through its own L2 - 4.4 x the algorithmic HBM traffic on the single-level c2 workload, whose deep
+// layers are all tail.) The tail is the range [n_whole, m_tiles * n_tiles) of the M-major tile order: a partial first
+// row of M-tiles, then whole rows. split = -1 for whole tiles.
+__device__ __forceinline__ void conv_unit(const ConvArgs& a, int bid, int& tile, int& split) {
+    if (bid < a.n_whole) {
+        tile = xcd_linear(bid, a.n_whole);
+        split = -1;
+        return;
+    }
+    const int S = a.splits;
+    const int rem = a.m_tiles * a.n_tiles - a.n_whole;
+    const int v = xcd_linear(bid - a.n_whole, rem * S);    // n_whole is a multiple of 8: XCD = (bid - n_whole) % 8
+    const int m0 = a.n_whole / a.n_tiles, n0 = a.n_whole - m0 * a.n_tiles;
+    const int c0 = min(rem, a.n_tiles - n0);               // tiles of the first (possibly partial) row
+    if (v < c0 * S) {
+        split = v / c0;
+        tile = a.n_whole + (v - split * c0);
+    } else {
+        const int w = v - c0 * S;
+        const int row = w / (S * a.n_tiles), inner = w - row * (S * a.n_tiles);
+        split = inner / a.n_tiles;
+        tile = (m0 + 1 + row) * a.n_tiles + (inner - split * a.n_tiles);
+    }
+}
+
 }  // namespace sm

@@ -141,14 +141,8 @@ void conv3x3_split_kernel(ConvArgs a) {
             __builtin_readcyclecounter();                                                                \
     }
 
-    int tile, split = -1;
-    if ((int)blockIdx.x < a.n_whole) {
-        tile = xcd_linear(blockIdx.x, a.n_whole);
-    } else {
-        const int v = blockIdx.x - a.n_whole;
-        tile = a.n_whole + v / a.splits;
-        split = v - (tile - a.n_whole) * a.splits;
-    }
+    int tile, split;
+    conv_unit(a, blockIdx.x, tile, split);   // XCD-aware order of whole tiles and of the tail's (tile, K-split) units
     const int m_tile = tile / a.n_tiles;
     const int n_glob = tile - m_tile * a.n_tiles;
     ConvProblem P = a.p[0];

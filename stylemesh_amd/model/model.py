@@ -7,15 +7,15 @@ run a step:
   forward + hand-written backward deposit the data-term gradient straight into ``param.grad`` (which aliases the
   engine's gradient arena); the returned ``loss`` is a detached scalar whose ``backward()`` is a no-op, and
   ``configure_optimizers`` returns the fused regulariser + Adam + clamp kernel wrapped as an optimizer.
-* ``forward`` / ``forward_with_loss`` reproduce the reference's autograd formulation through the differentiable
-  classes of ``model/texture`` and ``model/losses`` (used by the parity tests; slower: dense copies per call).
+* ``forward`` / ``forward_with_loss`` give the same step as an autograd graph over the differentiable classes of
+  ``model/texture`` and ``model/losses``, with the level masks / pixel weights taken from the fused engine's per-view
+  kernels (used by the parity tests; slower: dense copies per call).
 """
 from __future__ import annotations
 
 import os
 
 import torch
-import torch.nn.functional as F
 
 from ..runtime import ops
 from ..runtime.engine import EngineConfig, StepEngine
@@ -204,54 +204,62 @@ class TextureOptimizationStyleTransferPipeline(_Base):
     def update_batch_count(self, batch_idx, state):
         self.batches_per_epoch[state] = max(self.batches_per_epoch[state], batch_idx + 1)
 
+    def _level_constants(self, batch, shapes):
+        """Per UV level (mask, pixel weight or None) from the SAME kernels the fused engine's ``set_view`` runs
+        (``sm_level_masks``: eroded level masks + interpolation weights, model/model.py:204-239; ``sm_level_maps``: their
+        nearest up-sampling, the bilinear angle map and the product weight cos(theta) * depth weight, :195-202,245-251)."""
+        (_, _, _, _, _, rounded, other, interp_w, _, _, mask, angle_guidance, angle_degrees) = batch
+        dev = mask.device
+        h, w = mask.shape[-2:]
+        n = len(shapes)
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        mask_u8 = mask[0].to(torch.uint8).contiguous()
+        ag, adeg = f32(angle_guidance[0, 0]), f32(angle_degrees[0, 0])
+        if self.use_depth_scaling:
+            E, Wt = torch.empty(n, h, w, device=dev), torch.empty(n, h, w, device=dev)
+            ops.level_masks(rounded[0, 0].to(dev, torch.int64).contiguous(), other[0, 0].to(dev, torch.int64).contiguous(),
+                            f32(interp_w[0, 0]), mask_u8, n, E, Wt)
+        else:
+            maskf = mask_u8.float()
+        out = []
+        for i, (H, W) in enumerate(shapes):
+            if not self.use_depth_scaling and i != n - 1:      # only the last level carries the view (:253-254)
+                out.append((torch.zeros(1, 1, H, W, device=dev), None))
+                continue
+            M = torch.empty(H, W, device=dev)
+            want_pw = self.use_angle_weight or self.use_depth_scaling
+            pw = torch.empty(H, W, device=dev) if want_pw else None
+            passed = torch.empty(H, W, dtype=torch.uint8, device=dev)
+            ops.level_maps(E[i] if self.use_depth_scaling else maskf, Wt[i] if self.use_depth_scaling else None,
+                           ag if self.use_angle_weight else None, adeg, float(self.angle_threshold), h, w, H, W, M, pw,
+                           passed, torch.zeros(1, device=dev))
+            out.append((M[None, None], None if pw is None else pw[None, None]))
+        return out
+
     def forward_with_loss(self, batch, batch_idx, state):
-        """The reference's formulation (model/model.py:178-327): differentiable sampling, hooks on the predicted
-        images, ``ContentAndStyleLoss`` - every operator a HIP kernel, glue by autograd."""
+        """The autograd formulation of a step (what reference model/model.py:178-327 computes), for callers that want
+        ``loss.backward()`` through the differentiable classes: texture sampling (``texture.forward``: K1 / K2 under an
+        autograd.Function), ONE gradient hook per predicted image carrying the product's per-view pixel weight, the
+        ``ContentAndStyleLoss`` module over the level masks. Masks and weights are the fused engine's per-view constants
+        (``_level_constants``), not a restatement of the reference's erode / interpolate chain. The Trainer path
+        (``training_step``) does not come through here."""
         log_idx = batch_idx + self.current_epoch * self.batches_per_epoch[state]
         self.update_batch_count(batch_idx, state)
-        (input_rgb_image, _, _, depth, depth_level, rounded_depth_level, other_depth_level,
-         depth_level_interpolation_weight, _, uv_map, mask, angle_guidance, angle_degrees) = batch
-        pred_pyramid = self.forward(batch)
-        mask = mask.unsqueeze(1).float()
-        losses = {}
-
-        if self.use_angle_weight:
-            for p in pred_pyramid:
-                if p.requires_grad:
-                    p.register_hook(lambda g: g * F.interpolate(angle_guidance, g.shape[2:], mode='bilinear'))
-
-        def erode(x, kernel_size=3):
-            k = torch.ones(1, 1, kernel_size, kernel_size).type_as(x)
-            em = torch.clamp(F.conv2d(x, k, padding=(1, 1)) / kernel_size ** 2, 0, 1)
-            return x * (em == 1)
-
-        if self.use_depth_scaling:
-            pyramid_masks, weights = [], []
-            for i, p in enumerate(pred_pyramid):
-                m = ((rounded_depth_level == i) + (other_depth_level == i)).float() * mask
-                pyramid_masks.append((F.interpolate(erode(m), p.shape[2:], mode='nearest') > 0).float())
-                m1 = erode((rounded_depth_level == i) * mask) * depth_level_interpolation_weight
-                m2 = erode((other_depth_level == i) * mask) * (1 - depth_level_interpolation_weight)
-                weights.append(F.interpolate(m1 + m2, p.shape[2:], mode='nearest'))
-            for p in pred_pyramid:
-                if p.requires_grad:
-                    p.register_hook(lambda g: g * find_pyramid_size(weights, g)[1])
-        else:
-            pyramid_masks = [(F.interpolate(torch.zeros_like(mask), p.shape[2:], mode='nearest') > 0).float()
-                             for p in pred_pyramid]
-            pyramid_masks[-1] = (F.interpolate(mask, pred_pyramid[-1].shape[2:], mode='nearest') > 0).float()
-
-        pred_pyramid = [p for p, m in zip(pred_pyramid, pyramid_masks) if torch.sum(m) > 0]
-        pyramid_masks = [m for m in pyramid_masks if torch.sum(m) > 0]
-        style_loss, content_loss, _ = self.vgg_loss(pred_pyramid, input_rgb_image, pyramid_masks,
-                                                    angle_unnormalized=angle_degrees)
-        losses["content"] = self.loss_weights["content"] * content_loss
-        losses["style"] = self.loss_weights["style"] * style_loss
-        if self.loss_weights["tex_reg"] > 0:
-            losses["tex_reg"] = self.loss_weights["tex_reg"] * self.tex_reg_loss()
-        else:
-            losses["tex_reg"] = torch.zeros_like(losses["content"])
-        losses["total"] = sum(losses.values())
+        preds = self.forward(batch)
+        consts = self._level_constants(batch, [tuple(p.shape[2:]) for p in preds])
+        live = []
+        for p, (M, pw) in zip(preds, consts):
+            if pw is not None and p.requires_grad:
+                p.register_hook(lambda g, pw=pw: g * pw)
+            if bool(M.any()):                                   # the empty-level filter (:256-257)
+                live.append((p, M))
+        style_loss, content_loss, _ = self.vgg_loss([p for p, _ in live], batch[0], [M for _, M in live],
+                                                    angle_unnormalized=batch[12])
+        losses = {"content": self.loss_weights["content"] * content_loss,
+                  "style": self.loss_weights["style"] * style_loss}
+        reg_on = self.loss_weights["tex_reg"] > 0
+        losses["tex_reg"] = self.loss_weights["tex_reg"] * self.tex_reg_loss() if reg_on else torch.zeros_like(losses["content"])
+        losses["total"] = losses["content"] + losses["style"] + losses["tex_reg"]
         self._log_losses(losses, state, log_idx)
         return {"loss": losses["total"]}
 

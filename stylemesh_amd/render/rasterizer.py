@@ -118,6 +118,21 @@ def project_points(cam2world, intrinsics4, points_world):
     return np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy, pc[:, 2]], 1)
 
 
+def matterport_cam2world(extrinsics):
+    """The ``cam2world`` that ``render_maps`` / ``project_points`` need for a Matterport image, from the 4x4 extrinsic
+    matrix E of its ``.house`` record (row-major as in the file). The reference's Matterport renderer uses E DIRECTLY as
+    the OpenGL view matrix - ``render(glm::mat4(1.0f), extr, projection)``, scripts/matterport/render_uv/src/renderer/
+    mp_renderer.cpp:98,126 - with no look-at rebuild (the ScanNet renderer derives its view matrix from the pose's
+    columns instead, scannet_renderer.cpp:19-84). An OpenGL eye frame looks down -z with +y up; this build's camera
+    frame is x right, y towards larger row indices, z forward, and - as for ScanNet - file row j with ``flip = 0`` is
+    GL window row j counted from the BOTTOM: camera = diag(1, 1, -1) eye, i.e. ``world -> camera = D E`` and
+    ``cam2world = E^-1 D``. (The reference renders Matterport with ``flip = 1``, render_mipmap_matterport.py:17:
+    ``render_trajectory(..., flip=True)`` reverses the rows as ``saveUV`` does.)"""
+    E = np.asarray(extrinsics.detach().cpu() if torch.is_tensor(extrinsics) else extrinsics, dtype=np.float64).reshape(4, 4)
+    D = np.diag([1.0, 1.0, -1.0, 1.0])
+    return np.linalg.inv(E) @ D
+
+
 def box_room_mesh(room, device="cuda", subdiv: int = 1) -> Mesh:
     """The synthetic box room (``stylemesh_amd.data.synthetic.BoxRoom``) as a mesh: 6 faces x ``subdiv``^2 quads, UVs
     from the room's chart layout, normals pointing into the room."""

@@ -100,6 +100,70 @@ def test_projection_matrix_known_answer():
     assert y[1] > y[0]      # +y of the ScanNet camera frame (down) = larger row index
 
 
+def ref_pipeline_matterport(E, K, native_wh, render_wh, pts, flip, n=0.1, f=10.0):
+    """scripts/matterport/render_uv/src/renderer/mp_renderer.cpp:85-130 restated: ``extr = transpose(make_mat4(
+    image->extrinsics))`` turns the file's row-major floats into the matrix E as written; the intrinsics are scaled to the
+    buffer size (:101-107) and handed to the same ``camera_utils::perspective`` WITH THE BUFFER SIZE (:109); the view
+    matrix is E itself (:126, model matrix = identity); ``saveUV(filename, flip)`` as in the ScanNet renderer.
+    World points -> (window x, window y from the bottom, file row, linearised depth)."""
+    sx, sy = render_wh[0] / native_wh[0], render_wh[1] / native_wh[1]
+    Kb = np.array(K, dtype=np.float64)
+    Kb[0, 0] *= sx; Kb[1, 1] *= sy; Kb[0, 2] *= sx; Kb[1, 2] *= sy
+    P = ref_projection(Kb, render_wh[0], render_wh[1], n, f)
+    clip = (P @ np.asarray(E, dtype=np.float64) @ np.concatenate([pts, np.ones((len(pts), 1))], 1).T).T
+    ndc = clip[:, :3] / clip[:, 3:4]
+    xw = (ndc[:, 0] + 1) / 2 * render_wh[0]
+    yw = (ndc[:, 1] + 1) / 2 * render_wh[1]
+    z = ndc[:, 2]
+    lin = (2 * n * f) / (f + n - z * (f - n))
+    gl_row = np.floor(yw).astype(int)
+    return xw, yw, (render_wh[1] - 1 - gl_row) if flip else gl_row, lin
+
+
+@pytest.mark.parametrize("native_wh,render_wh", [((1280, 1024), (1280, 1024)), ((1280, 1024), (320, 256)), ((1280, 1024), (980, 784))])
+def test_matterport_view_convention_equals_the_reference_pipeline(native_wh, render_wh):
+    """The Matterport renderer uses the ``.house`` extrinsics as the view matrix directly (no look-at rebuild): the
+    product's ``matterport_cam2world`` + ``project_points`` reproduce window position, file row (flip = 0 and the
+    scripts' flip = 1) and linearised depth of that pipeline for random rigid E, off-centre principal points and
+    render sizes != the image size."""
+    from stylemesh_amd.render.rasterizer import matterport_cam2world, project_points, scaled_intrinsics
+    rng = np.random.default_rng(11)
+    K = np.eye(4)
+    K[0, 0], K[1, 1] = 1.05 * native_wh[0], 1.07 * native_wh[0]
+    K[0, 2], K[1, 2] = 0.49 * native_wh[0], 0.53 * native_wh[1]
+    for _ in range(5):
+        E = random_pose(rng)                                             # a rigid world -> eye transform
+        eye = np.stack([rng.uniform(-1.5, 1.5, 200), rng.uniform(-1.2, 1.2, 200), -rng.uniform(0.3, 8.0, 200)], 1)
+        Einv = np.linalg.inv(E)
+        pts = eye @ Einv[:3, :3].T + Einv[:3, 3]                         # world points in front of the GL camera (-z)
+        xw, yw, row0, lin = ref_pipeline_matterport(E, K, native_wh, render_wh, pts, flip=0)
+        _, _, row1, _ = ref_pipeline_matterport(E, K, native_wh, render_wh, pts, flip=1)
+        mine = project_points(matterport_cam2world(E), scaled_intrinsics(K, native_wh, render_wh), pts)
+        np.testing.assert_allclose(mine[:, 0], xw, rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(mine[:, 1], yw, rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(mine[:, 2], lin, rtol=1e-9)
+        np.testing.assert_allclose(mine[:, 2], -eye[:, 2], rtol=1e-9)   # depth = distance along the viewing direction
+        inside = (yw > 0) & (yw < render_wh[1]) & (np.abs(yw - np.round(yw)) > 1e-3)
+        assert np.array_equal(np.floor(mine[inside, 1]).astype(int), row0[inside])
+        assert np.array_equal(render_wh[1] - 1 - np.floor(mine[inside, 1]).astype(int), row1[inside])
+
+
+def test_matterport_view_known_answer():
+    """Hand-worked: E = identity, K = (fx 1000, fy 1000, cx 640, cy 512) at 1280 x 1024. The eye-space point
+    (0.1, 0.2, -2) (up-right of the axis, 2 m ahead) lands at window x = 640 + 1000 * 0.1 / 2 = 690, window y (from the
+    BOTTOM) = 512 + 1000 * 0.2 / 2 = 612: file row 612 with flip = 0, row 1023 - 612 = 411 with flip = 1; depth 2."""
+    from stylemesh_amd.render.rasterizer import matterport_cam2world, project_points
+    K = np.eye(3)
+    K[0, 0] = K[1, 1] = 1000.0
+    K[0, 2], K[1, 2] = 640.0, 512.0
+    pts = np.array([[0.1, 0.2, -2.0]])
+    xw, yw, row0, lin = ref_pipeline_matterport(np.eye(4), K, (1280, 1024), (1280, 1024), pts, flip=0)
+    np.testing.assert_allclose([xw[0], yw[0], lin[0]], [690.0, 612.0, 2.0], rtol=1e-12)
+    assert row0[0] == 612
+    x, y, z = project_points(matterport_cam2world(np.eye(4)), (1000.0, 1000.0, 640.0, 512.0), pts)[0]
+    np.testing.assert_allclose([x, y, z], [690.0, 612.0, 2.0], rtol=1e-12)
+
+
 def test_load_obj_applies_flip_uvs(tmp_path):
     """include/model.h:57 ``aiProcess_FlipUVs``: vt (0.25, 0.1) of the file is rendered as (0.25, 0.9)."""
     from stylemesh_amd.render.rasterizer import load_obj
