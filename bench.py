@@ -110,6 +110,8 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     for i in range(args.warmup):
         eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
     ops.CONV_TIMER = timer
+    if getattr(eng, "phase_timer", None) is not None:
+        eng.phase_timer.enabled = True
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -119,6 +121,8 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     barrier()
     dt = time.perf_counter() - t0
     ops.CONV_TIMER = None
+    if getattr(eng, "phase_timer", None) is not None:
+        eng.phase_timer.enabled = False
     return dt
 
 
@@ -145,6 +149,78 @@ def f32_leg(args, wl, cfg, schedule, dev, barrier):
                 "kernel": "conv3x3_mfma_kernel", "launches_timed": n}
     finally:
         ops.CONV_MODE, ops.GRAM_MODE = saved
+
+
+def exchange_report(eng, comm, reducer, args):
+    """N > 1: which communicator ran, and the event-timed exchange / update of the timed steps (rank 0's stream)."""
+    rep = {"communicator": "own RCCL communicator (sm_comm_init / sm_allreduce_grad)"
+           if type(comm).__name__ == "RcclComm" else "torch.distributed",
+           "bytes_per_step": getattr(reducer, "last_bytes", None),
+           "flagged_fraction_of_arena": None if not hasattr(reducer, "fraction") else round(reducer.fraction, 4)}
+    t = getattr(eng, "phase_timer", None)
+    if t is not None:
+        for tag, key in (("exchange", "exchange_ms"), ("update", "update_ms"), ("exchange+update", "exchange_update_ms")):
+            n, ms, _ = t.summary(tag)
+            if n:
+                rep[key] = round(ms / n, 4)
+                rep["steps_timed"] = n
+    return rep
+
+
+def scene_coverage_flags(eng, wl, n_views, seed=0):
+    """Ever-touched flags of a whole scene: the union of the chunks the UV maps of ``n_views`` random poses in the bench's
+    box room reach, rendered with the product's HIP rasteriser (65 us per frame) - what ``eng.touched`` holds after one
+    epoch over such a scene."""
+    from stylemesh_amd import render as R
+    from stylemesh_amd.runtime import ops
+    room = S.BoxRoom((12.0, 9.0, 3.0))
+    mesh = R.box_room_mesh(room, device="cuda", subdiv=8)
+    rng = np.random.default_rng(seed)
+    L = room.size
+    flags = torch.zeros_like(eng.touched)
+    vh, vw = wl["view_hw"]
+    for _ in range(n_views):
+        pos = np.array([rng.uniform(0.8, L[0] - 0.8), rng.uniform(0.8, L[1] - 0.8), rng.uniform(1.0, 1.7)])
+        K, c2w = S.camera_matrices(pos, rng.uniform(0, 2 * np.pi), rng.uniform(-0.35, 0.25), (vh, vw))
+        for h, w in wl["level_hw"]:
+            intr = np.array([K[0, 0] * w / vw, K[1, 1] * h / vh, (K[0, 2] + 0.5) * w / vw, (K[1, 2] + 0.5) * h / vh], np.float32)
+            uv = R.render_maps(mesh, c2w, intr, (h, w), znear=0.05, zfar=50.0)[0]
+            grid = (uv[..., :2] * 2.0 - 1.0).contiguous()
+            ops.tex_touch_flags(eng.grads, eng.arena.g, grid, None, flags, eng.touched_log2)
+    return flags
+
+
+def late_epoch_leg(eng, schedule, args, wl, barrier):
+    """The regime of a scene's LATER epochs: the ever-touched set of the sparse update is the whole
+    scene's coverage instead of the 2-3 views the main leg has seen. Same engine, same schedule, timed the same way."""
+    import copy
+    flags = scene_coverage_flags(eng, wl, args.late_epoch_views)
+    from stylemesh_amd.runtime import ops
+    ops.flags_or(eng.touched, flags)
+    eng._other_flags = None
+    frac = float((eng.touched != 0).float().mean())
+    a = copy.copy(args)
+    a.warmup = 5
+    dt = timed_leg(eng, schedule, a, wl, 1, None, barrier, None)
+    return {"value": round(a.steps / dt, 3), "unit": "views/s", "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "ever_touched_fraction_of_arena": round(frac, 4),
+            "views_seeded": args.late_epoch_views,
+            "note": "ever-touched flags pre-seeded with the coverage of a whole scene (UV maps of that many random poses, "
+                    "HIP rasteriser): the update's early half (side stream) walks all of it, the closing half the view's own chunks"}
+
+
+def measured_schedule(workload):
+    """The fixed schedule of one scene MEASURED on the product path (tools/run_schedule.py: directory loader, MiniTrainer,
+    the CLI's flags) - a committed record of a GPU-box run, the default bench run cannot afford 4 minutes of it."""
+    for rnd in ("r03",):
+        f = os.path.join(REPO, "profiles", rnd, f"schedule_{workload}.json")
+        if os.path.exists(f):
+            d = json.load(open(f))
+            return {"measured_schedule_s": d.get("measured_schedule_s"), "steps": d.get("steps"),
+                    "mean_views_per_s": d.get("mean_views_per_s"), "per_epoch_views_per_s": [e["views_per_s"] for e in d.get("per_epoch", [])],
+                    "source": f"profiles/{rnd}/{os.path.basename(f)} (python -m stylemesh_amd.model.optimize on a {d.get('views')}-view "
+                              "on-disk scene, texture exports and validation included)"}
+    return None
 
 
 def main():
@@ -178,6 +254,8 @@ def main():
                     "workload with v_mfma_f32_32x32x2_f32 everywhere (reported as 'f32_mode'; 0 = skip)")
     ap.add_argument("--dense-adam", action="store_true", help="fused update over every texel instead of the chunks "
                     "some view has touched so far")
+    ap.add_argument("--late-epoch-views", type=int, default=276, help="N = 1: views whose coverage seeds the ever-touched "
+                    "set of the 'late_epoch' leg (0 = skip the leg)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -241,6 +319,9 @@ def main():
         torch.cuda.synchronize()
 
     timer = None if args.no_conv_timer else ops.KernelTimer()
+    if world > 1:   # event-timed exchange and update of every step (two event pairs per step)
+        eng.phase_timer = ops.KernelTimer()
+        eng.phase_timer.enabled = False
     dt = timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer)
     active_levels = [lv.index for lv in eng.view if lv.active]
     losses = eng.losses()
@@ -324,10 +405,14 @@ def main():
                "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
                                 "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
                                         "zero-initialised texture); the fraction grows with the views of the scene"},
-               "exchange": None if world == 1 else ("own RCCL communicator (sm_comm_init / sm_allreduce_grad)"
-                                                    if type(comm).__name__ == "RcclComm" else "torch.distributed")}
+               "exchange": None if world == 1 else exchange_report(eng, comm, reducer, args)}
+        sched = measured_schedule(args.workload)
+        if sched is not None:
+            out["scene_schedule"].update(sched)
         if world == 1 and args.f32_steps > 0 and ops.CONV_MODE != "f32" and args.mfma is None:
             out["f32_mode"] = f32_leg(args, wl, cfg, schedule, dev, barrier)
+        if world == 1 and args.late_epoch_views > 0 and eng.touched is not None and not args.dense_adam:
+            out["late_epoch"] = late_epoch_leg(eng, schedule, args, wl, barrier)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:

@@ -448,6 +448,23 @@ int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void*
 
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 
+/* The compact form of the gradient arena that travels between the ranks (the reference has no collective: this is the
+ * exchange step of SURVEY.md section 8 e; runtime/distributed.py:SparseGradReducer sequences it).
+ *   sm_flags_compact: ascending list of the indices k with flags[k] != 0 into idx_out (capacity n_flags) and their
+ *     number into *count_out (device) - deterministic, so that ranks holding identical (max-all-reduced) flags derive
+ *     identical lists; ws: sm_flags_compact_ws_ints(n_flags) int32 of scratch. No host synchronisation.
+ *   sm_chunks_gather: compact[j][0 .. 2^chunk_log2) = arena[idx[j] << chunk_log2 ...] for j < n, where n = *n_idx_dev
+ *     if that (device) pointer is given - n_idx is then only the capacity the launch is sized for - else n_idx.
+ *   sm_chunks_scatter: the inverse copy, times `scale` (1 / world size if the caller wants the mean here).
+ * chunk_log2 in [2, 24]; the arena pointer must be 16-byte aligned. */
+size_t sm_flags_compact_ws_ints(size_t n_flags);
+int sm_flags_compact(const int32_t* flags, size_t n_flags, int32_t* idx_out, int32_t* count_out, int32_t* ws,
+                     void* stream);
+int sm_chunks_gather(const float* arena, const int32_t* idx, const int32_t* n_idx_dev, size_t n_idx, int chunk_log2,
+                     float* compact, void* stream);
+int sm_chunks_scatter(float* arena, const int32_t* idx, const int32_t* n_idx_dev, size_t n_idx, int chunk_log2,
+                      const float* compact, float scale, void* stream);
+
 /* RCCL over xGMI, one communicator per process (one process per GPU). The reference has no collective; this is the
  * exchange of the R-GPU step defined in SURVEY.md section 8 e. All return a ncclResult_t (0 = success).
  *   sm_comm_get_unique_id: rank 0 fills id_out (sm_comm_unique_id_bytes() bytes, HOST) and ships it to the other

@@ -13,7 +13,8 @@ class SyntheticSceneDataModule:
 
     def __init__(self, n_views=8, view_hw=S.SCANNET_VIEW_HW, level_hw=None, min_pyramid_depth=0.25, split=(0.8, 0.2),
                  index_repeat=1, sampler_mode="repeat", room_size=(12.0, 9.0, 3.0), seed=0, rank=0, world_size=1,
-                 use_depth_in_mask=True):
+                 use_depth_in_mask=True, prefetch=0):
+        self.prefetch = prefetch
         self.n_views, self.view_hw = n_views, tuple(view_hw)
         self.level_hw = list(level_hw) if level_hw else [tuple(view_hw)]
         self.min_pyramid_depth, self.split, self.index_repeat = min_pyramid_depth, split, index_repeat
@@ -40,7 +41,7 @@ class SyntheticSceneDataModule:
     def train_dataloader(self):
         from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes on every rank
         return scheduled_batches(self._view, self.train_indices, self.rank, self.world_size, self.index_repeat,
-                                 repeat=self.sampler_mode == "repeat")
+                                 repeat=self.sampler_mode == "repeat", prefetch=self.prefetch)
 
     def val_dataloader(self):
         return (self._view(i) for i in self.val_indices) if self.val_indices else None

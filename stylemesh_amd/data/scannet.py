@@ -151,7 +151,8 @@ class ScanNetSingleSceneDataModule:
 
     def __init__(self, root_path, scene, resize_size=256, pyramid_levels=5, min_pyramid_depth=0.25,
                  min_pyramid_height=32, max_images=-1, split=(0.8, 0.2), index_repeat=1, sampler_mode="repeat",
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, prefetch=2):
+        self.prefetch = prefetch   # views decoded ahead by a background thread (0 = decode inside the training loop)
         self.args = dict(root_path=join(root_path, "train/images"), scene=scene, resize_size=resize_size,
                          pyramid_levels=pyramid_levels, min_pyramid_depth=min_pyramid_depth,
                          min_pyramid_height=min_pyramid_height, max_images=max_images)
@@ -170,7 +171,7 @@ class ScanNetSingleSceneDataModule:
     def train_dataloader(self):
         from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes on every rank
         return scheduled_batches(lambda i: self.train_dataset[i], self.train_indices, self.rank, self.world_size,
-                                 self.index_repeat, repeat=self.sampler_mode == "repeat")
+                                 self.index_repeat, repeat=self.sampler_mode == "repeat", prefetch=self.prefetch)
 
     def val_dataloader(self):
         return (self.val_dataset[i] for i in self.val_indices) if self.val_indices else None

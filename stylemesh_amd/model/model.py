@@ -274,16 +274,18 @@ class TextureOptimizationStyleTransferPipeline(_Base):
         eng = self._ensure_engine(batch[0].device)
         log_idx = batch_idx + self.current_epoch * self.batches_per_epoch["train"]
         self.update_batch_count(batch_idx, "train")
-        eng.begin_step(batch, self.grad_reducer)   # set_view on a new view key; per-view collective by schedule position
         for p, g in zip(self._texture_params(), eng.grads):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():   # a foreign optimizer dropped / replaced .grad
                 eng.arena.g.zero_()
                 p.grad = g
-        lt = eng.loss_tensors()
-        eng.forward_backward()
-        if self.grad_reducer is not None:
-            self.grad_reducer(eng.arena.g)
-        losses = {k: v.clone() for k, v in lt.items()}
+        # the engine's own step up to the optimizer (set_view on a new view key, per-view collective by schedule position,
+        # step head, split update's early half, forward + backward, gradient exchange): the same launches ``bench.py``
+        # times - ``FusedTextureAdam.step`` (the Trainer's ``optimizer.step()``) closes the step
+        opt = getattr(self, "_fused_optimizer", None)
+        if opt is not None:   # the scheduler owns the learning rate: the split update's early half needs THIS step's
+            eng.cfg.learning_rate = opt.param_groups[0]["lr"]
+            eng.cfg.decay_gamma, eng.epoch = 1.0, 0
+        losses = dict(eng.step_compute(batch, self.grad_reducer))   # device tensors that stay valid: no copies
         losses["total"] = losses["content"] + losses["style"] + losses["tex_reg"]
         self._log_losses(losses, "train", log_idx)
         return {"loss": losses["total"].detach().requires_grad_()}   # backward() of this scalar is a no-op
@@ -343,7 +345,7 @@ class TextureOptimizationStyleTransferPipeline(_Base):
                                         normalize_transform=post())
 
     def configure_optimizers(self):
-        optimizer = FusedTextureAdam(self, self.learning_rate)
+        optimizer = self._fused_optimizer = FusedTextureAdam(self, self.learning_rate)
         scheduler = StepLR(optimizer, gamma=self.decay_gamma, step_size=self.decay_step_size)
         return [optimizer], [scheduler]
 

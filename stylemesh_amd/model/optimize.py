@@ -6,7 +6,9 @@ Differences, all outside the hot path: ``--dataset synthetic`` (seeded box-room 
 and ``--dataset matterport`` read
 the reference's on-disk scene / region layouts), ``--vgg_gatys_model_path random:<seed>`` for seeded He-normal weights
 when ``vgg_conv.pth`` is unavailable, ``--style_image_path synthetic:<seed>:<H>x<W>``, and no post-hoc mip-map
-render / video / evaluation (reference :167-234, out of scope). Multi-GPU: launch under
+render / video / evaluation (reference :167-234, out of scope). ``--num_workers`` > 0 (the reference's DataLoader
+worker count, data/abstract_dataset.py:480) switches the loaders' background view prefetch on (one thread is enough
+here: a view is decoded during the previous view's ``index_repeat`` steps). Multi-GPU: launch under
 ``torch.distributed.run``; views shard over ranks and the texture gradient is all-reduced over RCCL.
 """
 from __future__ import annotations
@@ -69,14 +71,15 @@ def main(args):
                                       view_hw=S.SCANNET_VIEW_HW, level_hw=heights,
                                       min_pyramid_depth=args.min_pyramid_depth, split=(args.train_split, args.val_split),
                                       index_repeat=args.index_repeat, sampler_mode=args.sampler_mode, rank=rank,
-                                      world_size=world)
+                                      world_size=world, prefetch=2 if args.num_workers > 0 else 0)
     elif args.dataset == "scannet":
         from ..data.scannet import ScanNetSingleSceneDataModule
         dm = ScanNetSingleSceneDataModule(args.root_path, args.scene, resize_size=args.resize_size,
                                           pyramid_levels=args.pyramid_levels, min_pyramid_depth=args.min_pyramid_depth,
                                           min_pyramid_height=args.min_pyramid_height, max_images=args.max_images,
                                           split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
-                                          sampler_mode=args.sampler_mode, rank=rank, world_size=world)
+                                          sampler_mode=args.sampler_mode, rank=rank, world_size=world,
+                                          prefetch=2 if args.num_workers > 0 else 0)
     elif args.dataset == "matterport":
         from ..data.matterport import MatterportSingleRegionDataModule
         dm = MatterportSingleRegionDataModule(args.root_path, args.scene, region_index=args.matterport_region_index,
@@ -84,7 +87,8 @@ def main(args):
                                               min_pyramid_depth=args.min_pyramid_depth,
                                               min_pyramid_height=args.min_pyramid_height, max_images=args.max_images,
                                               split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
-                                              sampler_mode=args.sampler_mode, rank=rank, world_size=world)
+                                              sampler_mode=args.sampler_mode, rank=rank, world_size=world,
+                                              prefetch=2 if args.num_workers > 0 else 0)
     else:
         raise ValueError(f"Unsupported dataset: {args.dataset}")
     dm.prepare_data()

@@ -50,6 +50,7 @@ class ViewBatch(tuple):
     ``new_view`` although its view key did not change, and still enters the per-view collective
     (``SparseGradReducer.new_view``) that the other ranks are entering."""
     new_view = None
+    upcoming = None   # optional callable: the NEXT view's decoded host items once ready (``ViewPrefetcher.peek``)
 
     def __new__(cls, items, new_view=None):
         self = super().__new__(cls, items)
@@ -57,19 +58,108 @@ class ViewBatch(tuple):
         return self
 
 
-def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repeat=1, repeat=True):
+def _pin_tree(x):
+    """Host tensors of a batch tuple into pinned memory (asynchronous H2D copies need it); lists keep their shape."""
+    import torch
+    if torch.is_tensor(x):
+        return x.pin_memory() if (not x.is_cuda and torch.cuda.is_available()) else x
+    if isinstance(x, (list, tuple)):
+        return type(x)(_pin_tree(u) for u in x)
+    return x
+
+
+class ViewPrefetcher:
+    """Decodes the views of a schedule AHEAD of the training loop, in a background thread.
+
+    The reference hides view loading behind the step with 4 DataLoader worker processes (data/abstract_dataset.py:480;
+    ``__getitem__`` :270-345 reads a jpg, a png and 6 ``.npy`` files and runs the numpy / PIL resizes). Here ONE thread is
+    enough: a view is optimised for ``index_repeat`` (20-100) consecutive steps - 0.1-0.6 s of GPU time - and its decode
+    (tens of ms, in numpy / PIL / file reads that release the GIL) runs during the PREVIOUS view's steps. Decoded
+    batches are pinned, so that the host-to-device copy the trainer issues is asynchronous (``MiniTrainer`` issues it
+    one view ahead, on a copy stream). ``depth`` decoded views are held at most (a 4-level ScanNet view is 14 MB)."""
+
+    def __init__(self, get_view, order, depth: int = 2, pin: bool = True):
+        import collections
+        import threading
+        self._get, self._order, self._pin = get_view, list(order), pin
+        self._ready = collections.deque()
+        self._cv = threading.Condition()
+        self._depth, self._stop = max(1, depth), False
+        self._thread = threading.Thread(target=self._run, name="stylemesh-view-prefetch", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            for i in self._order:
+                with self._cv:
+                    while len(self._ready) >= self._depth and not self._stop:
+                        self._cv.wait()
+                    if self._stop:
+                        return
+                items = self._get(i)
+                if self._pin:
+                    items = _pin_tree(items)
+                with self._cv:
+                    self._ready.append((i, items))
+                    self._cv.notify_all()
+            with self._cv:
+                self._ready.append(None)
+                self._cv.notify_all()
+        except BaseException as e:   # noqa: BLE001 - handed to the consumer, which re-raises it
+            with self._cv:
+                self._ready.append(e)
+                self._cv.notify_all()
+
+    def peek(self):
+        """The next decoded view's items if its decode has finished, else None (never blocks)."""
+        with self._cv:
+            head = self._ready[0] if self._ready else None
+        return head[1] if isinstance(head, tuple) else None
+
+    def __iter__(self):
+        try:
+            while True:
+                with self._cv:
+                    while not self._ready:
+                        self._cv.wait()
+                    head = self._ready.popleft()
+                    self._cv.notify_all()
+                if head is None:
+                    return
+                if isinstance(head, BaseException):
+                    raise head
+                yield head
+        finally:
+            self.close()
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+
+
+def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repeat=1, repeat=True, prefetch: int = 0):
     """The rank's train schedule as ``ViewBatch``es: views ``padded_shard(indices)``, each ``index_repeat``
     consecutive times (``repeat=False``: once, the 'sequential' sampler mode). Consecutive repeats yield the SAME
-    object (one decode / upload per view; callers may cache by identity), ``new_view`` marks the block boundaries."""
+    object (one decode / upload per view; callers may cache by identity), ``new_view`` marks the block boundaries.
+    ``prefetch`` > 0: views are decoded (and pinned) up to that many ahead by a ``ViewPrefetcher`` thread; every
+    yielded batch then carries ``upcoming`` - a callable returning the NEXT view's decoded items once they are ready -
+    so that the consumer can start its upload during the current view's steps."""
     rep = index_repeat if repeat else 1
-    for i in padded_shard(indices, rank, world_size):
-        n = rep[i] if isinstance(rep, list) else rep
-        if n < 1:
-            continue
-        items = get_view(i)
-        yield ViewBatch(items, new_view=True)
+    count = lambda i: rep[i] if isinstance(rep, list) else rep
+    order = [i for i in padded_shard(indices, rank, world_size) if count(i) >= 1]
+    if prefetch > 0:
+        source = ViewPrefetcher(get_view, order, depth=prefetch)
+        views, upcoming = iter(source), source.peek
+    else:
+        views, upcoming = ((i, get_view(i)) for i in order), None
+    for i, items in views:
+        first = ViewBatch(items, new_view=True)
+        first.upcoming = upcoming
+        yield first
         rest = ViewBatch(items, new_view=False)
-        for _ in range(n - 1):
+        rest.upcoming = upcoming
+        for _ in range(count(i) - 1):
             yield rest
 
 
@@ -216,23 +306,32 @@ class SparseGradReducer:
     """SUM all-reduce of the gradient arena restricted to the chunks any rank's current view can touch.
 
     A view writes gradient only where its UV maps land (a few % - tens of % of a 4096^2 hierarchical texture), and
-    which chunks those are depends only on the view, not on the step: ``new_view(flags)`` (a collective, once per
-    view change - the ranks' schedules change views in lock-step, ``rank_schedule``) max-reduces the per-rank touch
-    flags and keeps the index list; every step then gathers the flagged chunks into a compact buffer, all-reduces
-    that, and copies the sums back. Untouched chunks are zero on every rank and stay zero. Falls back to the dense
-    all-reduce when most chunks are dirty or the arena is not a whole number of chunks. Chunks are 64 floats (256 B):
-    a view's footprint is a 2-D blob of scattered texels in row-major planes, so 4 KB chunks flag 49 % of the arena
-    where 256 B chunks flag 14-24 % (exact non-zero fraction 8-11 %; bench views, tools/touch_fraction.py).
+    which chunks those are depends only on the view, not on the step. Per VIEW (a collective, driven by the schedule
+    position - the ranks' schedules change views in lock-step, ``rank_schedule``): the per-rank touch flags are
+    max-all-reduced and compacted ON THE DEVICE into the ascending list of flagged chunks (``sm_flags_compact``:
+    deterministic, so identical flags give identical lists on every rank); only the COUNT crosses to the host - RCCL
+    needs the element count of the all-reduce - and it rides the one read-back ``StepEngine.set_view`` does anyway
+    (``new_view_begin`` / ``new_view_end``). Per STEP: the flagged chunks are gathered into a compact buffer
+    (``sm_chunks_gather``), that buffer is all-reduced, and the sums are copied back (``sm_chunks_scatter``) - three
+    launches on the caller's stream, no host synchronisation. Untouched chunks are zero on every rank and stay zero.
+    Falls back to the dense all-reduce when most chunks are dirty or the arena is not a whole number of chunks.
+    Chunks are 64 floats (256 B): a view's footprint is a 2-D blob of scattered texels in row-major planes, so 4 KB
+    chunks flag 49 % of the arena where 256 B chunks flag 14-24 % (exact non-zero fraction 8-11 %; bench views,
+    tools/touch_fraction.py). CPU tensors (the gloo tests of the protocol) take the same steps with torch indexing.
     """
 
     def __init__(self, dist_module, world_size: int, chunk_log2: int = 6, dense_above: float = 0.75, n_pieces: int = 4):
         self.dist, self.world, self.chunk_log2, self.dense_above = dist_module, world_size, chunk_log2, dense_above
         self.n_pieces = n_pieces
-        self.idx = None
+        self.idx = None           # flagged chunk indices, ascending (device tensor; only the first n_idx entries count)
+        self.n_idx = 0
+        self.count_dev = None     # device int32 [1]: n_idx as the compaction left it
         self.cuts = None          # piece k exchanges idx[cuts[k]:cuts[k+1]] ...
         self.bounds = None        # ... and finishes the arena range [bounds[k], bounds[k+1])
         self.fraction = 1.0
         self.last_bytes = 0
+        self._buf = None
+        self._ws = None
 
     @property
     def chunk(self):
@@ -241,34 +340,87 @@ class SparseGradReducer:
     def n_chunks(self, numel: int) -> int:
         return -(-numel // self.chunk)
 
-    def new_view(self, flags):
-        """``flags``: int32 [n_chunks], non-zero where THIS rank's view can write. Collective."""
+    # ---- per view ------------------------------------------------------------------------------------------
+    def new_view_begin(self, flags):
+        """``flags``: int32 [n_chunks], non-zero where THIS rank's view can write; on return the union over the ranks
+        (in place). Collective. Enqueues the compaction; returns the device tensor that will hold the count (int32 [1])
+        - read it back whenever convenient and pass the value to ``new_view_end``."""
+        import torch
         self.dist.all_reduce(flags, op=self.dist.ReduceOp.MAX)
-        self.idx = flags.nonzero().flatten()          # one host sync per view change
-        self.fraction = self.idx.numel() / max(flags.numel(), 1)
-        n_idx = self.idx.numel()
-        k = max(1, min(self.n_pieces, n_idx))
-        self.cuts = [n_idx * j // k for j in range(k + 1)]
-        # arena range a piece completes: from its first flagged chunk up to the next piece's first flagged chunk
-        # (everything between flagged chunks is zero on every rank and needs no exchange)
-        firsts = self.idx[self.cuts[1:-1]].tolist() if k > 1 else []
-        self.bounds = [0] + [f * self.chunk for f in firsts] + [None]
+        n = flags.numel()
+        if flags.is_cuda:
+            from . import ops
+            if self.idx is None or self.idx.numel() < n or self.idx.device != flags.device:
+                self.idx = torch.empty(n, dtype=torch.int32, device=flags.device)
+                self._ws = torch.empty(ops.flags_compact_ws_ints(n), dtype=torch.int32, device=flags.device)
+                self.count_dev = torch.zeros(1, dtype=torch.int32, device=flags.device)
+            ops.flags_compact(flags, self.idx, self.count_dev, self._ws)
+        else:
+            self.idx = flags.nonzero().flatten().to(torch.int32)
+            self.count_dev = torch.tensor([self.idx.numel()], dtype=torch.int32)
+        self._n_flags = n
+        self.n_idx = None          # unknown until new_view_end
+        return self.count_dev
+
+    def new_view_end(self, count: int):
+        self.n_idx = int(count)
+        self.fraction = self.n_idx / max(self._n_flags, 1)
+        self.cuts = self.bounds = None    # the pipelined exchange derives its pieces on first use
+
+    def new_view(self, flags):
+        """``new_view_begin`` + one host read-back of the count + ``new_view_end`` (callers without a read-back of
+        their own to ride on)."""
+        self.new_view_end(int(self.new_view_begin(flags)))
+
+    def _pieces(self):
+        if self.cuts is None:
+            n_idx = self.n_idx
+            k = max(1, min(self.n_pieces, n_idx))
+            self.cuts = [n_idx * j // k for j in range(k + 1)]
+            # arena range a piece completes: from its first flagged chunk up to the next piece's first flagged chunk
+            # (everything between flagged chunks is zero on every rank and needs no exchange); one small read-back
+            firsts = self.idx[self.cuts[1:-1]].tolist() if k > 1 else []
+            self.bounds = [0] + [int(f) * self.chunk for f in firsts] + [None]
+        return self.cuts, self.bounds
+
+    # ---- per step ------------------------------------------------------------------------------------------
+    def _sparse(self, n):
+        return not (self.idx is None or self.n_idx is None or self.fraction > self.dense_above or n % self.chunk != 0)
+
+    def _gather(self, flat_grad, lo=0, hi=None):
+        """compact buffer holding chunks idx[lo:hi] of the arena"""
+        import torch
+        hi = self.n_idx if hi is None else hi
+        if flat_grad.is_cuda:
+            from . import ops
+            if self._buf is None or self._buf.numel() < self.n_idx * self.chunk or self._buf.device != flat_grad.device:
+                self._buf = torch.empty(self.n_idx * self.chunk, dtype=torch.float32, device=flat_grad.device)
+            buf = self._buf[lo * self.chunk:hi * self.chunk]
+            ops.chunks_gather(flat_grad, self.idx[lo:hi], hi - lo, self.chunk_log2, buf)
+            return buf
+        return flat_grad.view(-1, self.chunk).index_select(0, self.idx[lo:hi].long()).reshape(-1)
+
+    def _scatter(self, flat_grad, buf, lo=0, hi=None):
+        hi = self.n_idx if hi is None else hi
+        if flat_grad.is_cuda:
+            from . import ops
+            ops.chunks_scatter(flat_grad, self.idx[lo:hi], hi - lo, self.chunk_log2, buf)
+        else:
+            flat_grad.view(-1, self.chunk).index_copy_(0, self.idx[lo:hi].long(), buf.view(-1, self.chunk))
 
     def __call__(self, flat_grad):
         n = flat_grad.numel()
-        if self.idx is None or self.fraction > self.dense_above or n % self.chunk != 0:
+        if not self._sparse(n):
             self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM)
             self.last_bytes = 4 * n
             return
-        if self.idx.numel() == 0:      # no rank's view touches the texture: nothing to exchange (same on every rank)
+        if self.n_idx == 0:      # no rank's view touches the texture: nothing to exchange (same on every rank)
             self.last_bytes = 0
             return
-        g2 = flat_grad.view(-1, self.chunk)
-        buf = g2.index_select(0, self.idx)
+        buf = self._gather(flat_grad)
         self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
-        g2.index_copy_(0, self.idx, buf)
+        self._scatter(flat_grad, buf)
         self.last_bytes = 4 * buf.numel()
-
 
     def pipelined(self, flat_grad, update_range):
         """Exchange and update overlapped: the flagged chunks are all-reduced in ``n_pieces`` asynchronous pieces
@@ -276,11 +428,11 @@ class SparseGradReducer:
         soon as its sums have arrived, while the later pieces are still on the links. The ranges tile [0, n) in
         order; same arithmetic as ``__call__`` followed by one update over the whole arena. OPT-IN
         (``StepEngine.pipeline_exchange``, ``bench.py --pipeline-exchange``): verified functionally (2 ranks over gloo,
-        CPU and one shared GPU), not yet timed on RCCL hardware - the 1-GPU boxes of this round cannot."""
+        CPU and one shared GPU), not yet timed on RCCL hardware - the 1-GPU boxes cannot."""
         n = flat_grad.numel()
         dist = self.dist
-        sparse = not (self.idx is None or self.fraction > self.dense_above or n % self.chunk != 0)
-        if sparse and self.idx.numel() == 0:
+        sparse = self._sparse(n)
+        if sparse and self.n_idx == 0:
             self.last_bytes = 0
             update_range(0, n)
             return
@@ -295,15 +447,15 @@ class SparseGradReducer:
                 update_range(lo, hi)
             self.last_bytes = 4 * n
             return
-        g2 = flat_grad.view(-1, self.chunk)
-        buf = g2.index_select(0, self.idx)
-        k = len(self.cuts) - 1
-        works = [dist.all_reduce(buf[self.cuts[j]:self.cuts[j + 1]], op=dist.ReduceOp.SUM, async_op=True)
-                 for j in range(k)]
+        cuts, bounds = self._pieces()
+        buf = self._gather(flat_grad)
+        k = len(cuts) - 1
+        c = self.chunk
+        works = [dist.all_reduce(buf[cuts[j] * c:cuts[j + 1] * c], op=dist.ReduceOp.SUM, async_op=True) for j in range(k)]
         for j in range(k):
             works[j].wait()
-            g2.index_copy_(0, self.idx[self.cuts[j]:self.cuts[j + 1]], buf[self.cuts[j]:self.cuts[j + 1]])
-            update_range(self.bounds[j], n if self.bounds[j + 1] is None else self.bounds[j + 1])
+            self._scatter(flat_grad, buf[cuts[j] * c:cuts[j + 1] * c], cuts[j], cuts[j + 1])
+            update_range(bounds[j], n if bounds[j + 1] is None else bounds[j + 1])
         self.last_bytes = 4 * buf.numel()
 
 

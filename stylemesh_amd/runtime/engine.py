@@ -326,7 +326,11 @@ class StepEngine:
             self._pbuf[key] = factory()
         return self._pbuf[key]
 
-    def set_view(self, batch):
+    def set_view(self, batch, reducer=None):
+        """Per-view constants of ``batch``. ``reducer`` (multi-GPU, a ``SparseGradReducer``; only when the per-view
+        collective is due at this schedule position, see ``begin_step``): the max-all-reduce of the touch flags and the
+        device-side compaction of the exchange's chunk list are enqueued here, and the list's length rides the ONE host
+        read-back of this function - a view change costs no additional synchronisation on N > 1."""
         cfg = self.cfg
         rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
         dev = self.device
@@ -380,7 +384,15 @@ class StepEngine:
         for lv in levels:
             if hasattr(lv, "M"):
                 lv.active = True
+        self._union_flags = None
+        if reducer is not None:
+            flags = self.touch_flags(reducer.chunk_log2, levels)
+            count_dev = reducer.new_view_begin(flags)      # collective; flags = the union over the ranks, in place
+            msums = torch.cat([msums, count_dev.to(torch.float32)])    # (a chunk count < 2^24 is exact in fp32)
+            self._union_flags = flags
         sums = self._finish_view(levels, rgb_dev, msums)
+        if reducer is not None:
+            reducer.new_view_end(int(sums[-1]))
         if any(hasattr(lv, "M") and not sums[lv.index] > 0 for lv in levels):   # rare: an empty level -> redo without it
             for lv in levels:
                 if hasattr(lv, "M"):
@@ -988,25 +1000,43 @@ class StepEngine:
     def end_epoch(self):
         self.epoch += 1
 
-    def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None):
-        """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.
-        ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
+    def step_compute(self, batch, reducer=None, new_view=None, exchange=True):
+        """Everything of a training step BEFORE the optimizer: per-view work, the step head (regulariser loss of the
+        current texture, zero fills), the early half of the split update beside the forward pass, forward + backward
+        into the gradient arena and - ``exchange`` - the multi-GPU gradient exchange. Returns this step's losses as
+        device tensors that stay valid. ``optimizer_step`` closes the step (a Lightning-style caller does that from its
+        optimizer facade: ``model.FusedTextureAdam.step``)."""
         self.begin_step(batch, reducer, new_view)
         losses = self._step_begin()    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
-        if not (reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined")):
+        pipelined = reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph()
+        if not pipelined:
             self._adam_early()
         self.step_forward_backward()
         # content / style of loss_tensors() are views of the accumulators the NEXT step zeroes: hand out this step's
         # values (one 2-float copy), so that a caller may read them any number of steps later
         snap = self.loss_buf.clone()
         losses["content"], losses["style"] = snap[0:1], snap[1:2]
-        if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
-            self.exchange_and_update(world_size, reducer)
-            return losses
-        if reducer is not None:
-            reducer(self.arena.g)
-        self.optimizer_step(world_size)
+        if exchange and reducer is not None and not pipelined:
+            self._timed("exchange", lambda: reducer(self.arena.g))
         return losses
+
+    def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None):
+        """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.
+        ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
+        losses = self.step_compute(batch, reducer, new_view)
+        if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
+            self._timed("exchange+update", lambda: self.exchange_and_update(world_size, reducer))
+            return losses
+        self._timed("update", lambda: self.optimizer_step(world_size))
+        return losses
+
+    def _timed(self, tag, fn):
+        """Run ``fn``; when ``self.phase_timer`` is set (bench.py --gpus N: an ``ops.KernelTimer``), bracket it with HIP
+        events on the current stream so that the exchange and the update of a multi-GPU step can be told apart."""
+        t = getattr(self, "phase_timer", None)
+        if t is None or not t.enabled:
+            return fn()
+        return t.launch(fn, 0.0, tag)
 
     def begin_step(self, batch, reducer=None, new_view=None):
         """Per-view work at the head of a step. ``set_view`` runs when the batch's view KEY differs from the current
@@ -1022,19 +1052,25 @@ class StepEngine:
         else:
             key = self.view_key
         changed = self.view is None or key != self.view_key
-        if changed:
-            self.set_view(batch)
         if new_view is None:
             new_view = getattr(batch, "new_view", None)
+        # is the per-view collective due at this schedule position?
+        due = reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view)
+        in_set_view = due and changed and hasattr(reducer, "new_view_begin")
+        if changed:
+            self.set_view(batch, reducer if in_set_view else None)
         if reducer is not None and not hasattr(reducer, "new_view") and self.touched is not None:
             # A reducer that cannot union the ranks' footprints (the plain dense all-reduce, any callable): the other
             # ranks' gradients arrive in chunks this rank's views never flagged, which the sparse update would skip
             # without updating or zeroing them - every texel takes part in the update from now on
             self.touched = None
             self._other_flags = None
-        if reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view):
-            flags = self.touch_flags(reducer.chunk_log2)
-            reducer.new_view(flags)   # in place: now the union over the ranks' views
+        if due:
+            if in_set_view:
+                flags = self._union_flags     # set_view entered the collective and read the count with its own read-back
+            else:                             # a padded rank that keeps its view (or a reducer without the split form)
+                flags = self.touch_flags(reducer.chunk_log2)
+                reducer.new_view(flags)       # in place: now the union over the ranks' views
             if self.touched is not None:
                 if reducer.chunk_log2 == self.touched_log2:
                     ops.flags_or(self.touched, flags)   # the other ranks' gradients arrive with the exchange
@@ -1044,11 +1080,12 @@ class StepEngine:
                 else:
                     self.touched = None
 
-    def touch_flags(self, chunk_log2: int):
-        """int32 flag per 2^chunk_log2 floats of the gradient arena: can the current view's scatter write there?"""
+    def touch_flags(self, chunk_log2: int, levels=None):
+        """int32 flag per 2^chunk_log2 floats of the gradient arena: can the current view's scatter write there?
+        (``levels``: the levels of a view that is still being set up.)"""
         n_chunks = -(-self.arena.n // (1 << chunk_log2))
         flags = torch.zeros(n_chunks, dtype=torch.int32, device=self.device)
-        for lv in self.view:
+        for lv in (self.view if levels is None else levels):
             if lv.active:
                 ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, lv.pixel_weight, flags, chunk_log2)
         return flags

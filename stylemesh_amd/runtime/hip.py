@@ -88,6 +88,10 @@ SIGNATURES = {
     "sm_raster_maps": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "sm_mip_downsample": [_vp, _vp, _i, _i, _i, _vp],
     "sm_tex_sample_mip": [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "sm_flags_compact_ws_ints": [_sz],
+    "sm_flags_compact": [_vp, _sz, _vp, _vp, _vp, _vp],
+    "sm_chunks_gather": [_vp, _vp, _vp, _sz, _i, _vp, _vp],
+    "sm_chunks_scatter": [_vp, _vp, _vp, _sz, _i, _vp, _f, _vp],
     "sm_comm_unique_id_bytes": [],
     "sm_comm_get_unique_id": [_vp],
     "sm_comm_init": [_vp, _i, _vp, _i],
@@ -141,7 +145,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = _sz if name.endswith("_bytes") else _i
+        fn.restype = _sz if name.endswith(("_bytes", "_ws_ints")) else _i
     return lib
 
 

@@ -253,6 +253,33 @@ def flags_or(dst, src):
     hip.check(lib.sm_flags_or(ptr(dst), ptr(src), dst.numel(), hip.stream()), "sm_flags_or")
 
 
+def flags_compact(flags, idx_out, count_out, ws):
+    """Ascending indices of the non-zero ``flags`` (int32) into ``idx_out`` (int32, same length), their number into
+    ``count_out`` (int32 [1], device); ``ws``: int32 scratch of ``flags_compact_ws_ints(n)``. Deterministic, no sync."""
+    assert flags.dtype == idx_out.dtype == count_out.dtype == ws.dtype == torch.int32
+    assert idx_out.numel() >= flags.numel() and ws.numel() >= lib.sm_flags_compact_ws_ints(flags.numel())
+    hip.check(lib.sm_flags_compact(ptr(flags), flags.numel(), ptr(idx_out), ptr(count_out), ptr(ws), hip.stream()),
+              "sm_flags_compact")
+
+
+def flags_compact_ws_ints(n: int) -> int:
+    return lib.sm_flags_compact_ws_ints(n)
+
+
+def chunks_gather(arena, idx, n_idx: int, chunk_log2: int, compact, n_idx_dev=None):
+    """compact[j] = chunk idx[j] of ``arena`` (2^chunk_log2 floats each) for j < n (``n_idx_dev`` if given, else ``n_idx``)."""
+    assert compact.numel() >= n_idx << chunk_log2 and arena.data_ptr() % 16 == 0 and compact.data_ptr() % 16 == 0
+    hip.check(lib.sm_chunks_gather(ptr(arena), ptr(idx), ptr(n_idx_dev), n_idx, chunk_log2, ptr(compact), hip.stream()),
+              "sm_chunks_gather")
+
+
+def chunks_scatter(arena, idx, n_idx: int, chunk_log2: int, compact, scale: float = 1.0, n_idx_dev=None):
+    """The inverse of ``chunks_gather``: chunk idx[j] of ``arena`` = scale * compact[j]."""
+    assert compact.numel() >= n_idx << chunk_log2 and arena.data_ptr() % 16 == 0 and compact.data_ptr() % 16 == 0
+    hip.check(lib.sm_chunks_scatter(ptr(arena), ptr(idx), ptr(n_idx_dev), n_idx, chunk_log2, ptr(compact), scale,
+                                    hip.stream()), "sm_chunks_scatter")
+
+
 def clamp_sumsq(p, seg_end, sumsq_out=None):
     hip.check(lib.sm_clamp_sumsq(ptr(p), p.numel(), hip.size_array(seg_end), len(seg_end), CLAMP_LO, CLAMP_HI,
                                  ptr(sumsq_out), hip.stream()), "sm_clamp_sumsq")

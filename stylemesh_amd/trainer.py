@@ -63,19 +63,45 @@ class MiniTrainer:
         self.global_step = 0
         self.call_log = []   # hook names in call order (tests)
 
+    def _upload(self, batch):
+        mv = lambda t: t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t
+        return tuple(x if k == 8 else ([mv(u) for u in x] if isinstance(x, (list, tuple)) else mv(x))
+                     for k, x in enumerate(batch))
+
     def _to_device(self, batch):
         """Host batch -> device batch. The view index (element 8) stays on the host (reading it back would be a
         device-to-host sync per step); consecutive repeats of one view (same host tensors) reuse the device copy; the
-        schedule's ``new_view`` flag (``runtime.distributed.ViewBatch``) is carried over."""
+        schedule's ``new_view`` flag (``runtime.distributed.ViewBatch``) is carried over. With a prefetching loader
+        (``batch.upcoming``) the NEXT view is uploaded one view ahead on a copy stream, during the current view's steps:
+        a view change then finds its inputs resident in HBM (pinned host memory, asynchronous copies)."""
         from .runtime.distributed import ViewBatch
         last = getattr(self, "_last_dev", None)
+        ahead = getattr(self, "_ahead", None)
         if last is not None and last[0] is batch[0]:
             items = last[1]
+        elif ahead is not None and ahead[0] is batch[0]:
+            torch.cuda.current_stream().wait_event(ahead[2])
+            items = ahead[1]
+            self._last_dev, self._ahead = (batch[0], items), None
         else:
-            mv = lambda t: t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t
-            items = tuple(x if k == 8 else ([mv(u) for u in x] if isinstance(x, (list, tuple)) else mv(x))
-                          for k, x in enumerate(batch))
+            items = self._upload(batch)
             self._last_dev = (batch[0], items)
+        upcoming = getattr(batch, "upcoming", None)
+        if upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None:
+            nxt = upcoming()
+            if nxt is not None and nxt[0] is not batch[0]:
+                if not hasattr(self, "_copy_stream"):
+                    self._copy_stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(self._copy_stream):
+                    dev_items = self._upload(nxt)
+                    done = torch.cuda.Event()
+                    done.record()
+                main = torch.cuda.current_stream()
+                for x in dev_items:      # allocated on the copy stream, consumed on the main one
+                    for t in (x if isinstance(x, (list, tuple)) else [x]):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(main)
+                self._ahead = (nxt[0], dev_items, done)
         return ViewBatch(items, new_view=getattr(batch, "new_view", None))
 
     def _call(self, model, name, *a):
@@ -123,7 +149,13 @@ class MiniTrainer:
             if sched is not None:
                 sched.step()
             if self.progress and self.rank == 0:
-                print(f"epoch {epoch}: {self.global_step} steps, {time.time() - t0:.1f} s")
+                if self.device != "cpu" and torch.cuda.is_available():
+                    torch.cuda.synchronize()   # (the texture export of on_epoch_end has synchronised already)
+                print(f"epoch {epoch}: {self.global_step} steps, {time.time() - t0:.1f} s", flush=True)
+        if self.device != "cpu" and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self.progress and self.rank == 0:
+            print(f"fit: {time.time() - t0:.1f} s")
         if hasattr(self.logger, "flush"):
             self.logger.flush()
         return model

@@ -156,11 +156,15 @@ def _schedule_worker(rank, world, port, out_dir):
     eng.view, eng.view_key, eng._last_batch, eng.touched = None, None, None, None
     log = []
 
-    def set_view(batch):
+    def set_view(batch, reducer=None):
         eng.view, eng.view_key, eng._last_batch = [batch], batch[8], batch
         log.append(("set_view", batch[8]))
+        if reducer is not None:     # the real set_view enters the per-view collective itself when it is due
+            flags = touch_flags(reducer.chunk_log2)
+            reducer.new_view_end(int(reducer.new_view_begin(flags)))
+            eng._union_flags = flags
 
-    def touch_flags(chunk_log2):
+    def touch_flags(chunk_log2, levels=None):
         f = torch.zeros(n_chunks, dtype=torch.int32)
         f[(eng.view_key * 5) % n_chunks:(eng.view_key * 5) % n_chunks + 4] = 1
         return f
@@ -281,3 +285,43 @@ def test_comm_creation_failure_is_decided_collectively(tmp_path):
     assert r0["one_rank_fails"]["destroyed_after_explicit"] == [0] and r1["one_rank_fails"]["destroyed_after_explicit"] == []
     assert r0["all_fine"]["explicit"] == r1["all_fine"]["explicit"] == "RcclComm"
     assert r0["all_fine"]["default"] == r1["all_fine"]["default"] == "RcclComm"
+
+
+def test_view_prefetcher_order_peek_errors_and_early_close():
+    """``ViewPrefetcher`` (background decode of the schedule's views): order kept, at most ``depth`` views held, ``peek``
+    never blocks and shows the NEXT view once decoded, a decode error surfaces in the consumer, an abandoned iterator
+    stops the thread; ``scheduled_batches(prefetch=...)`` yields the same schedule as without."""
+    import threading
+    import time as _time
+    calls = []
+
+    def get(i):
+        calls.append(i)
+        _time.sleep(0.01)
+        return (torch.full((2,), float(i)),) + (None,) * 7 + (i,)
+    pf = D.ViewPrefetcher(get, range(6), depth=2, pin=False)
+    seen = []
+    for i, items in pf:
+        seen.append(i)
+        assert float(items[0][0]) == i and len(calls) <= len(seen) + 2 + 1    # never more than depth (+1 in flight) ahead
+        _time.sleep(0.03)
+        nxt = pf.peek()
+        assert nxt is None or float(nxt[0][0]) == i + 1
+    assert seen == list(range(6))
+
+    def bad(i):
+        if i == 2:
+            raise OSError("unreadable view")
+        return (i,)
+    with pytest.raises(OSError, match="unreadable"):
+        list(D.ViewPrefetcher(bad, range(4), depth=1, pin=False))
+    pf = D.ViewPrefetcher(get, range(100), depth=2, pin=False)
+    it = iter(pf)
+    next(it)
+    it.close()                      # abandoned after one view (limit_train_batches, an exception in the loop)
+    pf._thread.join(timeout=5)
+    assert not pf._thread.is_alive()
+    plain = [(b[8], b.new_view) for b in D.scheduled_batches(get, range(5), 1, 2, index_repeat=2)]
+    ahead = list(D.scheduled_batches(get, range(5), 1, 2, index_repeat=2, prefetch=2))
+    assert [(b[8], b.new_view) for b in ahead] == plain and all(callable(b.upcoming) for b in ahead)
+    assert ahead[0][0] is ahead[1][0]           # repeats of a view share the decoded tensors

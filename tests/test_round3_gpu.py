@@ -121,3 +121,77 @@ def test_more_than_eight_uv_levels_are_rejected():
     v[9] = [v[9][0]] * 9
     with pytest.raises(ValueError, match="UV levels"):
         eng.set_view(tuple(v))
+
+
+@pytest.mark.parametrize("n,p", [(1_044_480, 0.2), (1000, 0.5), (1025, 0.0), (70_000, 1.0), (3, 0.7)])
+def test_flags_compact_matches_nonzero(n, p):
+    """``sm_flags_compact``: the ascending index list of the flagged chunks and its length, without a host sync."""
+    require_gpu()
+    from stylemesh_amd.runtime import ops
+    g = torch.Generator(device="cuda").manual_seed(n)
+    flags = (torch.rand(n, device="cuda", generator=g) < p).to(torch.int32) * 7     # any non-zero value flags a chunk
+    idx = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(ops.flags_compact_ws_ints(n), dtype=torch.int32, device="cuda")
+    ops.flags_compact(flags, idx, cnt, ws)
+    want = flags.nonzero().flatten().to(torch.int32)
+    assert int(cnt) == want.numel()
+    assert torch.equal(idx[:want.numel()], want)
+    assert bool((idx[want.numel():] == -1).all())     # nothing written behind the list
+
+
+@pytest.mark.parametrize("chunk_log2", [2, 4, 6, 10])
+def test_chunks_gather_scatter_round_trip(chunk_log2):
+    require_gpu()
+    from stylemesh_amd.runtime import ops
+    chunk = 1 << chunk_log2
+    n_chunks = 5000
+    arena = torch.randn(n_chunks * chunk, device="cuda")
+    idx = torch.randperm(n_chunks, device="cuda")[:1777].sort().values.to(torch.int32)
+    buf = torch.full((idx.numel() * chunk + 64,), 3.0, device="cuda")
+    ops.chunks_gather(arena, idx, idx.numel(), chunk_log2, buf)
+    want = arena.view(-1, chunk).index_select(0, idx.long()).reshape(-1)
+    assert torch.equal(buf[:want.numel()], want) and bool((buf[want.numel():] == 3.0).all())
+    # device-side count: only the first *count chunks move, the launch is sized for the capacity
+    cnt = torch.tensor([1000], dtype=torch.int32, device="cuda")
+    buf2 = torch.zeros_like(buf)
+    ops.chunks_gather(arena, idx, idx.numel(), chunk_log2, buf2, n_idx_dev=cnt)
+    assert torch.equal(buf2[:1000 * chunk], want[:1000 * chunk]) and float(buf2[1000 * chunk:].abs().max()) == 0.0
+    out = torch.zeros_like(arena)
+    ops.chunks_scatter(out, idx, idx.numel(), chunk_log2, buf, scale=0.5)
+    ref = torch.zeros_like(arena)
+    ref.view(-1, chunk).index_copy_(0, idx.long(), 0.5 * want.view(-1, chunk))
+    assert torch.equal(out, ref)
+
+
+def test_sparse_reducer_on_the_device_matches_dense_sum():
+    """``SparseGradReducer`` with CUDA tensors (product kernels for the compaction / gather / scatter) against the plain
+    sums, one rank over a stand-in 'communicator' that doubles what it is given (= two ranks holding the same data)."""
+    require_gpu()
+    from stylemesh_amd.runtime.distributed import SparseGradReducer
+
+    class Doubler:
+        class ReduceOp:
+            SUM, MAX = "sum", "max"
+
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            if op == "sum":
+                t.mul_(2.0)
+    red = SparseGradReducer(Doubler, 2, chunk_log2=6)
+    n_chunks = 4096
+    flags = (torch.rand(n_chunks, device="cuda") < 0.3).to(torch.int32)
+    g = torch.randn(n_chunks * 64, device="cuda") * flags.repeat_interleave(64)
+    want = 2.0 * g
+    cnt = red.new_view_begin(flags.clone())
+    red.new_view_end(int(cnt))
+    assert red.n_idx == int(flags.sum()) and abs(red.fraction - red.n_idx / n_chunks) < 1e-9
+    red(g)
+    assert torch.equal(g, want) and red.last_bytes == red.n_idx * 256
+    # the pipelined form: ranges tile the arena in order
+    g2 = torch.randn(n_chunks * 64, device="cuda") * flags.repeat_interleave(64)
+    want2 = 2.0 * g2
+    ranges = []
+    red.pipelined(g2, lambda lo, hi: ranges.append((lo, hi)))
+    assert torch.equal(g2, want2) and ranges[0][0] == 0 and ranges[-1][1] == g2.numel()
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and len(ranges) == 4
