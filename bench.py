@@ -303,8 +303,10 @@ def main():
     # seeds whose view populates every UV level (the 4-level worst case the FLOP figure is quoted for)
     good = (0, 2, 6, 7, 9, 11, 12, 14, 16, 18, 22, 23, 26, 27, 29, 30, 32, 33, 35, 36, 37, 38, 39)
     seeds = [good[(v * world + rank) % len(good)] for v in range(max(1, n_views))]
-    views_cpu = make_views(wl, seeds)
-    views = [to_device(v, dev) for v in views_cpu]
+    distinct = {s_: v for s_, v in zip(sorted(set(seeds)), make_views(wl, sorted(set(seeds))))}   # (seeds repeat on long runs)
+    views_cpu = [distinct[s_] for s_ in seeds]
+    on_dev = {s_: to_device(v, dev) for s_, v in distinct.items()}
+    views = [on_dev[s_] for s_ in seeds]
     schedule = [views[(i // wl["index_repeat"]) % len(views)] for i in range(total_steps)]
 
     from stylemesh_amd.runtime.distributed import make_comm, make_grad_reducer, make_sparse_grad_reducer

@@ -169,9 +169,17 @@ class ScanNetSingleSceneDataModule:
         self.train_indices, self.val_indices = list(range(n_train)), list(range(n_train, n))
 
     def train_dataloader(self):
-        from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes on every rank
-        return scheduled_batches(lambda i: self.train_dataset[i], self.train_indices, self.rank, self.world_size,
-                                 self.index_repeat, repeat=self.sampler_mode == "repeat", prefetch=self.prefetch)
+        from ..runtime.distributed import DecodeProcess, scheduled_batches   # equal step counts + lock-step view changes
+        worker = None
+        if self.prefetch > 0:   # one persistent decode process for all epochs (re-started if an epoch was abandoned)
+            if getattr(self, "_worker", None) is None or not self._worker.alive() or self._worker.busy:
+                if getattr(self, "_worker", None) is not None:
+                    self._worker.close()
+                self._worker = DecodeProcess(self.train_dataset.__getitem__, depth=self.prefetch)
+            worker = self._worker
+        return scheduled_batches(self.train_dataset.__getitem__, self.train_indices, self.rank, self.world_size,
+                                 self.index_repeat, repeat=self.sampler_mode == "repeat", prefetch=self.prefetch,
+                                 worker=worker)
 
     def val_dataloader(self):
         return (self.val_dataset[i] for i in self.val_indices) if self.val_indices else None

@@ -39,8 +39,8 @@ def post(x: torch.Tensor) -> torch.Tensor:
     Unlike the reference this never mutates its argument (the reference's in-place ``mul_`` scales
     the live parameter when run on CPU, SURVEY.md section 4 hazard 2).
     """
-    x = x.detach().cpu().float() * (1.0 / 255.0)
-    mean = torch.tensor(IMAGENET_MEAN_BGR, dtype=x.dtype).view(3, 1, 1)
+    x = x.detach().float() * (1.0 / 255.0)      # on the tensor's own device (a 4096^2 texture: on the GPU)
+    mean = torch.tensor(IMAGENET_MEAN_BGR, dtype=x.dtype, device=x.device).view(3, 1, 1)
     x = x + mean
     return x[[2, 1, 0]].clamp(0, 1)
 

@@ -20,15 +20,42 @@ from .utils import from_grid_range
 
 
 def to_image(texture, startIndex=0, padChannels=True, normalize_transform=from_grid_range):
-    """Texture tensor -> PIL image (reference texture.py:10-19)."""
+    """Texture tensor -> PIL image (reference texture.py:10-19). The colour transform and the 8-bit quantisation run on
+    the tensor's own device; only the uint8 image (48 MB at 4096^2) crosses to the host."""
     from PIL import Image
-    texture = texture.detach().cpu()[startIndex:(startIndex + 3)].clone()
+    texture = texture.detach()[startIndex:(startIndex + 3)]
     if padChannels and texture.shape[0] != 3:
         c, (h, w) = 3 - texture.shape[0], texture.shape[1:]
         texture = torch.cat((texture, torch.zeros(c, h, w).type_as(texture)), dim=0)
-    texture = normalize_transform(texture).clamp(0, 1)
-    arr = (texture.permute(1, 2, 0) * 255.0 + 0.5).to(torch.uint8).numpy()   # ToPILImage of a float tensor
+    texture = normalize_transform(texture.clone()).clamp(0, 1)
+    arr = (texture.permute(1, 2, 0) * 255.0 + 0.5).to(torch.uint8).cpu().numpy()   # ToPILImage of a float tensor
     return Image.fromarray(arr)
+
+
+class _ImageWriter:
+    """JPEG encoding of the per-epoch texture exports off the training thread: ``save_image`` hands the finished PIL
+    image (a host copy: the texture keeps training) to ONE writer thread - the encoder runs in C without the
+    interpreter lock - and ``wait()`` (end of ``MiniTrainer.fit``, interpreter exit) joins what is pending. The
+    reference encodes five 4096^2-class JPEGs synchronously at every epoch end (model/model.py:378-385)."""
+
+    def __init__(self):
+        self._pool, self._pending = None, []
+
+    def save(self, image, path):
+        import atexit
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="stylemesh-texture-export")
+            atexit.register(self.wait)
+        self._pending.append(self._pool.submit(image.save, path))
+
+    def wait(self):
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
+
+
+IMAGE_WRITER = _ImageWriter()
 
 
 class _SampleFn(torch.autograd.Function):
@@ -85,7 +112,7 @@ class NeuralTexture(nn.Module):
         return self.data
 
     def save_image(self, dir, prefix="", normalize_transform=from_grid_range):
-        to_image(self.get_image(), normalize_transform=normalize_transform).save(join(dir, f"{prefix}texture.jpg"))
+        IMAGE_WRITER.save(to_image(self.get_image(), normalize_transform=normalize_transform), join(dir, f"{prefix}texture.jpg"))
 
     def save_layers(self, dir, prefix="", normalize_transform=from_grid_range):
         self.save_image(dir, prefix, normalize_transform)
@@ -134,7 +161,8 @@ class HierarchicalNeuralTexture(nn.Module):
 
     def save_image(self, dir, prefix="", normalize_transform=from_grid_range):
         with torch.no_grad():
-            to_image(self.get_image(), normalize_transform=normalize_transform).save(join(dir, f"{prefix}texture.jpg"))
+            IMAGE_WRITER.save(to_image(self.get_image(), normalize_transform=normalize_transform),
+                              join(dir, f"{prefix}texture.jpg"))
 
     def save_layers(self, dir, prefix="", normalize_transform=from_grid_range):
         for i, l in enumerate(self.layers):

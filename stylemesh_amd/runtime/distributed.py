@@ -68,27 +68,102 @@ def _pin_tree(x):
     return x
 
 
+LOADER_STATS = []   # the ViewPrefetchers of this process (one per epoch): their decode / wait times are diagnostics
+
+
+def _decode_main(get_view, tasks, results):
+    """Body of the decode PROCESS: per request (a list of view indices) the decoded views, in order, then None."""
+    import torch
+    torch.set_num_threads(2)
+    while True:
+        order = tasks.get()
+        if order is None:
+            return
+        for i in order:
+            try:
+                results.put((i, get_view(i)))
+            except BaseException as e:   # noqa: BLE001 - reported to the consumer, which raises it
+                results.put(("__error__", f"{type(e).__name__}: {e}"))
+                break
+        results.put(None)
+
+
+class DecodeProcess:
+    """ONE persistent worker process that decodes views (``get_view(i)``, picklable: a dataset's bound ``__getitem__``).
+    Why a process: the decode is a chain of numpy / PIL / torch calls with Python in between - run as a THREAD of the
+    training process it competes for the interpreter lock with the loop that enqueues ~200 kernel launches per step,
+    and both slow down (measured on the 276-view c3 scene: 235 ms per view decoded beside the loop against 56 ms
+    alone, the epoch 76 instead of ~150 views/s). The reference uses DataLoader worker processes for the same reason
+    (data/abstract_dataset.py:480). Decoded tensors come back through shared memory (torch.multiprocessing); the
+    process never touches the GPU. Started with 'spawn' (the parent has initialised HIP: no fork)."""
+
+    def __init__(self, get_view, depth: int = 2):
+        import torch.multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        self.tasks, self.results = ctx.Queue(), ctx.Queue(maxsize=max(1, depth))
+        self.proc = ctx.Process(target=_decode_main, args=(get_view, self.tasks, self.results), daemon=True,
+                                name="stylemesh-view-decode")
+        self.proc.start()
+        self.busy = False
+
+    def request(self, order):
+        assert not self.busy, "one request at a time"
+        self.busy = True
+        self.tasks.put(list(order))
+
+    def get(self):
+        item = self.results.get()
+        if item is None:
+            self.busy = False
+        return item
+
+    def alive(self):
+        return self.proc.is_alive()
+
+    def close(self):
+        if self.proc.is_alive():
+            self.proc.terminate()
+            self.proc.join(timeout=5)
+
+
 class ViewPrefetcher:
-    """Decodes the views of a schedule AHEAD of the training loop, in a background thread.
+    """Decodes the views of a schedule AHEAD of the training loop.
 
     The reference hides view loading behind the step with 4 DataLoader worker processes (data/abstract_dataset.py:480;
-    ``__getitem__`` :270-345 reads a jpg, a png and 6 ``.npy`` files and runs the numpy / PIL resizes). Here ONE thread is
-    enough: a view is optimised for ``index_repeat`` (20-100) consecutive steps - 0.1-0.6 s of GPU time - and its decode
-    (tens of ms, in numpy / PIL / file reads that release the GIL) runs during the PREVIOUS view's steps. Decoded
-    batches are pinned, so that the host-to-device copy the trainer issues is asynchronous (``MiniTrainer`` issues it
-    one view ahead, on a copy stream). ``depth`` decoded views are held at most (a 4-level ScanNet view is 14 MB)."""
+    ``__getitem__`` :270-345 reads a jpg, a png and 6 ``.npy`` files and runs the numpy / PIL resizes). Here ONE decoder
+    is enough: a view is optimised for ``index_repeat`` (20-100) consecutive steps - 0.1-0.6 s of GPU time - and its
+    decode (tens of ms) runs during the PREVIOUS view's steps: in a ``DecodeProcess`` (``worker``; default of the
+    directory loaders) or, for cheap / unpicklable ``get_view``s, in this object's own thread. A receiver thread pins the
+    decoded batches, so that the host-to-device copy the trainer issues is asynchronous (``MiniTrainer`` issues it one
+    view ahead, on a copy stream). ``depth`` decoded views are held at most (a 4-level ScanNet view is 14 MB)."""
 
-    def __init__(self, get_view, order, depth: int = 2, pin: bool = True):
+    def __init__(self, get_view, order, depth: int = 2, pin: bool = True, worker: "DecodeProcess | None" = None):
         import collections
         import threading
-        self._get, self._order, self._pin = get_view, list(order), pin
+        self._get, self._order, self._pin, self._worker = get_view, list(order), pin, worker
         self._ready = collections.deque()
         self._cv = threading.Condition()
-        self._depth, self._stop = max(1, depth), False
+        self._depth, self._stop, self._finished = max(1, depth), False, False
+        self.decode_s = 0.0     # time the thread spent decoding / receiving (and pinning) views
+        self.wait_s = 0.0       # time the consumer spent blocked on a view that was not ready
+        if worker is not None:
+            worker.request(self._order)
         self._thread = threading.Thread(target=self._run, name="stylemesh-view-prefetch", daemon=True)
         self._thread.start()
 
+    def _next(self, i):
+        if self._worker is None:
+            return i, self._get(i)
+        item = self._worker.get()
+        if item is None:
+            raise RuntimeError("the decode process ended its request early")
+        if item[0] == "__error__":
+            self._worker.get()   # the request's terminator
+            raise RuntimeError(f"view decode failed in the worker process: {item[1]}")
+        return item
+
     def _run(self):
+        import time
         try:
             for i in self._order:
                 with self._cv:
@@ -96,12 +171,17 @@ class ViewPrefetcher:
                         self._cv.wait()
                     if self._stop:
                         return
-                items = self._get(i)
+                t0 = time.perf_counter()
+                i, items = self._next(i)
                 if self._pin:
                     items = _pin_tree(items)
+                self.decode_s += time.perf_counter() - t0
                 with self._cv:
                     self._ready.append((i, items))
                     self._cv.notify_all()
+            if self._worker is not None:
+                assert self._worker.get() is None      # the request's terminator: the worker is free again
+            self._finished = True
             with self._cv:
                 self._ready.append(None)
                 self._cv.notify_all()
@@ -117,13 +197,16 @@ class ViewPrefetcher:
         return head[1] if isinstance(head, tuple) else None
 
     def __iter__(self):
+        import time
         try:
             while True:
+                t0 = time.perf_counter()
                 with self._cv:
                     while not self._ready:
                         self._cv.wait()
                     head = self._ready.popleft()
                     self._cv.notify_all()
+                self.wait_s += time.perf_counter() - t0
                 if head is None:
                     return
                 if isinstance(head, BaseException):
@@ -136,21 +219,28 @@ class ViewPrefetcher:
         with self._cv:
             self._stop = True
             self._cv.notify_all()
+        if self._worker is not None and not self._finished:
+            # abandoned mid-request (limit_train_batches, an exception in the loop): the worker still holds undelivered
+            # views of this request - end it; the owner starts a fresh one for the next epoch
+            self._worker.close()
 
 
-def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repeat=1, repeat=True, prefetch: int = 0):
+def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repeat=1, repeat=True, prefetch: int = 0,
+                      worker=None):
     """The rank's train schedule as ``ViewBatch``es: views ``padded_shard(indices)``, each ``index_repeat``
     consecutive times (``repeat=False``: once, the 'sequential' sampler mode). Consecutive repeats yield the SAME
     object (one decode / upload per view; callers may cache by identity), ``new_view`` marks the block boundaries.
-    ``prefetch`` > 0: views are decoded (and pinned) up to that many ahead by a ``ViewPrefetcher`` thread; every
+    ``prefetch`` > 0: views are decoded (and pinned) up to that many ahead by a ``ViewPrefetcher`` (in the ``worker``
+    ``DecodeProcess`` if one is given, else in a thread); every
     yielded batch then carries ``upcoming`` - a callable returning the NEXT view's decoded items once they are ready -
     so that the consumer can start its upload during the current view's steps."""
     rep = index_repeat if repeat else 1
     count = lambda i: rep[i] if isinstance(rep, list) else rep
     order = [i for i in padded_shard(indices, rank, world_size) if count(i) >= 1]
     if prefetch > 0:
-        source = ViewPrefetcher(get_view, order, depth=prefetch)
+        source = ViewPrefetcher(get_view, order, depth=prefetch, worker=worker)
         views, upcoming = iter(source), source.peek
+        LOADER_STATS.append(source)
     else:
         views, upcoming = ((i, get_view(i)) for i in order), None
     for i, items in views:

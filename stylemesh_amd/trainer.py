@@ -122,8 +122,14 @@ class MiniTrainer:
         if hasattr(opt, "world_size"):
             opt.world_size = self.world_size
         t0 = time.time()
+        def now():
+            if self.device != "cpu" and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return time.time()
         for epoch in range(self.max_epochs):
             model.current_epoch = epoch
+            t_epoch = now()
+            steps0 = self.global_step
             self._call(model, "on_train_epoch_start")
             for batch_idx, batch in enumerate(datamodule.train_dataloader()):
                 if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
@@ -134,6 +140,7 @@ class MiniTrainer:
                 out["loss"].backward()
                 opt.step()
                 self.global_step += 1
+            t_train = now()
             val_loader = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
             if val_loader is not None:
                 self._call(model, "on_validation_epoch_start")
@@ -149,13 +156,24 @@ class MiniTrainer:
             if sched is not None:
                 sched.step()
             if self.progress and self.rank == 0:
-                if self.device != "cpu" and torch.cuda.is_available():
-                    torch.cuda.synchronize()   # (the texture export of on_epoch_end has synchronised already)
-                print(f"epoch {epoch}: {self.global_step} steps, {time.time() - t0:.1f} s", flush=True)
+                t_end = now()
+                n = self.global_step - steps0
+                print(f"epoch {epoch}: {self.global_step} steps, {t_end - t0:.1f} s "
+                      f"[train loop {t_train - t_epoch:.2f} s = {n / max(t_train - t_epoch, 1e-9):.1f} steps/s, "
+                      f"validation + epoch-end hooks {t_end - t_train:.2f} s]", flush=True)
         if self.device != "cpu" and torch.cuda.is_available():
             torch.cuda.synchronize()
+        try:    # texture exports still being encoded by the writer thread
+            from .model.texture.texture import IMAGE_WRITER
+            IMAGE_WRITER.wait()
+        except ImportError:
+            pass
         if self.progress and self.rank == 0:
             print(f"fit: {time.time() - t0:.1f} s")
+            from .runtime.distributed import LOADER_STATS
+            if LOADER_STATS:
+                print(f"loader: decode {sum(p.decode_s for p in LOADER_STATS):.1f} s in the prefetch thread, "
+                      f"training loop blocked {sum(p.wait_s for p in LOADER_STATS):.1f} s waiting for views")
         if hasattr(self.logger, "flush"):
             self.logger.flush()
         return model

@@ -178,6 +178,11 @@ def test_sparse_reducer_on_the_device_matches_dense_sum():
         def all_reduce(t, op=None, async_op=False):
             if op == "sum":
                 t.mul_(2.0)
+
+            class Done:
+                def wait(self):
+                    pass
+            return Done() if async_op else None
     red = SparseGradReducer(Doubler, 2, chunk_log2=6)
     n_chunks = 4096
     flags = (torch.rand(n_chunks, device="cuda") < 0.3).to(torch.int32)

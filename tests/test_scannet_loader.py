@@ -98,3 +98,27 @@ def test_matterport_region_layout(tmp_path):
     dm = MatterportSingleRegionDataModule(str(tmp_path), "house1", region_index=2, resize_size=64, split=(0.75, 0.25))
     dm.setup()
     assert dm.train_indices == [0, 1, 2] and dm.val_indices == [3]
+
+
+def test_datamodule_prefetch_process_yields_the_same_schedule(tmp_path):
+    """The decode PROCESS behind the directory loader (default ``prefetch=2``): same views, same order, same tensors as
+    the in-loop decode; one worker serves consecutive epochs; an abandoned epoch does not poison the next."""
+    write_scene(str(tmp_path), "s", render_views(5), [64, 108])
+    kw = dict(resize_size=64, split=(0.8, 0.2), index_repeat=2)
+    plain = ScanNetSingleSceneDataModule(str(tmp_path), "s", prefetch=0, **kw)
+    ahead = ScanNetSingleSceneDataModule(str(tmp_path), "s", prefetch=2, **kw)
+    plain.setup(), ahead.setup()
+    want = list(plain.train_dataloader())
+    for epoch in range(2):
+        got = list(ahead.train_dataloader())
+        assert [int(b[8]) for b in got] == [int(b[8]) for b in want] == [0, 0, 1, 1, 2, 2, 3, 3]
+        for a, b in zip(got, want):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[9][1], b[9][1]) and torch.equal(a[10], b[10])
+            assert a.new_view == b.new_view
+    pid = ahead._worker.proc.pid
+    it = iter(ahead.train_dataloader())
+    next(it)
+    it.close()                                   # epoch abandoned after one step
+    got = list(ahead.train_dataloader())         # a fresh worker takes over
+    assert [int(b[8]) for b in got] == [0, 0, 1, 1, 2, 2, 3, 3] and ahead._worker.proc.pid != pid
+    ahead._worker.close()

@@ -114,7 +114,10 @@ def main():
         raise SystemExit(r.returncode)
     epochs = [(int(m.group(1)), int(m.group(2)), float(m.group(3)))
               for m in re.finditer(r"epoch (\d+): (\d+) steps, ([\d.]+) s", r.stdout)]
+    loops = [(float(m.group(1)), float(m.group(2)), float(m.group(3)))
+             for m in re.finditer(r"train loop ([\d.]+) s = ([\d.]+) steps/s, validation \+ epoch-end hooks ([\d.]+) s", r.stdout)]
     fit = re.search(r"fit: ([\d.]+) s", r.stdout)
+    ld = re.search(r"loader: decode ([\d.]+) s .* blocked ([\d.]+) s", r.stdout)
     n_train = int(0.99 * args.views)
     per_epoch = []
     prev_steps, prev_t = 0, 0.0
@@ -129,9 +132,13 @@ def main():
            "fit_seconds_incl_setup": None if fit is None else float(fit.group(1)),
            "cli_wall_clock_s_incl_process_start_and_style_setup": round(wall, 1),
            "mean_views_per_s": round(epochs[-1][1] / epochs[-1][2], 2) if epochs else None,
-           "per_epoch": per_epoch, "scene_write_s": round(t_scene, 1), "scene_size_gb": round(size_gb, 2),
+           "per_epoch": per_epoch,
+           "train_loop_views_per_s": [l[1] for l in loops], "train_loop_s": [l[0] for l in loops],
+           "validation_and_export_s": [l[2] for l in loops], "scene_write_s": round(t_scene, 1), "scene_size_gb": round(size_gb, 2),
            "scene_source": "HIP rasteriser (render_trajectory), ScanNet directory layout, jpg / png / npy files",
            "loader": f"ScanNetSingleSceneDataModule, prefetch thread {'on' if args.num_workers > 0 else 'off'}, pinned upload one view ahead",
+           "loader_decode_s": None if ld is None else float(ld.group(1)),
+           "training_loop_blocked_on_loader_s": None if ld is None else float(ld.group(2)),
            "texture_exports": len(tex), "command": " ".join(cmd[1:]).replace(root, "<scene-root>")}
     print(json.dumps(out))
     if args.out:
