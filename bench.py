@@ -320,6 +320,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from stylemesh_amd.runtime.engine import trunk_stream
+    main_stream = trunk_stream(dev)     # the step's trunk on a high-priority stream (the side streams keep normal priority)
+    if main_stream is not None:
+        torch.cuda.set_stream(main_stream)
     timer = None if args.no_conv_timer else ops.KernelTimer()
     if world > 1:   # event-timed exchange and update of every step (two event pairs per step)
         eng.phase_timer = ops.KernelTimer()

@@ -433,7 +433,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(ConvArgs a, const f
 #pragma unroll
         for (int j = 0; j < 4; ++j) in4[j] = interior(q + j, P.H, P.W, P.Wp);
         const int Cout = a.Cout;
-        for (int co = 0; co < Cout; co += 4) {   // four output channels per pass: their 27 weights each as scalar float4s
+        // small grids (a single 256 x 341 level is 86 blocks on 256 CUs): blockIdx.y walks groups of output channels, every
+        // group re-reading the 3-plane input window (a few KB, L2)
+        const int co_per = Cout / gridDim.y, co_begin = blockIdx.y * co_per;
+        for (int co = co_begin; co < co_begin + co_per; co += 4) {   // four output channels per pass: 27 weights each as scalar float4s
             // accumulators as pairs of output channels: the multiply-adds issue as v_pk_fma_f32 (two per instruction)
             f32x2 acc[2][4];
 #pragma unroll
@@ -478,7 +481,9 @@ static int launch_conv_c3_fwd(const ConvArgs& a0, int n_list, hipStream_t s) {
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + 1023) / 1024;
     const int n = a.tile_list ? n_list : a.tile_begin[a.n_problems];
     if (n == 0) return 0;
-    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(n), dim3(256), 0, s, a, a.wt, a.bias);
+    int gy = 1;   // >= ~4 blocks per CU in total; groups of at least 4 channels that divide Cout
+    while (n * gy < 4 * SM_NUM_CU && a.Cout % (gy * 2 * 4) == 0) gy *= 2;
+    hipLaunchKernelGGL(conv3x3_c3_fwd_kernel, dim3(n, gy), dim3(256), 0, s, a, a.wt, a.bias);
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -679,6 +684,43 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(PlaneGroup g, con
     int bx;
     const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
     dgrad_c3_body(P.a, wd, P.out, Cin, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), bx);
+}
+
+// The same for SMALL grids (one 256 x 341 level = 86 units of 1024 positions on 256 CUs: 39 us for 22 MB): ONE position
+// per thread, blockIdx.y = quarter of the 1024-position unit - four times the blocks, the same units / tile lists; the
+// nine taps of a channel are L1 hits of the neighbouring lanes' lines. Same accumulation order per output (channel-major,
+// taps row-major) as the four-position form: bit-identical results.
+__global__ __launch_bounds__(256) void conv3x3_dgrad_c3_small_kernel(PlaneGroup g, const float* __restrict__ wd, int Cin) {
+    int bx;
+    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
+    const int Wp = row_stride(P.W), plane = plane_size(P.H, P.W);
+    const int q = Wp + bx * 1024 + blockIdx.y * 256 + threadIdx.x;
+    if (q >= (P.H + 1) * Wp) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    float cur[9], nxt[9];
+#define SM_DGS_LOAD(dst_, ci_)                                                          \
+    {                                                                                   \
+        const float* p_ = P.a + (size_t)min((ci_), Cin - 1) * plane + q;                \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) dst_[ky * 3 + kx] = p_[(ky - 1) * Wp + kx - 1]; \
+    }
+    SM_DGS_LOAD(nxt, 0)
+    for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
+        SM_DGS_LOAD(nxt, ci + 1)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* w = wd + (t * Cin + ci) * 4;
+            acc[0] = fmaf(w[0], cur[t], acc[0]);
+            acc[1] = fmaf(w[1], cur[t], acc[1]);
+            acc[2] = fmaf(w[2], cur[t], acc[2]);
+        }
+    }
+#undef SM_DGS_LOAD
+    const bool in = interior(q, P.H, P.W, Wp);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P.out[(size_t)c * plane + q] = in ? acc[c] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
@@ -888,7 +930,10 @@ int sm_conv3x3_dgrad_c3_tiles(const sm_plane_problem* problems, int n, const flo
     if (int e = make_plane_group(g, problems, n, 0, tile_list)) return e;
     const int blocks = tile_list ? n_list : g.block_begin[n];
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
+    if (blocks < 2 * sm::SM_NUM_CU)   // a small grid: one position per thread, four blocks per unit
+        hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_small_kernel, dim3(blocks, 4), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
+    else
+        hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
     SM_LAUNCH_CHECK();
     return 0;
 }

@@ -75,6 +75,18 @@ class EngineConfig:
         return w
 
 
+def trunk_stream(device):
+    """A HIGH-priority HIP stream for the step's trunk (convs, pools, sampling, scatter, the closing update). The
+    engine's side streams - style branches with thousands of microseconds of slack, the early half of the split update -
+    are created at normal priority, so the hardware queues dispatch the trunk's workgroups first and the side work fills
+    what is left: measured +2-4 % on the c3 step (165.8 against 159.6-162.4 views/s, same box, alternating runs).
+    ``MiniTrainer.fit`` and ``bench.py`` make it the current stream (STYLEMESH_MAIN_PRIORITY=normal: keep the caller's)."""
+    if os.environ.get("STYLEMESH_MAIN_PRIORITY", "high") != "high" or not torch.cuda.is_available():
+        return None
+    torch.cuda.synchronize(device)
+    return torch.cuda.Stream(device=device, priority=-1)
+
+
 class TextureArena:
     """Texture, gradient and Adam moments of all layers back to back in four flat fp32 arenas; the layers are
     [3,H_l,W_l] views (the reference's Parameter layout, texture.py:29-32)."""
@@ -158,6 +170,14 @@ class StepEngine:
         # style layers whose branch runs on a side stream beside the conv trunk (grouped loss phase only)
         self.side_style_layers = tuple(x for x in os.environ.get("STYLEMESH_SIDE_STYLE", "r11").split(",") if x)
         self.side_streams = os.environ.get("STYLEMESH_SIDE_STREAMS", "1") != "0"
+        # WHERE in the forward pass the HBM-bound side work is forked (a conv output's name; 'head' = before the texture
+        # sampling). The split update's early half and the early style branches (relu1_1: Gram kernels over the largest
+        # planes) stream HBM at 3-4 TB/s: beside the head of the step - texture sampling, conv1_1, conv1_2, all
+        # HBM-bound themselves - they doubled those kernels' durations (0.41 instead of 0.22 ms before the first MFMA
+        # conv of the round-3 timeline); beside the deep, matrix-core-bound convs (conv3_x ...) they are nearly free.
+        self.early_update_at = os.environ.get("STYLEMESH_EARLY_UPDATE_AT", "r31")
+        self.early_style_at = os.environ.get("STYLEMESH_EARLY_STYLE_AT", "r31")
+        self._adam_early_pending = False
         self._step_zeroed = False      # the step's accumulators were zeroed by _step_begin
         self._loss_tables = None       # (signature, Gram / style-loss / Gram-backward problem tables, slab keys)
         self._gram_bwd_ws = {}         # (C, level, layer) -> scratch of the derivative matrices' operand images
@@ -203,6 +223,14 @@ class StepEngine:
         self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
         self.overlap_min_pixels = int(os.environ.get("STYLEMESH_OVERLAP_MIN_PIXELS", "400000"))
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
+
+    def _new_side_stream(self):
+        """Side streams carry work with slack (style branches joined many kernels later, the early half of the update);
+        STYLEMESH_SIDE_PRIORITY=low asks the hardware queues to dispatch the main stream's workgroups first."""
+        if os.environ.get("STYLEMESH_SIDE_PRIORITY", "") == "low":
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            return torch.cuda.Stream(device=self.device, priority=lo)
+        return torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ texture access
     def load_texture(self, layer_tensors):
@@ -505,10 +533,13 @@ class StepEngine:
         if self.view is None or self.targets is None:
             raise RuntimeError("set_style_image() and set_view() must be called first")
         cfg = self.cfg
+        from .vgg import OUT_NAMES as vgg_names
         w_style = float(cfg.loss_weights.get("style", 0.0))
         w_content = float(cfg.loss_weights.get("content", 0.0))
         active = [lv for lv in self.view if lv.active]
         if not active or self.deepest is None:
+            if self._adam_early_pending:
+                self._adam_early()
             self._zero_step_accumulators()
             return
         # layer-major over the active UV levels: every conv layer is ONE grouped launch over all levels
@@ -525,12 +556,14 @@ class StepEngine:
         style_on = w_style != 0.0
         side_layers = [l for l in cfg.style_layers if l != self.deepest] if (style_on and self.overlap_style) else []
         if side_layers:
+            if self._adam_early_pending:
+                self._adam_early()
             # A style layer's branch (masked Gram -> loss + derivative matrices -> Gram backward into grad[layer])
             # only has to finish before the backward pass reaches that layer: fork it onto a side stream right
             # after the layer's forward conv and join right before the dgrad that consumes grad[layer].
             main = torch.cuda.current_stream()
             while len(self._lv_streams) < len(active):
-                self._lv_streams.append(torch.cuda.Stream(device=self.device))
+                self._lv_streams.append(self._new_side_stream())
             done = {}
 
             def fork(layer):   # one side stream per UV level
@@ -581,7 +614,7 @@ class StepEngine:
             if side:
                 main = torch.cuda.current_stream()
                 if not self._lv_streams:
-                    self._lv_streams.append(torch.cuda.Stream(device=self.device))
+                    self._lv_streams.append(self._new_side_stream())
                 st = self._lv_streams[0]
                 last_early = max(early, key=depth_of) if early else None
 
@@ -600,17 +633,34 @@ class StepEngine:
                     for lv, b in zip(active, bufs):
                         self._content_term(lv, b, cfg.content_layers.index(layer), layer, w_content)
 
+                # the early style branches fork at ``early_style_at`` (never before their own layer exists)
+                fork_at = last_early
+                if early and self.early_style_at in vgg_names and depth_of(self.early_style_at) > depth_of(last_early) \
+                        and depth_of(self.early_style_at) <= depth_of(self.deepest):
+                    fork_at = self.early_style_at
+
                 def fork(layer):
-                    if layer == last_early:
+                    if layer == fork_at and early:
                         on_side(lambda: self._style_group(active, bufs, w_style, early), early)
-                    elif layer in side_content:
+                    if layer in side_content:
                         on_side(lambda: content_terms(layer), (layer,))
 
                 def join(layer):
                     done = side_done.pop(layer, None)
                     if done is not None:
                         main.wait_event(done)
-            self.vgg.forward_group(bufs, self.view_tiles, on_layer=fork if side else None, amax=self.amax)
+            upd_at = self.early_update_at if (self.early_update_at in vgg_names
+                                              and depth_of(self.early_update_at) <= depth_of(self.deepest)) else None
+
+            def on_layer(layer):
+                if self._adam_early_pending and layer == upd_at:
+                    self._adam_early()
+                if side:
+                    fork(layer)
+            if self._adam_early_pending and upd_at is None:
+                self._adam_early()
+            self.vgg.forward_group(bufs, self.view_tiles, on_layer=on_layer if (side or self._adam_early_pending) else None,
+                                   amax=self.amax)
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
@@ -632,7 +682,7 @@ class StepEngine:
             elif concurrent:
                 main = torch.cuda.current_stream()
                 while len(self._lv_streams) < len(active) - 1:
-                    self._lv_streams.append(torch.cuda.Stream(device=self.device))
+                    self._lv_streams.append(self._new_side_stream())
                 fork = torch.cuda.Event()
                 fork.record(main)
                 joins = []
@@ -921,6 +971,7 @@ class StepEngine:
         their update (step count of the update that closes this step) runs on a side stream beside the forward pass;
         ``_optimizer_launch`` then only walks the view's own chunks. Call after ``loss_tensors()`` (which reads the
         sum of squares this zeroes)."""
+        self._adam_early_pending = False
         if not (self.split_update and self.sparse_update and self.touched is not None and self._view_flags is not None
                 and not self._can_graph() and not torch.cuda.is_current_stream_capturing()
                 and self.view is not None and self._overlap_pays([lv for lv in self.view if lv.active])):
@@ -929,7 +980,7 @@ class StepEngine:
             self._other_flags = (self.touched, ((self.touched != 0) & (self._view_flags == 0)).to(torch.int32))
         main = torch.cuda.current_stream()
         while len(self._lv_streams) < 2:
-            self._lv_streams.append(torch.cuda.Stream(device=self.device))
+            self._lv_streams.append(self._new_side_stream())
         st = self._lv_streams[1]
         ev = torch.cuda.Event()
         ev.record(main)
@@ -1010,8 +1061,13 @@ class StepEngine:
         losses = self._step_begin()    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         pipelined = reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph()
         if not pipelined:
-            self._adam_early()
+            if self._can_graph() or self.early_update_at == "head":
+                self._adam_early()
+            else:
+                self._adam_early_pending = True   # forked inside the forward pass (``early_update_at``)
         self.step_forward_backward()
+        if self._adam_early_pending:              # (a forward pass that never reached the fork point)
+            self._adam_early()
         # content / style of loss_tensors() are views of the accumulators the NEXT step zeroes: hand out this step's
         # values (one 2-float copy), so that a caller may read them any number of steps later
         snap = self.loss_buf.clone()

@@ -117,6 +117,11 @@ class MiniTrainer:
         model.world_size = self.world_size
         if hasattr(model, "to") and self.device != "cpu":
             model.to(self.device)
+        if self.device != "cpu" and torch.cuda.is_available():
+            from .runtime.engine import trunk_stream
+            st = trunk_stream(self.device)       # high-priority stream for the step's trunk (side work fills the rest)
+            if st is not None:
+                torch.cuda.set_stream(st)
         optimizers, schedulers = model.configure_optimizers()
         opt, sched = optimizers[0], (schedulers[0] if schedulers else None)
         if hasattr(opt, "world_size"):
