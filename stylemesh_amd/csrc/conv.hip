@@ -686,43 +686,6 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(PlaneGroup g, con
     dgrad_c3_body(P.a, wd, P.out, Cin, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), bx);
 }
 
-// The same for SMALL grids (one 256 x 341 level = 86 units of 1024 positions on 256 CUs: 39 us for 22 MB): ONE position
-// per thread, blockIdx.y = quarter of the 1024-position unit - four times the blocks, the same units / tile lists; the
-// nine taps of a channel are L1 hits of the neighbouring lanes' lines. Same accumulation order per output (channel-major,
-// taps row-major) as the four-position form: bit-identical results.
-__global__ __launch_bounds__(256) void conv3x3_dgrad_c3_small_kernel(PlaneGroup g, const float* __restrict__ wd, int Cin) {
-    int bx;
-    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
-    const int Wp = row_stride(P.W), plane = plane_size(P.H, P.W);
-    const int q = Wp + bx * 1024 + blockIdx.y * 256 + threadIdx.x;
-    if (q >= (P.H + 1) * Wp) return;
-    float acc[3] = {0.f, 0.f, 0.f};
-    float cur[9], nxt[9];
-#define SM_DGS_LOAD(dst_, ci_)                                                          \
-    {                                                                                   \
-        const float* p_ = P.a + (size_t)min((ci_), Cin - 1) * plane + q;                \
-        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                \
-            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) dst_[ky * 3 + kx] = p_[(ky - 1) * Wp + kx - 1]; \
-    }
-    SM_DGS_LOAD(nxt, 0)
-    for (int ci = 0; ci < Cin; ++ci) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
-        SM_DGS_LOAD(nxt, ci + 1)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float* w = wd + (t * Cin + ci) * 4;
-            acc[0] = fmaf(w[0], cur[t], acc[0]);
-            acc[1] = fmaf(w[1], cur[t], acc[1]);
-            acc[2] = fmaf(w[2], cur[t], acc[2]);
-        }
-    }
-#undef SM_DGS_LOAD
-    const bool in = interior(q, P.H, P.W, Wp);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) P.out[(size_t)c * plane + q] = in ? acc[c] : 0.f;
-}
-
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PlaneGroup g) {
     int bx;
     const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
@@ -930,10 +893,9 @@ int sm_conv3x3_dgrad_c3_tiles(const sm_plane_problem* problems, int n, const flo
     if (int e = make_plane_group(g, problems, n, 0, tile_list)) return e;
     const int blocks = tile_list ? n_list : g.block_begin[n];
     if (blocks == 0) return 0;
-    if (blocks < 2 * sm::SM_NUM_CU)   // a small grid: one position per thread, four blocks per unit
-        hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_small_kernel, dim3(blocks, 4), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
-    else
-        hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
+    // (a one-position-per-thread form with four times the blocks for small grids measured SLOWER on the single-level
+    // workload: 45 against 39 us - nine 4-byte loads per channel instead of 1.5 sixteen-byte ones)
+    hipLaunchKernelGGL(sm::conv3x3_dgrad_c3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, wd, Cin);
     SM_LAUNCH_CHECK();
     return 0;
 }

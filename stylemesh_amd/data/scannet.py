@@ -151,8 +151,9 @@ class ScanNetSingleSceneDataModule:
 
     def __init__(self, root_path, scene, resize_size=256, pyramid_levels=5, min_pyramid_depth=0.25,
                  min_pyramid_height=32, max_images=-1, split=(0.8, 0.2), index_repeat=1, sampler_mode="repeat",
-                 rank=0, world_size=1, prefetch=2):
-        self.prefetch = prefetch   # views decoded ahead by a background thread (0 = decode inside the training loop)
+                 rank=0, world_size=1, prefetch=2, decode_workers=1):
+        self.prefetch = prefetch   # views decoded ahead of the training loop (0 = decode inside the loop)
+        self.decode_workers = decode_workers   # decode processes (the reference's DataLoader ``num_workers``)
         self.args = dict(root_path=join(root_path, "train/images"), scene=scene, resize_size=resize_size,
                          pyramid_levels=pyramid_levels, min_pyramid_depth=min_pyramid_depth,
                          min_pyramid_height=min_pyramid_height, max_images=max_images)
@@ -175,7 +176,8 @@ class ScanNetSingleSceneDataModule:
             if getattr(self, "_worker", None) is None or not self._worker.alive() or self._worker.busy:
                 if getattr(self, "_worker", None) is not None:
                     self._worker.close()
-                self._worker = DecodeProcess(self.train_dataset.__getitem__, depth=self.prefetch)
+                self._worker = DecodeProcess(self.train_dataset.__getitem__, depth=self.prefetch,
+                                             n_workers=self.decode_workers)
             worker = self._worker
         return scheduled_batches(self.train_dataset.__getitem__, self.train_indices, self.rank, self.world_size,
                                  self.index_repeat, repeat=self.sampler_mode == "repeat", prefetch=self.prefetch,

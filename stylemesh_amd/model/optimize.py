@@ -79,7 +79,8 @@ def main(args):
                                           min_pyramid_height=args.min_pyramid_height, max_images=args.max_images,
                                           split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
                                           sampler_mode=args.sampler_mode, rank=rank, world_size=world,
-                                          prefetch=2 if args.num_workers > 0 else 0)
+                                          prefetch=2 if args.num_workers > 0 else 0,
+                                          decode_workers=max(1, min(args.num_workers, 4)))
     elif args.dataset == "matterport":
         from ..data.matterport import MatterportSingleRegionDataModule
         dm = MatterportSingleRegionDataModule(args.root_path, args.scene, region_index=args.matterport_region_index,
@@ -88,7 +89,8 @@ def main(args):
                                               min_pyramid_height=args.min_pyramid_height, max_images=args.max_images,
                                               split=(args.train_split, args.val_split), index_repeat=args.index_repeat,
                                               sampler_mode=args.sampler_mode, rank=rank, world_size=world,
-                                              prefetch=2 if args.num_workers > 0 else 0)
+                                              prefetch=2 if args.num_workers > 0 else 0,
+                                              decode_workers=max(1, min(args.num_workers, 4)))
     else:
         raise ValueError(f"Unsupported dataset: {args.dataset}")
     dm.prepare_data()

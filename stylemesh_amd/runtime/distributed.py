@@ -58,6 +58,37 @@ class ViewBatch(tuple):
         return self
 
 
+class _PinnedRing:
+    """Pinned staging buffers for the decoded views, allocated ONCE: a ring of ``slots`` buffers per tensor position of
+    the batch structure, filled by ``copy_`` (a host memcpy). ``tensor.pin_memory()`` per view allocates fresh pinned
+    memory for ~20 tensors every time (hipHostMalloc: milliseconds each until the allocator's cache warms, and a
+    single-level view leaves only 24 ms per view): 23 ms per view measured in the receiver thread."""
+
+    def __init__(self, slots: int):
+        self.slots, self.turn, self.bufs = slots, 0, {}
+
+    def _put(self, x, path):
+        import torch
+        if torch.is_tensor(x):
+            if x.is_cuda or not torch.cuda.is_available():
+                return x
+            key = (path, tuple(x.shape), x.dtype)
+            ring = self.bufs.get(key)
+            if ring is None:
+                ring = self.bufs[key] = [torch.empty(x.shape, dtype=x.dtype).pin_memory() for _ in range(self.slots)]
+            dst = ring[self.turn % self.slots]
+            dst.copy_(x)
+            return dst
+        if isinstance(x, (list, tuple)):
+            return type(x)(self._put(u, path + (k,)) for k, u in enumerate(x))
+        return x
+
+    def stage(self, items):
+        out = self._put(items, ())
+        self.turn += 1
+        return out
+
+
 def _pin_tree(x):
     """Host tensors of a batch tuple into pinned memory (asynchronous H2D copies need it); lists keep their shape."""
     import torch
@@ -71,17 +102,64 @@ def _pin_tree(x):
 LOADER_STATS = []   # the ViewPrefetchers of this process (one per epoch): their decode / wait times are diagnostics
 
 
+def _pack_view(items):
+    """A decoded view as ONE flat uint8 tensor + a small description (worker side). Twenty tensors through a
+    torch.multiprocessing queue are twenty shared-memory hand-offs un-pickled under the training process's interpreter
+    lock; one buffer is one."""
+    import torch
+    chunks, off = [], [0]
+
+    def walk(x):
+        if torch.is_tensor(x):
+            t = x.detach().contiguous()
+            start = (off[0] + 15) // 16 * 16                      # 16-byte aligned pieces
+            nbytes = t.numel() * t.element_size()
+            chunks.append((start, t.reshape(-1).view(torch.uint8) if nbytes else None))
+            off[0] = start + nbytes
+            return ("t", start, tuple(t.shape), str(t.dtype).replace("torch.", ""))
+        if isinstance(x, (list, tuple)):
+            return ("l" if isinstance(x, list) else "u", [walk(u) for u in x])
+        return ("o", x)
+    meta = walk(items)
+    flat = torch.empty(max(off[0], 1), dtype=torch.uint8)
+    for start, b in chunks:
+        if b is not None:
+            flat[start:start + b.numel()] = b
+    return flat, meta
+
+
+def _unpack_view(flat, meta):
+    """Views into ``flat`` with the structure ``_pack_view`` saw (no copies)."""
+    import torch
+    kind = meta[0]
+    if kind == "t":
+        _, start, shape, dtype = meta
+        dt = getattr(torch, dtype)
+        n = 1
+        for d in shape:
+            n *= d
+        return flat[start:start + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shape)
+    if kind in ("l", "u"):
+        seq = [_unpack_view(flat, m) for m in meta[1]]
+        return seq if kind == "l" else tuple(seq)
+    return meta[1]
+
+
 def _decode_main(get_view, tasks, results):
     """Body of the decode PROCESS: per request (a list of view indices) the decoded views, in order, then None."""
     import torch
-    torch.set_num_threads(2)
+    torch.set_num_threads(1)
+    try:
+        os.nice(10)      # the training process's launch loop and its wake-ups from device syncs come first
+    except OSError:
+        pass
     while True:
         order = tasks.get()
         if order is None:
             return
         for i in order:
             try:
-                results.put((i, get_view(i)))
+                results.put((i,) + _pack_view(get_view(i)))
             except BaseException as e:   # noqa: BLE001 - reported to the consumer, which raises it
                 results.put(("__error__", f"{type(e).__name__}: {e}"))
                 break
@@ -89,41 +167,79 @@ def _decode_main(get_view, tasks, results):
 
 
 class DecodeProcess:
-    """ONE persistent worker process that decodes views (``get_view(i)``, picklable: a dataset's bound ``__getitem__``).
-    Why a process: the decode is a chain of numpy / PIL / torch calls with Python in between - run as a THREAD of the
+    """Persistent worker process(es) that decode views (``get_view(i)``, picklable: a dataset's bound ``__getitem__``).
+    Why processes: the decode is a chain of numpy / PIL / torch calls with Python in between - run as a THREAD of the
     training process it competes for the interpreter lock with the loop that enqueues ~200 kernel launches per step,
     and both slow down (measured on the 276-view c3 scene: 235 ms per view decoded beside the loop against 56 ms
     alone, the epoch 76 instead of ~150 views/s). The reference uses DataLoader worker processes for the same reason
-    (data/abstract_dataset.py:480). Decoded tensors come back through shared memory (torch.multiprocessing); the
-    process never touches the GPU. Started with 'spawn' (the parent has initialised HIP: no fork)."""
+    (data/abstract_dataset.py:480). ``n_workers`` > 1: worker k decodes every n-th view of a request and the results are
+    taken in order - a 4-level view (56 ms of decode per 130 ms of steps) needs one worker, a single-level view (its 20
+    steps last 24 ms) three. Decoded tensors come back through shared memory (torch.multiprocessing); the processes
+    never touch the GPU. Started with 'spawn' (the parent has initialised HIP: no fork)."""
 
-    def __init__(self, get_view, depth: int = 2):
+    def __init__(self, get_view, depth: int = 2, n_workers: int = 1):
         import torch.multiprocessing as mp
         ctx = mp.get_context("spawn")
-        self.tasks, self.results = ctx.Queue(), ctx.Queue(maxsize=max(1, depth))
-        self.proc = ctx.Process(target=_decode_main, args=(get_view, self.tasks, self.results), daemon=True,
-                                name="stylemesh-view-decode")
-        self.proc.start()
+        self.n = max(1, n_workers)
+        self.tasks = [ctx.Queue() for _ in range(self.n)]
+        self.results = [ctx.Queue(maxsize=max(1, depth)) for _ in range(self.n)]
+        self.procs = [ctx.Process(target=_decode_main, args=(get_view, self.tasks[k], self.results[k]), daemon=True,
+                                  name=f"stylemesh-view-decode-{k}") for k in range(self.n)]
+        # the decoders are single-threaded by construction (numpy indexing, PIL, small torch ops): keep their math
+        # libraries from spinning up one thread per VISIBLE core (256 on the GPU boxes, under a 16-CPU quota)
+        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        os.environ.update({k: "1" for k in saved})
+        try:
+            for p in self.procs:
+                p.start()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        self.proc = self.procs[0]
         self.busy = False
+        self._next, self._open = 0, 0
 
     def request(self, order):
         assert not self.busy, "one request at a time"
+        order = list(order)
         self.busy = True
-        self.tasks.put(list(order))
+        self._next, self._open = 0, self.n
+        for k in range(self.n):
+            self.tasks[k].put(order[k::self.n])
 
-    def get(self):
-        item = self.results.get()
-        if item is None:
-            self.busy = False
-        return item
+    class NotReady(Exception):
+        pass
+
+    def get(self, block: bool = True):
+        """The next view of the request, in request order; None once every worker has delivered its share.
+        ``block=False``: raises ``DecodeProcess.NotReady`` instead of waiting for a view that is still being decoded."""
+        import queue
+        while self._open > 0:
+            try:
+                item = self.results[self._next % self.n].get(block)
+            except queue.Empty:
+                raise DecodeProcess.NotReady()
+            if item is None:              # this worker's share is done: the shares end within one view of each other
+                self._open -= 1
+                self._next += 1
+                continue
+            self._next += 1
+            return item
+        self.busy = False
+        return None
 
     def alive(self):
-        return self.proc.is_alive()
+        return all(p.is_alive() for p in self.procs)
 
     def close(self):
-        if self.proc.is_alive():
-            self.proc.terminate()
-            self.proc.join(timeout=5)
+        for p in self.procs:
+            if p.is_alive():
+                p.terminate()
+        for p in self.procs:
+            p.join(timeout=5)
 
 
 class ViewPrefetcher:
@@ -135,7 +251,9 @@ class ViewPrefetcher:
     decode (tens of ms) runs during the PREVIOUS view's steps: in a ``DecodeProcess`` (``worker``; default of the
     directory loaders) or, for cheap / unpicklable ``get_view``s, in this object's own thread. A receiver thread pins the
     decoded batches, so that the host-to-device copy the trainer issues is asynchronous (``MiniTrainer`` issues it one
-    view ahead, on a copy stream). ``depth`` decoded views are held at most (a 4-level ScanNet view is 14 MB)."""
+    view ahead, on a copy stream). ``depth`` decoded views are held at most (a 4-level ScanNet view is 14 MB). With
+    pinning, a yielded view's HOST tensors live in a ring of staging buffers and stay valid until ``depth + 4`` further
+    views have been produced - a consumer that keeps host views longer must copy them."""
 
     def __init__(self, get_view, order, depth: int = 2, pin: bool = True, worker: "DecodeProcess | None" = None):
         import collections
@@ -144,23 +262,42 @@ class ViewPrefetcher:
         self._ready = collections.deque()
         self._cv = threading.Condition()
         self._depth, self._stop, self._finished = max(1, depth), False, False
-        self.decode_s = 0.0     # time the thread spent decoding / receiving (and pinning) views
+        # a view's pinned copy must outlive: the ready queue (depth), the view being trained on, the one uploaded ahead
+        self._ring = _PinnedRing(self._depth + 4) if pin else None
+        self.decode_s = 0.0     # time spent decoding / receiving (and pinning) views on the consumer's side
         self.wait_s = 0.0       # time the consumer spent blocked on a view that was not ready
+        self._thread = None
         if worker is not None:
+            # Decode PROCESSES: no thread in the training process at all. The consumer itself takes a finished view off
+            # the workers' queue (one un-pickle of a flat buffer + one memcpy into the pinned ring: 0.3-1.5 ms per view)
+            # - a receiver THREAD doing that beside the launch loop cost the loop 14 ms per view change through the
+            # interpreter lock (set_view: 19.9 ms with the thread, 5.8 ms without; round 3).
             worker.request(self._order)
-        self._thread = threading.Thread(target=self._run, name="stylemesh-view-prefetch", daemon=True)
-        self._thread.start()
+            self._head, self._taken = None, 0
+        else:
+            self._thread = threading.Thread(target=self._run, name="stylemesh-view-prefetch", daemon=True)
+            self._thread.start()
 
-    def _next(self, i):
-        if self._worker is None:
-            return i, self._get(i)
-        item = self._worker.get()
+    def _fetch(self, block: bool):
+        """(worker mode) The next decoded view as (index, items), ``None`` at the end of the request; with
+        ``block=False`` raises ``DecodeProcess.NotReady`` if it is still being decoded."""
+        import time
+        t0 = time.perf_counter()
+        item = self._worker.get(block)
         if item is None:
-            raise RuntimeError("the decode process ended its request early")
+            self._finished = True
+            return None
         if item[0] == "__error__":
-            self._worker.get()   # the request's terminator
             raise RuntimeError(f"view decode failed in the worker process: {item[1]}")
-        return item
+        i, flat, meta = item     # one flat buffer per view (``_pack_view``)
+        if self._pin and self._ring is not None:
+            flat = self._ring.stage(flat)          # ONE memcpy into the pinned ring
+        out = (i, _unpack_view(flat, meta))
+        dt = time.perf_counter() - t0
+        if block:
+            self.wait_s += dt
+        self.decode_s += dt
+        return out
 
     def _run(self):
         import time
@@ -172,15 +309,13 @@ class ViewPrefetcher:
                     if self._stop:
                         return
                 t0 = time.perf_counter()
-                i, items = self._next(i)
+                items = self._get(i)
                 if self._pin:
-                    items = _pin_tree(items)
+                    items = self._ring.stage(items)
                 self.decode_s += time.perf_counter() - t0
                 with self._cv:
                     self._ready.append((i, items))
                     self._cv.notify_all()
-            if self._worker is not None:
-                assert self._worker.get() is None      # the request's terminator: the worker is free again
             self._finished = True
             with self._cv:
                 self._ready.append(None)
@@ -192,6 +327,13 @@ class ViewPrefetcher:
 
     def peek(self):
         """The next decoded view's items if its decode has finished, else None (never blocks)."""
+        if self._worker is not None:
+            if self._head is None and not self._finished:
+                try:
+                    self._head = self._fetch(block=False)
+                except DecodeProcess.NotReady:
+                    return None
+            return self._head[1] if self._head is not None else None
         with self._cv:
             head = self._ready[0] if self._ready else None
         return head[1] if isinstance(head, tuple) else None
@@ -199,6 +341,16 @@ class ViewPrefetcher:
     def __iter__(self):
         import time
         try:
+            if self._worker is not None:
+                while True:
+                    head, self._head = self._head, None
+                    if head is None:
+                        if self._finished:
+                            return
+                        head = self._fetch(block=True)
+                        if head is None:
+                            return
+                    yield head
             while True:
                 t0 = time.perf_counter()
                 with self._cv:

@@ -354,12 +354,25 @@ class StepEngine:
             self._pbuf[key] = factory()
         return self._pbuf[key]
 
+    def _mark(self, name):
+        """Host-time marker inside ``set_view`` (STYLEMESH_SETVIEW_TIMING=1: seconds between consecutive markers)."""
+        if os.environ.get("STYLEMESH_SETVIEW_TIMING") != "1":
+            return
+        import time
+        now = time.perf_counter()
+        acc = self.__dict__.setdefault("set_view_marks", {})
+        last = self.__dict__.get("_mark_last")
+        if last is not None and name != "start":
+            acc[name] = acc.get(name, 0.0) + now - last
+        self._mark_last = now
+
     def set_view(self, batch, reducer=None):
         """Per-view constants of ``batch``. ``reducer`` (multi-GPU, a ``SparseGradReducer``; only when the per-view
         collective is due at this schedule position, see ``begin_step``): the max-all-reduce of the touch flags and the
         device-side compaction of the exchange's chunk list are enqueued here, and the list's length rides the ONE host
         read-back of this function - a view change costs no additional synchronisation on N > 1."""
         cfg = self.cfg
+        self._mark("start")
         rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
         dev = self.device
         if rgb.shape[0] != 1:
@@ -412,6 +425,7 @@ class StepEngine:
         for lv in levels:
             if hasattr(lv, "M"):
                 lv.active = True
+        self._mark("stage+level_maps")
         self._union_flags = None
         if reducer is not None:
             flags = self.touch_flags(reducer.chunk_log2, levels)
@@ -426,6 +440,7 @@ class StepEngine:
                 if hasattr(lv, "M"):
                     lv.active = bool(sums[lv.index] > 0)
             self._finish_view(levels, rgb_dev)
+        self._mark("finish_view")
         self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
         self._last_batch = batch
         if self.touched is not None:
@@ -468,6 +483,7 @@ class StepEngine:
             if n_act:
                 sizes = [float(math.prod(layer_hw(layer, lv.H, lv.W))) for lv in active]
                 ops.level_factors([lv.counts[layer] for lv in active], sizes, [lv.factor[layer] for lv in active])
+        self._mark("fv:layer_masks")
         # content target: VGG features of the captured image, resized per level (losses :294, :176-177)
         if cfg.content_layers and n_act:
             key = (h, w)
@@ -484,6 +500,7 @@ class StepEngine:
                     dst = self._persist(("ctarget", lv.index, layer, hl, wl), lambda: FMap(src.C, hl, wl, dev))
                     ops.fmap_resize_bilinear(src, dst)
                     lv.content_target[layer] = dst
+        self._mark("fv:content_target")
         self.view = levels
         self.view_consts = consts
         self.view_tiles = None
@@ -512,6 +529,7 @@ class StepEngine:
             skip = set(_vgg.POOL_OUTPUT) if (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2") else set()
             torch._foreach_zero_([g.buf for lv in active
                                   for name, g in self._level_bufs(lv.H, lv.W).grad.items() if name not in skip])
+        self._mark("fv:tile_lists(sync)")
         # identifies the step's launch sequence (grid sizes depend on the tile lists)
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in active),
                          None if self.view_tiles is None else tuple(v[0].numel() for v in self.view_tiles.values()))
@@ -523,6 +541,7 @@ class StepEngine:
             self._scatter_levels = [lv.index for lv in active]
         if msums is not None and sums_host is None:
             sums_host = msums.tolist()   # no tile lists to read along with
+        self._mark("fv:scatter_plan")
         return sums_host
 
     # ------------------------------------------------------------------ the step
@@ -1114,7 +1133,11 @@ class StepEngine:
         due = reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view)
         in_set_view = due and changed and hasattr(reducer, "new_view_begin")
         if changed:
+            import time
+            t0 = time.perf_counter()
             self.set_view(batch, reducer if in_set_view else None)
+            self.set_view_host_s = getattr(self, "set_view_host_s", 0.0) + time.perf_counter() - t0   # diagnostics
+            self.set_view_calls = getattr(self, "set_view_calls", 0) + 1
         if reducer is not None and not hasattr(reducer, "new_view") and self.touched is not None:
             # A reducer that cannot union the ranks' footprints (the plain dense all-reduce, any callable): the other
             # ranks' gradients arrive in chunks this rank's views never flagged, which the sparse update would skip

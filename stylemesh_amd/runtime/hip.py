@@ -157,7 +157,14 @@ def check(code: int, what: str = ""):
         raise RuntimeError(f"libstylemesh_hip: {what} failed with HIP error code {code}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """The current HIP stream's handle. Called once per kernel launch: ``torch.cuda.current_stream().cuda_stream`` builds a
+    Stream object every time (10 us, 0.4 ms of host time per single-level step); the raw getter is a plain C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

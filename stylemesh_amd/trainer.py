@@ -47,8 +47,16 @@ class JsonlLogger:
         pass
 
     def flush(self):
+        # device scalars cross to the host in ONE transfer per device (a float() per record is a synchronisation each:
+        # 200 of them per flush were 0.2 ms of host time per step on the single-level workload)
+        vals = [v for _, v, _ in self._pending]
+        dev = [i for i, v in enumerate(vals) if torch.is_tensor(v) and v.is_cuda]
+        if dev:
+            host = torch.stack([vals[i].detach().reshape(-1)[0].float() for i in dev]).tolist()
+            for i, h in zip(dev, host):
+                vals[i] = h
         with open(os.path.join(self.log_dir, self.file_name), "a") as f:
-            for tag, value, step in self._pending:
+            for (tag, _, step), value in zip(self._pending, vals):
                 f.write(json.dumps({"tag": tag, "step": int(step), "value": float(value)}) + "\n")
         self._pending.clear()
 
@@ -87,7 +95,8 @@ class MiniTrainer:
             items = self._upload(batch)
             self._last_dev = (batch[0], items)
         upcoming = getattr(batch, "upcoming", None)
-        if upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None:
+        if (upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None
+                and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
             nxt = upcoming()
             if nxt is not None and nxt[0] is not batch[0]:
                 if not hasattr(self, "_copy_stream"):
@@ -115,6 +124,8 @@ class MiniTrainer:
         except AttributeError:   # a real LightningModule exposes ``logger`` as a read-only property
             pass
         model.world_size = self.world_size
+        if hasattr(model, "_ensure_engine"):
+            model.fused_backward_done = True   # training_step's gradients are final: no autograd pass over its scalar
         if hasattr(model, "to") and self.device != "cpu":
             model.to(self.device)
         if self.device != "cpu" and torch.cuda.is_available():
@@ -122,6 +133,9 @@ class MiniTrainer:
             st = trunk_stream(self.device)       # high-priority stream for the step's trunk (side work fills the rest)
             if st is not None:
                 torch.cuda.set_stream(st)
+        if os.environ.get("STYLEMESH_SWITCH_INTERVAL"):   # experiment: interpreter-lock hand-over interval (seconds)
+            import sys
+            sys.setswitchinterval(float(os.environ["STYLEMESH_SWITCH_INTERVAL"]))
         optimizers, schedulers = model.configure_optimizers()
         opt, sched = optimizers[0], (schedulers[0] if schedulers else None)
         if hasattr(opt, "world_size"):
@@ -136,15 +150,42 @@ class MiniTrainer:
             t_epoch = now()
             steps0 = self.global_step
             self._call(model, "on_train_epoch_start")
-            for batch_idx, batch in enumerate(datamodule.train_dataloader()):
-                if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
+            timing = os.environ.get("STYLEMESH_TRAINER_TIMING") == "1"   # host-side seconds per phase of the loop
+            tm = getattr(self, "host_seconds", None) or {"next_batch": 0.0, "to_device": 0.0, "training_step": 0.0,
+                                                         "backward": 0.0, "optimizer_step": 0.0}
+            self.host_seconds = tm
+            loader = iter(datamodule.train_dataloader())
+            batch_idx = -1
+            while True:
+                t_a = time.perf_counter() if timing else 0.0
+                try:
+                    batch = next(loader)
+                except StopIteration:
                     break
+                batch_idx += 1
+                if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
+                    loader.close() if hasattr(loader, "close") else None
+                    break
+                t_b = time.perf_counter() if timing else 0.0
                 batch = self._to_device(batch)
                 opt.zero_grad()
+                t_c = time.perf_counter() if timing else 0.0
                 out = self._call(model, "training_step", batch, batch_idx)
-                out["loss"].backward()
+                t_d = time.perf_counter() if timing else 0.0
+                if not out.get("backward_done", False):    # (the fused module has deposited its gradients already)
+                    out["loss"].backward()
+                t_e = time.perf_counter() if timing else 0.0
                 opt.step()
                 self.global_step += 1
+                if timing:
+                    t_f = time.perf_counter()
+                    tm["next_batch"] += t_b - t_a; tm["to_device"] += t_c - t_b; tm["training_step"] += t_d - t_c
+                    tm["backward"] += t_e - t_d; tm["optimizer_step"] += t_f - t_e
+                    if getattr(batch, "new_view", False):     # the first step of a view (set_view inside), per VIEW
+                        tm["first_step_of_view_total"] = tm.get("first_step_of_view_total", 0.0) + (t_f - t_a)
+                        tm["first_steps"] = tm.get("first_steps", 0) + 1
+                        fs = tm.setdefault("_first", [0.0, 0.0, 0.0])
+                        fs[0] += t_b - t_a; fs[1] += t_c - t_b; fs[2] += t_d - t_c
             t_train = now()
             val_loader = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
             if val_loader is not None:
@@ -175,6 +216,20 @@ class MiniTrainer:
             pass
         if self.progress and self.rank == 0:
             print(f"fit: {time.time() - t0:.1f} s")
+            if getattr(self, "host_seconds", None) and os.environ.get("STYLEMESH_TRAINER_TIMING") == "1":
+                n = max(self.global_step, 1)
+                hs = dict(self.host_seconds)
+                nf = hs.pop("first_steps", 0)
+                first = hs.pop("first_step_of_view_total", 0.0)
+                fs = hs.pop("_first", None)
+                eng = getattr(model, "_engine", None)
+                if eng is not None and getattr(eng, "set_view_calls", 0):
+                    marks = getattr(eng, "set_view_marks", {})
+                    print(f"set_view: {1e3 * eng.set_view_host_s / eng.set_view_calls:.2f} ms of host time per call "
+                          f"(x{eng.set_view_calls})" + "".join(f" {k} {1e3 * v / eng.set_view_calls:.2f}" for k, v in marks.items()))
+                print("host ms per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in hs.items())
+                      + (f"; first step of a view {1e3 * first / nf:.2f} ms (x{nf}: next_batch {1e3 * fs[0] / nf:.2f}, "
+                         f"to_device {1e3 * fs[1] / nf:.2f}, training_step {1e3 * fs[2] / nf:.2f})" if nf else ""))
             from .runtime.distributed import LOADER_STATS
             if LOADER_STATS:
                 print(f"loader: decode {sum(p.decode_s for p in LOADER_STATS):.1f} s in the prefetch thread, "

@@ -106,7 +106,7 @@ def test_datamodule_prefetch_process_yields_the_same_schedule(tmp_path):
     write_scene(str(tmp_path), "s", render_views(5), [64, 108])
     kw = dict(resize_size=64, split=(0.8, 0.2), index_repeat=2)
     plain = ScanNetSingleSceneDataModule(str(tmp_path), "s", prefetch=0, **kw)
-    ahead = ScanNetSingleSceneDataModule(str(tmp_path), "s", prefetch=2, **kw)
+    ahead = ScanNetSingleSceneDataModule(str(tmp_path), "s", prefetch=2, decode_workers=3, **kw)   # 4 views over 3 workers
     plain.setup(), ahead.setup()
     want = list(plain.train_dataloader())
     for epoch in range(2):

@@ -118,6 +118,8 @@ def main():
              for m in re.finditer(r"train loop ([\d.]+) s = ([\d.]+) steps/s, validation \+ epoch-end hooks ([\d.]+) s", r.stdout)]
     fit = re.search(r"fit: ([\d.]+) s", r.stdout)
     ld = re.search(r"loader: decode ([\d.]+) s .* blocked ([\d.]+) s", r.stdout)
+    hm = re.search(r"host ms per step: (.*)", r.stdout)
+    sv = re.search(r"set_view: (.*)", r.stdout)
     n_train = int(0.99 * args.views)
     per_epoch = []
     prev_steps, prev_t = 0, 0.0
@@ -139,6 +141,8 @@ def main():
            "loader": f"ScanNetSingleSceneDataModule, prefetch thread {'on' if args.num_workers > 0 else 'off'}, pinned upload one view ahead",
            "loader_decode_s": None if ld is None else float(ld.group(1)),
            "training_loop_blocked_on_loader_s": None if ld is None else float(ld.group(2)),
+           "trainer_host_ms_per_step": None if hm is None else hm.group(1),
+           "set_view_host": None if sv is None else sv.group(1),
            "texture_exports": len(tex), "command": " ".join(cmd[1:]).replace(root, "<scene-root>")}
     print(json.dumps(out))
     if args.out:
