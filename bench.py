@@ -107,7 +107,11 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     """Warm-up + the timed region (barrier + synchronize on both sides). -> seconds of the timed region."""
     from stylemesh_amd.runtime import ops
     rep = wl["index_repeat"]
+    def ahead(i):   # during a view's second step: the NEXT view's constants are computed on a side stream (N = 1)
+        if world == 1 and i % rep == 1 and i - 1 + rep < len(schedule):
+            eng.prepare_view(schedule[i - 1 + rep])
     for i in range(args.warmup):
+        ahead(i)
         eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
     ops.CONV_TIMER = timer
     if getattr(eng, "phase_timer", None) is not None:
@@ -117,6 +121,7 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     for i in range(args.warmup, args.warmup + args.steps):
         if timer is not None:
             timer.enabled = (i - args.warmup) % args.timer_every == 0
+        ahead(i)
         eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
     barrier()
     dt = time.perf_counter() - t0

@@ -269,6 +269,12 @@ class TextureOptimizationStyleTransferPipeline(_Base):
                 self.loss_history[loss_type][state].append(loss.detach())   # device tensor: no host sync per step
                 self.logger.experiment.add_scalar(f"Batch/Loss/{state}/{loss_type}", loss.detach(), log_idx)
 
+    def prepare_view(self, batch, ready_event=None):
+        """Loader hook (``MiniTrainer``): the NEXT view's device batch is resident - let the engine compute its per-view
+        constants on a side stream during the current view's steps (``StepEngine.prepare_view``)."""
+        if self._engine is not None and self.grad_reducer is None:
+            self._engine.prepare_view(batch, ready_event)
+
     # ------------------------------------------------------------------ Lightning hooks
     def training_step(self, batch, batch_idx, optimizer_idx=0):
         eng = self._ensure_engine(batch[0].device)

@@ -291,7 +291,9 @@ SPLITK_WS_FLOATS = 16 << 20
 
 
 def splitk_workspace(device) -> torch.Tensor:
-    key = str(device)
+    # one scratch per (device, launch stream): conv launches of two streams (the step's trunk, a view being prepared
+    # ahead on a side stream) must not share their split-K partial slabs
+    key = (str(device), hip.stream())
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]

@@ -95,8 +95,10 @@ class MiniTrainer:
             items = self._upload(batch)
             self._last_dev = (batch[0], items)
         upcoming = getattr(batch, "upcoming", None)
+        # (from a view's SECOND step on: at its first step the engine's current view is still the previous one, and the
+        # per-view constants prepared here must be those of the view AFTER the engine's current one)
         if (upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None
-                and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
+                and not getattr(batch, "new_view", False) and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
             nxt = upcoming()
             if nxt is not None and nxt[0] is not batch[0]:
                 if not hasattr(self, "_copy_stream"):
@@ -111,6 +113,9 @@ class MiniTrainer:
                         if torch.is_tensor(t) and t.is_cuda:
                             t.record_stream(main)
                 self._ahead = (nxt[0], dev_items, done)
+                hook = getattr(getattr(self, "_model", None), "prepare_view", None)
+                if hook is not None and self.world_size == 1:   # the next view's per-view constants, one view ahead
+                    hook(ViewBatch(dev_items, new_view=True), done)
         return ViewBatch(items, new_view=getattr(batch, "new_view", None))
 
     def _call(self, model, name, *a):
@@ -124,6 +129,7 @@ class MiniTrainer:
         except AttributeError:   # a real LightningModule exposes ``logger`` as a read-only property
             pass
         model.world_size = self.world_size
+        self._model = model
         if hasattr(model, "_ensure_engine"):
             model.fused_backward_done = True   # training_step's gradients are final: no autograd pass over its scalar
         if hasattr(model, "to") and self.device != "cpu":
@@ -133,6 +139,23 @@ class MiniTrainer:
             st = trunk_stream(self.device)       # high-priority stream for the step's trunk (side work fills the rest)
             if st is not None:
                 torch.cuda.set_stream(st)
+        sampler = None
+        if os.environ.get("STYLEMESH_SAMPLE") == "1":   # diagnostics: where does the training thread sit? (2 ms sampling)
+            import collections
+            import sys
+            import threading
+            main_id, hist, stop = threading.get_ident(), collections.Counter(), threading.Event()
+
+            def sample():
+                while not stop.wait(0.002):
+                    f = sys._current_frames().get(main_id)
+                    chain = []
+                    while f is not None and len(chain) < 4:
+                        chain.append(f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}:{f.f_code.co_name}")
+                        f = f.f_back
+                    hist[" <- ".join(chain)] += 1
+            sampler = (threading.Thread(target=sample, daemon=True), hist, stop)
+            sampler[0].start()
         if os.environ.get("STYLEMESH_SWITCH_INTERVAL"):   # experiment: interpreter-lock hand-over interval (seconds)
             import sys
             sys.setswitchinterval(float(os.environ["STYLEMESH_SWITCH_INTERVAL"]))
@@ -214,6 +237,11 @@ class MiniTrainer:
             IMAGE_WRITER.wait()
         except ImportError:
             pass
+        if sampler is not None:
+            sampler[2].set()
+            tot = sum(sampler[1].values())
+            for k, v in sampler[1].most_common(14):
+                print(f"sample {100.0 * v / tot:5.1f} %  {k}")
         if self.progress and self.rank == 0:
             print(f"fit: {time.time() - t0:.1f} s")
             if getattr(self, "host_seconds", None) and os.environ.get("STYLEMESH_TRAINER_TIMING") == "1":
@@ -226,7 +254,7 @@ class MiniTrainer:
                 if eng is not None and getattr(eng, "set_view_calls", 0):
                     marks = getattr(eng, "set_view_marks", {})
                     print(f"set_view: {1e3 * eng.set_view_host_s / eng.set_view_calls:.2f} ms of host time per call "
-                          f"(x{eng.set_view_calls})" + "".join(f" {k} {1e3 * v / eng.set_view_calls:.2f}" for k, v in marks.items()))
+                          f"(x{eng.set_view_calls}, {getattr(eng, 'prepared_swaps', 0)} prepared ahead)" + "".join(f" {k} {1e3 * v / eng.set_view_calls:.2f}" for k, v in marks.items()))
                 print("host ms per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in hs.items())
                       + (f"; first step of a view {1e3 * first / nf:.2f} ms (x{nf}: next_batch {1e3 * fs[0] / nf:.2f}, "
                          f"to_device {1e3 * fs[1] / nf:.2f}, training_step {1e3 * fs[2] / nf:.2f})" if nf else ""))

@@ -200,3 +200,34 @@ def test_sparse_reducer_on_the_device_matches_dense_sum():
     red.pipelined(g2, lambda lo, hi: ranges.append((lo, hi)))
     assert torch.equal(g2, want2) and ranges[0][0] == 0 and ranges[-1][1] == g2.numel()
     assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and len(ranges) == 4
+
+
+def test_prepare_view_ahead_equals_set_view():
+    """``StepEngine.prepare_view``: the next view's constants computed on a side stream into the other buffer slot while
+    the current view's steps run; the swap at the view change gives the same training trajectory as computing them at
+    the view change. Lock-step (state copied before every step: two RUNS differ by the atomic order of the Gram sums)."""
+    require_gpu()
+    views = [_small_view(s) for s in MULTIVIEW_SEEDS[:3]]
+    a, b = _engine(), _engine()
+    b.prepare_ahead = False
+    sched = [views[k // 4 % 3] for k in range(20)]            # view changes every 4 steps, views come back
+    used = 0
+    for k, v in enumerate(sched):
+        for name in ("p", "m", "v"):
+            getattr(b.arena, name).copy_(getattr(a.arena, name))
+        b.sumsq.copy_(a.sumsq)
+        if b.touched is not None:
+            b.touched.copy_(a.touched)
+        if k % 4 == 1 and k + 3 < len(sched):
+            used += bool(a.prepare_view(sched[k + 3]))
+        la = a.losses(a.training_step(v))
+        lb = b.losses(b.training_step(v))
+        np.testing.assert_allclose(la["total"], lb["total"], rtol=1e-5)
+        err = (a.arena.p - b.arena.p).abs()
+        assert float((err > 1e-4).float().mean()) < 5e-3, (k, float(err.max()))
+        assert torch.equal(a.touched != 0, b.touched != 0)
+    assert used >= 3 and a._slot in (0, 1) and a._prepared is None
+    # a prepared view that is NOT the next one is dropped and the asked-for view is built normally
+    a.prepare_view(views[0])
+    a.training_step(views[1])
+    assert a.view_key == MULTIVIEW_SEEDS[1] or a.view_key is not None

@@ -109,6 +109,8 @@ def main():
     t0 = time.time()
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True)
     wall = time.time() - t0
+    if os.environ.get("STYLEMESH_SAMPLE") == "1":
+        print("\n".join(l for l in r.stdout.splitlines() if l.startswith("sample ")), file=sys.stderr)
     if r.returncode != 0:
         print(r.stdout[-3000:], r.stderr[-3000:], file=sys.stderr)
         raise SystemExit(r.returncode)
