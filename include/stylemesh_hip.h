@@ -200,7 +200,12 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
  * weight >= 2^-16 with fp32 accumulation (stylemesh_amd/csrc/conv_split_kernel.h). Activations / outputs are
  * the same fp32 planes; wt3 = the weights pre-split by the host: [9 taps][Cin/16][3 parts][2][Cout][8] bf16 (as
  * uint16 bit patterns; runtime/ops.py:pack_conv_split builds it from the fp32 tap-major pack). Cin % 16 == 0,
- * Cout % 64 == 0; tiles cover sm_conv_split_tile_positions() = 128 positions. Same flags / tile_list / ws semantics as sm_conv3x3_grouped.
+ * Cout % 64 == 0; tiles cover sm_conv_split_tile_positions() = 128 positions. Same flags / ws semantics as sm_conv3x3_grouped.
+ * tile_list (both split entry points, ABI 6): a list of 32-position SEGMENTS, not of whole tiles - entry =
+ * (problem << 24) | segment (segment s = positions [Wp + 32 s, Wp + 32 s + 32) of the padded plane), consumed
+ * tile positions / 32 entries per tile: ANY live segments of ONE problem form a tile (the dead 32-position ranges inside
+ * 128-position tiles were 8 % of all matrix instructions of a step); every problem's run is padded to a whole number of
+ * tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and must be a multiple of tile positions / 32.
  * Replaces the same reference operators (F.conv2d forward / backward of content_and_style_losses.py:11-32). */
 int sm_conv_split_tile_positions(void);
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,

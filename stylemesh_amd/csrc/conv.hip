@@ -224,32 +224,46 @@ template <int BM, int BN, int FLAGS>
 __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     const int tile = a.n_whole + blockIdx.x;
     const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
+    const int e_ = blockIdx.y * 256 + threadIdx.x;
+    const int row = e_ / (BN / 4), c4 = (e_ - row * (BN / 4)) * 4;   // this thread's float4 of the BM x BN slab
     ConvProblem P = a.p[0];
     int n_tile = n_glob;
-    if (a.tile_list) {
-        const int e = a.tile_list[n_glob];
-        const int gsel = e >> 24;
-        n_tile = e & 0xFFFFFF;
+    int q = 0;
+    bool alive = true;
+    if (a.tile_list && a.list_segments) {
+        // the split kernels' lists: BN / 32 entries per tile, (problem << 24) | 32-position segment, 0xFFFFFF = padding
+        const int* e = a.tile_list + (size_t)n_glob * (BN / 32);
+        const int gsel = e[0] >> 24;
 #pragma unroll
         for (int g = 1; g < SM_MAX_GROUP; ++g)
             if (g == gsel) P = a.p[g];
+        const int sg = e[c4 >> 5] & 0xFFFFFF;
+        alive = sg != 0xFFFFFF;
+        q = P.Wp + sg * 32 + (c4 & 31);
     } else {
+        if (a.tile_list) {
+            const int e = a.tile_list[n_glob];
+            const int gsel = e >> 24;
+            n_tile = e & 0xFFFFFF;
 #pragma unroll
-        for (int g = 1; g < SM_MAX_GROUP; ++g)
-            if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
-                P = a.p[g];
-                n_tile = n_glob - a.tile_begin[g];
-            }
+            for (int g = 1; g < SM_MAX_GROUP; ++g)
+                if (g == gsel) P = a.p[g];
+        } else {
+#pragma unroll
+            for (int g = 1; g < SM_MAX_GROUP; ++g)
+                if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
+                    P = a.p[g];
+                    n_tile = n_glob - a.tile_begin[g];
+                }
+        }
+        q = P.Wp + n_tile * BN + c4;
     }
-    const int m0 = m_tile * BM, q0 = P.Wp + n_tile * BN, q_end = (P.H + 1) * P.Wp;
+    const int m0 = m_tile * BM, q_end = (P.H + 1) * P.Wp;
     const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
     const float amax_seen = amax_peek(a.amax_out);   // beside the slab loads, not behind the stores
     {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
-        const int e = blockIdx.y * 256 + threadIdx.x;
-        const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
-        const int q = q0 + c4;
         float m = 0.f;            // max |output| of this thread (all lanes stay active for the wave reduction below)
-        if (q < q_end) {          // q_end and q are multiples of 4
+        if (alive && q < q_end) { // q_end and q are multiples of 4
             f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
             for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
             const int co = m0 + row;
@@ -294,7 +308,10 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     a.tile_begin[0] = 0;
     for (int g = 0; g < a.n_problems; ++g)
         a.tile_begin[g + 1] = a.tile_begin[g] + (a.p[g].H * a.p[g].Wp + BN - 1) / BN;
-    a.n_tiles = a.tile_list ? n_list : a.tile_begin[a.n_problems];
+    // the split kernels take SEGMENT lists (BN / 32 entries of 32 positions per tile), the fp32 kernel BN-position tiles
+    a.list_segments = SPLIT ? 1 : 0;
+    if (SPLIT && a.tile_list && n_list % (BN / 32) != 0) return (int)hipErrorInvalidValue;
+    a.n_tiles = a.tile_list ? (SPLIT ? n_list / (BN / 32) : n_list) : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
     constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN, NP)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
@@ -717,7 +734,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 5; }
+int sm_abi_version(void) { return 6; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {

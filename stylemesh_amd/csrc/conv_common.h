@@ -26,7 +26,10 @@ struct ConvArgs {
     int n_problems;
     // optional compact list of ACTIVE position tiles, entry = (problem << 24) | tile-in-problem; NULL = all tiles.
     // Tiles that cannot influence the loss (outside the receptive-field-dilated level mask) are simply absent.
+    // (the split kernels: BN / 32 entries per tile, (problem << 24) | 32-position SEGMENT, 0xFFFFFF = padding - any live
+    // segments of ONE problem form a tile; list_segments = 1)
     const int* tile_list;
+    int list_segments;
     const float* wt;
     const float* bias;
     int Cin_pad, Cout, n_tiles, m_tiles;   // n_tiles = position tiles of ALL problems

@@ -74,7 +74,7 @@ namespace sm {
 // (128-row tiles only: six slots of the 64 x 256 tile would be 99 KB per block - one block per CU)
 constexpr int conv_split_slots(int NP, int BM = 128) { return (NP == 2 && BM == 128 && SM_SPLIT2_RING6) ? 6 : 4; }
 constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) {
-    return (size_t)(conv_split_slots(NP, BM) * 2 * NP * (BN + 2)) * 16;
+    return (size_t)(conv_split_slots(NP, BM) * 2 * NP * (BN / 32 * 34)) * 16;   // 34 staged positions per 32-position segment
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -123,7 +123,12 @@ void conv3x3_split_kernel(ConvArgs a) {
     static_assert(BN == 128 || BN == 256, "activation staging: BN / 128 (k-group, position) units per thread + a 2 x 2 x 8 halo");
     constexpr int NU = BN / 128;          // staging units per thread and slice
     constexpr int KC = 16;
-    constexpr int BNP = BN + 2;           // positions incl. one halo position on each side
+    // A block's BN positions are BN / 32 SEGMENTS of 32 consecutive positions - with an active-tile list ANY live segments
+    // of one problem (ConvArgs::tile_list holds segments, round 3: the dead work inside 128-position tiles was 8 % of all
+    // MFMAs), else consecutive ones. Every segment is staged with its own halo: 34 positions per segment and slice.
+    constexpr int SEG = BN / 32;
+    constexpr int SEGP = 34;
+    constexpr int BNP = SEG * SEGP;       // staged positions per slice
     constexpr int SLICE = 2 * NP * BNP;   // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     f32x4* Bs = smem4;                    // [4 slots][SLICE]
@@ -146,27 +151,39 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int m_tile = tile / a.n_tiles;
     const int n_glob = tile - m_tile * a.n_tiles;
     ConvProblem P = a.p[0];
-    int n_tile = n_glob;
+    int qs[SEG];        // first position of each segment (index into the padded plane); block-uniform
+    bool live[SEG];     // false: a padding entry of the list (nothing is stored for it)
     if (a.tile_list) {
-        const int e = a.tile_list[n_glob];
-        const int gsel = e >> 24;
-        n_tile = e & 0xFFFFFF;
+        const int* e = a.tile_list + (size_t)n_glob * SEG;   // SEG entries (problem << 24) | segment, 0xFFFFFF = padding
+        const int gsel = e[0] >> 24;
 #pragma unroll
         for (int g = 1; g < SM_MAX_GROUP; ++g)
             if (g == gsel) P = a.p[g];
+        const int s0 = e[0] & 0xFFFFFF;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const int sg = e[i] & 0xFFFFFF;
+            live[i] = sg != 0xFFFFFF;
+            qs[i] = P.Wp + (live[i] ? sg : s0) * 32;        // (a padding entry stages segment 0's data again)
+        }
     } else {
+        int n_tile = n_glob;
 #pragma unroll
         for (int g = 1; g < SM_MAX_GROUP; ++g)
             if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
                 P = a.p[g];
                 n_tile = n_glob - a.tile_begin[g];
             }
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            live[i] = true;
+            qs[i] = P.Wp + n_tile * BN + 32 * i;
+        }
     }
     const int n_chunks = a.Cin_pad / KC;
     const int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
     const int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
     const int m0 = m_tile * BM;
-    const int q0 = P.Wp + n_tile * BN;
 
     const float amax_seen = split < 0 ? amax_peek(a.amax_out) : 0.f;   // whole tiles record their output's bound
     f32x16 acc[MI][NJ];
@@ -202,10 +219,29 @@ void conv3x3_split_kernel(ConvArgs a) {
     // resource base one row + one float before the plane (inside the guard), so that every offset is >= 0
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(P.in) - P.Wp - 1, 0, 0x7ffffff0, 0x00020000);
-    const int b_src = (b_kg * 8 * P.plane + q0 + b_px) * 4;   // bytes, relative to the shifted base, row ky = 0
-    const int b_dst = b_kg * BNP + b_px;                      // + part * 2 * BNP (+ slot * SLICE)
-    const int h_kg = l31 >> 4, h_px = BN + ((l31 >> 3) & 1), h_c = l31 & 7;
-    const int h_src = ((h_kg * 8 + h_c) * P.plane + q0 + h_px) * 4;   // bytes, same base
+    // unit u of this thread: position b_px + 128 u of the block = position (b_px & 31) of segment (b_px >> 5) + 4 u;
+    // LDS position p of a segment holds input position qs - 1 + p (p = 0: left halo)
+    int b_src[NU], b_dst[NU], b_q[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int q_seg = qs[4 * u];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if ((b_px >> 5) == k) q_seg = qs[4 * u + k];
+        b_q[u] = q_seg + (b_px & 31);                              // position index + 1 of the staged element, row ky = 1
+        b_src[u] = (b_kg * 8 * P.plane + b_q[u]) * 4;              // bytes, relative to the shifted base, row ky = 0
+        b_dst[u] = b_kg * BNP + ((b_px >> 5) + 4 * u) * SEGP + (b_px & 31);   // + part * 2 * BNP (+ slot * SLICE)
+    }
+    // the two remaining positions of every segment (p = 32, 33): wave w fetches those of segment w (SEG = 4) or of
+    // segments 2 w + (lane >> 5) (SEG = 8) - 2 positions x 2 k-groups x 8 channels = 32 single elements per segment
+    const int h_kg = l31 >> 4, h_which = (l31 >> 3) & 1, h_c = l31 & 7;
+    int h_seg = SEG == 4 ? wave : 2 * wave + lhi;
+    int h_qs = qs[0];
+#pragma unroll
+    for (int k = 1; k < SEG; ++k)
+        if (h_seg == k) h_qs = qs[k];
+    const int h_q = h_qs + 32 + h_which;                          // position index + 1 of the halo element, row ky = 1
+    const int h_src = ((h_kg * 8 + h_c) * P.plane + h_q) * 4;     // bytes, same base
     // UNPOOL: the operand is the max-pool backward of the pooled gradient `in`, taken on the fly. Geometry of the pooled
     // planes, and row / column (in the un-pooled image) of the CENTRE-row position of every staging unit of this thread
     // (slice ky reads row + ky - 1); -1 marks the padding column left of the image.
@@ -217,11 +253,11 @@ void conv3x3_split_kernel(ConvArgs a) {
         code_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P.code), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int qc = q0 + b_px + u * 128 - 1;
+            const int qc = b_q[u] - 1;
             up_y[u] = qc / P.Wp - 1;
             up_x[u] = qc - (up_y[u] + 1) * P.Wp - 1;
         }
-        const int qh = q0 + h_px - 1;
+        const int qh = h_q - 1;
         up_hy = qh / P.Wp - 1;
         up_hx = qh - (up_hy + 1) * P.Wp - 1;
     }
@@ -232,7 +268,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         off_ = ok_ ? (((y_) >> 1) + 1) * up_Wp + ((x_) >> 1) + 1 : 0;                                    \
         par_ = ok_ ? ((((y_) & 1) << 1) | ((x_) & 1)) : -1;                                              \
     }
-    const int h_dst = (h_kg * BNP + h_px) * 8 + h_c;          // in bf16 elements (+ part * 2 * BNP * 8)
+    const int h_dst = (h_kg * BNP + h_seg * SEGP + 32 + h_which) * 8 + h_c;   // in bf16 elements (+ part * 2 * BNP * 8)
     // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
     // the MFMA time to hide the same fetch latency behind: its ring is deeper
     constexpr int AD = NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
@@ -276,7 +312,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
         _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                   \
             _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
-                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src, so_ + c * P.plane * 4 + u * 512, 0)); \
+                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src[u], so_ + c * P.plane * 4, 0)); \
         rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0)); \
     }
 #define SM_STORE_B(set_, slot_)                                                                          \
@@ -289,9 +325,9 @@ void conv3x3_split_kernel(ConvArgs a) {
                 split3(rbs[set_][u][c], h, m, l);                                                        \
                 vh[c] = h; vm[c] = m; vl[c] = l;                                                         \
             }                                                                                            \
-            d_[b_dst + u * 128] = __builtin_bit_cast(f32x4, vh);                                         \
-            d_[b_dst + u * 128 + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                               \
-            d_[b_dst + u * 128 + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                               \
+            d_[b_dst[u]] = __builtin_bit_cast(f32x4, vh);                                                \
+            d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                                      \
+            d_[b_dst[u] + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
         }                                                                                                \
         __bf16 h, m, l;                                                                                  \
         split3(rhs[set_], h, m, l);                                                                      \
@@ -314,8 +350,8 @@ void conv3x3_split_kernel(ConvArgs a) {
                 const _Float16 h_ = (_Float16)xs_;                                                       \
                 vh[c] = h_; vl[c] = (_Float16)(xs_ - (float)h_);                                         \
             }                                                                                            \
-            d_[b_dst + u * 128] = __builtin_bit_cast(f32x4, vh);                                         \
-            d_[b_dst + u * 128 + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                               \
+            d_[b_dst[u]] = __builtin_bit_cast(f32x4, vh);                                                \
+            d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
         }                                                                                                \
         const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
         const _Float16 h_ = (_Float16)xs_;                                                               \
@@ -328,7 +364,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         const f32x4* bf_ = b_frag + (slot_) * SLICE + (kx_);                                             \
         _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                   \
             _Pragma("unroll") for (int i = 0; i < NJ; ++i)                                               \
-                dst_[i][s] = bf_[s * 2 * BNP + i * 32];                                                  \
+                dst_[i][s] = bf_[s * 2 * BNP + i * SEGP];                                                \
     }
 
     SM_TS(0)
@@ -357,7 +393,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     // slot of slice ky of the current / of the next chunk
 #define SM_CUR_SLOT(ky_) (RING6 ? base + (ky_) : (base + (ky_)) & 3)
 #define SM_NEXT_SLOT(ky_) (RING6 ? (3 - base) + (ky_) : (base + 3 + (ky_)) & 3)
-    const f32x4* b_frag = Bs + lhi * BNP + wn + l31;
+    const f32x4* b_frag = Bs + lhi * BNP + (wn / 32) * SEGP + l31;   // n-tile i of the wave = segment wn / 32 + i
     f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 bf16 / fp16)
 #if SM_SPLIT_PREFETCH_B
     SM_READ_B(fb, 0, 0)
@@ -525,8 +561,13 @@ void conv3x3_split_kernel(ConvArgs a) {
     float vmax = 0.f;   // max |output| of this lane: the operand scale of the conv that consumes this tensor (NP = 2)
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
-        const int q = q0 + wn + nj * 32 + l31;
-        if (q >= q_end) continue;
+        int q_seg = qs[0];
+        bool alive = live[0];
+#pragma unroll
+        for (int k = 1; k < SEG; ++k)
+            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
+        const int q = q_seg + l31;
+        if (!alive || q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {

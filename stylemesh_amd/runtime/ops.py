@@ -341,6 +341,16 @@ def conv_tile_positions(cin_pad: int, cout: int) -> int:
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 
+def conv_list_format(cin_pad: int, cout: int):
+    """(positions per active-list entry, entries per tile) of the kernel ``conv3x3_grouped`` will pick: the split kernels
+    take 32-position SEGMENTS, tile positions / 32 of them per tile (any live segments of one level, padded per level with
+    (level << 24) | 0xFFFFFF: ``sparsity.build_tile_lists``); the fp32 kernel whole tiles (entries per tile 0)."""
+    bn = conv_tile_positions(cin_pad, cout)
+    if CONV_MODE in ("split", "split2") and split_eligible(cin_pad, cout):
+        return 32, bn // 32
+    return bn, 0
+
+
 def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
                     wt2=None, amax_in=None, amax_out=None):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code]), ...] (FMaps; with a

@@ -41,28 +41,36 @@ def need_maps(M: torch.Tensor, H: int, W: int, injected, last_layer: str) -> dic
 
 def build_tile_lists(needs, last_layer: str, extra=None):
     """``needs``: one ``need_maps`` dict per level of the grouped launch (in problem order).
-    Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, n_all_tiles)}.
+    Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, list capacity)};
+    for the split conv kernels the entries are 32-position SEGMENTS, ``ops.conv_list_format`` of them per tile.
     ``extra``: optional 1-D float device tensor that rides along in the one read-back; then returns (dict, list)."""
     from . import hip
+    import numpy as np
     dev = next(iter(needs[0].values())).device
-    jobs = []            # (key, layer, bn)
+    import os
+    coarse = os.environ.get("STYLEMESH_SEGMENT_LISTS", "1") == "0"   # A/B: flag whole tiles, as round 2 did
+
+    def fmt(cin_pad, cout):
+        bn, group = ops.conv_list_format(cin_pad, cout)
+        return (bn * group, group) if (coarse and group > 0) else (bn, group)
+    jobs = []            # (key, layer, bn, group): group > 0 = a SEGMENT list (bn = 32) consumed `group` entries per tile
     for kind, src, dst, cin, cout in NODES[:depth_of(last_layer) + 1]:
         if kind == "pool":
             # forward and backward are both indexed by blocks of the POOLED plane: one list, key ('pool', output layer)
-            jobs.append((("pool", dst), dst, ops.plane_tile_positions(1)))
+            jobs.append((("pool", dst), dst, ops.plane_tile_positions(1), 0))
             continue
-        jobs.append(((kind, "f"), dst, ops.conv_tile_positions(4 if cin == 3 else cin, cout)))
+        jobs.append(((kind, "f"), dst) + fmt(4 if cin == 3 else cin, cout))
         if src != "img":
-            jobs.append(((kind, "b"), src, ops.conv_tile_positions(cout, cin)))
+            jobs.append(((kind, "b"), src) + fmt(cout, cin))
         else:
-            jobs.append((("img", "d"), "img", ops.plane_tile_positions(0)))   # conv1_1's data gradient
+            jobs.append((("img", "d"), "img", ops.plane_tile_positions(0), 0))   # conv1_1's data gradient
     # flags of a (layer, tile size) pair are shared by the conv that produces the layer and the dgrad that produces
     # its gradient; all flags go into ONE buffer, the levels of a pair next to each other: every list is then one
     # contiguous slice of the compacted buffer, and a single nonzero + a single read-back serve all of them
     seg = {}             # (layer, bn) -> [offset of level 0, ..., offset of level n-1, end]
     starts, shifts = [], []
     total = 0
-    for _, layer, bn in jobs:
+    for _, layer, bn, _ in jobs:
         if (layer, bn) in seg:
             continue
         offs = []
@@ -82,7 +90,7 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     which = torch.searchsorted(starts_d, active, right=True) - 1
     entries = (active + torch.tensor(shifts, device=dev)[which]).to(torch.int32)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(flags.to(torch.int64), 0)])
-    bounds = sorted({o[0] for o in seg.values()} | {o[-1] for o in seg.values()})
+    bounds = sorted({b for o in seg.values() for b in o})     # every (layer, tile size, level) boundary
     picked = csum[torch.tensor(bounds, device=dev)]
     if extra is None:
         host, extra_host = picked.tolist(), None                              # the one read-back
@@ -91,9 +99,50 @@ def build_tile_lists(needs, last_layer: str, extra=None):
         host, extra_host = [int(v) for v in both[:len(bounds)]], both[len(bounds):]
     cnt = dict(zip(bounds, host))
     out = {}
-    for key, layer, bn in jobs:
+    # Segment lists (the split conv kernels: any `group` live 32-position segments of ONE level form a tile): per level the
+    # run of live entries padded to a multiple of `group` with (level << 24) | 0xFFFFFF. One gather builds all of them: the
+    # index list is assembled on the host from the counts just read (entry n_entries + g = level g's padding entry).
+    if coarse:   # A/B: whole tiles - every live tile contributes all of its `group` segments
+        for key, layer, bn, group in jobs:
+            if group > 0:
+                offs = seg[(layer, bn)]
+                lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
+                n_all = offs[-1] - offs[0]
+                g_of = lst >> 24
+                t_of = lst & 0xFFFFFF
+                segs = (t_of[:, None] * group + torch.arange(group, device=dev, dtype=torch.int32)[None, :])
+                out[key] = (((g_of[:, None] << 24) | segs).reshape(-1).to(torch.int32), lst.numel() / max(n_all, 1),
+                            n_all * group)
+        jobs = [j for j in jobs if j[3] <= 0]
+    n_ent = int(entries.numel())
+    idx_parts, spans = [], {}
+    pos = 0
+    for key, layer, bn, group in jobs:
         offs = seg[(layer, bn)]
-        lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
+        if group <= 0:
+            continue
+        if (layer, bn, group) not in spans:
+            begin, live = pos, 0
+            for g in range(len(needs)):
+                a, b = cnt[offs[g]], cnt[offs[g + 1]]
+                idx_parts.append(np.arange(a, b, dtype=np.int64))
+                pad = (-(b - a)) % group
+                if pad:
+                    idx_parts.append(np.full(pad, n_ent + g, dtype=np.int64))
+                pos += (b - a) + pad
+                live += b - a
+            spans[(layer, bn, group)] = (begin, pos, live)
+    if spans:
+        pads = torch.tensor([(g << 24) | 0xFFFFFF for g in range(len(needs))], dtype=torch.int32, device=dev)
+        idx_dev = torch.from_numpy(np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.int64)).to(dev, non_blocking=True)
+        seg_entries = torch.cat([entries, pads])[idx_dev]
+    for key, layer, bn, group in jobs:
+        offs = seg[(layer, bn)]
         n_all = offs[-1] - offs[0]
-        out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
+        if group > 0:
+            begin, end, live = spans[(layer, bn, group)]
+            out[key] = (seg_entries[begin:end], live / max(n_all, 1), n_all + group * len(needs))
+        else:
+            lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
+            out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
     return out if extra is None else (out, extra_host)
