@@ -202,10 +202,11 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
  * uint16 bit patterns; runtime/ops.py:pack_conv_split builds it from the fp32 tap-major pack). Cin % 16 == 0,
  * Cout % 64 == 0; tiles cover sm_conv_split_tile_positions() = 128 positions. Same flags / ws semantics as sm_conv3x3_grouped.
  * tile_list (both split entry points, ABI 6): a list of 32-position SEGMENTS, not of whole tiles - entry =
- * (problem << 24) | segment (segment s = positions [Wp + 32 s, Wp + 32 s + 32) of the padded plane), consumed
- * tile positions / 32 entries per tile: ANY live segments of ONE problem form a tile (the dead 32-position ranges inside
- * 128-position tiles were 8 % of all matrix instructions of a step); every problem's run is padded to a whole number of
- * tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and must be a multiple of tile positions / 32.
+ * (problem << 24) | q, q = index of the segment's first position in the padded plane (a multiple of 4, >= Wp; segments
+ * of one launch must not overlap), consumed tile positions / 32 entries per tile: ANY live segments of ONE problem form
+ * a tile (the dead 32-position ranges inside 128-position tiles were 8-17 % of all matrix instructions of a step);
+ * every problem's run is padded to a whole number of tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and
+ * must be a multiple of tile positions / 32. sm_cover_segments builds such lists from need maps.
  * Replaces the same reference operators (F.conv2d forward / backward of content_and_style_losses.py:11-32). */
 int sm_conv_split_tile_positions(void);
 int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,
@@ -450,6 +451,18 @@ int sm_need_step(const float* need_out, int ho, int wo, int mode, const float* M
 /* flags[t] = does position tile t (bn positions, sm_conv_tile_positions) of an (h,w) plane hold a needed pixel;
  * flags has ceil(h * sm_fmap_row_stride(w) / bn) entries. */
 int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void* stream);
+
+/* Active SEGMENT lists of the split conv kernels (sm_conv3x3_grouped_split / _split2: tile_list): for up to 64 need maps
+ * in one launch, cover the needed positions of each plane with disjoint 32-position segments that start at any multiple
+ * of 4 (greedy over the flattened padded plane). starts receives (tag << 24) | q, q = first position of a segment as an
+ * index into the padded plane (ascending; at most cap entries), *count their number (device). Once per view. */
+typedef struct {
+    const float* need;   /* [h][w] 0 / 1 */
+    int32_t* starts;
+    int32_t* count;
+    int h, w, tag, cap;
+} sm_cover_problem;
+int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream);
 
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 

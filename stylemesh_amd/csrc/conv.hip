@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     int q = 0;
     bool alive = true;
     if (a.tile_list && a.list_segments) {
-        // the split kernels' lists: BN / 32 entries per tile, (problem << 24) | 32-position segment, 0xFFFFFF = padding
+        // the split kernels' lists: BN / 32 entries per tile, (problem << 24) | first position of a segment, 0xFFFFFF = padding
         const int* e = a.tile_list + (size_t)n_glob * (BN / 32);
         const int gsel = e[0] >> 24;
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
             if (g == gsel) P = a.p[g];
         const int sg = e[c4 >> 5] & 0xFFFFFF;
         alive = sg != 0xFFFFFF;
-        q = P.Wp + sg * 32 + (c4 & 31);
+        q = sg + (c4 & 31);
     } else {
         if (a.tile_list) {
             const int e = a.tile_list[n_glob];

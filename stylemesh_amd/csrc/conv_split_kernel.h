@@ -154,7 +154,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     int qs[SEG];        // first position of each segment (index into the padded plane); block-uniform
     bool live[SEG];     // false: a padding entry of the list (nothing is stored for it)
     if (a.tile_list) {
-        const int* e = a.tile_list + (size_t)n_glob * SEG;   // SEG entries (problem << 24) | segment, 0xFFFFFF = padding
+        const int* e = a.tile_list + (size_t)n_glob * SEG;   // SEG entries (problem << 24) | first position, 0xFFFFFF = padding
         const int gsel = e[0] >> 24;
 #pragma unroll
         for (int g = 1; g < SM_MAX_GROUP; ++g)
@@ -164,7 +164,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int i = 0; i < SEG; ++i) {
             const int sg = e[i] & 0xFFFFFF;
             live[i] = sg != 0xFFFFFF;
-            qs[i] = P.Wp + (live[i] ? sg : s0) * 32;        // (a padding entry stages segment 0's data again)
+            qs[i] = live[i] ? sg : s0;                      // (a padding entry stages segment 0's data again)
         }
     } else {
         int n_tile = n_glob;

@@ -236,9 +236,90 @@ __global__ __launch_bounds__(256) void tile_flags_kernel(const float* __restrict
     else if (lane == 0) flags[t] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Active lists of the split conv kernels: cover the needed positions of a plane with 32-position segments that may
+// START at any multiple of 4 (not on a 32-position grid) and never overlap: greedy left to right over the flattened
+// padded plane - the next segment starts at the first needed position not yet covered, rounded down to a multiple of 4
+// (a data-gradient epilogue that adds into its output must never see a position twice, so segments are disjoint).
+// Against segments on the aligned grid this drops another 3.6 % of the listed positions (5 bench views, FLOP-weighted:
+// 0.659 -> 0.635 of dense; the exact need is 0.589). One block per need map: all threads pack the map into one bit per
+// position in LDS (<= 103 KB for a 784 x 1045 plane), then ONE lane walks the bits - a chain of <= positions / 32 steps of
+// LDS latency each, all maps of all levels in one launch, once per view (in prepare_view: beside the previous view's steps).
+// ---------------------------------------------------------------------------------------------------
+#define SM_COVER_MAX 64
+struct CoverProblem {
+    const float* need;     // [h][w] 0 / 1
+    int32_t* starts;       // out: (tag << 24) | first position q of each segment (index into the padded plane)
+    int32_t* count;        // out: number of segments
+    int h, w, tag, cap;
+};
+struct CoverGroup {
+    CoverProblem p[SM_COVER_MAX];
+};
+
+__global__ __launch_bounds__(256) void cover_segments_kernel(CoverGroup g) {
+    extern __shared__ uint32_t bits[];
+    const CoverProblem P = g.p[blockIdx.x];
+    const int Wp = row_stride(P.w);
+    const int n_pos = P.h * Wp;                       // positions of rows 1 .. h, relative to q = Wp
+    const int n_words = (n_pos + 31) / 32 + 2;        // + a zero tail the 64-bit window may read
+    for (int wd = threadIdx.x; wd < n_words; wd += 256) {
+        uint32_t v = 0;
+        const int base = wd * 32;
+        if (base < n_pos) {
+            int r = base / Wp, x = base - r * Wp;
+#pragma unroll 4
+            for (int b = 0; b < 32; ++b) {
+                if (base + b < n_pos && x >= 1 && x <= P.w && P.need[(size_t)r * P.w + x - 1] > 0.f) v |= 1u << b;
+                if (++x == Wp) { x = 0; ++r; }
+            }
+        }
+        bits[wd] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int n = 0, cursor = 0;                            // cursor: a multiple of 4; everything before it is covered or dead
+    while (cursor < n_pos) {
+        const int wd = cursor >> 5, sh = cursor & 31;
+        const uint64_t lo = bits[wd], mid = bits[wd + 1], hi = bits[wd + 2];
+        const uint64_t win = sh ? (((lo | (mid << 32)) >> sh) | (hi << (64 - sh))) : (lo | (mid << 32));
+        if (win == 0) { cursor += 64; continue; }
+        const int p = cursor + __builtin_ctzll(win);
+        const int st = p & ~3;                        // >= cursor
+        if (n < P.cap) P.starts[n] = (P.tag << 24) | (Wp + st);
+        ++n;
+        cursor = st + 32;
+    }
+    *P.count = n;
+}
+
 }  // namespace sm
 
 extern "C" {
+
+int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream) {
+    if (n < 1 || n > SM_COVER_MAX) return (int)hipErrorInvalidValue;
+    sm::CoverGroup g;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        if (problems[i].h < 1 || problems[i].w < 1 || problems[i].tag < 0 || problems[i].tag > 127) return (int)hipErrorInvalidValue;
+        g.p[i] = sm::CoverProblem{problems[i].need, problems[i].starts, problems[i].count, problems[i].h, problems[i].w,
+                                  problems[i].tag, problems[i].cap};
+        const size_t words = ((size_t)problems[i].h * sm::row_stride(problems[i].w) + 31) / 32 + 2;
+        lds = words * 4 > lds ? words * 4 : lds;
+    }
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {   // > 64 KB of dynamic LDS needs the opt-in
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm::cover_segments_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(sm::cover_segments_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, g);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
 
 int sm_need_step(const float* need_out, int ho, int wo, int mode, const float* M, int H, int W, float* need_src, int hs,
                  int ws, void* stream) {

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sm_level_factors": [_vp, _vp, _i, _vp, _vp],
     "sm_need_step": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "sm_tile_flags": [_vp, _i, _i, _i, _vp, _vp],
+    "sm_cover_segments": [_vp, _i, _vp],
     "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
@@ -128,6 +129,12 @@ class GramBwdProblem(C.Structure):
                 ("D1", C.c_void_p), ("dfeat", C.c_void_p), ("ws", C.c_void_p), ("amax_feat", C.c_void_p),
                 ("amax_d", C.c_void_p), ("amax_out", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("relu_gate", C.c_int)]
+
+
+class CoverProblem(C.Structure):
+    """sm_cover_problem of include/stylemesh_hip.h"""
+    _fields_ = [("need", C.c_void_p), ("starts", C.c_void_p), ("count", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
+                ("tag", C.c_int), ("cap", C.c_int)]
 
 
 class PlaneProblem(C.Structure):

@@ -642,6 +642,16 @@ def need_step(need_out, mode, M, need_src):
               "sm_need_step")
 
 
+def cover_segments(problems):
+    """``problems``: [(need [h,w] float tensor, starts int32 tensor, count int32 [1] tensor, tag), ...] (<= 64): disjoint
+    32-position segments covering the needed positions of every plane, starts as (tag << 24) | q (``sm_cover_segments``)."""
+    arr = (hip.CoverProblem * len(problems))()
+    for i, (need, starts, count, tag) in enumerate(problems):
+        h, w = need.shape
+        arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel())
+    hip.check(lib.sm_cover_segments(arr, len(problems), hip.stream()), "sm_cover_segments")
+
+
 def tile_flags(need, bn, flags):
     h, w = need.shape
     hip.check(lib.sm_tile_flags(ptr(need), h, w, bn, ptr(flags), hip.stream()), "sm_tile_flags")

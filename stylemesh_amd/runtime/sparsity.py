@@ -64,13 +64,33 @@ def build_tile_lists(needs, last_layer: str, extra=None):
             jobs.append(((kind, "b"), src) + fmt(cout, cin))
         else:
             jobs.append((("img", "d"), "img", ops.plane_tile_positions(0), 0))   # conv1_1's data gradient
+    free = not coarse and os.environ.get("STYLEMESH_SEGMENT_STARTS", "free") == "free"   # A/B: 'grid' = aligned segments
+    # --- segment jobs with FREE starts: one greedy cover per (layer, level) need map, all in one launch
+    cover = {}           # layer -> (starts tensor [levels, cap], offsets, counts tensor)
+    cover_problems = []
+    if free:
+        seg_layers = sorted({layer for _, layer, _, group in jobs if group > 0})
+        caps = {layer: max(nd[layer].shape[0] * hip.row_stride(nd[layer].shape[1]) // 32 + 2 for nd in needs)
+                for layer in seg_layers}
+        n_prob = len(seg_layers) * len(needs)
+        counts_dev = torch.zeros(max(n_prob, 1), dtype=torch.int32, device=dev)
+        k = 0
+        for layer in seg_layers:
+            starts = torch.empty(len(needs), caps[layer], dtype=torch.int32, device=dev)
+            cover[layer] = (starts, k)
+            for g, nd in enumerate(needs):
+                cover_problems.append((nd[layer], starts[g], counts_dev[k:k + 1], g))
+                k += 1
+        for i in range(0, len(cover_problems), 64):
+            ops.cover_segments(cover_problems[i:i + 64])
     # flags of a (layer, tile size) pair are shared by the conv that produces the layer and the dgrad that produces
     # its gradient; all flags go into ONE buffer, the levels of a pair next to each other: every list is then one
     # contiguous slice of the compacted buffer, and a single nonzero + a single read-back serve all of them
+    flag_jobs = [j for j in jobs if not (free and j[3] > 0)]
     seg = {}             # (layer, bn) -> [offset of level 0, ..., offset of level n-1, end]
     starts, shifts = [], []
     total = 0
-    for _, layer, bn, _ in jobs:
+    for _, layer, bn, _ in flag_jobs:
         if (layer, bn) in seg:
             continue
         offs = []
@@ -92,16 +112,18 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(flags.to(torch.int64), 0)])
     bounds = sorted({b for o in seg.values() for b in o})     # every (layer, tile size, level) boundary
     picked = csum[torch.tensor(bounds, device=dev)]
-    if extra is None:
-        host, extra_host = picked.tolist(), None                              # the one read-back
-    else:   # counts < 2^53 and the extras (mask sums) are exact in float64
-        both = torch.cat([picked.to(torch.float64), extra.to(torch.float64)]).tolist()
-        host, extra_host = [int(v) for v in both[:len(bounds)]], both[len(bounds):]
+    parts = [picked.to(torch.float64)]
+    if free:
+        parts.append(counts_dev.to(torch.float64))
+    if extra is not None:   # counts < 2^53 and the extras (mask sums) are exact in float64
+        parts.append(extra.to(torch.float64))
+    both = torch.cat(parts).tolist()                                   # the one read-back
+    host = [int(v) for v in both[:len(bounds)]]
+    n_cov = counts_dev.numel() if free else 0
+    cov_counts = [int(v) for v in both[len(bounds):len(bounds) + n_cov]]
+    extra_host = both[len(bounds) + n_cov:] if extra is not None else None
     cnt = dict(zip(bounds, host))
     out = {}
-    # Segment lists (the split conv kernels: any `group` live 32-position segments of ONE level form a tile): per level the
-    # run of live entries padded to a multiple of `group` with (level << 24) | 0xFFFFFF. One gather builds all of them: the
-    # index list is assembled on the host from the counts just read (entry n_entries + g = level g's padding entry).
     if coarse:   # A/B: whole tiles - every live tile contributes all of its `group` segments
         for key, layer, bn, group in jobs:
             if group > 0:
@@ -110,39 +132,67 @@ def build_tile_lists(needs, last_layer: str, extra=None):
                 n_all = offs[-1] - offs[0]
                 g_of = lst >> 24
                 t_of = lst & 0xFFFFFF
-                segs = (t_of[:, None] * group + torch.arange(group, device=dev, dtype=torch.int32)[None, :])
-                out[key] = (((g_of[:, None] << 24) | segs).reshape(-1).to(torch.int32), lst.numel() / max(n_all, 1),
+                wp = torch.tensor([hip.row_stride(nd[layer].shape[1]) for nd in needs], dtype=torch.int32, device=dev)
+                q = (t_of[:, None] * group + torch.arange(group, device=dev, dtype=torch.int32)[None, :]) * 32 + wp[g_of.long()][:, None]
+                out[key] = (((g_of[:, None] << 24) | q).reshape(-1).to(torch.int32), lst.numel() / max(n_all, 1),
                             n_all * group)
         jobs = [j for j in jobs if j[3] <= 0]
-    n_ent = int(entries.numel())
+    # Segment lists (the split conv kernels: any `group` live 32-position segments of ONE level form a tile): per level the
+    # run of live entries padded to a multiple of `group` with (level << 24) | 0xFFFFFF. One gather builds all of them: the
+    # index list is assembled on the host from the counts just read (behind the sources: one padding entry per level).
     idx_parts, spans = [], {}
     pos = 0
+    if free:
+        src_parts, src_base = [], {}
+        base = 0
+        for layer, (st, k0) in cover.items():
+            src_base[layer] = base
+            src_parts.append(st.reshape(-1))
+            base += st.numel()
+        n_src = base
+    else:
+        n_src = int(entries.numel())
     for key, layer, bn, group in jobs:
-        offs = seg[(layer, bn)]
-        if group <= 0:
+        if group <= 0 or (layer, bn, group) in spans:
             continue
-        if (layer, bn, group) not in spans:
-            begin, live = pos, 0
-            for g in range(len(needs)):
-                a, b = cnt[offs[g]], cnt[offs[g + 1]]
-                idx_parts.append(np.arange(a, b, dtype=np.int64))
-                pad = (-(b - a)) % group
-                if pad:
-                    idx_parts.append(np.full(pad, n_ent + g, dtype=np.int64))
-                pos += (b - a) + pad
-                live += b - a
-            spans[(layer, bn, group)] = (begin, pos, live)
+        begin, live, n_all = pos, 0, 0
+        for g in range(len(needs)):
+            if free:
+                st, k0 = cover[layer]
+                n_g = cov_counts[k0 + g]
+                a = src_base[layer] + g * st.shape[1]
+                idx_parts.append(np.arange(a, a + n_g, dtype=np.int64))
+                h, w = needs[g][layer].shape
+                n_all += (h * hip.row_stride(w) + 31) // 32
+            else:
+                offs = seg[(layer, bn)]
+                a, b_ = cnt[offs[g]], cnt[offs[g + 1]]
+                n_g = b_ - a
+                idx_parts.append(np.arange(a, b_, dtype=np.int64))
+                n_all = offs[-1] - offs[0]
+            pad = (-n_g) % group
+            if pad:
+                idx_parts.append(np.full(pad, n_src + g, dtype=np.int64))
+            pos += n_g + pad
+            live += n_g
+        spans[(layer, bn, group)] = (begin, pos, live, n_all)
     if spans:
         pads = torch.tensor([(g << 24) | 0xFFFFFF for g in range(len(needs))], dtype=torch.int32, device=dev)
         idx_dev = torch.from_numpy(np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.int64)).to(dev, non_blocking=True)
-        seg_entries = torch.cat([entries, pads])[idx_dev]
+        source = torch.cat(src_parts + [pads]) if free else torch.cat([entries, pads])
+        seg_entries = source[idx_dev]
     for key, layer, bn, group in jobs:
-        offs = seg[(layer, bn)]
-        n_all = offs[-1] - offs[0]
         if group > 0:
-            begin, end, live = spans[(layer, bn, group)]
-            out[key] = (seg_entries[begin:end], live / max(n_all, 1), n_all + group * len(needs))
+            begin, end, live, n_all = spans[(layer, bn, group)]
+            lst = seg_entries[begin:end]
+            if not free:   # aligned segments from the flags: (level << 24) | segment -> (level << 24) | first position
+                wp = torch.tensor([hip.row_stride(nd[layer].shape[1]) for nd in needs], dtype=torch.int32, device=dev)
+                g_of, s_of = lst >> 24, lst & 0xFFFFFF
+                lst = torch.where(s_of == 0xFFFFFF, lst, (g_of << 24) | (s_of * 32 + wp[g_of.long()]))
+            out[key] = (lst, live / max(n_all, 1), n_all + group * len(needs))
         else:
+            offs = seg[(layer, bn)]
+            n_all = offs[-1] - offs[0]
             lst = entries[cnt[offs[0]]:cnt[offs[-1]]]
             out[key] = (lst, lst.numel() / max(n_all, 1), n_all)
     return out if extra is None else (out, extra_host)

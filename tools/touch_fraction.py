@@ -16,7 +16,7 @@ views = bench.make_views(wl, [0, 2, 6, 7])
 union = {}
 for i, v in enumerate(views):
     eng.set_view(bench.to_device(v, torch.device("cuda")))
-    for cl in (5, 6, 7):
+    for cl in (4, 5, 6):
         f = eng.touch_flags(cl)
         union[cl] = f if cl not in union else torch.maximum(union[cl], f)
         print(f"view {i} chunk 2^{cl}: touched {float(f.float().mean()):.3f}   union so far {float(union[cl].float().mean()):.3f}")
