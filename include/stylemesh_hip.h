@@ -483,6 +483,12 @@ int sm_chunks_gather(const float* arena, const int32_t* idx, const int32_t* n_id
 int sm_chunks_scatter(float* arena, const int32_t* idx, const int32_t* n_idx_dev, size_t n_idx, int chunk_log2,
                       const float* compact, float scale, void* stream);
 
+/* A HIP stream confined to n_cus (8 .. 256, a multiple of 8 is spread evenly: n_cus / 8 compute units of every XCD) of
+ * the device's compute units - for work with slack that should share few CUs with the step's trunk (the Python host's
+ * side streams, STYLEMESH_SIDE_CUS). Returns a hipError_t. */
+int sm_stream_create_cu_subset(int n_cus, void** stream_out);
+int sm_stream_destroy(void* stream);
+
 /* RCCL over xGMI, one communicator per process (one process per GPU). The reference has no collective; this is the
  * exchange of the R-GPU step defined in SURVEY.md section 8 e. All return a ncclResult_t (0 = success).
  *   sm_comm_get_unique_id: rank 0 fills id_out (sm_comm_unique_id_bytes() bytes, HOST) and ships it to the other

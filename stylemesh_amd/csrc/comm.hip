@@ -12,6 +12,22 @@
 
 extern "C" {
 
+// A HIP stream whose kernels run on a SUBSET of the compute units: the low `n_cus` bits of the queue's CU mask. The
+// driver deals mask bits round-robin to the 8 XCDs (bit b -> XCD b % 8) and, inside an XCD, to its shader engines, so
+// the low n bits are n / 8 CUs of every XCD, spread over its engines. For the engine's side streams: HBM-bound work
+// with slack (style branches, the early half of the update) then shares n CUs with the conv trunk instead of all 256.
+int sm_stream_create_cu_subset(int n_cus, void** stream_out) {
+    if (n_cus < 8 || n_cus > 256 || stream_out == nullptr) return (int)hipErrorInvalidValue;
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < n_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
+    *stream_out = (void*)s;
+    return (int)e;
+}
+
+int sm_stream_destroy(void* stream) { return stream ? (int)hipStreamDestroy((hipStream_t)stream) : 0; }
+
 size_t sm_comm_unique_id_bytes(void) { return sizeof(ncclUniqueId); }
 
 int sm_comm_get_unique_id(void* id_out) {

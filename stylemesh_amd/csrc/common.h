@@ -73,6 +73,28 @@ __device__ __forceinline__ float amax_read(const float* amax) {
     return v;
 }
 
+// Loads / stores of the HBM-bound kernels that run on side streams beside the conv trunk (style branches): with
+// -DSM_SIDE_NT=1 they carry the non-temporal hint (streamed once: do not displace the trunk's operands from L2 / MALL).
+#ifndef SM_SIDE_NT
+#define SM_SIDE_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T side_load(const T* p) {
+#if SM_SIDE_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void side_store(T v, T* p) {
+#if SM_SIDE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int row_stride(int W) { return round_up(W + 1, 4); }
 __host__ __device__ inline int plane_size(int H, int W) { return round_up((H + 2) * row_stride(W), 64); }

@@ -270,7 +270,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         (void)k_;                                                                           \
         const float* p_ = bsrc + (size_t)chunk_ * 16 * KS * plane;                          \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[set_][ks][c] = p_[(size_t)(ks * 16 + c) * plane]; \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[set_][ks][c] = side_load(p_ + (size_t)(ks * 16 + c) * plane); \
     }
 #define SM_STORE_B(set_, s_, buf_)                                                          \
     {                                                                                       \
@@ -338,7 +338,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
             float v = acc[0][nj][r];
             if (NP == 2) v *= out_scale;
             if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
-            dfeat[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = v;
+            side_store(v, dfeat + o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane);
             vmax = fmaxf(vmax, fabsf(v));
         }
     }
@@ -513,11 +513,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4
         }                                                                                               \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
             const float* pa_ = a_src + (size_t)r * CP * plane + q_;                                     \
-            const f32x4 a0_ = *reinterpret_cast<const f32x4*>(pa_), a1_ = *reinterpret_cast<const f32x4*>(pa_ + 4); \
+            const f32x4 a0_ = side_load(reinterpret_cast<const f32x4*>(pa_)), a1_ = side_load(reinterpret_cast<const f32x4*>(pa_ + 4)); \
             _Pragma("unroll") for (int c = 0; c < 4; ++c) { rA[set_][r][c] = a0_[c]; rA[set_][r][4 + c] = a1_[c]; } \
             if constexpr (!DIAG) {                                                                                \
                 const float* pb_ = b_src + (size_t)r * CP * plane + q_;                                 \
-                const f32x4 b0_ = *reinterpret_cast<const f32x4*>(pb_), b1_ = *reinterpret_cast<const f32x4*>(pb_ + 4); \
+                const f32x4 b0_ = side_load(reinterpret_cast<const f32x4*>(pb_)), b1_ = side_load(reinterpret_cast<const f32x4*>(pb_ + 4)); \
                 _Pragma("unroll") for (int c = 0; c < 4; ++c) { rB[set_][r][c] = b0_[c]; rB[set_][r][4 + c] = b1_[c]; } \
             }                                                                                           \
         }                                                                                               \

@@ -235,6 +235,13 @@ class StepEngine:
     def _new_side_stream(self):
         """Side streams carry work with slack (style branches joined many kernels later, the early half of the update);
         STYLEMESH_SIDE_PRIORITY=low asks the hardware queues to dispatch the main stream's workgroups first."""
+        n_cus = int(os.environ.get("STYLEMESH_SIDE_CUS", "0"))
+        if n_cus > 0:   # a queue confined to n_cus compute units (n_cus / 8 of every XCD): see sm_stream_create_cu_subset
+            import ctypes
+            out = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                ops.hip.check(ops.hip.lib.sm_stream_create_cu_subset(n_cus, ctypes.byref(out)), "sm_stream_create_cu_subset")
+            return torch.cuda.ExternalStream(out.value, device=self.device)
         if os.environ.get("STYLEMESH_SIDE_PRIORITY", "") == "low":
             lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
             return torch.cuda.Stream(device=self.device, priority=lo)

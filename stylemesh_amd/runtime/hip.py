@@ -93,6 +93,8 @@ SIGNATURES = {
     "sm_flags_compact": [_vp, _sz, _vp, _vp, _vp, _vp],
     "sm_chunks_gather": [_vp, _vp, _vp, _sz, _i, _vp, _vp],
     "sm_chunks_scatter": [_vp, _vp, _vp, _sz, _i, _vp, _f, _vp],
+    "sm_stream_create_cu_subset": [_i, _vp],
+    "sm_stream_destroy": [_vp],
     "sm_comm_unique_id_bytes": [],
     "sm_comm_get_unique_id": [_vp],
     "sm_comm_init": [_vp, _i, _vp, _i],

@@ -343,11 +343,13 @@ def test_conv3x3_split2_fused_pool_backward(rt, C, cout, H, W, monkeypatch):
     assert_close(da.to_dense(), x.grad, 0, 0)
 
 
-@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 60, 70), (512, 512, 33, 45), (256, 64, 40, 52)])
-def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, monkeypatch):
-    """Fewer tiles than CUs: every tile is a K-split tail reduced by the second pass. Repeated launches must be
-    bit-identical (fixed summation order) and match an fp64 convolution."""
-    monkeypatch.setattr(rt.ops, "CONV_MODE", "split")
+@pytest.mark.parametrize("mode", ["split", "split2"])
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 60, 70), (512, 512, 33, 45), (256, 64, 40, 52), (512, 512, 16, 21)])
+def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, mode, monkeypatch):
+    """Fewer tiles than CUs: every tile is a K-split tail reduced by the second pass. Repeated launches into the same
+    workspace must be bit-identical (fixed summation order), match an fp64 convolution and record the true output
+    maximum."""
+    monkeypatch.setattr(rt.ops, "CONV_MODE", mode)
     torch.manual_seed(cin + H)
     x = F.relu(torch.randn(1, cin, H, W) * 2)
     wgt = torch.randn(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5
@@ -355,16 +357,18 @@ def test_conv3x3_split_tail_units_deterministic(rt, cin, cout, H, W, monkeypatch
     ref = F.relu(F.conv2d(x.double(), wgt.double(), b.double(), padding=1))[0]
     xin = rt.FMap(cin, H, W).from_dense(x[0])
     w = dev(rt.ops.pack_conv_fwd(wgt))
-    w3 = rt.ops.pack_conv_split(w)
+    w3, w2 = rt.ops.pack_conv_split(w), rt.ops.pack_conv_split2(w)
     first = None
     for rep in range(25):
         out = rt.FMap(cout, H, W)
-        rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3)
+        amax_in, amax_out = rt.ops.new_amax("cuda", float(x.abs().max())), rt.ops.new_amax("cuda")
+        rt.ops.conv3x3(xin, w, dev(b), out, rt.hip.EPI_BIAS_RELU, wt3=w3, wt2=w2, amax_in=amax_in, amax_out=amax_out)
         got = out.to_dense()
         if first is None:
             first = got
             d = got.double().cpu() - ref
             assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max())
+            assert float(amax_out.max()) == float(got.abs().max())
         else:
             assert torch.equal(got, first), rep
 
