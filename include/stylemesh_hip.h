@@ -39,13 +39,15 @@ extern "C" {
 #define SM_EPI_BIAS_RELU 1 /* out = relu(acc + bias[co])                                  (forward)  */
 #define SM_EPI_RELU_MASK 2 /* out = gate[co][q] > 0 ? v : 0                               (dgrad)    */
 #define SM_EPI_ADD 4       /* v += out[co][q] (value already in the output buffer) before the gate   */
+#define SM_EPI_POOL 8      /* with SM_EPI_BIAS_RELU, sm_conv3x3_grouped_split2 only: store the 2x2 max-pooled map and the
+                            * pool's argmax codes (sm_conv_problem::pool_out / pool_code) INSTEAD of out     (forward)  */
 
 /* ---- layout helpers (host, pure functions) -------------------------------------------------------- */
 int sm_fmap_row_stride(int W);        /* Wp */
 int sm_fmap_plane(int H, int W);      /* floats per channel plane (multiple of 64) */
 int sm_abi_version(void);
 /* sizeof of the problem structs of this header as the library was compiled (which: 0 sm_conv_problem, 1
- * sm_plane_problem, 2 sm_gram_problem, 3 sm_style_problem, 4 sm_gram_bwd_problem; anything else: -1) - a binding checks
+ * sm_plane_problem, 2 sm_gram_problem, 3 sm_style_problem, 4 sm_gram_bwd_problem, 5 sm_cover_problem; anything else: -1) - a binding checks
  * its own struct layouts against it. */
 int sm_sizeof_problem(int which);
 
@@ -184,6 +186,15 @@ typedef struct {
      * <= 0): operand(y, x) = in(y/2, x/2) if code(y/2, x/2) == (y & 1) * 2 + (x & 1) else 0. Replaces the
      * sm_maxpool2x2_bwd_relu pass (2.75 plane-sizes of traffic) and the re-read of its output. */
     const uint32_t* unpool_code;
+    /* sm_conv3x3_grouped_split2 with flags SM_EPI_BIAS_RELU | SM_EPI_POOL only (ABI 7; NULL elsewhere): the forward conv
+     * BELOW a 2x2 max-pool (F.max_pool2d of the VGG, content_and_style_losses.py:56-68) takes the maxima in its epilogue:
+     * pool_out [Cout][plane(H/2, W/2)] receives the pooled map, pool_code [Cout / 8][plane(H/2, W/2)] the argmax codes
+     * (the formats of sm_maxpool2x2_fwd_codes_tiles, bit-identical values), `out` is NOT written - the pre-pool map has
+     * no other reader. Needs a tile_list whose segments come in vertical PAIRS (entries 2k, 2k + 1 = the same 32 columns
+     * of image rows 2Y and 2Y + 1, first column even: sm_cover_segments with pair_w). Replaces the pool pass and 1.75
+     * plane sizes of HBM traffic per pool. */
+    float* pool_out;
+    uint32_t* pool_code;
 } sm_conv_problem;
 /* "amax" bounds. An amax argument is a DEVICE array of sm_amax_floats() floats (64 slots, 256 bytes apart), zeroed by
  * the caller before the first launch that records into it; its VALUE is the maximum over the slots. Writers atomically
@@ -461,6 +472,11 @@ typedef struct {
     int32_t* starts;
     int32_t* count;
     int h, w, tag, cap;
+    /* 0: as above. > 0 (ABI 7): PAIR mode for a conv with SM_EPI_POOL - need is the need map of the POOLED plane
+     * [h][w], pair_w the width of the full-resolution plane the conv writes (w == pair_w / 2); every pooled row Y is
+     * covered with runs of 16 windows starting at any window X0, and each run becomes TWO entries: the segment of
+     * image row 2Y that starts at column 2 X0, then the one right below it (row 2Y + 1). */
+    int pair_w;
 } sm_cover_problem;
 int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream);
 

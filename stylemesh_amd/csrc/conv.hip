@@ -287,6 +287,59 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     }
 }
 
+// Tail second pass of a forward conv with SM_EPI_POOL (split kernels; the tile's segments are vertical pairs, see
+// conv_split_kernel.h): block = (tail tile, 8-channel group, two segment pairs); thread = (channel of the group, one of
+// the 32 pooling windows): sums the K-splits of its four elements, bias + ReLU, 2x2 maximum + argmax code; the eight
+// channels' nibbles meet through three lane exchanges. Writes the pooled map and the code image only.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
+    const int tile = a.n_whole + blockIdx.x;
+    const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
+    const int c = threadIdx.x & 7, w = threadIdx.x >> 3;         // channel of the group, window 0..31 of the block
+    const int pair = blockIdx.z * 2 + (w >> 4), X = w & 15;      // segment pair of the tile, window of the pair
+    const int* e = a.tile_list + (size_t)n_glob * (BN / 32);
+    const int gsel = e[0] >> 24;
+    ConvProblem P = a.p[0];
+#pragma unroll
+    for (int g = 1; g < SM_MAX_GROUP; ++g)
+        if (g == gsel) P = a.p[g];
+    const int sg = e[2 * pair] & 0xFFFFFF;
+    const float amax_seen = amax_peek(a.amax_out);
+    float m = 0.f;
+    unsigned code = 4u;
+    bool ok = false;
+    int qo = 0;
+    const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
+    const int row = blockIdx.y * 8 + c;
+    if (sg != 0xFFFFFF) {
+        const int q = sg + 2 * X;
+        const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
+        ok = ((yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
+        qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
+        const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN) + (size_t)row * BN + pair * 64 + 2 * X;
+        f32x2 t = *reinterpret_cast<const f32x2*>(wt), b = *reinterpret_cast<const f32x2*>(wt + 32);
+        for (int s = 1; s < a.splits; ++s) {
+            t += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN));
+            b += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN) + 32);
+        }
+        const float bv = a.bias[m_tile * BM + row];
+        const float v00 = fmaxf(t[0] + bv, 0.f), v01 = fmaxf(t[1] + bv, 0.f), v10 = fmaxf(b[0] + bv, 0.f), v11 = fmaxf(b[1] + bv, 0.f);
+        m = v00;
+        code = 0u;
+        if (v01 > m) { m = v01; code = 1u; }
+        if (v10 > m) { m = v10; code = 2u; }
+        if (v11 > m) { m = v11; code = 3u; }
+        if (!(m > 0.f)) code = 4u;
+        if (ok) P.pool_out[(size_t)(m_tile * BM + row) * plane_o + qo] = m;
+    }
+    unsigned word = code << (4 * c);
+    word |= (unsigned)__shfl_xor((int)word, 1, 64);
+    word |= (unsigned)__shfl_xor((int)word, 2, 64);
+    word |= (unsigned)__shfl_xor((int)word, 4, 64);
+    if (ok && c == 0) P.pool_code[(size_t)((m_tile * BM) / 8 + blockIdx.y) * plane_o + qo] = word;
+    record_amax(a.amax_out, ok ? m : 0.f, amax_seen);
+}
+
 // max |x| over the interior rows of C planes (producers without an amax epilogue: the deepest loss layer's gradient)
 __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict__ in, int plane, int q_begin, int q_end,
                                                         float* amax_out) {
@@ -369,7 +422,10 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     }
     SM_LAUNCH_CHECK();
     if (rem > 0) {
-        hipLaunchKernelGGL((conv_tail_epilogue_kernel<BM, BN, FLAGS>), dim3(rem, BM * BN / 1024), dim3(256), 0, s, a);
+        if constexpr ((FLAGS & SM_EPI_POOL) != 0)
+            hipLaunchKernelGGL((conv_tail_pool_kernel<BM, BN>), dim3(rem, BM / 8, BN / 128), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_tail_epilogue_kernel<BM, BN, FLAGS>), dim3(rem, BM * BN / 1024), dim3(256), 0, s, a);
         SM_LAUNCH_CHECK();
     }
     return 0;
@@ -734,7 +790,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 6; }
+int sm_abi_version(void) { return 7; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
@@ -757,6 +813,7 @@ static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, si
     }
     switch (flags) {
         case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
+        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU | SM_EPI_POOL>(a, n_list, ws_floats, s);
         case 0: return sm::dispatch_conv_split2<0>(a, n_list, ws_floats, s);
         case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
         case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
@@ -827,8 +884,13 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
         unpool += problems[g].unpool_code != nullptr;
         a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].unpool_code,
                                  problems[g].H, problems[g].W, sm::row_stride(problems[g].W),
-                                 sm::plane_size(problems[g].H, problems[g].W)};
+                                 sm::plane_size(problems[g].H, problems[g].W), problems[g].pool_out, problems[g].pool_code};
+        if ((flags & SM_EPI_POOL) != 0 && (problems[g].pool_out == nullptr || problems[g].pool_code == nullptr ||
+                                          problems[g].H < 2 || problems[g].W < 2))
+            return (int)hipErrorInvalidValue;
     }
+    // the pooling epilogue needs the segment PAIRS of a list (sm_cover_segments, pair_w) and 8-channel code groups
+    if ((flags & SM_EPI_POOL) != 0 && (tile_list == nullptr || bias == nullptr || unpool != 0)) return (int)hipErrorInvalidValue;
     a.n_problems = n_problems;
     a.wt = reinterpret_cast<const float*>(wt2);
     a.bias = bias;

@@ -18,6 +18,10 @@ struct ConvProblem {
     // input, computed on the fly: in[q/2] where code[q/2] == parity(q), else 0.
     const uint32_t* code;
     int H, W, Wp, plane;
+    // fp16x2 kernel, flag SM_EPI_POOL (forward conv below a max-pool): the launch writes the 2x2-pooled map
+    // [Cout][plane(H/2, W/2)] and the pool's argmax codes [Cout / 8][plane(H/2, W/2)] (same formats) INSTEAD of `out`.
+    float* pool_out;
+    uint32_t* pool_code;
 };
 
 struct ConvArgs {

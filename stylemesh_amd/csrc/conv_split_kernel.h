@@ -559,6 +559,60 @@ void conv3x3_split_kernel(ConvArgs a) {
                 bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
     }
     float vmax = 0.f;   // max |output| of this lane: the operand scale of the conv that consumes this tensor (NP = 2)
+    if constexpr ((FLAGS & SM_EPI_POOL) != 0) {
+        // Forward conv BELOW a 2x2 max-pool: the tile's segments come in vertical pairs (entries 2k, 2k + 1 of the list:
+        // the same 32 columns of image rows 2Y and 2Y + 1, first column even), so every pooling window lies inside one
+        // wave - rows in two accumulator tiles of the same lane, columns in neighbouring lanes. The epilogue stores the
+        // POOLED map and the pool's argmax codes (the formats of maxpool_fwd_codes_kernel); the full-resolution output,
+        // which only the pool would read, is never written: no pool pass, 1.75 plane sizes of HBM traffic less.
+        static_assert(FLAGS == (SM_EPI_BIAS_RELU | SM_EPI_POOL) && NJ % 2 == 0, "forward epilogue, segment pairs per wave");
+        const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
+#pragma unroll
+        for (int pj = 0; pj < NJ; pj += 2) {
+            int q_seg = qs[0];
+            bool alive = live[0];
+#pragma unroll
+            for (int k = 1; k < SEG; ++k)
+                if (wn / 32 + pj == k) { q_seg = qs[k]; alive = live[k]; }
+            if (!alive) continue;                                  // (wave-uniform: a padding pair)
+            const int q = q_seg + l31;                             // this lane's position in the upper row
+            const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
+            // even lanes own a window; a segment that runs past the end of its row holds nothing there
+            const bool ok = ((l31 | yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
+            const int qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                unsigned codes[4] = {0u, 0u, 0u, 0u};              // one dword per 8-channel group: this lane's 4 nibbles
+                const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * plane_o + qo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = acc[mi][pj][r], b = acc[mi][pj + 1][r];
+                    if (NP == 2) { t *= out_scale; b *= out_scale; }
+                    const float bv = bias4[mi][r >> 2][r & 3];
+                    t = fmaxf(t + bv, 0.f);
+                    b = fmaxf(b + bv, 0.f);
+                    const float tp = __shfl_xor(t, 1, 64), bp = __shfl_xor(b, 1, 64);
+                    // first maximum in row-major order (strict '>' scan, as max_pool2d_with_indices); 4: maximum <= 0
+                    float m = t;
+                    unsigned c = 0u;
+                    if (tp > m) { m = tp; c = 1u; }
+                    if (b > m) { m = b; c = 2u; }
+                    if (bp > m) { m = bp; c = 3u; }
+                    if (!(m > 0.f)) c = 4u;
+                    vmax = ok ? fmaxf(vmax, m) : vmax;         // (bound of the POOLED map: what the next conv reads)
+                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] = m;
+                    codes[r >> 2] |= c << (4 * ((r & 3) + 4 * lhi));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned full = codes[g] | (unsigned)__shfl_xor((int)codes[g], 32, 64);   // channels 8g + 0..3 | 4..7
+                    if (ok && lhi == 0) P.pool_code[(size_t)((m0 + wm + mi * 32) / 8 + g) * plane_o + qo] = full;
+                }
+            }
+        }
+        record_amax(a.amax_out, vmax, amax_seen);
+        return;
+    }
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         int q_seg = qs[0];

@@ -740,6 +740,7 @@ int sm_sizeof_problem(int which) {
         case 2: return (int)sizeof(sm_gram_problem);
         case 3: return (int)sizeof(sm_style_problem);
         case 4: return (int)sizeof(sm_gram_bwd_problem);
+        case 5: return (int)sizeof(sm_cover_problem);
         default: return -1;
     }
 }

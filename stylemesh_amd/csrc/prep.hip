@@ -252,14 +252,69 @@ struct CoverProblem {
     int32_t* starts;       // out: (tag << 24) | first position q of each segment (index into the padded plane)
     int32_t* count;        // out: number of segments
     int h, w, tag, cap;
+    int pair_w;
 };
 struct CoverGroup {
     CoverProblem p[SM_COVER_MAX];
 };
 
+// PAIR mode (P.pair_w > 0): `need` is the need map of a POOLED plane; row Y of it is covered with runs of 16 windows
+// (one thread per row: count, exclusive scan over the rows, write), each run emitted as the two 32-position segments of
+// the full-resolution plane that hold its windows - rows 2Y and 2Y + 1, columns 2 X0 .. 2 X0 + 31.
+__device__ void cover_pairs(const CoverProblem& P, uint32_t* bits) {
+    const int rw = (P.w + 31) / 32 + 1;                 // words per pooled row (+ a zero word behind it)
+    int* row_off = reinterpret_cast<int*>(bits + P.h * rw);
+    for (int i = threadIdx.x; i < P.h * rw; i += 256) {
+        const int Y = i / rw, wd = i - Y * rw;
+        uint32_t v = 0;
+        for (int b = 0; b < 32; ++b) {
+            const int X = wd * 32 + b;
+            if (X < P.w && P.need[(size_t)Y * P.w + X] > 0.f) v |= 1u << b;
+        }
+        bits[i] = v;
+    }
+    __syncthreads();
+    for (int Y = threadIdx.x; Y < P.h; Y += 256) {      // segments of row Y
+        int n = 0, cursor = 0;
+        while (cursor < P.w) {
+            const int wd = cursor >> 5, sh = cursor & 31;
+            const uint64_t win = ((uint64_t)bits[Y * rw + wd] | ((uint64_t)(wd + 1 < rw ? bits[Y * rw + wd + 1] : 0u) << 32)) >> sh;
+            if (win == 0) { cursor += 64 - sh; continue; }
+            cursor += __builtin_ctzll(win) + 16;
+            ++n;
+        }
+        row_off[Y] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int Y = 0; Y < P.h; ++Y) { const int n = row_off[Y]; row_off[Y] = tot; tot += n; }
+        *P.count = 2 * tot;
+    }
+    __syncthreads();
+    const int Wp = row_stride(P.pair_w);
+    for (int Y = threadIdx.x; Y < P.h; Y += 256) {
+        int n = row_off[Y], cursor = 0;
+        while (cursor < P.w) {
+            const int wd = cursor >> 5, sh = cursor & 31;
+            const uint64_t win = ((uint64_t)bits[Y * rw + wd] | ((uint64_t)(wd + 1 < rw ? bits[Y * rw + wd + 1] : 0u) << 32)) >> sh;
+            if (win == 0) { cursor += 64 - sh; continue; }
+            const int X0 = cursor + __builtin_ctzll(win);
+            const int q = (2 * Y + 1) * Wp + 2 * X0 + 1;
+            if (2 * n + 1 < P.cap) {
+                P.starts[2 * n] = (P.tag << 24) | q;
+                P.starts[2 * n + 1] = (P.tag << 24) | (q + Wp);
+            }
+            ++n;
+            cursor = X0 + 16;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cover_segments_kernel(CoverGroup g) {
     extern __shared__ uint32_t bits[];
     const CoverProblem P = g.p[blockIdx.x];
+    if (P.pair_w > 0) { cover_pairs(P, bits); return; }
     const int Wp = row_stride(P.w);
     const int n_pos = P.h * Wp;                       // positions of rows 1 .. h, relative to q = Wp
     const int n_words = (n_pos + 31) / 32 + 2;        // + a zero tail the 64-bit window may read
@@ -303,9 +358,12 @@ int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream) {
     size_t lds = 0;
     for (int i = 0; i < n; ++i) {
         if (problems[i].h < 1 || problems[i].w < 1 || problems[i].tag < 0 || problems[i].tag > 127) return (int)hipErrorInvalidValue;
+        if (problems[i].pair_w != 0 && problems[i].pair_w / 2 != problems[i].w) return (int)hipErrorInvalidValue;
         g.p[i] = sm::CoverProblem{problems[i].need, problems[i].starts, problems[i].count, problems[i].h, problems[i].w,
-                                  problems[i].tag, problems[i].cap};
-        const size_t words = ((size_t)problems[i].h * sm::row_stride(problems[i].w) + 31) / 32 + 2;
+                                  problems[i].tag, problems[i].cap, problems[i].pair_w};
+        const size_t words = problems[i].pair_w > 0
+            ? (size_t)problems[i].h * ((problems[i].w + 31) / 32 + 1) + problems[i].h     // bit rows + row offsets
+            : ((size_t)problems[i].h * sm::row_stride(problems[i].w) + 31) / 32 + 2;
         lds = words * 4 > lds ? words * 4 : lds;
     }
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;

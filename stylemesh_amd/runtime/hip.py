@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
 
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
-EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD = 1, 2, 4
+EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL = 1, 2, 4, 8
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -107,7 +107,7 @@ SIGNATURES = {
 class ConvProblem(C.Structure):
     """sm_conv_problem of include/stylemesh_hip.h"""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int),
-                ("unpool_code", C.c_void_p)]
+                ("unpool_code", C.c_void_p), ("pool_out", C.c_void_p), ("pool_code", C.c_void_p)]
 
 
 class GramProblem(C.Structure):
@@ -136,7 +136,7 @@ class GramBwdProblem(C.Structure):
 class CoverProblem(C.Structure):
     """sm_cover_problem of include/stylemesh_hip.h"""
     _fields_ = [("need", C.c_void_p), ("starts", C.c_void_p), ("count", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
-                ("tag", C.c_int), ("cap", C.c_int)]
+                ("tag", C.c_int), ("cap", C.c_int), ("pair_w", C.c_int)]
 
 
 class PlaneProblem(C.Structure):

@@ -353,9 +353,11 @@ def conv_list_format(cin_pad: int, cout: int):
 
 def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
                     wt2=None, amax_in=None, amax_out=None):
-    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code]), ...] (FMaps; with a
-    ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel takes the pool's
-    backward on the fly, see ``maxpool_fwd_grouped``).
+    """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code[, pooled, pool_code]]), ...]
+    (FMaps; with a ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel
+    takes the pool's backward on the fly, see ``maxpool_fwd_grouped``; with ``flags & EPI_POOL`` - 'split2' mode, a
+    PAIR list from ``sparsity.build_tile_lists`` - the launch writes the pooled map ``pooled`` and its argmax codes
+    ``pool_code`` instead of ``out``).
     ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
     ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
     ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
@@ -375,11 +377,19 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
             assert CONV_MODE == "split2" and inp.C >= cin_pad and out.C == cout
             assert (inp.H, inp.W) == (out.H // 2, out.W // 2) and code.dtype == torch.int32
             assert code.numel() >= inp.C // 8 * inp.plane
-        arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code))
+        pooled, pool_code = (prob[4], prob[5]) if len(prob) > 5 else (None, None)
+        if flags & hip.EPI_POOL:
+            assert CONV_MODE == "split2" and tile_list is not None and pooled is not None and pool_code.dtype == torch.int32
+            assert (pooled.C, pooled.H, pooled.W) == (cout, out.H // 2, out.W // 2) and pool_code.numel() >= cout // 8 * pooled.plane
+        arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code),
+                                 None if pooled is None else pooled.ptr, ptr(pool_code))
         cin_true = 3 if cin_pad == 4 else cin_pad
         flops += 2.0 * 9 * cin_true * cout * out.H * out.W
-        # algorithmic HBM bytes: input read once, output written once, + the epilogue's gate / addend reads
+        # algorithmic HBM bytes: input read once, output written once (pooled: a quarter + 1/2 byte of codes per element),
+        # + the epilogue's gate / addend reads
         streams = cout + (cout if flags & hip.EPI_RELU_MASK else 0) + (cout if flags & hip.EPI_ADD else 0)
+        if flags & hip.EPI_POOL:
+            streams = cout * (0.25 + 0.125 / 4)
         nbytes += 4.0 * streams * out.H * out.W + (4.0 if code is None else 4.5) * cin_true * inp.H * inp.W
 
     use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
@@ -643,12 +653,14 @@ def need_step(need_out, mode, M, need_src):
 
 
 def cover_segments(problems):
-    """``problems``: [(need [h,w] float tensor, starts int32 tensor, count int32 [1] tensor, tag), ...] (<= 64): disjoint
+    """``problems``: [(need [h,w] float tensor, starts int32 tensor, count int32 [1] tensor, tag[, pair_w]), ...] (<= 64): disjoint
     32-position segments covering the needed positions of every plane, starts as (tag << 24) | q (``sm_cover_segments``)."""
     arr = (hip.CoverProblem * len(problems))()
-    for i, (need, starts, count, tag) in enumerate(problems):
+    for i, prob in enumerate(problems):
+        need, starts, count, tag = prob[:4]
+        pair_w = prob[4] if len(prob) > 4 else 0   # > 0: PAIR mode (``need`` = need map of the pooled plane, see the header)
         h, w = need.shape
-        arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel())
+        arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel(), int(pair_w))
     hip.check(lib.sm_cover_segments(arr, len(problems), hip.stream()), "sm_cover_segments")
 
 

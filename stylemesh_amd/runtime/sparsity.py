@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .vgg import NODES, depth_of, layer_hw
+from .vgg import NODES, POOL_OUTPUT, PRE_POOL, depth_of, fuse_pool_fwd, layer_hw
 
 
 def need_maps(M: torch.Tensor, H: int, W: int, injected, last_layer: str) -> dict:
@@ -53,33 +53,53 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     def fmt(cin_pad, cout):
         bn, group = ops.conv_list_format(cin_pad, cout)
         return (bn * group, group) if (coarse and group > 0) else (bn, group)
+    free = not coarse and os.environ.get("STYLEMESH_SEGMENT_STARTS", "free") == "free"   # A/B: 'grid' = aligned segments
+    pairs = free and fuse_pool_fwd()
+
+    def cover_src(g, layer):
+        """(need map the cover runs on, pair_w, (h, w) of the plane the segments index) of a cover key."""
+        if isinstance(layer, tuple):
+            h, w = needs[g][layer[1]].shape
+            return needs[g][POOL_OUTPUT[layer[1]]], w, (h, w)
+        return needs[g][layer], 0, tuple(needs[g][layer].shape)
     jobs = []            # (key, layer, bn, group): group > 0 = a SEGMENT list (bn = 32) consumed `group` entries per tile
     for kind, src, dst, cin, cout in NODES[:depth_of(last_layer) + 1]:
         if kind == "pool":
             # forward and backward are both indexed by blocks of the POOLED plane: one list, key ('pool', output layer)
             jobs.append((("pool", dst), dst, ops.plane_tile_positions(1), 0))
             continue
-        jobs.append(((kind, "f"), dst) + fmt(4 if cin == 3 else cin, cout))
+        f = fmt(4 if cin == 3 else cin, cout)
+        if pairs and f[1] > 0 and dst in PRE_POOL and POOL_OUTPUT[dst] in needs[0]:
+            # the conv below a pool takes the maxima in its epilogue (EPI_POOL): its segments come in vertical PAIRS
+            # that cover the need map of the POOLED plane; key (conv, 'fp'), cover key ('pair', layer)
+            jobs.append(((kind, "fp"), ("pair", dst)) + f)
+        else:
+            jobs.append(((kind, "f"), dst) + f)
         if src != "img":
             jobs.append(((kind, "b"), src) + fmt(cout, cin))
         else:
             jobs.append((("img", "d"), "img", ops.plane_tile_positions(0), 0))   # conv1_1's data gradient
-    free = not coarse and os.environ.get("STYLEMESH_SEGMENT_STARTS", "free") == "free"   # A/B: 'grid' = aligned segments
     # --- segment jobs with FREE starts: one greedy cover per (layer, level) need map, all in one launch
     cover = {}           # layer -> (starts tensor [levels, cap], offsets, counts tensor)
     cover_problems = []
     if free:
-        seg_layers = sorted({layer for _, layer, _, group in jobs if group > 0})
-        caps = {layer: max(nd[layer].shape[0] * hip.row_stride(nd[layer].shape[1]) // 32 + 2 for nd in needs)
-                for layer in seg_layers}
+        seg_layers = sorted({layer for _, layer, _, group in jobs if group > 0}, key=str)
+
+        def cap_of(g, layer):
+            nd, pair_w, (h, w) = cover_src(g, layer)
+            if pair_w:
+                return 2 * nd.shape[0] * ((nd.shape[1] + 15) // 16 + 1) + 2
+            return h * hip.row_stride(w) // 32 + 2
+        caps = {layer: max(cap_of(g, layer) for g in range(len(needs))) for layer in seg_layers}
         n_prob = len(seg_layers) * len(needs)
         counts_dev = torch.zeros(max(n_prob, 1), dtype=torch.int32, device=dev)
         k = 0
         for layer in seg_layers:
             starts = torch.empty(len(needs), caps[layer], dtype=torch.int32, device=dev)
             cover[layer] = (starts, k)
-            for g, nd in enumerate(needs):
-                cover_problems.append((nd[layer], starts[g], counts_dev[k:k + 1], g))
+            for g in range(len(needs)):
+                nd, pair_w, _ = cover_src(g, layer)
+                cover_problems.append((nd, starts[g], counts_dev[k:k + 1], g, pair_w))
                 k += 1
         for i in range(0, len(cover_problems), 64):
             ops.cover_segments(cover_problems[i:i + 64])
@@ -162,7 +182,7 @@ def build_tile_lists(needs, last_layer: str, extra=None):
                 n_g = cov_counts[k0 + g]
                 a = src_base[layer] + g * st.shape[1]
                 idx_parts.append(np.arange(a, a + n_g, dtype=np.int64))
-                h, w = needs[g][layer].shape
+                h, w = cover_src(g, layer)[2]
                 n_all += (h * hip.row_stride(w) + 31) // 32
             else:
                 offs = seg[(layer, bn)]
@@ -189,7 +209,10 @@ def build_tile_lists(needs, last_layer: str, extra=None):
                 wp = torch.tensor([hip.row_stride(nd[layer].shape[1]) for nd in needs], dtype=torch.int32, device=dev)
                 g_of, s_of = lst >> 24, lst & 0xFFFFFF
                 lst = torch.where(s_of == 0xFFFFFF, lst, (g_of << 24) | (s_of * 32 + wp[g_of.long()]))
-            out[key] = (lst, live / max(n_all, 1), n_all + group * len(needs))
+            # capacity of the persistent list buffer: every segment of every level (pair lists: every run the cover can
+            # emit - a short row still takes a whole pair) + one padded tile per level
+            cap = sum(cap_of(g, layer) for g in range(len(needs))) if (free and isinstance(layer, tuple)) else n_all
+            out[key] = (lst, live / max(n_all, 1), cap + group * len(needs))
         else:
             offs = seg[(layer, bn)]
             n_all = offs[-1] - offs[0]

@@ -55,6 +55,14 @@ NODE_BELOW = {out: (kind, src) for kind, src, out, _, _ in NODES}               
 FUSE_POOL_BWD = os.environ.get("STYLEMESH_FUSE_POOL_BWD", "1") != "0"
 
 
+def fuse_pool_fwd() -> bool:
+    """fp16x2 mode, grouped passes with active lists: the forward conv BELOW a pool takes the 2x2 maxima (and writes the
+    argmax codes) in its epilogue (``hip.EPI_POOL``; its list holds vertical segment pairs, ``sparsity.build_tile_lists``
+    key (conv, 'fp')) - no pool pass, and the pre-pool map, which nothing else reads once the pool backward is fused
+    too, is never written."""
+    return FUSE_POOL_BWD and ops.CONV_MODE == "split2" and os.environ.get("STYLEMESH_FUSE_POOL_FWD", "1") != "0"
+
+
 class AmaxBook:
     """One device float per VGG tensor: an upper bound of max |x| of the activation ('a:<layer>') or gradient
     ('g:<layer>') planes, recorded by the kernel that writes them (``amax_out``) and read by the fp16x2-split conv that
@@ -159,13 +167,30 @@ class VGGNet:
         assert all(b.last == last for b in bufs)
         am = amax if _amax_on() else None
         assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
+        pooled_by_conv = set()   # pools whose output the conv below them has already written (EPI_POOL)
         for kind, src, out, _, _ in NODES[:last + 1]:
             if kind == "pool":
+                if out in pooled_by_conv:
+                    continue
                 fused = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(out in b.code for b in bufs)
                 ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
                                         tiles[("pool", out)][0] if tiles else None,
                                         [b.code[out] for b in bufs] if fused else None)
+            elif tiles and (kind, "fp") in tiles and fuse_pool_fwd() and all(POOL_OUTPUT[out] in b.code for b in bufs):
+                po = POOL_OUTPUT[out]
+                tl, frac = tiles[(kind, "fp")]
+                ops.conv3x3_grouped([(b.act[src], b.act[out], None, None, b.act[po], b.code[po]) for b in bufs],
+                                    self.wf[kind], self.bias[kind], hip.EPI_BIAS_RELU | hip.EPI_POOL, tl, frac,
+                                    self.wf3[kind], self.wf2[kind],
+                                    None if am is None or src == "img" else am.act_bound(src),
+                                    None if am is None else am["a:" + out])
+                pooled_by_conv.add(po)
+                if on_layer is not None:
+                    on_layer(out)
             else:
+                if tiles and (kind, "f") not in tiles:
+                    raise RuntimeError(f"{kind}: the tile lists were built for the pooling epilogue (STYLEMESH_FUSE_POOL_FWD) "
+                                       "but this pass cannot use it (no code buffers / mode changed since set_view)")
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
                                     hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind], self.wf2[kind],

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_layout_helpers_are_pure_host_functions():
     from stylemesh_amd.runtime import hip
-    assert hip.lib.sm_abi_version() == 6
+    assert hip.lib.sm_abi_version() == 7
     for W in (1, 3, 4, 21, 341, 1045):
         wp = hip.row_stride(W)
         assert wp % 4 == 0 and wp >= W + 1 and wp < W + 5
@@ -35,7 +35,8 @@ def test_layout_helpers_are_pure_host_functions():
 def test_problem_struct_layouts_match_the_library():
     """The ctypes mirrors of the header's problem structs have the sizes the library was compiled with."""
     from stylemesh_amd.runtime import hip
-    for which, kind in enumerate((hip.ConvProblem, hip.PlaneProblem, hip.GramProblem, hip.StyleProblem, hip.GramBwdProblem)):
+    for which, kind in enumerate((hip.ConvProblem, hip.PlaneProblem, hip.GramProblem, hip.StyleProblem, hip.GramBwdProblem,
+                                  hip.CoverProblem)):
         assert hip.lib.sm_sizeof_problem(which) == ctypes.sizeof(kind), kind.__name__
     assert hip.lib.sm_sizeof_problem(99) == -1
 

@@ -231,3 +231,131 @@ def test_prepare_view_ahead_equals_set_view():
     a.prepare_view(views[0])
     a.training_step(views[1])
     assert a.view_key == MULTIVIEW_SEEDS[1] or a.view_key is not None
+
+
+def _pair_list(ops, hip, need_pooled_list, full_hw_list, group):
+    """Segment-pair lists (``sm_cover_segments`` pair mode) of several problems, each padded to whole tiles."""
+    parts, covers = [], []
+    for g, (nd, (H, W)) in enumerate(zip(need_pooled_list, full_hw_list)):
+        cap = 2 * nd.shape[0] * ((nd.shape[1] + 15) // 16 + 1) + 2
+        starts = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+        count = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.cover_segments([(nd, starts, count, g, W)])
+        n = int(count)
+        assert 0 < n <= cap and n % 2 == 0
+        st = starts[:n]
+        pad = (-n) % group
+        parts.append(torch.cat([st, torch.full((pad,), (g << 24) | 0xFFFFFF, dtype=torch.int32, device="cuda")]))
+        covers.append(st.cpu().numpy())
+    return torch.cat(parts), covers
+
+
+def test_cover_segments_pair_mode():
+    """Pair mode: every needed window of the pooled map lies in exactly one run of 16 windows; a run = the segment of
+    image row 2Y starting at an even column + the segment right below it."""
+    require_gpu()
+    from stylemesh_amd.runtime import hip, ops
+    g = torch.Generator().manual_seed(5)
+    for (H, W) in [(37, 50), (64, 85), (16, 21), (256, 341)]:
+        Ho, Wo = H // 2, W // 2
+        nd = (torch.rand(Ho, Wo, generator=g) < 0.15).float()
+        nd[Ho // 2, :] = 1.0            # a full row
+        nd[:, Wo - 1] = 1.0             # the last window of every row
+        (lst, covers) = _pair_list(ops, hip, [nd.cuda()], [(H, W)], 4)
+        st = covers[0] & 0xFFFFFF
+        Wp = hip.row_stride(W)
+        top, bot = st[0::2], st[1::2]
+        assert (bot == top + Wp).all()
+        y, x = top // Wp - 1, top % Wp - 1
+        assert (y % 2 == 0).all() and (x % 2 == 0).all() and (y >= 0).all() and (y + 1 < 2 * Ho).all() and (x >= 0).all()
+        covered = np.zeros((Ho, Wo), np.int32)
+        for yy, xx in zip(y // 2, x // 2):
+            covered[yy, xx:min(xx + 16, Wo)] += 1
+        assert covered.max() == 1                              # disjoint
+        assert (covered[nd.numpy() > 0] == 1).all()            # complete
+
+
+@pytest.mark.parametrize("C,cout,hws", [(64, 64, [(37, 50)]), (64, 64, [(150, 201), (64, 85)]), (128, 128, [(40, 53), (33, 47)]),
+                                        (256, 256, [(21, 30)]), (512, 512, [(12, 17), (16, 21)]), (64, 64, [(256, 341)])])
+def test_conv_pooling_epilogue_matches_conv_then_pool(C, cout, hws, monkeypatch):
+    """EPI_POOL (the forward conv below a pool stores the pooled map + argmax codes instead of its output) against the
+    same conv with the same segment-pair list followed by the pool pass: bit-identical pooled values, codes and bound,
+    whole tiles and K-split tail tiles, several levels in one launch, odd sizes."""
+    require_gpu()
+    import torch.nn.functional as F
+    from stylemesh_amd.runtime import hip, ops
+    from stylemesh_amd.runtime.fmap import FMap
+    monkeypatch.setattr(ops, "CONV_MODE", "split2")
+    torch.manual_seed(C + len(hws))
+    wgt = torch.randn(cout, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    b = (torch.randn(cout) * 0.3).cuda()
+    w = ops.pack_conv_fwd(wgt).cuda()
+    w2 = ops.pack_conv_split2(w)
+    _, group = ops.conv_list_format(C, cout)
+    xs, needs = [], []
+    for (H, W) in hws:
+        x = F.relu(torch.randn(C, H, W) * 2)
+        x[:, : H // 3] = 0            # whole windows of zeros (code 4) and exact ties
+        xs.append(x)
+        nd = torch.zeros(H // 2, W // 2)
+        nd[: max(1, H // 3), :] = 1
+        nd[:, W // 4:] = 1
+        needs.append(nd.cuda())
+    lst, _ = _pair_list(ops, hip, needs, hws, group)
+    amax_in = ops.new_amax("cuda", max(float(x.abs().max()) for x in xs))
+    ins = [FMap(C, H, W).from_dense(x.cuda()) for x, (H, W) in zip(xs, hws)]
+    # reference: conv with the same list, then the pool pass over the whole plane
+    outs = [FMap(cout, H, W) for (H, W) in hws]
+    ops.conv3x3_grouped([(i, o, None) for i, o in zip(ins, outs)], w, b, hip.EPI_BIAS_RELU, lst, 1.0, None, w2, amax_in,
+                        ops.new_amax("cuda"))
+    pooled_ref = [FMap(cout, H // 2, W // 2) for (H, W) in hws]
+    codes_ref = [torch.zeros(cout // 8 * p.plane, dtype=torch.int32, device="cuda") for p in pooled_ref]
+    ops.maxpool_fwd_grouped(list(zip(outs, pooled_ref)), None, codes_ref)
+    # fused
+    outs2 = [FMap(cout, H, W) for (H, W) in hws]
+    pooled = [FMap(cout, H // 2, W // 2) for (H, W) in hws]
+    codes = [torch.zeros(cout // 8 * p.plane, dtype=torch.int32, device="cuda") for p in pooled]
+    amax_out = ops.new_amax("cuda")
+    for rep in range(2):   # (the second launch into the same buffers: nothing depends on their previous content)
+        ops.conv3x3_grouped([(i, o, None, None, p, c) for i, o, p, c in zip(ins, outs2, pooled, codes)], w, b,
+                            hip.EPI_BIAS_RELU | hip.EPI_POOL, lst, 1.0, None, w2, amax_in, amax_out)
+    true_max = 0.0
+    for nd, p, pr, c, cr, o2 in zip(needs, pooled, pooled_ref, codes, codes_ref, outs2):
+        assert float(o2.planes.abs().max()) == 0.0            # the full-resolution output is not written
+        assert p.border_is_zero()
+        m = nd > 0
+        got, ref = p.to_dense(), pr.to_dense()
+        assert torch.equal(got[:, m], ref[:, m])
+        cg = c.view(cout // 8, -1)[:, :(p.H + 2) * p.Wp].view(cout // 8, p.H + 2, p.Wp)[:, 1:p.H + 1, 1:p.W + 1]
+        cf = cr.view(cout // 8, -1)[:, :(p.H + 2) * p.Wp].view(cout // 8, p.H + 2, p.Wp)[:, 1:p.H + 1, 1:p.W + 1]
+        assert torch.equal(cg[:, m], cf[:, m])
+        assert int(((cg[:, m] & 0xF) == 4).sum()) > 0          # closed windows occur
+        true_max = max(true_max, float(got.abs().max()))
+    assert float(amax_out.max()) == true_max
+
+
+def test_engine_step_with_and_without_pooling_epilogue(monkeypatch):
+    """The step with the pools taken in the conv epilogues (default) against the same step with separate pool passes:
+    same losses and gradients up to the summation-order differences of differently composed tiles."""
+    require_gpu()
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("STYLEMESH_FUSE_POOL_FWD", fuse)
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        eng = _engine(random_init=True)
+        view = _small_view(MULTIVIEW_SEEDS[0])
+        eng.set_view(view)
+        keys = set(eng.view_tiles)
+        assert (("conv1_2", "fp") in keys) == (fuse == "1") and (("conv1_2", "f") in keys) == (fuse == "0")
+        losses = [eng.losses(eng.training_step(view)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res[fuse] = (losses, eng.arena.p.clone())
+    for step, (a, b) in enumerate(zip(res["1"][0], res["0"][0])):
+        # the first step runs on identical textures; afterwards the lr-1 Adam steps amplify last-bit differences
+        tol = 1e-5 if step == 0 else 5e-3
+        for k in a:
+            assert abs(float(a[k]) - float(b[k])) <= tol * abs(float(b[k])) + 1e-6, (step, k, a[k], b[k])
+    d = (res["1"][1] - res["0"][1]).abs()
+    # (Adam at lr 1 turns last-bit gradient differences into +-lr steps on a few texels: compare the bulk)
+    assert float((d > 1e-3).float().mean()) < 0.02
