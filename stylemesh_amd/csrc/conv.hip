@@ -572,6 +572,9 @@ static int dispatch_conv(const ConvArgs& a, int n_list, size_t ws_floats, hipStr
     return launch_conv<128, 128, 8, 2, 2, FLAGS>(a, n_list, ws_floats, s);
 }
 
+#ifndef SM_DGRAD_C3_XCD
+#define SM_DGRAD_C3_XCD 1
+#endif
 // ---------------------------------------------------------------------------------------------------
 // First-layer data gradient (64 -> 3 channels): far too thin for the matrix cores (M = 3), so a VALU kernel:
 // one thread per position q, 3 accumulators, weights read through the scalar cache (wave-uniform).
@@ -755,7 +758,14 @@ __device__ __forceinline__ PlaneProblem pick_problem(const PlaneGroup& g, int k)
 
 __global__ __launch_bounds__(256) void conv3x3_dgrad_c3_kernel(PlaneGroup g, const float* __restrict__ wd, int Cin) {
     int bx;
-    const PlaneProblem P = pick_problem(g, locate_problem(g, blockIdx.x, bx));
+    // a block is ~one image row of the 64 gradient planes and reads the rows above and below it as well: blocks are
+    // dealt to the XCDs in contiguous runs (SM_DGRAD_C3_XCD), so that a row is fetched into one L2 instead of three
+#if SM_DGRAD_C3_XCD
+    const int b = xcd_linear(blockIdx.x, gridDim.x);
+#else
+    const int b = blockIdx.x;
+#endif
+    const PlaneProblem P = pick_problem(g, locate_problem(g, b, bx));
     dgrad_c3_body(P.a, wd, P.out, Cin, P.H, P.W, row_stride(P.W), plane_size(P.H, P.W), bx);
 }
 
