@@ -127,7 +127,9 @@ int sm_tex_scatter_planned(const uint32_t* keys, const uint64_t* vals, size_t n_
  * flag is 0 are skipped without being read. Exact ONLY while every skipped element has p = g = m = v = 0 (a
  * zero-initialised texture, texture.py:26-28, that no view has reached yet: its regulariser gradient
  * reg_coef * p and its Adam update are then exactly 0); the caller ORs sm_tex_touch_flags of every view it has
- * ever optimised into the flags and passes NULL for textures that start non-zero (random_init, from_tensor). */
+ * ever optimised into the flags and passes NULL for textures that start non-zero (random_init, from_tensor).
+ * g may be NULL (ABI 7): the data-term gradient is then taken as zero wherever the launch walks and is neither read nor
+ * zeroed (the host's split update: the chunks the current views cannot reach, updated beside the forward pass). */
 int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t* seg_end,
                   const float* reg_coef, int n_seg, float lr, double beta1, double beta2, float eps,
                   double bias_corr1, double bias_corr2, float grad_scale, float clamp_lo, float clamp_hi,

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         if (full) {
             *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
             if (ADAM) {
-                *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
+                // g == NULL: the data-term gradient is known to be zero wherever this launch walks (the early half of
+                // the split update) - neither read nor zeroed: 6 instead of 8 streams
+                *reinterpret_cast<float4*>(gv) = g ? *reinterpret_cast<const float4*>(g + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
                 *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
             }
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 const bool ok = i0 + j < n;
                 pv[j] = ok ? p[i0 + j] : 0.f;
                 if (ADAM) {
-                    gv[j] = ok ? g[i0 + j] : 0.f;
+                    gv[j] = (ok && g) ? g[i0 + j] : 0.f;
                     mv[j] = ok ? m[i0 + j] : 0.f;
                     vv[j] = ok ? v[i0 + j] : 0.f;
                 }
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             if (ADAM) {
                 *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
                 *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vv);
-                if (zero_grad) *reinterpret_cast<float4*>(g + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (zero_grad && g) *reinterpret_cast<float4*>(g + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             for (int j = 0; j < 4 && i0 + j < n; ++j) {
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 if (ADAM) {
                     m[i0 + j] = mv[j];
                     v[i0 + j] = vv[j];
-                    if (zero_grad) g[i0 + j] = 0.f;
+                    if (zero_grad && g) g[i0 + j] = 0.f;
                 }
             }
         }

@@ -211,7 +211,8 @@ def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.
     """``lo`` / ``hi``: update only arena elements [lo, hi) (multiples of 4; the pipelined multi-GPU exchange updates
     the arena range by range) - same kernel on offset pointers, segment ends shifted and clipped to the range.
     ``touched``: int32 flag per 2^touched_log2 floats of the WHOLE arena; chunks with flag 0 are skipped (exact only for
-    elements with p = g = m = v = 0, see sm_adam_fused)."""
+    elements with p = g = m = v = 0, see sm_adam_fused). ``g`` may be None: the data-term gradient is zero wherever
+    the launch walks (neither read nor zeroed)."""
     if lo != 0 or (hi is not None and hi != p.numel()):
         hi = p.numel() if hi is None else hi
         assert lo % 4 == 0 and 0 <= lo <= hi <= p.numel()
@@ -220,7 +221,7 @@ def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.
         if touched is not None:
             assert lo % (1 << touched_log2) == 0, "range start must be chunk-aligned"
             touched = touched[lo >> touched_log2:]
-        p, g, m, v = p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi]
+        p, g, m, v = p[lo:hi], (None if g is None else g[lo:hi]), m[lo:hi], v[lo:hi]
         seg_end = [min(max(int(e) - lo, 0), hi - lo) for e in seg_end]
     n = p.numel()
     bc1 = 1.0 - beta1 ** step

@@ -787,6 +787,29 @@ def test_adam_fused_by_ranges_equals_one_launch(rt):
     assert_close(res[1][3], res[0][3], 1e-5, 0)
 
 
+def test_adam_fused_without_gradient_pointer_equals_zero_gradient(rt):
+    """g = NULL (the early half of the split update: chunks whose data-term gradient is known to be zero) gives the bits of
+    a launch over an all-zero gradient arena, which it neither reads nor writes; flagged chunks only."""
+    torch.manual_seed(4)
+    n = 3 * 64 * 64 + 3 * 32 * 32 + 8
+    seg_end = [3 * 64 * 64, n]
+    reg = [0.3, 0.0]
+    p0 = (torch.randn(n) * 60).clamp(O.CLAMP_LO, O.CLAMP_HI)
+    m0, v0 = torch.randn(n) * 0.1, torch.rand(n) * 0.01
+    flags = (torch.rand(-(-n // 64)) < 0.5).int().cuda()
+    res = []
+    for with_g in (True, False):
+        P, M, V = dev(p0), dev(m0), dev(v0)
+        G = torch.zeros(n).cuda() if with_g else None
+        sumsq = torch.zeros(2).cuda()
+        rt.ops.adam_fused(P, G, M, V, seg_end, reg, 1.0, 5, grad_scale=1.0, sumsq_out=sumsq, touched=flags, touched_log2=6)
+        res.append((P, M, V, sumsq))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert_close(res[1][3], res[0][3], 1e-5, 0)   # (block sums meet in atomics: order not fixed)
+    assert not torch.equal(res[0][0], dev(p0))
+
+
 # ------------------------------------------------------------------ per-view constants
 def test_view_constants_match_oracle(rt):
     from golden_cases import SMALL_LEVEL_HW, SMALL_ROOM, SMALL_VIEW_HW
