@@ -214,6 +214,27 @@ def late_epoch_leg(eng, schedule, args, wl, barrier):
                     "HIP rasteriser): the update's early half (side stream) walks all of it, the closing half the view's own chunks"}
 
 
+def many_views_leg(eng, wl, args, dev, barrier, good, first_seeds):
+    """The same engine and workload over ELEVEN more views (one warm-up view, then ``many_views_steps`` timed steps = ten
+    views at index_repeat steps per view): the main leg's 2-3 views are the first of the camera path and happen to carry 20 % more
+    listed conv work than the average view - this leg is the rate a scene's schedule sees (compare
+    scene_schedule.mean_views_per_s, measured through the CLI)."""
+    import copy
+    rep = wl["index_repeat"]
+    n_views = 1 + (args.many_views_steps + rep - 1) // rep
+    seeds = [good[v % len(good)] for v in range(n_views)]
+    made = dict(first_seeds)
+    todo = sorted(set(seeds) - set(made))
+    made.update({s_: to_device(v, dev) for s_, v in zip(todo, make_views(wl, todo))})
+    a = copy.copy(args)
+    a.warmup, a.steps = rep, args.many_views_steps
+    schedule = [made[seeds[(i // rep) % n_views]] for i in range(a.warmup + a.steps)]
+    dt = timed_leg(eng, schedule, a, wl, 1, None, barrier, None)
+    return {"value": round(a.steps / dt, 3), "unit": "views/s", "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "views": n_views - 1,
+            "note": "same engine, timed like the main leg, no per-launch events"}
+
+
 def measured_schedule(workload):
     """The fixed schedule of one scene MEASURED on the product path (tools/run_schedule.py: directory loader, MiniTrainer,
     the CLI's flags) - a committed record of a GPU-box run, the default bench run cannot afford 4 minutes of it."""
@@ -259,6 +280,8 @@ def main():
                     "workload with v_mfma_f32_32x32x2_f32 everywhere (reported as 'f32_mode'; 0 = skip)")
     ap.add_argument("--dense-adam", action="store_true", help="fused update over every texel instead of the chunks "
                     "some view has touched so far")
+    ap.add_argument("--many-views-steps", type=int, default=200, help="N = 1: timed steps of the 'many_views' leg (the same "
+                    "workload over ten more views instead of the main leg's first two or three; 0 = skip the leg)")
     ap.add_argument("--late-epoch-views", type=int, default=276, help="N = 1: views whose coverage seeds the ever-touched "
                     "set of the 'late_epoch' leg (0 = skip the leg)")
     args = ap.parse_args()
@@ -422,6 +445,8 @@ def main():
             out["scene_schedule"].update(sched)
         if world == 1 and args.f32_steps > 0 and ops.CONV_MODE != "f32" and args.mfma is None:
             out["f32_mode"] = f32_leg(args, wl, cfg, schedule, dev, barrier)
+        if world == 1 and args.many_views_steps > 0:
+            out["many_views"] = many_views_leg(eng, wl, args, dev, barrier, good, on_dev)
         if world == 1 and args.late_epoch_views > 0 and eng.touched is not None and not args.dense_adam:
             out["late_epoch"] = late_epoch_leg(eng, schedule, args, wl, barrier)
         if world == 1 and args.cpu_steps > 0:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: does side-stream overlap (loss branches, early half of the update) pay on the single-level c2 step?
 run() {
-  env "$@" python bench.py --workload c2 --steps 200 --warmup 20 --cpu-steps 0 --f32-steps 0 --no-conv-timer 2>/dev/null | python -c "
+  env "$@" python bench.py --workload c2 --steps 200 --warmup 20 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --no-conv-timer 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); le=d.get('late_epoch') or {}
 print('$*:', d['value'], 'views/s', d['ms_per_step'], 'ms; late_epoch', le.get('value'))"
 }

@@ -7,7 +7,7 @@ TAG=${1:-q}; WL=${2:-c2}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 30 --warmup 5 --cpu-steps 0 --f32-steps 0 --no-conv-timer > $OUT/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 30 --warmup 5 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --no-conv-timer > $OUT/prof.log 2>&1
 cd $R
 cp $OUT/prof/run_kernel_stats.csv $OUT/${WL}_kernel_stats.csv
 python3 tools/step_timeline.py $OUT/prof/run_kernel_trace.csv 3 > $OUT/${WL}_step_timeline.txt

@@ -9,9 +9,9 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py --workload $WL > $OUT/${WL}_bench_full.json 2> $OUT/${WL}_bench_full.err
 tail -c 600 $OUT/${WL}_bench_full.json
-python bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 > $OUT/${WL}_bench.json 2> $OUT/${WL}_bench.err
+python bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 > $OUT/${WL}_bench.json 2> $OUT/${WL}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 > $OUT/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 > $OUT/prof.log 2>&1
 cd $R
 cp $OUT/prof/run_kernel_stats.csv $OUT/${WL}_kernel_stats.csv
 python3 tools/conv_trace_split.py $OUT/prof/run_kernel_trace.csv $OUT/${WL}_conv_launch_classes.csv > /dev/null

@@ -12,7 +12,7 @@ mkdir -p $OUT
 python bench.py --workload $WL > $OUT/${WL}_bench_full.json 2> $OUT/${WL}_bench_full.err
 tail -c 400 $OUT/${WL}_bench_full.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --late-epoch-views 0 > $OUT/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 > $OUT/prof.log 2>&1
 cd $R
 cp $OUT/prof/run_kernel_stats.csv $OUT/${WL}_kernel_stats.csv
 python3 tools/conv_trace_split.py $OUT/prof/run_kernel_trace.csv $OUT/${WL}_conv_launch_classes.csv $([ "$WL" = "c2" ] && echo 1000000 || echo 100) > /dev/null
@@ -23,7 +23,7 @@ rm -rf gpurun_out/traffic gpurun_out/pmc_bench
 mkdir -p gpurun_out/traffic gpurun_out/pmc_bench
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/traffic/$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/traffic/$c.log 2>&1
   echo "pmc $c rc=$?"
 done
 cd $R
@@ -34,7 +34,7 @@ if [ "$WL" = "c3" ]; then
   cd /tmp
   for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-    timeout 420 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$tag -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/pmc_bench/$tag.log 2>&1
+    timeout 420 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$tag -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/pmc_bench/$tag.log 2>&1
     echo "pmc $tag rc=$?"
   done
   cd $R
