@@ -382,6 +382,12 @@ class StepEngine:
         if last is not None and name != "start":
             acc[name] = acc.get(name, 0.0) + now - last
         self._mark_last = now
+        # caching-allocator misses (hipMalloc) per phase: a view whose temporaries do not fit the cached blocks stalls here
+        n = torch.cuda.memory_stats().get("num_device_alloc", 0) if torch.cuda.is_available() else 0
+        if name != "start" and n != self.__dict__.get("_mark_allocs", n):
+            misses = self.__dict__.setdefault("set_view_alloc_misses", {})
+            misses[name] = misses.get(name, 0) + n - self._mark_allocs
+        self._mark_allocs = n
 
     VIEW_ATTRS = ("view", "view_consts", "view_tiles", "view_sig", "_scatter_plan", "_scatter_levels", "view_key",
                   "_last_batch", "_view_flags", "_other_flags", "_union_flags", "_pending_grad_zero")

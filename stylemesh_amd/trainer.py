@@ -20,6 +20,16 @@ import time
 import torch
 
 
+
+def _alloc_note(device) -> str:
+    """Device allocations so far (caching-allocator misses: each is a hipMalloc and a stall of the launch loop) - a
+    first epoch that is slower than the later ones shows here."""
+    if device == "cpu" or not torch.cuda.is_available():
+        return ""
+    st = torch.cuda.memory_stats()
+    return (f" [device allocs {st.get('num_device_alloc', 0)}, frees {st.get('num_device_free', 0)}, "
+            f"reserved {st.get('reserved_bytes.all.current', 0) / 2 ** 30:.1f} GiB]")
+
 class JsonlLogger:
     """TensorBoard-shaped scalar logger (``logger.experiment.add_scalar(s)``) writing JSON lines; device tensors
     are only converted when the line is written, every ``flush_every`` records (no per-step host sync)."""
@@ -229,7 +239,7 @@ class MiniTrainer:
                 n = self.global_step - steps0
                 print(f"epoch {epoch}: {self.global_step} steps, {t_end - t0:.1f} s "
                       f"[train loop {t_train - t_epoch:.2f} s = {n / max(t_train - t_epoch, 1e-9):.1f} steps/s, "
-                      f"validation + epoch-end hooks {t_end - t_train:.2f} s]", flush=True)
+                      f"validation + epoch-end hooks {t_end - t_train:.2f} s]" + _alloc_note(self.device), flush=True)
         if self.device != "cpu" and torch.cuda.is_available():
             torch.cuda.synchronize()
         try:    # texture exports still being encoded by the writer thread
@@ -254,7 +264,8 @@ class MiniTrainer:
                 if eng is not None and getattr(eng, "set_view_calls", 0):
                     marks = getattr(eng, "set_view_marks", {})
                     print(f"set_view: {1e3 * eng.set_view_host_s / eng.set_view_calls:.2f} ms of host time per call "
-                          f"(x{eng.set_view_calls}, {getattr(eng, 'prepared_swaps', 0)} prepared ahead)" + "".join(f" {k} {1e3 * v / eng.set_view_calls:.2f}" for k, v in marks.items()))
+                          f"(x{eng.set_view_calls}, {getattr(eng, 'prepared_swaps', 0)} prepared ahead)" + "".join(f" {k} {1e3 * v / eng.set_view_calls:.2f}" for k, v in marks.items())
+                          + "; allocator misses: " + str(getattr(eng, "set_view_alloc_misses", {})))
                 print("host ms per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in hs.items())
                       + (f"; first step of a view {1e3 * first / nf:.2f} ms (x{nf}: next_batch {1e3 * fs[0] / nf:.2f}, "
                          f"to_device {1e3 * fs[1] / nf:.2f}, training_step {1e3 * fs[2] / nf:.2f})" if nf else ""))

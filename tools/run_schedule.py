@@ -111,6 +111,8 @@ def main():
     wall = time.time() - t0
     if os.environ.get("STYLEMESH_SAMPLE") == "1":
         print("\n".join(l for l in r.stdout.splitlines() if l.startswith("sample ")), file=sys.stderr)
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith(("epoch ", "fit:", "loader:", "set_view:", "host ms"))),
+          file=sys.stderr)
     if r.returncode != 0:
         print(r.stdout[-3000:], r.stderr[-3000:], file=sys.stderr)
         raise SystemExit(r.returncode)
