@@ -180,6 +180,8 @@ def build_tile_lists(needs, last_layer: str, extra=None):
             if free:
                 st, k0 = cover[layer]
                 n_g = cov_counts[k0 + g]
+                if n_g > st.shape[1]:
+                    raise RuntimeError(f"segment cover of {layer}: {n_g} entries exceed the buffer's {st.shape[1]}")
                 a = src_base[layer] + g * st.shape[1]
                 idx_parts.append(np.arange(a, a + n_g, dtype=np.int64))
                 h, w = cover_src(g, layer)[2]
