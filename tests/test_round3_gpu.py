@@ -242,7 +242,7 @@ def _pair_list(ops, hip, need_pooled_list, full_hw_list, group):
         count = torch.zeros(1, dtype=torch.int32, device="cuda")
         ops.cover_segments([(nd, starts, count, g, W)])
         n = int(count)
-        assert 0 < n <= cap and n % 2 == 0
+        assert 0 <= n <= cap and n % 2 == 0 and (n > 0 or float(nd.sum()) == 0)
         st = starts[:n]
         pad = (-n) % group
         parts.append(torch.cat([st, torch.full((pad,), (g << 24) | 0xFFFFFF, dtype=torch.int32, device="cuda")]))
@@ -276,7 +276,8 @@ def test_cover_segments_pair_mode():
 
 
 @pytest.mark.parametrize("C,cout,hws", [(64, 64, [(37, 50)]), (64, 64, [(150, 201), (64, 85)]), (128, 128, [(40, 53), (33, 47)]),
-                                        (256, 256, [(21, 30)]), (512, 512, [(12, 17), (16, 21)]), (64, 64, [(256, 341)])])
+                                        (256, 256, [(21, 30)]), (512, 512, [(12, 17), (16, 21)]), (64, 64, [(256, 341)]),
+                                        (64, 64, [(2, 2), (5, 3)]), (128, 128, [(3, 5), (40, 53)])])
 def test_conv_pooling_epilogue_matches_conv_then_pool(C, cout, hws, monkeypatch):
     """EPI_POOL (the forward conv below a pool stores the pooled map + argmax codes instead of its output) against the
     same conv with the same segment-pair list followed by the pool pass: bit-identical pooled values, codes and bound,
@@ -300,6 +301,8 @@ def test_conv_pooling_epilogue_matches_conv_then_pool(C, cout, hws, monkeypatch)
         nd = torch.zeros(H // 2, W // 2)
         nd[: max(1, H // 3), :] = 1
         nd[:, W // 4:] = 1
+        if (H, W) == (64, 85):
+            nd[:] = 0                 # a level without a single needed window: no list entries, nothing written
         needs.append(nd.cuda())
     lst, _ = _pair_list(ops, hip, needs, hws, group)
     amax_in = ops.new_amax("cuda", max(float(x.abs().max()) for x in xs))
@@ -329,7 +332,10 @@ def test_conv_pooling_epilogue_matches_conv_then_pool(C, cout, hws, monkeypatch)
         cg = c.view(cout // 8, -1)[:, :(p.H + 2) * p.Wp].view(cout // 8, p.H + 2, p.Wp)[:, 1:p.H + 1, 1:p.W + 1]
         cf = cr.view(cout // 8, -1)[:, :(p.H + 2) * p.Wp].view(cout // 8, p.H + 2, p.Wp)[:, 1:p.H + 1, 1:p.W + 1]
         assert torch.equal(cg[:, m], cf[:, m])
-        assert int(((cg[:, m] & 0xF) == 4).sum()) > 0          # closed windows occur
+        if bool(m.any()) and p.H * p.W > 4:
+            assert int(((cg[:, m] & 0xF) == 4).sum()) > 0      # closed windows occur
+        if not bool(m.any()):
+            assert float(p.planes.abs().max()) == 0.0          # nothing of an empty level is written
         true_max = max(true_max, float(got.abs().max()))
     assert float(amax_out.max()) == true_max
 
