@@ -815,6 +815,11 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
 
 static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
+        if (flags == (SM_EPI_RELU_MASK | SM_EPI_GRAM)) {   // + the Gram backward of the 64-channel output layer; whole tiles only
+            if (a.Cout != 64) return (int)hipErrorInvalidValue;
+            a.ws = nullptr;
+            return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+        }
         switch (flags) {
             case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);
             case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, ws_floats, s);
@@ -894,7 +899,13 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
         unpool += problems[g].unpool_code != nullptr;
         a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].unpool_code,
                                  problems[g].H, problems[g].W, sm::row_stride(problems[g].W),
-                                 sm::plane_size(problems[g].H, problems[g].W), problems[g].pool_out, problems[g].pool_code};
+                                 sm::plane_size(problems[g].H, problems[g].W), problems[g].pool_out, problems[g].pool_code,
+                                 reinterpret_cast<const sm::f32x4*>(problems[g].gram_ws), problems[g].gram_mask0,
+                                 problems[g].gram_mask1, problems[g].gram_amax_feat, problems[g].gram_amax_d};
+        if ((flags & SM_EPI_GRAM) != 0 && (problems[g].gram_ws == nullptr || problems[g].gram_mask0 == nullptr ||
+                                          problems[g].gram_amax_feat == nullptr || problems[g].gram_amax_d == nullptr ||
+                                          problems[g].gate == nullptr || problems[g].unpool_code == nullptr))
+            return (int)hipErrorInvalidValue;
         if ((flags & SM_EPI_POOL) != 0 && (problems[g].pool_out == nullptr || problems[g].pool_code == nullptr ||
                                           problems[g].H < 2 || problems[g].W < 2))
             return (int)hipErrorInvalidValue;

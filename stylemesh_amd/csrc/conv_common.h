@@ -22,6 +22,15 @@ struct ConvProblem {
     // [Cout][plane(H/2, W/2)] and the pool's argmax codes [Cout / 8][plane(H/2, W/2)] (same formats) INSTEAD of `out`.
     float* pool_out;
     uint32_t* pool_code;
+    // fp16x2 kernel, flag SM_EPI_GRAM (data gradient whose output layer is a 64-channel STYLE layer): the launch adds
+    // the masked Gram backward of that layer, sum_k m_k(q) (D_k F)(q), in its epilogue instead of reading it from `out`.
+    // gram_p = the operand images of D0 / D1 (gram_d_pack_group_kernel; P1 = P0 + 6 C^2 / 16 units), gram_mask0 / 1 the
+    // layer's mask planes (mask1 optional), gram_amax_feat / _d the bounds of F (= `gate`) and of D. F is `gate`.
+    const f32x4* gram_p;
+    const float* gram_mask0;
+    const float* gram_mask1;
+    const float* gram_amax_feat;
+    const float* gram_amax_d;
 };
 
 struct ConvArgs {

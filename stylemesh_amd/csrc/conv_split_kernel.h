@@ -58,6 +58,36 @@
 
 namespace sm {
 
+// ---- helpers of the SM_EPI_GRAM epilogue: the arithmetic of gram_backward_body (gram_split_kernels.h), restated here so
+// that the fused form reproduces its bits (same operand scales, same fp16 pairs, same product order)
+typedef _Float16 cg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float conv_gram_pow2_scale(float amax, float& inv) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    const int ex = (int)((bits >> 23) & 0xff);
+    if (ex < 16 || ex > 250) { inv = 1.f; return 1.f; }
+    inv = __builtin_bit_cast(float, (unsigned)(ex - 14) << 23);
+    return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);
+}
+__device__ __forceinline__ void conv_gram_split(const float (&x)[8], float sm, f32x4& vh, f32x4& vl) {
+    cg_f16x8 h, l;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float xs = x[c] * sm;
+        const _Float16 a = (_Float16)xs;
+        h[c] = a;
+        l[c] = (_Float16)(xs - (float)a);
+    }
+    vh = __builtin_bit_cast(f32x4, h);
+    vl = __builtin_bit_cast(f32x4, l);
+}
+__device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2], const f32x4 (&fb)[2]) {
+#define SM_H(x_) __builtin_bit_cast(cg_f16x8, x_)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[0]), acc, 0, 0, 0);
+#undef SM_H
+}
+
 // NP = number of parts an fp32 operand is split into:
 //   NP = 3  bf16 x 3 (above): 6 partial products per fp32 product, no scaling needed (bf16 has the fp32 exponent range);
 //   NP = 2  fp16 x 2: x s = h + l with h = fp16(x s), l = fp16(x s - h): 2 x 11 = 22 significand bits, products
@@ -613,6 +643,20 @@ void conv3x3_split_kernel(ConvArgs a) {
         record_amax(a.amax_out, vmax, amax_seen);
         return;
     }
+    // SM_EPI_GRAM: the output layer is a 64-channel style layer and this epilogue adds its masked Gram backward,
+    // sum_k m_k(q) (D_k F)(q), F = the gate operand - four 16-channel steps per mask on the matrix cores for each of the
+    // wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
+    // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
+    constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
+    float g_fscale = 1.f, g_oscale = 1.f;
+    if constexpr (GRAM) {
+        static_assert(NP == 2 && MI == 1 && BM == 64 && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
+                      "the Gram term replaces the addend of a 64-channel data gradient");
+        float inv_f, inv_d;
+        g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
+        conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
+        g_oscale = inv_f * inv_d;
+    }
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         int q_seg = qs[0];
@@ -621,6 +665,44 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int k = 1; k < SEG; ++k)
             if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
         const int q = q_seg + l31;
+        f32x16 accg;
+        if constexpr (GRAM) {
+            if (!alive) continue;                                    // (wave-uniform: a padding segment)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+            const bool valid = q < q_end;
+            const int qc = valid ? q : q_seg;                          // (lanes past the plane's end load a valid address)
+            const float mk0 = valid ? P.gram_mask0[qc] : 0.f;
+            const float mk1 = (valid && P.gram_mask1) ? P.gram_mask1[qc] : 0.f;
+            const bool any0 = __ballot(mk0 != 0.f) != 0ull, any1 = __ballot(mk1 != 0.f) != 0ull;
+            if (any0 || any1) {
+                const f32x4* gp = P.gram_p + lhi * BM + wm + l31;    // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
+                const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
+#pragma unroll
+                for (int chunk = 0; chunk < 2; ++chunk) {
+                    float rb[2][8];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            rb[ks][c] = P.gate[(size_t)(chunk * 32 + ks * 16 + lhi * 8 + c) * P.plane + qc];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (k == 0 ? !any0 : !any1) continue;          // (wave-uniform)
+                        const float sm_ = ((k == 0 ? mk0 : mk1) != 0.f) ? g_fscale : 0.f;
+                        const f32x4* gk = k == 0 ? gp : gp1;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            f32x4 fa[2], fb[2];
+                            fa[0] = gk[((chunk * 2 + ks) * 4 + 0) * BM];
+                            fa[1] = gk[((chunk * 2 + ks) * 4 + 2) * BM];
+                            conv_gram_split(rb[ks], sm_, fb[0], fb[1]);
+                            conv_gram_mfma(accg, fa, fb);
+                        }
+                    }
+                }
+            }
+        }
         if (!alive || q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
@@ -641,6 +723,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 if (NP == 2) v *= out_scale;
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += prev[r];
+                if constexpr (GRAM) v += accg[r] * g_oscale;
                 if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
                 v = inside ? v : 0.f;
                 P.out[o] = v;

@@ -710,6 +710,7 @@ int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_p
         const sm_gram_bwd_problem& q = problems[i];
         if (q.C % 64 != 0 || q.ws == nullptr || q.amax_feat == nullptr || q.amax_d == nullptr || q.D0 == nullptr)
             return (int)hipErrorInvalidValue;
+        if (q.dfeat == nullptr) continue;   // pack only: the caller's conv epilogue consumes the operand images (SM_EPI_GRAM)
         if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
     }
     // operand images of all derivative matrices in one launch

@@ -230,6 +230,7 @@ class StepEngine:
         self._adam_early_done = None   # event: the update of the other chunks (issued at the head of the step) is done
         self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
         self.early_update_skips_grad = os.environ.get("STYLEMESH_EARLY_UPDATE_READS_GRAD", "0") != "1"
+        self._gram_fused = {}
         self.overlap_min_pixels = int(os.environ.get("STYLEMESH_OVERLAP_MIN_PIXELS", "400000"))
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
@@ -721,6 +722,7 @@ class StepEngine:
             #   * the other style layers fork when the forward pass is done, deepest first - the order the backward pass
             #     needs them in.
             grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
+            self._gram_fused = {}   # style layers whose Gram backward this step's data-gradient convs take (EPI_GRAM)
             # (only for steps long enough to pay for the extra events and stream switches on the host: a single
             # 256 x 341 level is host-bound, its step 3 % slower with them)
             use_side = (grouped and self.side_streams and self._overlap_pays(active)
@@ -759,9 +761,13 @@ class StepEngine:
                         and depth_of(self.early_style_at) <= depth_of(self.deepest):
                     fork_at = self.early_style_at
 
+                # relu1_1's Gram backward moves into the epilogue of conv1_2's data gradient (EPI_GRAM): its branch only
+                # packs the derivative matrices
+                fuse = tuple(l for l in early if self._can_fuse_gram_bwd(l, bufs))
+
                 def fork(layer):
                     if layer == fork_at and early:
-                        on_side(lambda: self._style_group(active, bufs, w_style, early), early)
+                        on_side(lambda: self._style_group(active, bufs, w_style, early, fuse), early)
                     if layer in side_content:
                         on_side(lambda: content_terms(layer), (layer,))
 
@@ -823,7 +829,8 @@ class StepEngine:
                 for lv, b in zip(active, bufs):
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax,
-                                    start_bound_recorded=start_bound, before_layer=join if side else None)
+                                    start_bound_recorded=start_bound, before_layer=join if side else None,
+                                    gram_terms=self._gram_fused)
             for done in side_done.values():
                 torch.cuda.current_stream().wait_event(done)
         if not accumulate_grad:
@@ -837,7 +844,7 @@ class StepEngine:
                 ops.tex_sample_bwd(self.grads, lv.grid, b.grad["img"], lv.pixel_weight)
         self._grad_dirty = True
 
-    def _style_group(self, active, bufs, w_style, layers):
+    def _style_group(self, active, bufs, w_style, layers, fuse_layers=()):
         """The style branches (masked Gram -> loss value + derivative matrices -> Gram backward into ``grad[layer]``) of
         the given style ``layers`` over ALL active levels, as grouped launches on the current stream (fp16x2 mode): masked
         Grams (one launch per tile class), loss + derivative matrices (one), their operand images (one), Gram backward
@@ -861,11 +868,14 @@ class StepEngine:
                 self._loss_tables.pop(next(iter(self._loss_tables)))
             self._loss_tables[sig] = {}
         tables = self._loss_tables[sig]
-        tab = tables.get(layers)
+        fuse_layers = tuple(l for l in fuse_layers if l in layers)
+        layers_key = (layers, fuse_layers)
+        tab = tables.get(layers_key)
         if tab is None:
             from . import hip
             multi = cfg.style_pyramid_mode == "multi"
             fwd, sty, bwd, keys = [], [], [], []
+            fused = {l: [] for l in fuse_layers}   # layer -> per level (ws, mask0, mask1, amax_feat, amax_d) for EPI_GRAM
             for lv, b in zip(active, bufs):
                 for layer in layers:
                     li = cfg.style_layers.index(layer)
@@ -896,14 +906,19 @@ class StepEngine:
                     # the deepest layer's gradient starts the backward pass: its bound is recorded here (unless a
                     # content term also writes that buffer)
                     rec = layer == self.deepest and layer not in cfg.content_layers and ops.CONV_MODE == "split2"
-                    bwd.append(ops.gram_bwd_problem(f, m0, m1, D0, D1, b.grad[layer], ws, af, ad,
+                    # a fused layer: only the operand images of D are packed here; the data-gradient conv that produces
+                    # this layer's gradient adds the Gram backward in its epilogue (vgg.backward_group, EPI_GRAM)
+                    bwd.append(ops.gram_bwd_problem(f, m0, m1, D0, D1, None if layer in fused else b.grad[layer], ws, af, ad,
                                                     relu_gate=(layer == self.deepest),
                                                     amax_out=self.amax["g:" + layer] if rec else None))
+                    if layer in fused:
+                        fused[layer].append((ws, m0, m1 if D1 is not None else None, af, ad))
                     keys.append(key)
-            tab = tables[layers] = (ops.struct_array(hip.GramProblem, fwd),
-                                                  ops.struct_array(hip.StyleProblem, sty),
-                                                  ops.struct_array(hip.GramBwdProblem, bwd), keys)
-        fwd, sty, bwd, keys = tab
+            tab = tables[layers_key] = (ops.struct_array(hip.GramProblem, fwd),
+                                        ops.struct_array(hip.StyleProblem, sty),
+                                        ops.struct_array(hip.GramBwdProblem, bwd), keys, fused)
+        fwd, sty, bwd, keys, fused = tab
+        self._gram_fused.update(fused)
         assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
         ops.gram_masked_grouped(fwd)
         self._gram_clean.difference_update(keys)
@@ -1084,6 +1099,18 @@ class StepEngine:
 
     def _touched_arg(self):
         return (self.touched, self.touched_log2) if (self.sparse_update and self.touched is not None) else (None, 0)
+
+    def _can_fuse_gram_bwd(self, layer, bufs) -> bool:
+        """The Gram backward of ``layer`` can ride in the epilogue of the data-gradient conv that produces the layer's
+        gradient: a 64-channel style layer right below a conv that itself sits below a pool (relu1_1 / conv1_2: the
+        fp16x2 kernel's 64 x 256 tile holds all channels of a position), fp16x2 arithmetic on both sides, fused pool
+        backward. STYLEMESH_FUSE_GRAM_BWD=0 keeps the separate launch."""
+        from . import vgg as _vgg
+        if os.environ.get("STYLEMESH_FUSE_GRAM_BWD", "1") == "0" or layer != "r11" or layer in self.cfg.content_layers:
+            return False
+        return (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2" and ops.GRAM_MODE == "split2"
+                and self.cfg.style_pyramid_mode in ("multi", "single") and all(b.code for b in bufs)
+                and bufs[0].act[layer].C == 64 and depth_of(self.deepest) > depth_of("p1"))
 
     def _overlap_pays(self, active) -> bool:
         """Side-stream overlap costs the host a few events and stream switches per step: worth it when the GPU step is

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
 
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
-EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL = 1, 2, 4, 8
+EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL, EPI_GRAM = 1, 2, 4, 8, 16
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 
@@ -107,7 +107,9 @@ SIGNATURES = {
 class ConvProblem(C.Structure):
     """sm_conv_problem of include/stylemesh_hip.h"""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int),
-                ("unpool_code", C.c_void_p), ("pool_out", C.c_void_p), ("pool_code", C.c_void_p)]
+                ("unpool_code", C.c_void_p), ("pool_out", C.c_void_p), ("pool_code", C.c_void_p),
+                ("gram_ws", C.c_void_p), ("gram_mask0", C.c_void_p), ("gram_mask1", C.c_void_p),
+                ("gram_amax_feat", C.c_void_p), ("gram_amax_d", C.c_void_p)]
 
 
 class GramProblem(C.Structure):

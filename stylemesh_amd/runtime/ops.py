@@ -358,7 +358,9 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     (FMaps; with a ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel
     takes the pool's backward on the fly, see ``maxpool_fwd_grouped``; with ``flags & EPI_POOL`` - 'split2' mode, a
     PAIR list from ``sparsity.build_tile_lists`` - the launch writes the pooled map ``pooled`` and its argmax codes
-    ``pool_code`` instead of ``out``).
+    ``pool_code`` instead of ``out``; with ``flags & EPI_GRAM`` a 7th element (ws, mask0, mask1-or-None, amax_feat,
+    amax_d) - the operand images ``gram_backward_grouped`` left in ``ws`` for a problem without ``dfeat`` and the style
+    layer's masks / bounds - makes the epilogue add the layer's masked Gram backward).
     ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
     ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
     ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
@@ -382,8 +384,13 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         if flags & hip.EPI_POOL:
             assert CONV_MODE == "split2" and tile_list is not None and pooled is not None and pool_code.dtype == torch.int32
             assert (pooled.C, pooled.H, pooled.W) == (cout, out.H // 2, out.W // 2) and pool_code.numel() >= cout // 8 * pooled.plane
+        gram = prob[6] if len(prob) > 6 else None
+        if flags & hip.EPI_GRAM:
+            assert CONV_MODE == "split2" and gram is not None and code is not None and cout == 64 and gate is not None
+        gws, gm0, gm1, gaf, gad = gram if gram is not None else (None,) * 5
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code),
-                                 None if pooled is None else pooled.ptr, ptr(pool_code))
+                                 None if pooled is None else pooled.ptr, ptr(pool_code),
+                                 ptr(gws), ptr(gm0), ptr(gm1), ptr(gaf), ptr(gad))
         cin_true = 3 if cin_pad == 4 else cin_pad
         flops += 2.0 * 9 * cin_true * cout * out.H * out.W
         # algorithmic HBM bytes: input read once, output written once (pooled: a quarter + 1/2 byte of codes per element),
@@ -559,9 +566,11 @@ def style_problem(S0, S1, counts, factor, targets, term_mask, skip_if_empty, wei
 def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate,
                      amax_out=None) -> "hip.GramBwdProblem":
     """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own;
-    ``amax_out`` (optional amax bound): max |dfeat| is max-ed into it."""
+    ``amax_out`` (optional amax bound): max |dfeat| is max-ed into it. ``dfeat`` None: only the operand images of D0 / D1
+    are written into ``ws`` (a conv launch with ``EPI_GRAM`` consumes them)."""
     assert ws.numel() >= lib.sm_gram_backward_split_ws_bytes(feat.C)
-    return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, ptr(ws), ptr(amax_feat),
+    return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), None if dfeat is None else dfeat.ptr,
+                              ptr(ws), ptr(amax_feat),
                               ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate))
 
 

@@ -200,7 +200,7 @@ class VGGNet:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
     def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None,
-                       amax: AmaxBook | None = None, start_bound_recorded=False):
+                       amax: AmaxBook | None = None, start_bound_recorded=False, gram_terms=None):
         """``backward`` for several levels at once (same injected layers on every level). ``amax``: as in
         ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here unless
         the loss kernels recorded it themselves (``start_bound_recorded``)."""
@@ -233,8 +233,17 @@ class VGGNet:
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
+                gt = gram_terms.get(src) if gram_terms else None
+                if gt is not None:
+                    # the style layer's Gram backward is computed in this launch's epilogue instead of being read from
+                    # grad[src] (``gram_terms[src]``: per level (ws, mask0, mask1, amax_feat, amax_d), engine._style_group)
+                    if unpool is None or len(gt) != len(bufs) or ops.CONV_MODE != "split2":
+                        raise RuntimeError(f"{kind}: a fused Gram backward needs the un-pooling fp16x2 data gradient")
+                    flags = hip.EPI_RELU_MASK | hip.EPI_GRAM
                 if unpool is not None:
                     probs = [(b.grad[unpool], b.grad[src], b.act[src], b.code[unpool]) for b in bufs]
+                    if gt is not None:
+                        probs = [p + (None, None, g) for p, g in zip(probs, gt)]
                     unpool = None
                 else:
                     probs = [(b.grad[out], b.grad[src], b.act[src]) for b in bufs]

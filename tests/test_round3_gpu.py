@@ -365,3 +365,114 @@ def test_engine_step_with_and_without_pooling_epilogue(monkeypatch):
     d = (res["1"][1] - res["0"][1]).abs()
     # (Adam at lr 1 turns last-bit gradient differences into +-lr steps on a few texels: compare the bulk)
     assert float((d > 1e-3).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("hws,two_masks", [([(37, 50)], True), ([(150, 201), (64, 85)], True), ([(40, 53)], False)])
+def test_conv_gram_epilogue_matches_gram_backward_then_add(hws, two_masks, monkeypatch):
+    """EPI_GRAM (the data-gradient conv that produces a 64-channel style layer's gradient adds that layer's masked Gram
+    backward in its epilogue) against the two-launch form - Gram backward into the gradient plane, then the conv with
+    EPI_ADD: the same bits (same operand images, scales, fp16 pairs and product order), one or two masks, several levels,
+    with and without an active-segment list."""
+    require_gpu()
+    import torch.nn.functional as F
+    from stylemesh_amd.runtime import hip, ops
+    from stylemesh_amd.runtime.fmap import FMap
+    monkeypatch.setattr(ops, "CONV_MODE", "split2")
+    monkeypatch.setattr(ops, "GRAM_MODE", "split2")
+    C = 64
+    torch.manual_seed(len(hws) * 7 + two_masks)
+    wgt = torch.randn(C, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    wd = ops.pack_conv_dgrad(wgt).cuda()
+    wd2 = ops.pack_conv_split2(wd)
+    D0 = (torch.randn(C, C) * 3e-3).cuda()
+    D1 = (torch.randn(C, C) * 1e-3).cuda() if two_masks else None
+    feats, masks, dps, codes, covers = [], [], [], [], []
+    for g, (H, W) in enumerate(hws):
+        f = F.relu(torch.randn(C, H, W) * 2)
+        feats.append(FMap(C, H, W).from_dense(f.cuda()))
+        mk = torch.zeros(2, H, W)
+        sel = torch.rand(H, W)
+        mk[0] = (sel < 0.3).float()
+        mk[1] = ((sel >= 0.3) & (sel < 0.45)).float()
+        mk[:, H // 2:, : W // 3] = 0                 # a region neither mask reaches
+        masks.append(FMap(2, H, W).from_dense(mk.cuda()))
+        act = F.relu(torch.randn(C, H, W))
+        a, pooled = FMap(C, H, W).from_dense(act.cuda()), FMap(C, H // 2, W // 2)
+        code = torch.zeros(C // 8 * pooled.plane, dtype=torch.int32, device="cuda")
+        ops.maxpool_fwd_grouped([(a, pooled)], None, [code])
+        codes.append(code)
+        dps.append(FMap(C, H // 2, W // 2).from_dense((torch.randn(C, H // 2, W // 2) * 1e-4).cuda()))
+    af = ops.new_amax("cuda", max(float(f.planes.abs().max()) for f in feats))
+    ad = ops.new_amax("cuda", max(float(D0.abs().max()), float(D1.abs().max()) if two_masks else 0.0))
+    amax_in = ops.new_amax("cuda", max(float(d.planes.abs().max()) for d in dps))
+
+    def mptr(m, k):
+        return m.channel_ptr(k)
+    for use_list in (False, True):
+        lst = None
+        if use_list:   # free-start segments over a need map that leaves holes
+            _, group = ops.conv_list_format(C, C)
+            parts = []
+            for g, (H, W) in enumerate(hws):
+                nd = (torch.rand(H, W) < 0.4).float().cuda()
+                cap = H * hip.row_stride(W) // 32 + 2
+                starts = torch.empty(cap, dtype=torch.int32, device="cuda")
+                count = torch.zeros(1, dtype=torch.int32, device="cuda")
+                ops.cover_segments([(nd, starts, count, g)])
+                n = int(count)
+                parts.append(torch.cat([starts[:n], torch.full(((-n) % group,), (g << 24) | 0xFFFFFF, dtype=torch.int32,
+                                                                  device="cuda")]))
+            lst = torch.cat(parts)
+        # two launches: Gram backward into the gradient plane, then the conv adds it (no K-split: same sums)
+        ref = [FMap(C, H, W) for (H, W) in hws]
+        ws1 = [torch.empty(ops.gram_backward_ws_bytes(C), dtype=torch.uint8, device="cuda") for _ in hws]
+        ops.gram_backward_grouped(ops.struct_array(hip.GramBwdProblem, [
+            ops.gram_bwd_problem(f, mptr(m, 0), mptr(m, 1) if two_masks else None, D0, D1, r, w_, af, ad, relu_gate=False)
+            for f, m, r, w_ in zip(feats, masks, ref, ws1)]))
+        assert max(float(r.planes.abs().max()) for r in ref) > 0
+        tiny = torch.zeros(4, device="cuda")
+        with monkeypatch.context() as mp:
+            mp.setattr(ops, "splitk_workspace", lambda device: tiny)
+            ops.conv3x3_grouped([(d, r, f, c) for d, r, f, c in zip(dps, ref, feats, codes)], wd, None,
+                                hip.EPI_RELU_MASK | hip.EPI_ADD, lst, 1.0, None, wd2, amax_in, ops.new_amax("cuda"))
+        # one launch
+        out = [FMap(C, H, W) for (H, W) in hws]
+        ws2 = [torch.empty(ops.gram_backward_ws_bytes(C), dtype=torch.uint8, device="cuda") for _ in hws]
+        ops.gram_backward_grouped(ops.struct_array(hip.GramBwdProblem, [
+            ops.gram_bwd_problem(f, mptr(m, 0), mptr(m, 1) if two_masks else None, D0, D1, None, w_, af, ad, relu_gate=False)
+            for f, m, w_ in zip(feats, masks, ws2)]))
+        amax_out = ops.new_amax("cuda")
+        ops.conv3x3_grouped([(d, o, f, c, None, None, (w_, mptr(m, 0), mptr(m, 1) if two_masks else None, af, ad))
+                             for d, o, f, c, w_, m in zip(dps, out, feats, codes, ws2, masks)], wd, None,
+                            hip.EPI_RELU_MASK | hip.EPI_GRAM, lst, 1.0, None, wd2, amax_in, amax_out)
+        for o, r in zip(out, ref):
+            if use_list:   # (the reference plane keeps the bare Gram term where the list has no segment)
+                written = o.planes != 0
+                assert torch.equal(o.planes[written], r.planes[written]) and int(written.sum()) > 0
+            else:
+                assert torch.equal(o.planes, r.planes)
+            assert o.border_is_zero()
+        assert float(amax_out.max()) == max(float(o.planes.abs().max()) for o in out)
+
+
+def test_engine_step_with_and_without_gram_epilogue(monkeypatch):
+    """The step with relu1_1's Gram backward inside conv1_2's data-gradient launch against the separate Gram-backward
+    launch: the same losses, the same gradient up to the K-split of tail tiles (the fused launch runs whole tiles)."""
+    require_gpu()
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("STYLEMESH_FUSE_GRAM_BWD", fuse)
+        monkeypatch.setenv("STYLEMESH_OVERLAP_MIN_PIXELS", "0")     # the small test view takes the side-stream path
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        eng = _engine(random_init=True)
+        view = _small_view(MULTIVIEW_SEEDS[0])
+        losses = [eng.losses(eng.training_step(view)) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert bool(eng._gram_fused) == (fuse == "1")
+        res[fuse] = (losses, eng.arena.p.clone())
+    for k in res["1"][0][0]:
+        a, b = res["1"][0][0][k], res["0"][0][0][k]
+        assert abs(a - b) <= 1e-6 * abs(b) + 1e-6, (k, a, b)
+    d = (res["1"][1] - res["0"][1]).abs()
+    assert float((d > 1e-3).float().mean()) < 0.02
