@@ -39,7 +39,7 @@ extern "C" {
 #define SM_EPI_BIAS_RELU 1 /* out = relu(acc + bias[co])                                  (forward)  */
 #define SM_EPI_RELU_MASK 2 /* out = gate[co][q] > 0 ? v : 0                               (dgrad)    */
 #define SM_EPI_ADD 4       /* v += out[co][q] (value already in the output buffer) before the gate   */
-#define SM_EPI_GRAM 16     /* with SM_EPI_RELU_MASK and unpool_code, sm_conv3x3_grouped_split2 only, Cout = 64: v += the masked
+#define SM_EPI_GRAM 16     /* with SM_EPI_RELU_MASK and unpool_code, sm_conv3x3_grouped_split2 only, Cout = 64 / 128: v += the masked
                             * Gram backward of the output layer (sm_conv_problem::gram_*), computed in the epilogue   (dgrad)    */
 #define SM_EPI_POOL 8      /* with SM_EPI_BIAS_RELU, sm_conv3x3_grouped_split2 only: store the 2x2 max-pooled map and the
                             * pool's argmax codes (sm_conv_problem::pool_out / pool_code) INSTEAD of out     (forward)  */
@@ -199,8 +199,9 @@ typedef struct {
      * plane sizes of HBM traffic per pool. */
     float* pool_out;
     uint32_t* pool_code;
-    /* sm_conv3x3_grouped_split2 with flags SM_EPI_RELU_MASK | SM_EPI_GRAM only (ABI 7; NULL elsewhere), Cout = 64, all
-     * problems with unpool_code: the conv's OUTPUT layer is a style layer (relu1_1 for conv1_2's data gradient) whose masked
+    /* sm_conv3x3_grouped_split2 with flags SM_EPI_RELU_MASK | SM_EPI_GRAM only (ABI 7; NULL elsewhere), Cout = 64 or 128
+     * (the kernel's row tile then holds all channels of a position), all problems with unpool_code: the conv's OUTPUT layer
+     * is a style layer (relu1_1 / relu2_1 for the data gradients of conv1_2 / conv2_2) whose masked
      * Gram backward (content_and_style_losses.py:301-340 through autograd: sum over the masks k of m_k(q) (D_k F)(q),
      * F = `gate`) is added in the epilogue - the bits of sm_gram_backward_split2_grouped's result - instead of being
      * written by that call and read back through SM_EPI_ADD. gram_ws: the operand images of D0 / D1 as

@@ -816,9 +816,12 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
 static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
         if (flags == (SM_EPI_RELU_MASK | SM_EPI_GRAM)) {   // + the Gram backward of the 64-channel output layer; whole tiles only
-            if (a.Cout != 64) return (int)hipErrorInvalidValue;
             a.ws = nullptr;
-            return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+            if (a.Cout == 64)
+                return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+            if (a.Cout == 128)   // (four waves of 32 rows: the 128-row tile holds all channels of its positions)
+                return sm::launch_conv<128, 128, 16, 4, 1, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+            return (int)hipErrorInvalidValue;
         }
         switch (flags) {
             case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);

@@ -643,15 +643,15 @@ void conv3x3_split_kernel(ConvArgs a) {
         record_amax(a.amax_out, vmax, amax_seen);
         return;
     }
-    // SM_EPI_GRAM: the output layer is a 64-channel style layer and this epilogue adds its masked Gram backward,
-    // sum_k m_k(q) (D_k F)(q), F = the gate operand - four 16-channel steps per mask on the matrix cores for each of the
-    // wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
+    // SM_EPI_GRAM: the output layer is a style layer of C = BM channels (the block's row tile holds all of them) and this
+    // epilogue adds its masked Gram backward, sum_k m_k(q) (D_k F)(q), F = the gate operand - C / 16 sixteen-channel steps
+    // per mask on the matrix cores for each of the wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
     // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
     constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
     float g_fscale = 1.f, g_oscale = 1.f;
     if constexpr (GRAM) {
-        static_assert(NP == 2 && MI == 1 && BM == 64 && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
-                      "the Gram term replaces the addend of a 64-channel data gradient");
+        static_assert(NP == 2 && MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
+                      "the Gram term replaces the addend of a data gradient whose row tile holds all C = BM channels");
         float inv_f, inv_d;
         g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
         conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
@@ -679,7 +679,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 const f32x4* gp = P.gram_p + lhi * BM + wm + l31;    // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
                 const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
 #pragma unroll
-                for (int chunk = 0; chunk < 2; ++chunk) {
+                for (int chunk = 0; chunk < BM / 32; ++chunk) {
                     float rb[2][8];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)

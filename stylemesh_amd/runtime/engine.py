@@ -793,7 +793,8 @@ class StepEngine:
             start_bound = False
             if grouped:
                 for l in late:   # deepest first: each branch has its own event
-                    on_side(lambda l=l: self._style_group(active, bufs, w_style, (l,)), (l,))
+                    on_side(lambda l=l: self._style_group(active, bufs, w_style, (l,),
+                                                          (l,) if self._can_fuse_gram_bwd(l, bufs) else ()), (l,))
                 on_main = [l for l in cfg.style_layers if l not in early and l not in late]
                 self._style_group(active, bufs, w_style, on_main)
                 injected = set(cfg.style_layers)
@@ -1102,15 +1103,17 @@ class StepEngine:
 
     def _can_fuse_gram_bwd(self, layer, bufs) -> bool:
         """The Gram backward of ``layer`` can ride in the epilogue of the data-gradient conv that produces the layer's
-        gradient: a 64-channel style layer right below a conv that itself sits below a pool (relu1_1 / conv1_2: the
-        fp16x2 kernel's 64 x 256 tile holds all channels of a position), fp16x2 arithmetic on both sides, fused pool
-        backward. STYLEMESH_FUSE_GRAM_BWD=0 keeps the separate launch."""
+        gradient: a 64- / 128-channel style layer right below a conv that itself sits below a pool (relu1_1 / conv1_2,
+        relu2_1 / conv2_2: the fp16x2 kernel's 64 x 256 / 128 x 128 tile holds all channels of a position), fp16x2
+        arithmetic on both sides, fused pool backward. STYLEMESH_FUSE_GRAM_BWD=<layers> (default r11,r21; 0 = none)."""
         from . import vgg as _vgg
-        if os.environ.get("STYLEMESH_FUSE_GRAM_BWD", "1") == "0" or layer != "r11" or layer in self.cfg.content_layers:
+        which = os.environ.get("STYLEMESH_FUSE_GRAM_BWD", "r11,r21")
+        if layer not in which.split(",") or layer not in ("r11", "r21") or layer in self.cfg.content_layers:
             return False
+        pool_above = {"r11": "p1", "r21": "p2"}[layer]   # conv1_2 / conv2_2 sit right below these pools
         return (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2" and ops.GRAM_MODE == "split2"
                 and self.cfg.style_pyramid_mode in ("multi", "single") and all(b.code for b in bufs)
-                and bufs[0].act[layer].C == 64 and depth_of(self.deepest) > depth_of("p1"))
+                and bufs[0].act[layer].C in (64, 128) and depth_of(self.deepest) > depth_of(pool_above))
 
     def _overlap_pays(self, active) -> bool:
         """Side-stream overlap costs the host a few events and stream switches per step: worth it when the GPU step is

@@ -386,7 +386,7 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
             assert (pooled.C, pooled.H, pooled.W) == (cout, out.H // 2, out.W // 2) and pool_code.numel() >= cout // 8 * pooled.plane
         gram = prob[6] if len(prob) > 6 else None
         if flags & hip.EPI_GRAM:
-            assert CONV_MODE == "split2" and gram is not None and code is not None and cout == 64 and gate is not None
+            assert CONV_MODE == "split2" and gram is not None and code is not None and cout in (64, 128) and gate is not None
         gws, gm0, gm1, gaf, gad = gram if gram is not None else (None,) * 5
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code),
                                  None if pooled is None else pooled.ptr, ptr(pool_code),

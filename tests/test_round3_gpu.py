@@ -367,10 +367,11 @@ def test_engine_step_with_and_without_pooling_epilogue(monkeypatch):
     assert float((d > 1e-3).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("hws,two_masks", [([(37, 50)], True), ([(150, 201), (64, 85)], True), ([(40, 53)], False)])
-def test_conv_gram_epilogue_matches_gram_backward_then_add(hws, two_masks, monkeypatch):
-    """EPI_GRAM (the data-gradient conv that produces a 64-channel style layer's gradient adds that layer's masked Gram
-    backward in its epilogue) against the two-launch form - Gram backward into the gradient plane, then the conv with
+def test_conv_gram_epilogue_matches_gram_backward_then_add(hws, two_masks, C, monkeypatch):
+    """EPI_GRAM (the data-gradient conv that produces a 64- / 128-channel style layer's gradient adds that layer's masked
+    Gram backward in its epilogue) against the two-launch form - Gram backward into the gradient plane, then the conv with
     EPI_ADD: the same bits (same operand images, scales, fp16 pairs and product order), one or two masks, several levels,
     with and without an active-segment list."""
     require_gpu()
@@ -379,8 +380,7 @@ def test_conv_gram_epilogue_matches_gram_backward_then_add(hws, two_masks, monke
     from stylemesh_amd.runtime.fmap import FMap
     monkeypatch.setattr(ops, "CONV_MODE", "split2")
     monkeypatch.setattr(ops, "GRAM_MODE", "split2")
-    C = 64
-    torch.manual_seed(len(hws) * 7 + two_masks)
+    torch.manual_seed(len(hws) * 7 + two_masks + C)
     wgt = torch.randn(C, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
     wd = ops.pack_conv_dgrad(wgt).cuda()
     wd2 = ops.pack_conv_split2(wd)
@@ -456,12 +456,12 @@ def test_conv_gram_epilogue_matches_gram_backward_then_add(hws, two_masks, monke
 
 
 def test_engine_step_with_and_without_gram_epilogue(monkeypatch):
-    """The step with relu1_1's Gram backward inside conv1_2's data-gradient launch against the separate Gram-backward
-    launch: the same losses, the same gradient up to the K-split of tail tiles (the fused launch runs whole tiles)."""
+    """The step with the Gram backward of relu1_1 / relu2_1 inside the data-gradient launches of conv1_2 / conv2_2 against
+    the separate Gram-backward launches: the same losses, the same gradient up to the K-split of tail tiles (the fused launch runs whole tiles)."""
     require_gpu()
     res = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("STYLEMESH_FUSE_GRAM_BWD", fuse)
+        monkeypatch.setenv("STYLEMESH_FUSE_GRAM_BWD", "r11,r21" if fuse == "1" else "0")
         monkeypatch.setenv("STYLEMESH_OVERLAP_MIN_PIXELS", "0")     # the small test view takes the side-stream path
         torch.manual_seed(11)
         torch.cuda.manual_seed(11)
@@ -469,7 +469,7 @@ def test_engine_step_with_and_without_gram_epilogue(monkeypatch):
         view = _small_view(MULTIVIEW_SEEDS[0])
         losses = [eng.losses(eng.training_step(view)) for _ in range(2)]
         torch.cuda.synchronize()
-        assert bool(eng._gram_fused) == (fuse == "1")
+        assert set(eng._gram_fused) == ({"r11", "r21"} if fuse == "1" else set())
         res[fuse] = (losses, eng.arena.p.clone())
     for k in res["1"][0][0]:
         a, b = res["1"][0][0][k], res["0"][0][0][k]
