@@ -421,7 +421,8 @@ typedef struct {
     const float* mask1;
     const float* D0;
     const float* D1;
-    float* dfeat;
+    float* dfeat;           /* NULL (ABI 7): only the operand images of D0 / D1 are written into ws - a conv launch with
+                             * SM_EPI_GRAM (sm_conv_problem::gram_ws) computes this problem's result in its epilogue */
     void* ws;
     const float* amax_feat;
     const float* amax_d;
