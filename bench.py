@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: views/s of the texture-optimisation step (fwd + bwd into the texture gradient + fused
-Adam) on synthetic ScanNet-shaped input. One process per GPU; for N > 1 launch with
-``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`` (views shard over ranks, the
-texture gradient is all-reduced over RCCL before the update: SURVEY.md section 8 e).
+Adam) on synthetic ScanNet-shaped input. One process per GPU.
+
+``python bench.py --gpus N`` started plainly (no WORLD_SIZE in the environment) launches N fresh rank processes itself
+(``stylemesh_amd/launch.py``: decided before anything touches the GPU; the parent relays rank 0's JSON line and exits with
+the ranks' worst return code); under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it is one of
+the ranks. Views shard over the ranks and the texture gradient is all-reduced over RCCL before the update (SURVEY.md
+section 8 e, BASELINE config 5); ``--replicas`` instead runs N INDEPENDENT scenes, one per GPU, no communicator (BASELINE
+config 4) and reports the aggregate and the per-GPU rates. ``STYLEMESH_DIST_BACKEND=gloo`` runs either protocol with the
+ranks sharing the visible GPU(s) (a functional check on a 1-GPU box, not a measurement).
 
 Prints ONE JSON line on rank 0 (contract in the task description): whole-job views/s, the roofline of the
 dominant kernel (the fp16x2-split MFMA implicit-GEMM conv - fp32 operands split into two fp16 parts, fp32 accumulate -
@@ -39,10 +45,30 @@ WORKLOADS = {
     "c5": dict(tex=4096, level_hw=S.MATTERPORT_LEVEL_HW, view_hw=S.MATTERPORT_VIEW_HW, mode="multi", thr=40.0, angle=True,
                depth=True, index_repeat=100, min_depth=0.2, desc="Matterport with_angle_and_depth, 4096^2 hier-4 texture, "
                "4 UV levels 256x320..784x980"),
+    # optimize_texture_scannet_with_angle.sh:3-20 - angle weighting on, depth scaling off, ONE UV level
+    "with_angle": dict(tex=4096, level_hw=[S.SCANNET_VIEW_HW], view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0, angle=True,
+                       depth=False, index_repeat=20, min_depth=0.25, desc="ScanNet with_angle, 4096^2 hier-4 texture, 1 UV "
+                       "level 256x341, multi style pyramid, angle reweighting, no depth scaling"),
+    # optimize_texture_scannet_dip.sh:3-20 - flat texture, no regulariser, 10-deep Gram history, a NEW view every step
+    # (RepeatingSampler with index_repeat 1, data/abstract_dataset.py:498-512)
+    "dip": dict(tex=4096, level_hw=[S.SCANNET_VIEW_HW], view_hw=S.SCANNET_VIEW_HW, mode="single", thr=3000.0, angle=False,
+                depth=False, index_repeat=1, min_depth=0.25, n_layers=1, gram_mode="average", decay=15,
+                loss_weights={"content": 7e1, "style": 1e-3, "tex_reg": 0.0},
+                desc="ScanNet dip, 4096^2 1-layer texture, 1 UV level 256x341, single style pyramid, gram_mode average, "
+                "index_repeat 1 (a view change every step)"),
 }
 LOSS_WEIGHTS = {"content": 7e1, "style": 1e-4, "tex_reg": 5e3}
 STYLE_WEIGHTS = [1000., 1000., 10., 10., 1000.]
 STYLE_HW = (1528, 1200)   # "The Scream" (styles/120styles/17.jpg) is 1200 x 1528 px
+
+
+def engine_config(wl):
+    from stylemesh_amd.runtime.engine import EngineConfig
+    return EngineConfig(tex_w=wl["tex"], tex_h=wl["tex"], hierarchical=True, n_layers=wl.get("n_layers", 4),
+                        style_weights=STYLE_WEIGHTS, angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"],
+                        gram_mode=wl.get("gram_mode", "current"), use_angle_weight=wl["angle"],
+                        use_depth_scaling=wl["depth"], loss_weights=dict(wl.get("loss_weights", LOSS_WEIGHTS)),
+                        learning_rate=1.0, decay_step_size=wl.get("decay", 3))
 
 
 def make_views(wl, seeds):
@@ -76,11 +102,13 @@ def cpu_baseline(wl, view_cpu, steps):
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     env = os.environ.get("STYLEMESH_CPU_THREADS")
     counts = [int(env)] if env else sorted({max(1, min(avail, c)) for c in (32, 64)})
-    cfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=wl["thr"],
-                         style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"], use_depth_scaling=wl["depth"],
-                         loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
+    cfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], gram_mode=wl.get("gram_mode", "current"),
+                         use_angle_weight=wl["angle"], use_depth_scaling=wl["depth"],
+                         loss_weights=dict(wl.get("loss_weights", LOSS_WEIGHTS)), learning_rate=1.0,
+                         decay_step_size=wl.get("decay", 3))
     torch.set_num_threads(counts[0])
-    pipe = O.OraclePipeline(S.seeded_vgg_state(0), S.style_image(1, *STYLE_HW), cfg, (wl["tex"], wl["tex"]))
+    pipe = O.OraclePipeline(S.seeded_vgg_state(0), S.style_image(1, *STYLE_HW), cfg, (wl["tex"], wl["tex"]),
+                            n_layers=wl.get("n_layers", 4))
     best, tried = None, []
     for threads in counts:
         torch.set_num_threads(threads)
@@ -107,12 +135,21 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     """Warm-up + the timed region (barrier + synchronize on both sides). -> seconds of the timed region."""
     from stylemesh_amd.runtime import ops
     rep = wl["index_repeat"]
-    def ahead(i):   # during a view's second step: the NEXT view's constants are computed on a side stream (N = 1)
-        if world == 1 and i % rep == 1 and i - 1 + rep < len(schedule):
+    solo = world == 1 or reducer is None   # (a replica is a single-rank job)
+
+    def ahead(i):   # during a view's second step: the NEXT view's constants are computed on a side stream
+        if solo and rep > 1 and i % rep == 1 and i - 1 + rep < len(schedule):
             eng.prepare_view(schedule[i - 1 + rep])
-    for i in range(args.warmup):
+
+    def upcoming(i):   # index_repeat 1: every step changes the view - the next one is prepared beside THIS step
+        return schedule[i + 1] if (solo and rep == 1 and i + 1 < len(schedule)) else None
+
+    def step(i):
         ahead(i)
-        eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
+        eng.training_step(schedule[i], world_size=world if reducer is not None else 1, reducer=reducer,
+                          new_view=(i % rep == 0), next_batch=upcoming(i))
+    for i in range(args.warmup):
+        step(i)
     ops.CONV_TIMER = timer
     if getattr(eng, "phase_timer", None) is not None:
         eng.phase_timer.enabled = True
@@ -121,8 +158,7 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
     for i in range(args.warmup, args.warmup + args.steps):
         if timer is not None:
             timer.enabled = (i - args.warmup) % args.timer_every == 0
-        ahead(i)
-        eng.training_step(schedule[i], world_size=world, reducer=reducer, new_view=(i % rep == 0))
+        step(i)
     barrier()
     dt = time.perf_counter() - t0
     ops.CONV_TIMER = None
@@ -162,6 +198,11 @@ def exchange_report(eng, comm, reducer, args):
            if type(comm).__name__ == "RcclComm" else "torch.distributed",
            "bytes_per_step": getattr(reducer, "last_bytes", None),
            "flagged_fraction_of_arena": None if not hasattr(reducer, "fraction") else round(reducer.fraction, 4)}
+    if hasattr(comm, "info"):
+        rep["rccl"] = comm.info()          # ranks RCCL saw, its version, link type of this rank's device to the others
+    else:
+        rep["process_group"] = {"backend": str(comm.get_backend()), "nranks": comm.get_world_size()}
+    rep["pipelined"] = bool(eng.pipeline_exchange)
     t = getattr(eng, "phase_timer", None)
     if t is not None:
         for tag, key in (("exchange", "exchange_ms"), ("update", "update_ms"), ("exchange+update", "exchange_update_ms")):
@@ -238,23 +279,26 @@ def many_views_leg(eng, wl, args, dev, barrier, good, first_seeds):
 def measured_schedule(workload):
     """The fixed schedule of one scene MEASURED on the product path (tools/run_schedule.py: directory loader, MiniTrainer,
     the CLI's flags) - a committed record of a GPU-box run, the default bench run cannot afford 4 minutes of it."""
-    for rnd in ("r03",):
+    for rnd in ("r04", "r03"):
         f = os.path.join(REPO, "profiles", rnd, f"schedule_{workload}.json")
         if os.path.exists(f):
             d = json.load(open(f))
-            return {"measured_schedule_s": d.get("measured_schedule_s"), "steps": d.get("steps"),
+            return {"measured_schedule_s": d.get("measured_schedule_s"), "measured_schedule_live": False, "steps": d.get("steps"),
                     "mean_views_per_s": d.get("mean_views_per_s"), "per_epoch_views_per_s": [e["views_per_s"] for e in d.get("per_epoch", [])],
-                    "source": f"profiles/{rnd}/{os.path.basename(f)} (python -m stylemesh_amd.model.optimize on a {d.get('views')}-view "
+                    "source": f"committed record profiles/{rnd}/{os.path.basename(f)}, not measured in this run (python -m stylemesh_amd.model.optimize on a {d.get('views')}-view "
                               "on-disk scene, texture exports and validation included)"}
     return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
+    ap.add_argument("--replicas", action="store_true", help="BASELINE config 4: the N ranks optimise N INDEPENDENT scenes, "
+                    "one per GPU - no communicator, no gradient exchange (a CPU-side barrier brackets the timed region); "
+                    "reports the aggregate and the per-GPU views/s")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-conv-timer", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--dense", action="store_true", help="run the VGG convs on every tile instead of only the tiles that "
@@ -268,7 +312,8 @@ def main():
     ap.add_argument("--atomic-scatter", action="store_true", help="texture scatter with the tiled atomic kernel (one launch "
                     "per UV level) instead of the sorted gather over the per-view plan")
     ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
-                    "with the update of each arena range issued as its sums arrive (default: exchange, then update)")
+                    "with the update of each arena range issued as its sums arrive (default: exchange, then update; "
+                    "STYLEMESH_PIPELINE_EXCHANGE=1 selects it for the trainer)")
     ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate), 'split' "
                     "(bf16x3-split operands, 6 partial products) or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
@@ -284,53 +329,95 @@ def main():
                     "workload over ten more views instead of the main leg's first two or three; 0 = skip the leg)")
     ap.add_argument("--late-epoch-views", type=int, default=276, help="N = 1: views whose coverage seeds the ever-touched "
                     "set of the 'late_epoch' leg (0 = skip the leg)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=None, help="self-launched N > 1 runs: seconds after which the "
+                    "rank processes are ended (default: none)")
+    return ap.parse_args(argv)
+
+
+def arena_checksum(eng):
+    """Exact checksum of the texture values (sum of the fp32 bit patterns as int64, in slices: no 2 GB temporary)."""
+    p = eng.arena.p
+    tot = torch.zeros((), dtype=torch.int64, device=p.device)
+    for lo in range(0, p.numel(), 1 << 26):
+        tot += p[lo:lo + (1 << 26)].view(torch.int32).to(torch.int64).sum()
+    return int(tot)
+
+
+def gather_values(dist, backend, dev, values, dtype=torch.float64):
+    """[values of rank 0, values of rank 1, ...] on every rank (a small all_gather on the process group's own device)."""
+    t = torch.tensor(values, dtype=dtype, device=dev if backend == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def main():
+    args = parse_args()
+    from stylemesh_amd import launch
+    if launch.needs_launch(args.gpus, os.environ):
+        # plain `python bench.py --gpus N`: N fresh rank processes, decided before this process touches the GPU
+        # (torch.cuda.device_count() does not initialise HIP on this image); the parent relays rank 0's JSON line
+        sys.exit(launch.launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                               device_count=torch.cuda.device_count, timeout_s=args.launch_timeout))
+    run(args)
+
+
+def run(args):
     wl = WORKLOADS[args.workload]
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (python bench.py --gpus N launches its "
+                         "own ranks) or under torch.distributed.run with --nproc-per-node N")
     # STYLEMESH_DIST_BACKEND=gloo: functional test of the N > 1 protocol on a 1-GPU box (all ranks share cuda:0)
     backend = os.environ.get("STYLEMESH_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < world:
+        raise SystemExit(f"bench.py --gpus {world}: {n_dev} GPU(s) visible, one rank per GPU needs {world}")
     if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
+        local_rank %= max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
+        if args.replicas:
+            backend = "gloo"                 # config 4: no RCCL anywhere - the process group only carries barriers / timings
+            dist.init_process_group("gloo")
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
+    sharded = world > 1 and not args.replicas   # views of ONE scene over the ranks, gradient exchange every step
 
     from stylemesh_amd.runtime import ops
-    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    from stylemesh_amd.runtime.engine import StepEngine
     if args.mfma is not None:
         ops.CONV_MODE = args.mfma
         ops.GRAM_MODE = args.mfma   # the Gram kernels follow the conv mode
 
-    cfg = EngineConfig(tex_w=wl["tex"], tex_h=wl["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
-                       angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], use_angle_weight=wl["angle"],
-                       use_depth_scaling=wl["depth"], loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0,
-                       decay_step_size=3)
+    cfg = engine_config(wl)
     eng = StepEngine(cfg, S.seeded_vgg_state(0), device=dev)
     eng.set_style_image(S.style_image(1, *STYLE_HW))
     eng.use_graphs = args.graphs
     eng.sparse_tiles = not args.dense
     eng.overlap_style = args.overlap_style
-    eng.pipeline_exchange = args.pipeline_exchange
+    eng.pipeline_exchange = args.pipeline_exchange or os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0") == "1"
     eng.planned_scatter = not args.atomic_scatter
     eng.sparse_update = not args.dense_adam
 
-    # views of the scene shard over ranks: rank r takes views r, r + R, ... ; each is repeated index_repeat times
+    # sharded: views of the scene shard over ranks - rank r takes views r, r + R, ... ; replicas: every rank has a scene
+    # (a camera path) of its own; each view is repeated index_repeat times
     total_steps = args.warmup + args.steps
     n_views = (total_steps + wl["index_repeat"] - 1) // wl["index_repeat"]
     # seeds whose view populates every UV level (the 4-level worst case the FLOP figure is quoted for)
     good = (0, 2, 6, 7, 9, 11, 12, 14, 16, 18, 22, 23, 26, 27, 29, 30, 32, 33, 35, 36, 37, 38, 39)
-    seeds = [good[(v * world + rank) % len(good)] for v in range(max(1, n_views))]
+    if args.replicas:
+        seeds = [good[(v + 5 * rank) % len(good)] for v in range(max(1, n_views))]
+    else:
+        seeds = [good[(v * world + rank) % len(good)] for v in range(max(1, n_views))]
     distinct = {s_: v for s_, v in zip(sorted(set(seeds)), make_views(wl, sorted(set(seeds))))}   # (seeds repeat on long runs)
     views_cpu = [distinct[s_] for s_ in seeds]
     on_dev = {s_: to_device(v, dev) for s_, v in distinct.items()}
@@ -340,8 +427,10 @@ def main():
     from stylemesh_amd.runtime.distributed import make_comm, make_grad_reducer, make_sparse_grad_reducer
     # the gradient exchange runs on the product's own RCCL communicator (csrc/comm.hip); torch.distributed carries
     # the unique id, the barriers and the max-over-ranks of the timing
-    comm = make_comm(dist, rank, world, dev) if world > 1 else None
-    reducer = make_grad_reducer(comm, world) if args.dense_allreduce else make_sparse_grad_reducer(comm, world)
+    comm = make_comm(dist, rank, world, dev) if sharded else None
+    reducer = None
+    if sharded:
+        reducer = make_grad_reducer(comm, world) if args.dense_allreduce else make_sparse_grad_reducer(comm, world)
 
     def barrier():
         if world > 1:
@@ -353,18 +442,22 @@ def main():
     if main_stream is not None:
         torch.cuda.set_stream(main_stream)
     timer = None if args.no_conv_timer else ops.KernelTimer()
-    if world > 1:   # event-timed exchange and update of every step (two event pairs per step)
+    if sharded:   # event-timed exchange and update of every step (two event pairs per step)
         eng.phase_timer = ops.KernelTimer()
         eng.phase_timer.enabled = False
-    dt = timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer)
+    dt_own = timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer)
     active_levels = [lv.index for lv in eng.view if lv.active]
     losses = eng.losses()
     touched_fraction = None if eng.touched is None else float(eng.touched.float().mean())
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dt, per_rank_dt, ranks_consistent = dt_own, [dt_own], None
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+        per_rank_dt = [v[0] for v in gather_values(dist, backend, dev, [dt_own])]
+        dt = max(per_rank_dt)                         # the job's time = the slowest rank's
+        if sharded:
+            # every rank applied the same update to the same all-reduced gradient: the textures must be IDENTICAL, bit for bit
+            sums = [v[0] for v in gather_values(dist, backend, dev, [arena_checksum(eng)], torch.int64)]
+            ranks_consistent = len(set(sums)) == 1
 
     roofline = None
     if timer is not None:
@@ -377,14 +470,14 @@ def main():
         products = {"split": 6, "split2": 3}.get(tag)
         peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None   # HBM bytes per conv launch from the committed PMC pass of this workload
-        for rnd in ("r03", "r02", "r01"):   # (offline: PMC runs cannot be live inside bench.py)
+        for rnd in ("r04", "r03", "r02", "r01"):   # (offline: PMC runs cannot be live inside bench.py)
             tf = os.path.join(REPO, "profiles", rnd, f"conv_traffic_{args.workload}_{tag}.json")
             if os.path.exists(tf):
                 traffic, traffic_src = round(json.load(open(tf))["hbm_bytes_per_launch"]), f"profiles/{rnd}/{os.path.basename(tf)}"
                 break
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_unit": f"HBM bytes per launch (PMC pass, {traffic_src})",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_live": False,
+                    "traffic_unit": f"HBM bytes per launch (committed PMC pass, {traffic_src}; not measured in this run)",
                     "algorithmic_bytes_per_launch": round(timer.bytes.get(tag, 0.0) / max(n, 1)),
                     "kernel": {"split": "conv3x3_split_kernel<NP=3> (bf16 x 3)", "split2": "conv3x3_split_kernel<NP=2> (fp16 x 2)"}
                     .get(tag, "conv3x3_mfma_kernel"),
@@ -404,6 +497,17 @@ def main():
 
     if rank == 0:
         value = world * args.steps / dt
+        lw = wl.get("loss_weights", LOSS_WEIGHTS)
+        if args.replicas and world > 1:
+            parallelism = f"{world} independent scenes, one per GPU, no communicator (BASELINE config 4)"
+        elif world > 1:
+            parallelism = f"views sharded over {world} rank(s)" + (
+                ", RCCL all-reduce of the 267 MB texture gradient per step" if args.dense_allreduce else
+                f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
+                f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)"
+                + (f", in {reducer.n_pieces} pieces overlapped with the update" if eng.pipeline_exchange else ""))
+        else:
+            parallelism = "views sharded over 1 rank(s)"
         out = {"metric": "views/sec (fwd+bwd into 4096^2 texture)" if wl["tex"] == 4096 else
                f"views/sec (fwd+bwd into {wl['tex']}^2 texture)", "value": round(value, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -414,32 +518,35 @@ def main():
                               "matrix cores with every fp32 operand split into 3 bf16 parts (6 partial products, fp32 accumulate)",
                               "split2": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the fp16 "
                               "matrix cores with every fp32 operand (scaled by a power of two from its tensor's recorded "
-                              "max) split into 2 fp16 parts = 22 significand bits (3 partial products, fp32 accumulate)"}
+                              "max) split into 2 fp16 parts = 22 significand bits (3 partial products, fp32 accumulate) - an "
+                              "emulation of the fp32 multiply, NOT native fp32: the strict-fp32 number of this run is f32_mode"}
                .get(ops.CONV_MODE, "fp32 throughout (v_mfma_f32_32x32x2_f32 convolutions)")
                + ("; error vs an fp64 convolution <= the fp32-MFMA kernel's (tests/test_kernels_gpu.py, tools/bench_conv_split.py); "
                   "STYLEMESH_CONV_MODE=f32 selects the fp32-MFMA kernel (the f32_mode leg)" if ops.CONV_MODE != "f32" else ""),
                "data": "synthetic",
-               "config": {"workload": f"{args.workload}: {wl['desc']}", "texture": f"{wl['tex']}x{wl['tex']} x 4 layers",
+               "config": {"workload": f"{args.workload}: {wl['desc']}",
+                          "texture": f"{wl['tex']}x{wl['tex']} x {wl.get('n_layers', 4)} layer(s)",
                           "active_uv_levels": active_levels, "views_per_step": world,
                           "index_repeat": wl["index_repeat"], "style_image": f"synthetic {STYLE_HW[1]}x{STYLE_HW[0]}",
-                          "vgg_weights": "He-normal, seeded", "parallelism": f"views sharded over {world} rank(s)"
-                          + ((", RCCL all-reduce of the 267 MB texture gradient per step" if args.dense_allreduce else
-                              f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
-                              f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)"
-                              + (f", in {reducer.n_pieces} pieces overlapped with the update" if args.pipeline_exchange else ""))
-                             if world > 1 else "")},
+                          "loss_weights": lw, "gram_mode": wl.get("gram_mode", "current"),
+                          "vgg_weights": "He-normal, seeded", "parallelism": parallelism},
                # BASELINE.json's second metric: the reference has no convergence criterion, a scene is trained for a
                # fixed schedule (SURVEY.md section 8 d): 7 epochs x index_repeat x 0.99 V views, V = 276 for ScanNet
                # scene0000_00 at every 20th frame. Projected from the measured rate (view changes are inside it).
                "scene_schedule": {"views": 273, "epochs": 7, "index_repeat": wl["index_repeat"],
                                   "steps": 7 * wl["index_repeat"] * 273,
-                                  "projected_wall_clock_s": round(7 * wl["index_repeat"] * 273 / value, 1),
-                                  "note": "fixed schedule of one scene / measured views per second"},
+                                  "projected_wall_clock_s": round(7 * wl["index_repeat"] * 273 / (value / world), 1),
+                                  "note": "fixed schedule of one scene / measured views per second per scene"},
                "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()},
                "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
                                 "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
                                         "zero-initialised texture); the fraction grows with the views of the scene"},
-               "exchange": None if world == 1 else exchange_report(eng, comm, reducer, args)}
+               "exchange": exchange_report(eng, comm, reducer, args) if sharded else None}
+        if world > 1:
+            out["per_rank_views_per_s"] = [round(args.steps / t, 3) for t in per_rank_dt]
+            out["ranks_consistent"] = ranks_consistent
+            out["launched_by"] = os.environ.get("STYLEMESH_LAUNCHED_BY", "external launcher (torch.distributed.run)")
+            out["process_group_backend"] = backend
         sched = measured_schedule(args.workload)
         if sched is not None:
             out["scene_schedule"].update(sched)
@@ -453,9 +560,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
-        if hasattr(comm, "destroy"):
+        if comm is not None and hasattr(comm, "destroy"):
             comm.destroy()
         dist.destroy_process_group()
 

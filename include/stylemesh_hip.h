@@ -483,9 +483,13 @@ int sm_need_step(const float* need_out, int ho, int wo, int mode, const float* M
 int sm_tile_flags(const float* need, int h, int w, int bn, uint8_t* flags, void* stream);
 
 /* Active SEGMENT lists of the split conv kernels (sm_conv3x3_grouped_split / _split2: tile_list): for up to 64 need maps
- * in one launch, cover the needed positions of each plane with disjoint 32-position segments that start at any multiple
+ * in one call, cover the needed positions of each plane with disjoint 32-position segments that start at any multiple
  * of 4 (greedy over the flattened padded plane). starts receives (tag << 24) | q, q = first position of a segment as an
- * index into the padded plane (ascending; at most cap entries), *count their number (device). Once per view. */
+ * index into the padded plane (ascending; at most cap entries), *count their number (device). Once per view.
+ * ABI 8: the cover is computed in parallel (bit images -> per-chunk tables of the greedy's 8 possible entry states ->
+ * one scan per map -> emission: four launches, no limit on the plane size beyond the 24-bit position of a list entry;
+ * the lists are those of the sequential greedy, bit for bit) and needs ws: sm_cover_segments_ws_bytes(problems, n)
+ * bytes of 16-byte-aligned device scratch. */
 typedef struct {
     const float* need;   /* [h][w] 0 / 1 */
     int32_t* starts;
@@ -497,7 +501,8 @@ typedef struct {
      * image row 2Y that starts at column 2 X0, then the one right below it (row 2Y + 1). */
     int pair_w;
 } sm_cover_problem;
-int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream);
+size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n);
+int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 
@@ -538,6 +543,13 @@ int sm_comm_init(void** comm_out, int n_ranks, const void* unique_id, int rank);
 int sm_comm_destroy(void* comm);
 int sm_allreduce_grad(void* comm, float* g, size_t n, void* stream);
 int sm_allreduce_flags_max(void* comm, int32_t* flags, size_t n, void* stream);
+/* (ABI 8) What the communicator actually is, for the record a multi-GPU run leaves behind: info_out[0..3] (HOST ints) =
+ * ranks in the communicator (ncclCommCount), this rank (ncclCommUserRank), its HIP device (ncclCommCuDevice), the RCCL
+ * version (ncclGetVersion). */
+int sm_comm_info(void* comm, int* info_out);
+/* (ABI 8) The link between two HIP devices of this node as the runtime reports it (hipExtGetLinkTypeAndHopCount):
+ * *link_type = HSA_AMD_LINK_INFO_TYPE_* (1 = PCIe, 4 = xGMI), *hops = hop count. Returns a hipError_t. */
+int sm_device_link(int device_a, int device_b, int* link_type, int* hops);
 
 /* ---- E1: multi-view consistency metric --------------------------------------- */
 

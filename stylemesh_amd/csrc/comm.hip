@@ -60,4 +60,22 @@ int sm_allreduce_flags_max(void* comm, int32_t* flags, size_t n, void* stream) {
     return (int)ncclAllReduce(flags, flags, n, ncclInt32, ncclMax, (ncclComm_t)comm, (hipStream_t)stream);
 }
 
+int sm_comm_info(void* comm, int* info_out) {
+    if (comm == nullptr || info_out == nullptr) return (int)ncclInvalidArgument;
+    ncclResult_t r = ncclCommCount((ncclComm_t)comm, &info_out[0]);
+    if (r == ncclSuccess) r = ncclCommUserRank((ncclComm_t)comm, &info_out[1]);
+    if (r == ncclSuccess) r = ncclCommCuDevice((ncclComm_t)comm, &info_out[2]);
+    if (r == ncclSuccess) r = ncclGetVersion(&info_out[3]);
+    return (int)r;
+}
+
+int sm_device_link(int device_a, int device_b, int* link_type, int* hops) {
+    if (link_type == nullptr || hops == nullptr) return (int)hipErrorInvalidValue;
+    uint32_t t = 0, h = 0;
+    const hipError_t e = hipExtGetLinkTypeAndHopCount(device_a, device_b, &t, &h);
+    *link_type = (int)t;
+    *hops = (int)h;
+    return (int)e;
+}
+
 }  // extern "C"

@@ -800,7 +800,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 7; }
+int sm_abi_version(void) { return 8; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {

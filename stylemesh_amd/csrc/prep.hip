@@ -242,139 +242,227 @@ __global__ __launch_bounds__(256) void tile_flags_kernel(const float* __restrict
 // padded plane - the next segment starts at the first needed position not yet covered, rounded down to a multiple of 4
 // (a data-gradient epilogue that adds into its output must never see a position twice, so segments are disjoint).
 // Against segments on the aligned grid this drops another 3.6 % of the listed positions (5 bench views, FLOP-weighted:
-// 0.659 -> 0.635 of dense; the exact need is 0.589). One block per need map: all threads pack the map into one bit per
-// position in LDS (<= 103 KB for a 784 x 1045 plane), then ONE lane walks the bits - a chain of <= positions / 32 steps of
-// LDS latency each, all maps of all levels in one launch, once per view (in prepare_view: beside the previous view's steps).
+// 0.659 -> 0.635 of dense; the exact need is 0.589).
+//
+// Round 4: the SAME greedy cover, computed in parallel. Round 3 packed a whole need map into LDS and walked it on ONE
+// lane of one block per map: a chain of positions / 32 dependent LDS reads - 2.0 ms on average, 4.2 ms for a view's
+// largest maps, on every view change, and a hard 160 KB limit on the plane size. The greedy has a tiny state: at a CHUNK
+// boundary (2048 positions) all that matters is how far the last segment of the chunks before sticks out into this one,
+// e = 0, 4, ..., 28 positions. So: (1) pack the need maps to bits in global memory (wave ballots, coalesced reads);
+// (2) every chunk is walked for each of its 8 possible entry states, in parallel: (exit state, segment count) per entry;
+// (3) one thread per map composes the chunk tables left to right - 400 table look-ups for the largest map instead of
+// 25 000 dependent LDS reads - and leaves every chunk its true entry state and output offset; (4) every chunk is walked
+// once more from its true entry state and writes its segments. Four short launches for all ~56 maps of a view, no limit
+// on the plane size, the lists bit-identical to the one-lane walk (tests/test_round4_gpu.py restates it on the host).
+// PAIR mode (a conv with the pooling epilogue) is the same pipeline with chunk = one row of the pooled need map: rows are
+// independent there (entry state always 0), the scan is a plain prefix sum of the rows' counts.
 // ---------------------------------------------------------------------------------------------------
 #define SM_COVER_MAX 64
+#define SM_COVER_CHUNK_WORDS 64                       // 2048 positions per chunk
 struct CoverProblem {
     const float* need;     // [h][w] 0 / 1
     int32_t* starts;       // out: (tag << 24) | first position q of each segment (index into the padded plane)
     int32_t* count;        // out: number of segments
     int h, w, tag, cap;
     int pair_w;
-};
+    int word_base;         // first word of this map's bits in the workspace
+    int chunk_base;        // first chunk of this map in the workspace's table / state arrays
+};                         // (56 bytes: 64 of them + three pointers stay below the 4 KB of kernel arguments)
 struct CoverGroup {
     CoverProblem p[SM_COVER_MAX];
+    uint32_t* bits;
+    uint4* table;          // per chunk: 8 x uint16 = (segments << 3) | exit state / 4, one per entry state
+    uint32_t* state;       // per chunk: (offset of its first segment << 3) | entry state / 4
 };
 
-// PAIR mode (P.pair_w > 0): `need` is the need map of a POOLED plane; row Y of it is covered with runs of 16 windows
-// (one thread per row: count, exclusive scan over the rows, write), each run emitted as the two 32-position segments of
-// the full-resolution plane that hold its windows - rows 2Y and 2Y + 1, columns 2 X0 .. 2 X0 + 31.
-__device__ void cover_pairs(const CoverProblem& P, uint32_t* bits) {
-    const int rw = (P.w + 31) / 32 + 1;                 // words per pooled row (+ a zero word behind it)
-    int* row_off = reinterpret_cast<int*>(bits + P.h * rw);
-    for (int i = threadIdx.x; i < P.h * rw; i += 256) {
-        const int Y = i / rw, wd = i - Y * rw;
-        uint32_t v = 0;
-        for (int b = 0; b < 32; ++b) {
-            const int X = wd * 32 + b;
-            if (X < P.w && P.need[(size_t)Y * P.w + X] > 0.f) v |= 1u << b;
+__host__ __device__ inline int cover_row_words(int w) { return (w + 31) / 32 + 1; }   // pair mode: + a zero word behind a row
+// words of a map's bit image (flat: the positions of rows 1 .. h of the padded plane + two zero tail words; pair: h rows
+// of cover_row_words + one word the walk may read behind the last row) and its chunks (pair: one per pooled row)
+__host__ __device__ inline int cover_words(int h, int w, int pair_w) {
+    return pair_w > 0 ? h * cover_row_words(w) + 1 : (h * row_stride(w) + 31) / 32 + 2;
+}
+__host__ __device__ inline int cover_chunks(int h, int w, int pair_w) {
+    return pair_w > 0 ? h : (h * row_stride(w) + SM_COVER_CHUNK_WORDS * 32 - 1) / (SM_COVER_CHUNK_WORDS * 32);
+}
+
+// (1) bits. One wave = 64 consecutive positions per ballot = two words; a block of 4 waves makes 64 words.
+__global__ __launch_bounds__(256) void cover_pack_kernel(CoverGroup g) {
+    const CoverProblem& P = g.p[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first_word = blockIdx.x * 64 + wave * 16;
+    const int n_words = cover_words(P.h, P.w, P.pair_w);
+    if (first_word >= n_words) return;
+    const int Wp = row_stride(P.w), n_pos = P.h * Wp, rw = cover_row_words(P.w);
+    for (int k = 0; k < 8; ++k) {
+        const int wd = first_word + 2 * k;
+        if (wd >= n_words) break;
+        bool bit = false;
+        if (P.pair_w > 0) {             // word wd = row wd / rw, columns (wd % rw) * 32 ...; a row is a whole number of words
+            const int wl = wd + (lane >> 5);
+            const int Y = wl / rw, X = (wl - Y * rw) * 32 + (lane & 31);
+            bit = Y < P.h && X < P.w && P.need[(size_t)Y * P.w + X] > 0.f;
+        } else {
+            const int i = wd * 32 + lane;
+            if (i < n_pos) {
+                const int r = i / Wp, x = i - r * Wp;
+                bit = x >= 1 && x <= P.w && P.need[(size_t)r * P.w + x - 1] > 0.f;
+            }
         }
-        bits[i] = v;
-    }
-    __syncthreads();
-    for (int Y = threadIdx.x; Y < P.h; Y += 256) {      // segments of row Y
-        int n = 0, cursor = 0;
-        while (cursor < P.w) {
-            const int wd = cursor >> 5, sh = cursor & 31;
-            const uint64_t win = ((uint64_t)bits[Y * rw + wd] | ((uint64_t)(wd + 1 < rw ? bits[Y * rw + wd + 1] : 0u) << 32)) >> sh;
-            if (win == 0) { cursor += 64 - sh; continue; }
-            cursor += __builtin_ctzll(win) + 16;
-            ++n;
+        const unsigned long long m = __ballot(bit);
+        if (lane == 0) {
+            g.bits[P.word_base + wd] = (uint32_t)m;
+            if (wd + 1 < n_words) g.bits[P.word_base + wd + 1] = (uint32_t)(m >> 32);
         }
-        row_off[Y] = n;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int Y = 0; Y < P.h; ++Y) { const int n = row_off[Y]; row_off[Y] = tot; tot += n; }
-        *P.count = 2 * tot;
+}
+
+// The walk of one chunk from entry state e (positions relative to the chunk's first position): calls emit(st) for every
+// segment whose first needed position lies in the chunk, returns the exit state. `words` holds the chunk's bits and at
+// least one readable word behind them. FLAT mode: segment start = first needed position rounded down to 4, next cursor =
+// start + 32. PAIR mode (n_bits = the row's width, align1): start = the first needed window itself, next cursor = + 16.
+template <bool PAIR, typename Emit>
+__device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, int n_bits, int e, Emit emit) {
+    int cursor = e, end = e;     // end: one past the last position covered so far (skipping zeros covers nothing)
+    while (cursor < n_bits) {
+        const int wd = cursor >> 5, sh = cursor & 31;
+        uint64_t win = ((uint64_t)words[wd] | ((uint64_t)words[wd + 1] << 32)) >> sh;   // >= 33 valid bits from cursor on
+        const int valid = n_bits - cursor;                                              // bits of THIS chunk in the window
+        if (valid < 64) win &= (1ull << valid) - 1ull;
+        if (win == 0) { cursor += 64 - sh; continue; }
+        const int p = cursor + __builtin_ctzll(win);
+        const int st = PAIR ? p : (p & ~3);
+        emit(st);
+        cursor = end = st + (PAIR ? 16 : 32);
     }
-    __syncthreads();
-    const int Wp = row_stride(P.pair_w);
-    for (int Y = threadIdx.x; Y < P.h; Y += 256) {
-        int n = row_off[Y], cursor = 0;
-        while (cursor < P.w) {
-            const int wd = cursor >> 5, sh = cursor & 31;
-            const uint64_t win = ((uint64_t)bits[Y * rw + wd] | ((uint64_t)(wd + 1 < rw ? bits[Y * rw + wd + 1] : 0u) << 32)) >> sh;
-            if (win == 0) { cursor += 64 - sh; continue; }
-            const int X0 = cursor + __builtin_ctzll(win);
-            const int q = (2 * Y + 1) * Wp + 2 * X0 + 1;
+    return end > n_bits ? end - n_bits : 0;
+}
+
+// (2) chunk tables. thread = (chunk, entry state); pair mode uses entry state 0 only.
+__global__ __launch_bounds__(256) void cover_table_kernel(CoverGroup g) {
+    const CoverProblem& P = g.p[blockIdx.y];
+    const int chunk = blockIdx.x * 32 + (threadIdx.x >> 3), e8 = threadIdx.x & 7;
+    if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
+    int n = 0, ex = 0;
+    if (P.pair_w > 0) {
+        if (e8 == 0) {
+            const int rw = cover_row_words(P.w);
+            cover_walk<true>(g.bits + P.word_base + chunk * rw, P.w, 0, [&](int) { ++n; });
+        }
+    } else {
+        const int n_pos = P.h * row_stride(P.w);
+        const int bits_here = min(SM_COVER_CHUNK_WORDS * 32, n_pos - chunk * SM_COVER_CHUNK_WORDS * 32);
+        ex = cover_walk<false>(g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS, bits_here, e8 * 4, [&](int) { ++n; });
+    }
+    reinterpret_cast<uint16_t*>(g.table + P.chunk_base + chunk)[e8] = (uint16_t)((n << 3) | (ex >> 2));
+}
+
+// (3) compose the tables left to right: one thread per map, the table rows staged through LDS.
+__global__ __launch_bounds__(64) void cover_scan_kernel(CoverGroup g) {
+    const CoverProblem& P = g.p[blockIdx.x];
+    const uint4* __restrict__ tab = g.table + P.chunk_base;
+    uint32_t* __restrict__ state = g.state + P.chunk_base;
+    constexpr int BATCH = 512;                       // table rows staged in LDS per round (a dependent global load per
+    __shared__ uint4 rows[BATCH];                    // chunk would cost ~0.5 us each)
+    __shared__ uint32_t out[BATCH];
+    int e8 = 0, base = 0;                            // (meaningful on thread 0 only)
+    const int n_chunks = cover_chunks(P.h, P.w, P.pair_w);
+    for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
+        const int nb = min(BATCH, n_chunks - c0);
+        for (int i = threadIdx.x; i < nb; i += 64) rows[i] = tab[c0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < nb; ++i) {
+                const uint4 row = rows[i];
+                out[i] = ((uint32_t)base << 3) | (uint32_t)e8;
+                const uint32_t d = e8 < 4 ? (e8 < 2 ? row.x : row.y) : (e8 < 6 ? row.z : row.w);
+                const uint32_t t = (e8 & 1) ? (d >> 16) : (d & 0xffffu);
+                base += (int)(t >> 3);
+                e8 = (int)(t & 7u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 64) state[c0 + i] = out[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *P.count = P.pair_w > 0 ? 2 * base : base;
+}
+
+// (4) every chunk once more, from its true entry state, writing its segments.
+__global__ __launch_bounds__(256) void cover_emit_kernel(CoverGroup g) {
+    const CoverProblem& P = g.p[blockIdx.y];
+    const int chunk = blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
+    const uint32_t s = g.state[P.chunk_base + chunk];
+    int n = (int)(s >> 3);
+    if (P.pair_w > 0) {
+        const int rw = cover_row_words(P.w), Wp = row_stride(P.pair_w);
+        cover_walk<true>(g.bits + P.word_base + chunk * rw, P.w, 0, [&](int X0) {
+            const int q = (2 * chunk + 1) * Wp + 2 * X0 + 1;     // chunk = pooled row Y: image rows 2Y and 2Y + 1
             if (2 * n + 1 < P.cap) {
                 P.starts[2 * n] = (P.tag << 24) | q;
                 P.starts[2 * n + 1] = (P.tag << 24) | (q + Wp);
             }
             ++n;
-            cursor = X0 + 16;
-        }
+        });
+    } else {
+        const int Wp = row_stride(P.w), n_pos = P.h * Wp, first = chunk * SM_COVER_CHUNK_WORDS * 32;
+        const int bits_here = min(SM_COVER_CHUNK_WORDS * 32, n_pos - first);
+        cover_walk<false>(g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS, bits_here, (int)(s & 7u) * 4, [&](int st) {
+            if (n < P.cap) P.starts[n] = (P.tag << 24) | (Wp + first + st);
+            ++n;
+        });
     }
-}
-
-__global__ __launch_bounds__(256) void cover_segments_kernel(CoverGroup g) {
-    extern __shared__ uint32_t bits[];
-    const CoverProblem P = g.p[blockIdx.x];
-    if (P.pair_w > 0) { cover_pairs(P, bits); return; }
-    const int Wp = row_stride(P.w);
-    const int n_pos = P.h * Wp;                       // positions of rows 1 .. h, relative to q = Wp
-    const int n_words = (n_pos + 31) / 32 + 2;        // + a zero tail the 64-bit window may read
-    for (int wd = threadIdx.x; wd < n_words; wd += 256) {
-        uint32_t v = 0;
-        const int base = wd * 32;
-        if (base < n_pos) {
-            int r = base / Wp, x = base - r * Wp;
-#pragma unroll 4
-            for (int b = 0; b < 32; ++b) {
-                if (base + b < n_pos && x >= 1 && x <= P.w && P.need[(size_t)r * P.w + x - 1] > 0.f) v |= 1u << b;
-                if (++x == Wp) { x = 0; ++r; }
-            }
-        }
-        bits[wd] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    int n = 0, cursor = 0;                            // cursor: a multiple of 4; everything before it is covered or dead
-    while (cursor < n_pos) {
-        const int wd = cursor >> 5, sh = cursor & 31;
-        const uint64_t lo = bits[wd], mid = bits[wd + 1], hi = bits[wd + 2];
-        const uint64_t win = sh ? (((lo | (mid << 32)) >> sh) | (hi << (64 - sh))) : (lo | (mid << 32));
-        if (win == 0) { cursor += 64; continue; }
-        const int p = cursor + __builtin_ctzll(win);
-        const int st = p & ~3;                        // >= cursor
-        if (n < P.cap) P.starts[n] = (P.tag << 24) | (Wp + st);
-        ++n;
-        cursor = st + 32;
-    }
-    *P.count = n;
 }
 
 }  // namespace sm
 
 extern "C" {
 
-int sm_cover_segments(const sm_cover_problem* problems, int n, void* stream) {
-    if (n < 1 || n > SM_COVER_MAX) return (int)hipErrorInvalidValue;
-    sm::CoverGroup g;
-    size_t lds = 0;
+static void cover_extent(const sm_cover_problem& p, int* n_words, int* n_chunks) {
+    *n_words = sm::cover_words(p.h, p.w, p.pair_w);
+    *n_chunks = sm::cover_chunks(p.h, p.w, p.pair_w);
+}
+
+size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n) {
+    size_t words = 0, chunks = 0;
     for (int i = 0; i < n; ++i) {
-        if (problems[i].h < 1 || problems[i].w < 1 || problems[i].tag < 0 || problems[i].tag > 127) return (int)hipErrorInvalidValue;
-        if (problems[i].pair_w != 0 && problems[i].pair_w / 2 != problems[i].w) return (int)hipErrorInvalidValue;
-        g.p[i] = sm::CoverProblem{problems[i].need, problems[i].starts, problems[i].count, problems[i].h, problems[i].w,
-                                  problems[i].tag, problems[i].cap, problems[i].pair_w};
-        const size_t words = problems[i].pair_w > 0
-            ? (size_t)problems[i].h * ((problems[i].w + 31) / 32 + 1) + problems[i].h     // bit rows + row offsets
-            : ((size_t)problems[i].h * sm::row_stride(problems[i].w) + 31) / 32 + 2;
-        lds = words * 4 > lds ? words * 4 : lds;
+        int w, c;
+        cover_extent(problems[i], &w, &c);
+        words += (size_t)((w + 3) & ~3);
+        chunks += (size_t)c;
     }
-    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {   // > 64 KB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sm::cover_segments_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_set = lds;
+    return words * 4 + chunks * 16 + chunks * 4 + 64;
+}
+
+int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 1 || n > SM_COVER_MAX || ws == nullptr || ((uintptr_t)ws & 15)) return (int)hipErrorInvalidValue;
+    if (ws_bytes < sm_cover_segments_ws_bytes(problems, n)) return (int)hipErrorInvalidValue;
+    sm::CoverGroup g;
+    int words = 0, chunks = 0, max_words = 0, max_chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        const sm_cover_problem& p = problems[i];
+        if (p.h < 1 || p.w < 1 || p.tag < 0 || p.tag > 127) return (int)hipErrorInvalidValue;
+        if (p.pair_w != 0 && p.pair_w / 2 != p.w) return (int)hipErrorInvalidValue;
+        const long plane_rows = (p.pair_w > 0 ? 2l * p.h : (long)p.h) + 2;
+        if (plane_rows * sm::row_stride(p.pair_w > 0 ? p.pair_w : p.w) >= 0xFFFFFFl)
+            return (int)hipErrorInvalidValue;                      // a list entry holds the position in 24 bits
+        int nw, nc;
+        cover_extent(p, &nw, &nc);
+        if (p.pair_w > 0 && (p.w + 15) / 16 + 1 > 8191) return (int)hipErrorInvalidValue;   // 13-bit counts per chunk
+        g.p[i] = sm::CoverProblem{p.need, p.starts, p.count, p.h, p.w, p.tag, p.cap, p.pair_w, words, chunks};
+        words += (nw + 3) & ~3;
+        chunks += nc;
+        max_words = nw > max_words ? nw : max_words;
+        max_chunks = nc > max_chunks ? nc : max_chunks;
     }
-    hipLaunchKernelGGL(sm::cover_segments_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, g);
+    g.bits = static_cast<uint32_t*>(ws);
+    g.table = reinterpret_cast<uint4*>(g.bits + words);            // (words is a multiple of 4: 16-byte aligned)
+    g.state = reinterpret_cast<uint32_t*>(g.table + chunks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sm::cover_pack_kernel, dim3((max_words + 63) / 64, n), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(sm::cover_table_kernel, dim3((max_chunks + 31) / 32, n), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(sm::cover_scan_kernel, dim3(n), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(sm::cover_emit_kernel, dim3((max_chunks + 255) / 256, n), dim3(256), 0, st, g);
     SM_LAUNCH_CHECK();
     return 0;
 }

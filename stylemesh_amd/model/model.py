@@ -62,7 +62,13 @@ class FusedTextureAdam:
         eng = self.module._engine
         eng.cfg.learning_rate = self.param_groups[0]["lr"]
         eng.cfg.decay_gamma, eng.epoch = 1.0, 0    # the scheduler owns the learning rate
-        eng.optimizer_step(self.world_size)
+        reducer = getattr(self.module, "grad_reducer", None)
+        if reducer is not None and eng.pipeline_exchange and hasattr(reducer, "pipelined") and not eng._can_graph():
+            # STYLEMESH_PIPELINE_EXCHANGE=1: ``step_compute`` left the gradient un-exchanged - all-reduce it in pieces,
+            # the update of each arena range issued as its sums arrive (``StepEngine.exchange_and_update``)
+            eng.exchange_and_update(self.world_size, reducer)
+        else:
+            eng.optimizer_step(self.world_size)
 
     def _eng(self):
         return self.module._ensure_engine(self.param_groups[0]["params"][0].device)
@@ -273,7 +279,9 @@ class TextureOptimizationStyleTransferPipeline(_Base):
         """Loader hook (``MiniTrainer``): the NEXT view's device batch is resident - let the engine compute its per-view
         constants on a side stream during the current view's steps (``StepEngine.prepare_view``)."""
         if self._engine is not None and self.grad_reducer is None:
-            self._engine.prepare_view(batch, ready_event)
+            # (deferred to the engine's next ``begin_step``: with index_repeat 1 the loader knows the next view before the
+            # engine has made the current one current)
+            self._engine.request_prepare(batch, ready_event)
 
     # ------------------------------------------------------------------ Lightning hooks
     def training_step(self, batch, batch_idx, optimizer_idx=0):

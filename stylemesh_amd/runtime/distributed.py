@@ -99,7 +99,26 @@ def _pin_tree(x):
     return x
 
 
-LOADER_STATS = []   # the ViewPrefetchers of this process (one per epoch): their decode / wait times are diagnostics
+class _LoaderStat:
+    """decode / wait seconds of one epoch's ``ViewPrefetcher`` - scalars only: holding the prefetcher itself would keep
+    its ring of pinned staging buffers (6 x 14 MB for a 4-level view) alive for every epoch of the run."""
+
+    def __init__(self, source):
+        self._source = source
+        self.decode_s = self.wait_s = 0.0
+
+    def settle(self):
+        if self._source is not None:
+            self.decode_s, self.wait_s, self._source = self._source.decode_s, self._source.wait_s, None
+
+
+class _LoaderStats(list):
+    def settle(self):
+        for st in self:
+            st.settle()
+
+
+LOADER_STATS = _LoaderStats()   # per epoch: decode / wait seconds of its ViewPrefetcher (diagnostics)
 
 
 def _pack_view(items):
@@ -199,6 +218,7 @@ class DecodeProcess:
                 else:
                     os.environ[k] = v
         self.proc = self.procs[0]
+        self.ring = None      # pinned staging ring of the consumer side (``ViewPrefetcher``), kept across epochs
         self.busy = False
         self._next, self._open = 0, 0
 
@@ -263,7 +283,13 @@ class ViewPrefetcher:
         self._cv = threading.Condition()
         self._depth, self._stop, self._finished = max(1, depth), False, False
         # a view's pinned copy must outlive: the ready queue (depth), the view being trained on, the one uploaded ahead
-        self._ring = _PinnedRing(self._depth + 4) if pin else None
+        self._ring = None
+        if pin and worker is not None:    # ONE ring for the life of the decode process(es): epochs re-use it
+            if getattr(worker, "ring", None) is None or worker.ring.slots != self._depth + 4:
+                worker.ring = _PinnedRing(self._depth + 4)
+            self._ring = worker.ring
+        elif pin:
+            self._ring = _PinnedRing(self._depth + 4)
         self.decode_s = 0.0     # time spent decoding / receiving (and pinning) views on the consumer's side
         self.wait_s = 0.0       # time the consumer spent blocked on a view that was not ready
         self._thread = None
@@ -392,17 +418,22 @@ def scheduled_batches(get_view, indices, rank: int, world_size: int, index_repea
     if prefetch > 0:
         source = ViewPrefetcher(get_view, order, depth=prefetch, worker=worker)
         views, upcoming = iter(source), source.peek
-        LOADER_STATS.append(source)
+        stat = _LoaderStat(source)
+        LOADER_STATS.append(stat)
     else:
-        views, upcoming = ((i, get_view(i)) for i in order), None
-    for i, items in views:
-        first = ViewBatch(items, new_view=True)
-        first.upcoming = upcoming
-        yield first
-        rest = ViewBatch(items, new_view=False)
-        rest.upcoming = upcoming
-        for _ in range(count(i) - 1):
-            yield rest
+        views, upcoming, stat = ((i, get_view(i)) for i in order), None, None
+    try:
+        for i, items in views:
+            first = ViewBatch(items, new_view=True)
+            first.upcoming = upcoming
+            yield first
+            rest = ViewBatch(items, new_view=False)
+            rest.upcoming = upcoming
+            for _ in range(count(i) - 1):
+                yield rest
+    finally:
+        if stat is not None:
+            stat.settle()      # keep the two numbers, let go of the prefetcher and its pinned ring
 
 
 class _ReduceOp:
@@ -500,6 +531,25 @@ class RcclComm:
             done.record()
         tensor.record_stream(self._side)
         return _Work(done)
+
+    def info(self):
+        """What RCCL says the communicator is (``sm_comm_info``) and how the runtime links this rank's device to the others
+        (``sm_device_link``: 4 = xGMI, 1 = PCIe) - the record a multi-GPU run leaves behind."""
+        import ctypes
+        hip = self._hip
+        raw = (ctypes.c_int * 4)()
+        hip.check(hip.lib.sm_comm_info(self.handle, raw), "sm_comm_info")
+        out = {"nranks": raw[0], "rank": raw[1], "device": raw[2], "rccl_version": raw[3]}
+        links = []
+        n_dev = self._torch.cuda.device_count()
+        for other in range(min(self.world_size, n_dev)):
+            if other == raw[2]:
+                continue
+            t, h = ctypes.c_int(), ctypes.c_int()
+            if hip.lib.sm_device_link(raw[2], other, ctypes.byref(t), ctypes.byref(h)) == 0:
+                links.append({"to_device": other, "type": {4: "xgmi", 1: "pcie"}.get(t.value, str(t.value)), "hops": h.value})
+        out["links"] = links
+        return out
 
     def destroy(self):
         if self.handle:

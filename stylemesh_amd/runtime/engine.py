@@ -160,6 +160,7 @@ class StepEngine:
         self._slot = 0             # slot of the CURRENT view's constants
         self._wslot = 0            # slot set_view is writing (differs from _slot while the next view is being prepared)
         self._prepared = None      # (view key, slot, per-view attributes, done event) of a view prepared ahead
+        self._prepare_request = None   # (batch, ready event): prepare_view to run after the next begin_step
         self._plans = [None, None]       # scatter plan per slot
         self._slot_released = [None, None]   # event: the steps that read this slot's constants have been enqueued
         self._prep_stream = None
@@ -203,7 +204,7 @@ class StepEngine:
         self._lv_streams = []
         # N > 1, opt-in: all-reduce the gradient in pieces and update each arena range as soon as its sums arrive
         # (functionally verified over gloo; not yet timed under RCCL, so the plain exchange-then-update is the default)
-        self.pipeline_exchange = False
+        self.pipeline_exchange = os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0") == "1"
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
@@ -432,6 +433,13 @@ class StepEngine:
             for a, v in current.items():
                 setattr(self, a, v)
         return True
+
+    def drop_prepared(self):
+        """Forget a view prepared ahead (or asked for) that will not be the next one - an epoch cut short, a schedule that
+        changed: its launches are ordered before whatever the current stream does next, its slot is free again."""
+        prep, self._prepared, self._prepare_request = self._prepared, None, None
+        if prep is not None:
+            torch.cuda.current_stream().wait_event(prep[3])
 
     def set_view(self, batch, reducer=None):
         """Make ``batch`` the current view: swap in the constants ``prepare_view`` computed ahead if they are this
@@ -1209,13 +1217,30 @@ class StepEngine:
     def end_epoch(self):
         self.epoch += 1
 
+    def request_prepare(self, batch, ready_event=None):
+        """Ask for ``prepare_view(batch, ready_event)`` to run right after the NEXT ``begin_step`` has made its own batch
+        current. ``prepare_view`` writes the buffer slot the current view does not use, so it may only run once the view
+        before it has been swapped in: a caller that learns about view i + 1 BEFORE it steps view i (index_repeat 1: every
+        step is the first of its view - ``RepeatingSampler`` of data/abstract_dataset.py:498-512 with the dip scripts'
+        ``--index_repeat 1``) leaves the request here instead of calling ``prepare_view`` too early."""
+        self._prepare_request = (batch, ready_event)
+
     def step_compute(self, batch, reducer=None, new_view=None, exchange=True):
         """Everything of a training step BEFORE the optimizer: per-view work, the step head (regulariser loss of the
         current texture, zero fills), the early half of the split update beside the forward pass, forward + backward
         into the gradient arena and - ``exchange`` - the multi-GPU gradient exchange. Returns this step's losses as
         device tensors that stay valid. ``optimizer_step`` closes the step (a Lightning-style caller does that from its
         optimizer facade: ``model.FusedTextureAdam.step``)."""
+        if self._adam_early_done is not None:
+            # the previous step's early half of the split update was never closed by ``optimizer_step`` (a foreign
+            # optimizer, a skipped step): the texels outside the view carry an update the view's own texels lack
+            raise RuntimeError("step_compute() was called again before optimizer_step() closed the previous step: the "
+                               "split update needs exactly one optimizer_step per step (STYLEMESH_SPLIT_UPDATE=0 "
+                               "disables the split)")
         self.begin_step(batch, reducer, new_view)
+        req, self._prepare_request = self._prepare_request, None
+        if req is not None and reducer is None:
+            self.prepare_view(*req)
         losses = self._step_begin()    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         pipelined = reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph()
         if not pipelined:
@@ -1234,9 +1259,13 @@ class StepEngine:
             self._timed("exchange", lambda: reducer(self.arena.g))
         return losses
 
-    def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None):
+    def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None, next_batch=None):
         """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.
-        ``new_view``: see ``begin_step``. Returns this step's losses as device tensors that stay valid."""
+        ``new_view``: see ``begin_step``. ``next_batch``: the view of the NEXT step when it differs from this one - its
+        per-view constants are prepared beside this step (``request_prepare``). Returns this step's losses as device
+        tensors that stay valid."""
+        if next_batch is not None:
+            self.request_prepare(next_batch)
         losses = self.step_compute(batch, reducer, new_view)
         if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
             self._timed("exchange+update", lambda: self.exchange_and_update(world_size, reducer))

@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
 
+ABI_VERSION = 8          # sm_abi_version() of the library this binding was written against
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
 EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL, EPI_GRAM = 1, 2, 4, 8, 16
@@ -78,7 +79,8 @@ SIGNATURES = {
     "sm_level_factors": [_vp, _vp, _i, _vp, _vp],
     "sm_need_step": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "sm_tile_flags": [_vp, _i, _i, _i, _vp, _vp],
-    "sm_cover_segments": [_vp, _i, _vp],
+    "sm_cover_segments_ws_bytes": [_vp, _i],
+    "sm_cover_segments": [_vp, _i, _vp, _sz, _vp],
     "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
@@ -101,6 +103,8 @@ SIGNATURES = {
     "sm_comm_destroy": [_vp],
     "sm_allreduce_grad": [_vp, _vp, _sz, _vp],
     "sm_allreduce_flags_max": [_vp, _vp, _sz, _vp],
+    "sm_comm_info": [_vp, _vp],
+    "sm_device_link": [_i, _i, _vp, _vp],
 }
 
 
@@ -161,6 +165,9 @@ def _load():
 
 
 lib = _load()
+if lib.sm_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.sm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                      "(stylemesh_amd/csrc/build.sh)")
 
 
 def check(code: int, what: str = ""):

@@ -670,8 +670,22 @@ def cover_segments(problems):
         need, starts, count, tag = prob[:4]
         pair_w = prob[4] if len(prob) > 4 else 0   # > 0: PAIR mode (``need`` = need map of the pooled plane, see the header)
         h, w = need.shape
+        rows, width = (2 * h + 2, pair_w) if pair_w else (h + 2, w)
+        if rows * hip.row_stride(width) >= 0xFFFFFF:
+            raise ValueError(f"segment list of a {rows - 2} x {width} plane: a list entry holds the position in 24 bits "
+                             f"(planes up to ~16.7 M padded positions); STYLEMESH_SEGMENT_LISTS=0 lists whole tiles instead")
         arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel(), int(pair_w))
-    hip.check(lib.sm_cover_segments(arr, len(problems), hip.stream()), "sm_cover_segments")
+    nbytes = lib.sm_cover_segments_ws_bytes(arr, len(problems))
+    dev = problems[0][0].device
+    ws = _COVER_WS.get(dev)
+    if ws is None or ws.numel() < nbytes:    # grow-only scratch (bit images + chunk tables), one per device
+        if ws is not None:
+            torch.cuda.synchronize(dev)      # (launches of another stream may still be using the old one; rare)
+        ws = _COVER_WS[dev] = torch.empty(max(2 * nbytes, 8 << 20), dtype=torch.uint8, device=dev)
+    hip.check(lib.sm_cover_segments(arr, len(problems), ptr(ws), ws.numel(), hip.stream()), "sm_cover_segments")
+
+
+_COVER_WS = {}
 
 
 def tile_flags(need, bn, flags):

@@ -105,10 +105,10 @@ class MiniTrainer:
             items = self._upload(batch)
             self._last_dev = (batch[0], items)
         upcoming = getattr(batch, "upcoming", None)
-        # (from a view's SECOND step on: at its first step the engine's current view is still the previous one, and the
-        # per-view constants prepared here must be those of the view AFTER the engine's current one)
+        # (also at a view's FIRST step - with index_repeat 1 there is no other: the module's hook leaves a request that the
+        # engine serves once this batch's own view has become current, ``StepEngine.request_prepare``)
         if (upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None
-                and not getattr(batch, "new_view", False) and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
+                and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
             nxt = upcoming()
             if nxt is not None and nxt[0] is not batch[0]:
                 if not hasattr(self, "_copy_stream"):
@@ -144,11 +144,21 @@ class MiniTrainer:
             model.fused_backward_done = True   # training_step's gradients are final: no autograd pass over its scalar
         if hasattr(model, "to") and self.device != "cpu":
             model.to(self.device)
+        caller_stream = None
         if self.device != "cpu" and torch.cuda.is_available():
             from .runtime.engine import trunk_stream
             st = trunk_stream(self.device)       # high-priority stream for the step's trunk (side work fills the rest)
             if st is not None:
+                caller_stream = torch.cuda.current_stream()
                 torch.cuda.set_stream(st)
+        try:
+            return self._fit(model, datamodule)
+        finally:
+            if caller_stream is not None:        # (hand the caller's stream back, ordered behind the training)
+                caller_stream.wait_stream(torch.cuda.current_stream())
+                torch.cuda.set_stream(caller_stream)
+
+    def _fit(self, model, datamodule):
         sampler = None
         if os.environ.get("STYLEMESH_SAMPLE") == "1":   # diagnostics: where does the training thread sit? (2 ms sampling)
             import collections
@@ -183,6 +193,12 @@ class MiniTrainer:
             t_epoch = now()
             steps0 = self.global_step
             self._call(model, "on_train_epoch_start")
+            # a view uploaded / prepared ahead that the previous epoch never reached (limit_train_batches, an exception):
+            # forget it, or upload-ahead and prepare-ahead would stay off for the rest of the run
+            self._ahead = None
+            eng = getattr(model, "_engine", None)
+            if eng is not None and hasattr(eng, "drop_prepared"):
+                eng.drop_prepared()
             timing = os.environ.get("STYLEMESH_TRAINER_TIMING") == "1"   # host-side seconds per phase of the loop
             tm = getattr(self, "host_seconds", None) or {"next_batch": 0.0, "to_device": 0.0, "training_step": 0.0,
                                                          "backward": 0.0, "optimizer_step": 0.0}
@@ -271,6 +287,7 @@ class MiniTrainer:
                          f"to_device {1e3 * fs[1] / nf:.2f}, training_step {1e3 * fs[2] / nf:.2f})" if nf else ""))
             from .runtime.distributed import LOADER_STATS
             if LOADER_STATS:
+                LOADER_STATS.settle()
                 print(f"loader: decode {sum(p.decode_s for p in LOADER_STATS):.1f} s in the prefetch thread, "
                       f"training loop blocked {sum(p.wait_s for p in LOADER_STATS):.1f} s waiting for views")
         if hasattr(self.logger, "flush"):

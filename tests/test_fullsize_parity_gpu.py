@@ -5,7 +5,12 @@ synthetic views (VERDICT r2 task 1):
   (reference model/model.py:178-327, scripts/train/optimize_texture_scannet_with_angle_and_depth.sh);
 * c2 - ScanNet only2D: 2048^2 hier-4 texture, one UV level 256x341, single (optimize_texture_scannet_only2D.sh);
 * c5 - Matterport with_angle_and_depth: 4096^2, UV levels 256x320 .. 784x980, angle 40, min_pyramid_depth 0.2
-  (scripts/train/optimize_texture_matterport_with_angle_and_depth.sh:11-15).
+  (scripts/train/optimize_texture_matterport_with_angle_and_depth.sh:11-15);
+* with_angle - ScanNet with_angle: 4096^2 hier-4, ONE UV level, multi, angle weighting on, depth scaling off
+  (scripts/train/optimize_texture_scannet_with_angle.sh:3-20);
+* dip - ScanNet dip: 4096^2 ONE-layer texture, tex_reg 0, style 1e-3, single, ``gram_mode average`` (the 10-deep
+  detached Gram history of content_and_style_losses.py:319-323), ``index_repeat 1`` = a NEW view every step
+  (scripts/train/optimize_texture_scannet_dip.sh:3-20; data/abstract_dataset.py:498-512).
 
 Two kinds of test, both in the default fp16x2-split arithmetic AND with v_mfma_f32_32x32x2_f32 everywhere
 (STYLEMESH_CONV_MODE / GRAM_MODE = f32), on three view seeds per config and the full-size 1528 x 1200 style image:
@@ -51,11 +56,21 @@ CASES = {
                depth=False, min_depth=0.25, seeds=(2, 6, 9), active=[0]),
     "c5": dict(tex=4096, level_hw=S.MATTERPORT_LEVEL_HW, view_hw=S.MATTERPORT_VIEW_HW, mode="multi", thr=40.0, angle=True,
                depth=True, min_depth=0.2, seeds=(2, 6, 9), active=None),
+    "with_angle": dict(tex=4096, level_hw=[S.SCANNET_VIEW_HW], view_hw=S.SCANNET_VIEW_HW, mode="multi", thr=30.0,
+                       angle=True, depth=False, min_depth=0.25, seeds=(2, 6, 9), active=[0]),
+    "dip": dict(tex=4096, level_hw=[S.SCANNET_VIEW_HW], view_hw=S.SCANNET_VIEW_HW, mode="single", thr=3000.0, angle=False,
+                depth=False, min_depth=0.25, seeds=(2, 6, 9), active=[0], n_layers=1, gram_mode="average", decay=15,
+                loss_weights={"content": 7e1, "style": 1e-3, "tex_reg": 0.0}),
 }
 MODES = ("split2", "f32")
-# one step, gradient: fraction of the touched texels beyond the tight bound, and max |err| / max |ref| (= 2 x measured)
+# one step, gradient: fraction of the touched texels beyond the tight bound, and max |err| / max |ref| per arithmetic mode
+# (= 2 x the largest value measured over the three seeds, profiles/r03/fullsize_parity_final.json and profiles/r04/: the
+# maximum is the size of the largest max-pool argmax FLIP of the case - which window flips differs between the modes, in
+# both directions: c3 seed 9 split2 2.4e-2 / f32 0.8e-2, c5 seed 2 split2 0.6e-2 / f32 1.2e-2, c5 seed 9 0.15e-2 / 0.5e-2)
 FLIP_FRAC_MAX = 0.005
-MAX_ERR = {"c3": 5e-2, "c2": 1e-2, "c5": 2.5e-2}
+MAX_ERR = {"c3": {"split2": 5e-2, "f32": 1.8e-2}, "c2": {"split2": 5e-3, "f32": 5e-3},
+           "c5": {"split2": 1.3e-2, "f32": 2.5e-2}, "with_angle": {"split2": 2e-2, "f32": 2e-2},
+           "dip": {"split2": 2e-2, "f32": 2e-2}}
 
 
 def seeded_texture(tex, n_layers=4, amp=60.0):
@@ -65,7 +80,16 @@ def seeded_texture(tex, n_layers=4, amp=60.0):
             for i in range(n_layers)]
 
 
+_SESSION = {}     # what this session's tests measured (the summary test reads THIS, not a file of some earlier run)
+
+
+@pytest.fixture(scope="session")
+def parity_results():
+    return _SESSION
+
+
 def _record(name, entry):
+    _SESSION[name] = entry
     out_dir = os.path.join(REPO, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, "fullsize_parity.json")
@@ -103,9 +127,12 @@ def _view(c, seed):
 
 def _oracle(c, tex0):
     ocfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=c["thr"],
-                          style_pyramid_mode=c["mode"], use_angle_weight=c["angle"], use_depth_scaling=c["depth"],
-                          loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
-    return O.OraclePipeline(_vgg(), _style(), ocfg, (c["tex"], c["tex"]), init_layers=tex0, targets=_oracle_targets())
+                          style_pyramid_mode=c["mode"], gram_mode=c.get("gram_mode", "current"),
+                          use_angle_weight=c["angle"], use_depth_scaling=c["depth"],
+                          loss_weights=dict(c.get("loss_weights", LOSS_WEIGHTS)), learning_rate=1.0,
+                          decay_step_size=c.get("decay", 3))
+    return O.OraclePipeline(_vgg(), _style(), ocfg, (c["tex"], c["tex"]), n_layers=c.get("n_layers", 4), init_layers=tex0,
+                            targets=_oracle_targets())
 
 
 def _engine(c, mode, tex0, monkeypatch):
@@ -113,13 +140,20 @@ def _engine(c, mode, tex0, monkeypatch):
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
     monkeypatch.setattr(ops, "CONV_MODE", mode)
     monkeypatch.setattr(ops, "GRAM_MODE", mode)
-    cfg = EngineConfig(tex_w=c["tex"], tex_h=c["tex"], hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
-                       angle_threshold=c["thr"], style_pyramid_mode=c["mode"], use_angle_weight=c["angle"],
-                       use_depth_scaling=c["depth"], loss_weights=dict(LOSS_WEIGHTS), learning_rate=1.0, decay_step_size=3)
+    cfg = EngineConfig(tex_w=c["tex"], tex_h=c["tex"], hierarchical=True, n_layers=c.get("n_layers", 4),
+                       style_weights=STYLE_WEIGHTS, angle_threshold=c["thr"], style_pyramid_mode=c["mode"],
+                       gram_mode=c.get("gram_mode", "current"), use_angle_weight=c["angle"], use_depth_scaling=c["depth"],
+                       loss_weights=dict(c.get("loss_weights", LOSS_WEIGHTS)), learning_rate=1.0,
+                       decay_step_size=c.get("decay", 3))
     eng = StepEngine(cfg, _vgg())
     eng.load_texture(tex0)
     eng.set_style_image(_style())
     return eng
+
+
+def _tex0(c):
+    n = c.get("n_layers", 4)
+    return _shared(("tex", c["tex"], n), lambda: seeded_texture(c["tex"], n))
 
 
 def _coverage(eng):
@@ -142,7 +176,7 @@ def test_one_step_matches_oracle_at_full_size(name, seed_index, monkeypatch):
     seed = c["seeds"][seed_index]
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     view = _view(c, seed)
-    tex0 = _shared(("tex", c["tex"]), lambda: seeded_texture(c["tex"]))
+    tex0 = _tex0(c)
 
     pipe = _oracle(c, tex0)
     rec = {}
@@ -175,7 +209,7 @@ def test_one_step_matches_oracle_at_full_size(name, seed_index, monkeypatch):
         reg = torch.cat([(k * p).reshape(-1) for k, p in zip(eng.reg_coef, tex0)])
         # texels no pixel of the view maps to: an exactly-zero data term here, the regulariser's gradient alone there
         assert (~touched).any() and float(g_data[~touched].abs().max()) == 0.0
-        assert float((g_ref - reg)[~touched].abs().max()) <= 1e-6 * float(reg.abs().max()) + 1e-12
+        assert float((g_ref - reg)[~touched].abs().max()) <= 1e-6 * float(reg.abs().max()) + 1e-12 * mx
         frac_touched = float(touched.float().mean())
         assert 0.0 < frac_touched < 0.6
         err = (g_mine - g_ref).abs()
@@ -194,17 +228,17 @@ def test_one_step_matches_oracle_at_full_size(name, seed_index, monkeypatch):
         e = entry[mode]
         assert e["fraction_of_touched_texels_beyond_tight_bound"] <= FLIP_FRAC_MAX, \
             f"{name} {mode}: {fracs[mode]:.5f} of the touched texels beyond 1e-3|ref| + 2e-4 max|ref|"
-        assert e["max_err_over_max_ref"] <= MAX_ERR[name], f"{name} {mode}: max err {e['max_err_over_max_ref']:.3e} of max|ref|"
+        assert e["max_err_over_max_ref"] <= MAX_ERR[name][mode], \
+            f"{name} {mode}: max err {e['max_err_over_max_ref']:.3e} of max|ref|"
 
 
-def test_split_arithmetic_adds_no_flips_over_all_cases():
+def test_split_arithmetic_adds_no_flips_over_all_cases(parity_results):
     """Flips are discrete events (a case can show 0 in one mode and 0.1 % in the other): the comparison between the
-    fp16x2-split and the fp32-MFMA arithmetic is made over ALL the cases of the test above."""
-    path = os.path.join(REPO, "gpurun_out", "fullsize_parity.json")
-    data = json.load(open(path)) if os.path.exists(path) else {}
-    cases = [v for k, v in data.items() if "_seed" in k and all(m in v for m in MODES)]
+    fp16x2-split and the fp32-MFMA arithmetic is made over ALL the one-step cases THIS session has run (the session
+    fixture the test above records into; no file of an earlier run is read)."""
+    cases = [v for k, v in parity_results.items() if "_seed" in k and all(m in v for m in MODES)]
     if len(cases) < 6:
-        pytest.skip("needs the one-step cases of this session")
+        pytest.skip("needs the one-step cases of this session (run the whole file)")
     key = "fraction_of_touched_texels_beyond_tight_bound"
     mean = {m: float(np.mean([v[m][key] for v in cases])) for m in MODES}
     worst = {m: float(np.max([v[m]["max_err_over_max_ref"] for v in cases])) for m in MODES}
@@ -246,7 +280,15 @@ def _flat(tensors):
 LOCK_TIGHT_FRAC, LOCK_LOOSE_FRAC = 0.01, 0.001   # (measured: <= 0.31 % / <= 0.032 %)
 
 
-@pytest.mark.parametrize("name", ["c3", "c2"])
+# name -> (steps, the step's view = seeds[view_of_step(k)]): five steps with ONE view change for the index_repeat 20 / 100
+# scripts; dip runs index_repeat 1 - a new view EVERY step - for 12 steps, so that the 10-deep Gram history fills and wraps
+K_SCHEDULES = {"c3": (K_STEPS, lambda k: 0 if k < SWITCH_AT else 1), "c2": (K_STEPS, lambda k: 0 if k < SWITCH_AT else 1),
+               "c5": (K_STEPS, lambda k: 0 if k < SWITCH_AT else 1), "with_angle": (K_STEPS, lambda k: 0 if k < SWITCH_AT else 1),
+               "dip": (12, lambda k: k)}
+DIP_SEEDS = (2, 6, 9, 0, 7, 11, 12, 14, 16, 18, 22, 23)
+
+
+@pytest.mark.parametrize("name", ["c3", "c2", "c5", "with_angle", "dip"])
 def test_k_steps_texture_values_match_oracle_at_full_size(name, monkeypatch):
     """Texture VALUES over five training steps with a view change inside (north_star: 'outputs match the reference
     PyTorch path's texture values'; reference model/model.py:178-327 + Adam :387-395), two ways, both modes:
@@ -263,16 +305,22 @@ def test_k_steps_texture_values_match_oracle_at_full_size(name, monkeypatch):
     require_gpu()
     c = CASES[name]
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    views = [_view(c, c["seeds"][0]), _view(c, c["seeds"][1])]
-    tex0 = _shared(("tex", c["tex"]), lambda: seeded_texture(c["tex"]))
-    schedule = [views[0] if k < SWITCH_AT else views[1] for k in range(K_STEPS)]
+    n_steps, view_of = K_SCHEDULES[name]
+    seeds = DIP_SEEDS if name == "dip" else c["seeds"]
+    views = {}
+    for k in range(n_steps):
+        if view_of(k) not in views:
+            views[view_of(k)] = _view(c, seeds[view_of(k)])
+    tex0 = _tex0(c)
+    schedule = [views[view_of(k)] for k in range(n_steps)]
 
     pipe, ctrl = _oracle(c, tex0), _oracle(c, tex0)
     free, lock = {}, {}
     for mode in MODES:
         free[mode] = _engine(c, mode, tex0, monkeypatch)
         lock[mode] = _engine(c, mode, tex0, monkeypatch)
-    entry = {"steps": K_STEPS, "view_change_before_step": SWITCH_AT + 1, "texels": int(free["split2"].arena.n),
+    entry = {"steps": n_steps, "view_change_before_step": "every" if name == "dip" else SWITCH_AT + 1,
+             "texels": int(free["split2"].arena.n),
              "control": [], "free": {m: [] for m in MODES}, "lock_step": {m: [] for m in MODES}}
     clamp = lambda t: t.clamp(O.CLAMP_LO, O.CLAMP_HI)
     t_oracle = 0.0
@@ -313,7 +361,7 @@ def test_k_steps_texture_values_match_oracle_at_full_size(name, monkeypatch):
     print(f"\n[{name} k-step] {json.dumps(entry)}")
     _record(f"{name}_ksteps", entry)
     for mode in MODES:
-        for k in range(K_STEPS):
+        for k in range(n_steps):
             m = entry["lock_step"][mode][k]
             what = f"{name} {mode} lock-step, step {k + 1}: {m}"
             if k == 0:

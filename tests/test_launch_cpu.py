@@ -1,0 +1,99 @@
+"""The single-node rank launcher behind ``python bench.py --gpus N`` (stylemesh_amd/launch.py): argument / environment
+plan, device check, exit-code logic and output relay - with stand-in rank programs, no GPU."""
+import io
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import REPO
+from stylemesh_amd import launch
+
+
+def test_launch_is_needed_only_for_a_plain_start_with_several_ranks():
+    assert launch.needs_launch(2, {})
+    assert not launch.needs_launch(1, {})
+    assert not launch.needs_launch(8, {"WORLD_SIZE": "8"})       # torch.distributed.run (the driver) already made the ranks
+
+
+def test_rank_plans_carry_the_rendezvous_environment():
+    plans = launch.rank_plans(4, ["bench.py", "--gpus", "4", "--steps", "20"], {"PATH": "/bin", "FOO": "1"}, 29511, python="py")
+    assert len(plans) == 4
+    for r, (cmd, env) in enumerate(plans):
+        assert cmd == ["py", "bench.py", "--gpus", "4", "--steps", "20"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"]) == (str(r), str(r), "4")
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29511" and env["FOO"] == "1"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    kept = launch.rank_plans(1, ["x"], {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, 1)[0][1]
+    assert kept["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"             # an explicit setting is the caller's
+
+
+def test_device_check_refuses_too_few_gpus_with_one_message():
+    assert launch.check_devices(2, 8, "nccl") is None
+    msg = launch.check_devices(8, 1, "nccl")
+    assert "8" in msg and "1 GPU" in msg
+    assert launch.check_devices(2, 1, "gloo") is None            # functional mode: ranks share the device
+    assert launch.check_devices(2, 0, "gloo") is not None
+    err = io.StringIO()
+    rc = launch.launch(8, ["never-started"], env={}, device_count=lambda: 1, err=err)
+    assert rc == launch.RC_NO_DEVICES and err.getvalue().count("\n") == 1
+
+
+def test_worst_rc():
+    assert launch.worst_rc([0, 0, 0]) == 0
+    assert launch.worst_rc([0, 3, 1]) == 3
+    assert launch.worst_rc([0, -9]) == 137                       # killed by SIGKILL
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "rank.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_run_ranks_relays_rank0_stdout_and_reports_success(tmp_path):
+    prog = _script(tmp_path, """
+        import os, sys
+        r = os.environ["RANK"]
+        print('{"rank": %s, "world": %s}' % (r, os.environ["WORLD_SIZE"]))
+        print("noise from rank " + r, file=sys.stderr)
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.run_ranks(launch.rank_plans(3, [prog], dict(os.environ), launch.free_port()), out=out, err=err)
+    assert rc == 0
+    assert out.getvalue() == '{"rank": 0, "world": 3}\n'         # ONE line on stdout: rank 0's
+    assert '[rank 1] {"rank": 1, "world": 3}' in err.getvalue() and "[rank 2] noise from rank 2" in err.getvalue()
+
+
+def test_run_ranks_ends_the_survivors_when_a_rank_fails(tmp_path):
+    prog = _script(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(600)          # a rank stuck in a collective whose peer has died
+    """)
+    import time
+    t0 = time.monotonic()
+    rc = launch.run_ranks(launch.rank_plans(2, [prog], dict(os.environ), launch.free_port()), out=io.StringIO(),
+                          err=io.StringIO(), grace_s=0.5)
+    assert time.monotonic() - t0 < 30
+    assert rc != 0
+
+
+def test_run_ranks_timeout(tmp_path):
+    prog = _script(tmp_path, "import time; time.sleep(600)\n")
+    rc = launch.run_ranks(launch.rank_plans(2, [prog], dict(os.environ), launch.free_port()), timeout_s=1.0,
+                          out=io.StringIO(), err=io.StringIO(), grace_s=0.5)
+    assert rc == launch.RC_TIMEOUT
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
+    """`python bench.py --gpus 8` on a box without 8 GPUs: one message, exit code RC_NO_DEVICES, no rank started."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "STYLEMESH_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    assert r.returncode == launch.RC_NO_DEVICES, (r.returncode, r.stderr[-400:])
+    assert "one rank per GPU" in r.stderr and r.stdout == ""
