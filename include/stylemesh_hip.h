@@ -49,7 +49,8 @@ int sm_fmap_row_stride(int W);        /* Wp */
 int sm_fmap_plane(int H, int W);      /* floats per channel plane (multiple of 64) */
 int sm_abi_version(void);
 /* sizeof of the problem structs of this header as the library was compiled (which: 0 sm_conv_problem, 1
- * sm_plane_problem, 2 sm_gram_problem, 3 sm_style_problem, 4 sm_gram_bwd_problem, 5 sm_cover_problem; anything else: -1) - a binding checks
+ * sm_plane_problem, 2 sm_gram_problem, 3 sm_style_problem, 4 sm_gram_bwd_problem, 5 sm_cover_problem, 6 sm_view_masks_desc,
+ * 7 sm_view_layer_mask, 8 sm_view_resize, 9 sm_view_lists_desc, 10 sm_view_list, 11 sm_call; anything else: -1) - a binding checks
  * its own struct layouts against it. */
 int sm_sizeof_problem(int which);
 
@@ -495,7 +496,9 @@ typedef struct {
     int32_t* starts;
     int32_t* count;
     int h, w, tag, cap;
-    /* 0: as above. > 0 (ABI 7): PAIR mode for a conv with SM_EPI_POOL - need is the need map of the POOLED plane
+    /* < 0 (ABI 8): TILE mode - aligned tiles of -pair_w positions (a divisor of 2048) instead of segments: starts
+     * receives (tag << 24) | t for every tile t that holds a needed position (sm_tile_flags + compaction in one).
+     * 0: as above. > 0 (ABI 7): PAIR mode for a conv with SM_EPI_POOL - need is the need map of the POOLED plane
      * [h][w], pair_w the width of the full-resolution plane the conv writes (w == pair_w / 2); every pooled row Y is
      * covered with runs of 16 windows starting at any window X0, and each run becomes TWO entries: the segment of
      * image row 2Y that starts at column 2 X0, then the one right below it (row 2Y + 1). */
@@ -503,6 +506,94 @@ typedef struct {
 } sm_cover_problem;
 size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n);
 int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the per-view constants of a whole view in TWO calls (ABI 8) ------------------------------------------------
+ * Everything below depends on the view only; the reference recomputes it every step (model/model.py:204-254,
+ * content_and_style_losses.py:146-217). Rounds 1-3 sequenced it from the Python host with one call per (level, layer):
+ * 130 (one UV level) to 250 (four) launches per view change = 2.6 - 4.3 ms of HOST time, which bounds the schedules that
+ * change the view every step (--index_repeat 1, scripts/train/optimize_texture_scannet_dip.sh:16). The two entry points
+ * take a whole view's tables and issue grouped launches (one per kind over all levels / layers). Descriptors and the
+ * tables they point to are HOST memory, read during the call; every other pointer is device memory. */
+#define SM_VIEW_MAX_LEVELS 8
+#define SM_VIEW_MAX_LAYERS 24      /* 'img' + the outputs of the VGG nodes up to the deepest loss layer */
+#define SM_VIEW_MAX_LISTS 48
+typedef struct {
+    int H, W;                  /* resolution of the UV level */
+    int has_maps;              /* 0: the level takes no part (without depth scaling all but the last, model.py:253-254) */
+    float* M;                  /* out [H][W]: the level's mask (sm_level_maps) */
+    float* pixel_weight;       /* out [H][W] or NULL */
+    uint8_t* passed;           /* out [H][W] */
+    float* m_sum;              /* out: sum of M (zeroed by the call) */
+} sm_view_level;
+typedef struct {
+    int level;                 /* index into sm_view_masks_desc.levels */
+    int loss_layer;            /* the level factors are normalised over the entries of one loss layer (:181,200-204) */
+    int hl, wl;                /* the loss layer's resolution at that level */
+    float* mask_planes;        /* out: three padded planes [plane(hl, wl)]: all, passed, failed (sm_layer_masks) */
+    float* counts;             /* out [3] (zeroed by the call) */
+    float* factor;             /* out [1] */
+} sm_view_layer_mask;
+typedef struct {
+    const float* src; int C, h, w;   /* padded planar source */
+    float* dst; int H, W;            /* padded planar destination (sm_fmap_resize_bilinear) */
+} sm_view_resize;
+typedef struct {
+    const uint8_t* mask;             /* [h][w] */
+    const float* angle_guidance;     /* [h][w] or NULL (no angle weighting) */
+    const float* angle_degrees;      /* [h][w] */
+    const int64_t* rounded;          /* depth scaling: [h][w] level indices + interpolation weight; else all NULL */
+    const int64_t* other;
+    const float* interp_w;
+    int h, w;
+    float angle_threshold;
+    float* E;                        /* scratch [n_levels][h][w] with depth scaling, [h][w] without */
+    float* Wt;                       /* scratch [n_levels][h][w] with depth scaling, NULL without */
+    int n_levels;
+    sm_view_level levels[SM_VIEW_MAX_LEVELS];
+    int n_masks;                     /* <= 64 */
+    const sm_view_layer_mask* masks;
+    int n_resizes;                   /* <= 16: content targets (the content pass must have run on this stream) */
+    const sm_view_resize* resizes;
+} sm_view_masks_desc;
+/* sm_level_masks + sm_level_maps of every level, sm_layer_masks of every (level, loss layer), sm_level_factors of every
+ * loss layer, the content targets' resizes: five launches. */
+int sm_view_masks(const sm_view_masks_desc* desc, void* stream);
+
+typedef struct {
+    int layer;                 /* index of the need map the list is built from (pair mode: the POOLED layer) */
+    int mode;                  /* 0: free 32-position segments, 1: segment pairs (sm_cover_segments pair mode; the conv's
+                                * full-resolution output is layer `pair_layer`), 2: aligned tiles of `bn` positions,
+                                * entry = (level << 24) | tile (bn divides 2048) */
+    int bn;
+    int pair_layer;
+    int group;                 /* every level's run is padded to a multiple of `group` entries with (level << 24) | 0xFFFFFF */
+    int32_t* out;              /* the list: the levels' runs back to back */
+    int cap;
+    int32_t* staging;          /* scratch of the covers: n_levels x staging_cap entries */
+    int staging_cap;
+} sm_view_list;
+typedef struct {
+    int n_levels;                                   /* the ACTIVE levels; list entries carry the index into this table */
+    const float* M[SM_VIEW_MAX_LEVELS];             /* level masks [H][W] */
+    int H[SM_VIEW_MAX_LEVELS], W[SM_VIEW_MAX_LEVELS];
+    int n_layers;                                   /* layer 0 = the image, layer j + 1 = output of VGG node j */
+    int node_is_pool[SM_VIEW_MAX_LAYERS];           /* node j (produces layer j + 1 ...) */
+    int node_src[SM_VIEW_MAX_LAYERS];               /* ... from this layer */
+    int injected[SM_VIEW_MAX_LAYERS];               /* per layer: a loss reads it (the level mask is OR-ed into its need) */
+    float* need[SM_VIEW_MAX_LEVELS][SM_VIEW_MAX_LAYERS];   /* out: need maps [h][w] of every (level, layer) */
+    int lh[SM_VIEW_MAX_LEVELS][SM_VIEW_MAX_LAYERS];
+    int lw[SM_VIEW_MAX_LEVELS][SM_VIEW_MAX_LAYERS];
+    int n_lists;
+    const sm_view_list* lists;
+    int32_t* summary;          /* out, device: per list [n_list (padded entries), live entries of level 0 .. 7] = 9 ints */
+    void* ws;                  /* scratch: sm_view_lists_ws_bytes(desc) bytes, 16-byte aligned */
+    size_t ws_bytes;
+} sm_view_lists_desc;
+/* The dead-tile analysis of a view (runtime/sparsity.py): the need maps of every (level, layer) - one launch per VGG node
+ * over all levels - then every active list of the step's conv / pool launches (covers of all lists in batches of 64 maps,
+ * one concatenation launch). No host synchronisation: the caller reads `summary` back when it needs the grid sizes. */
+size_t sm_view_lists_ws_bytes(const sm_view_lists_desc* desc);
+int sm_view_lists(const sm_view_lists_desc* desc, void* stream);
 
 /* ---- multi-GPU: SURVEY.md section 8 e --------------------------------------------------------------- */
 
@@ -550,6 +641,31 @@ int sm_comm_info(void* comm, int* info_out);
 /* (ABI 8) The link between two HIP devices of this node as the runtime reports it (hipExtGetLinkTypeAndHopCount):
  * *link_type = HSA_AMD_LINK_INFO_TYPE_* (1 = PCIe, 4 = xGMI), *hops = hop count. Returns a hipError_t. */
 int sm_device_link(int device_a, int device_b, int* link_type, int* hops);
+
+/* ---- R1: launch tables (ABI 8) ------------------------------------------------------------------------------
+ * A training step of the Python host is a fixed sequence of calls into this library; sm_call_replay issues a recorded
+ * sequence with ONE call (csrc/replay.hip). An entry holds the id of an entry point whose last parameter is the stream
+ * (sm_call_id(name); -1: not replayable) and its arguments as 64-bit words in declaration order: pointers and integers
+ * by value, a float as its bit pattern in the low 32 bits, a double as its bit pattern. The recorded stream word is
+ * ignored: every call is issued on `stream`. skip != 0: the entry is passed over (a launch whose active list is empty
+ * for the current view). HOST arrays an argument points to (problem tables) must stay alive and are read at replay
+ * time - the host may update them, and any argument word, between replays. Returns the first non-zero return code and
+ * the index of the call that produced it. */
+#define SM_CALL_MAX_ARGS 24
+typedef struct {
+    int fn;
+    int n_args;
+    int skip;
+    int reserved;
+    uint64_t args[SM_CALL_MAX_ARGS];
+} sm_call;
+int sm_call_id(const char* name);
+int sm_call_n_args(int id);
+int sm_call_replay(const sm_call* calls, int n, void* stream, int* failed_index);
+/* dst[0 .. n) = src[0 .. n) / = 0 on the stream (device memory): the two torch operations of a step - the clone of the
+ * loss pair, the fill of the sums of squares - as library calls, so that a recorded step has no gap in it. */
+int sm_copy_floats(float* dst, const float* src, size_t n, void* stream);
+int sm_zero_floats(float* dst, size_t n, void* stream);
 
 /* ---- E1: multi-view consistency metric --------------------------------------- */
 

@@ -6,7 +6,7 @@ OUT=../libstylemesh_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function"
 mkdir -p ../../build
 objs=()
-for f in conv texture gram prep comm eval raster scatter_plan exchange; do
+for f in conv texture gram prep comm eval raster scatter_plan exchange replay; do
   o=../../build/$f.o
   stale=0
   for dep in "$f.hip" *.h ../../include/stylemesh_hip.h; do

@@ -742,6 +742,12 @@ int sm_sizeof_problem(int which) {
         case 3: return (int)sizeof(sm_style_problem);
         case 4: return (int)sizeof(sm_gram_bwd_problem);
         case 5: return (int)sizeof(sm_cover_problem);
+        case 6: return (int)sizeof(sm_view_masks_desc);
+        case 7: return (int)sizeof(sm_view_layer_mask);
+        case 8: return (int)sizeof(sm_view_resize);
+        case 9: return (int)sizeof(sm_view_lists_desc);
+        case 10: return (int)sizeof(sm_view_list);
+        case 11: return (int)sizeof(sm_call);
         default: return -1;
     }
 }

@@ -343,7 +343,18 @@ __global__ __launch_bounds__(256) void cover_table_kernel(CoverGroup g) {
     const int chunk = blockIdx.x * 32 + (threadIdx.x >> 3), e8 = threadIdx.x & 7;
     if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
     int n = 0, ex = 0;
-    if (P.pair_w > 0) {
+    if (P.pair_w < 0) {                   // TILE mode: live tiles of -pair_w positions in this chunk (entry state unused)
+        if (e8 == 0) {
+            const int tw = -P.pair_w / 32;                                    // words per tile (bn >= 64) ...
+            const uint32_t* wds = g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS;
+            const int n_words = cover_words(P.h, P.w, P.pair_w) - chunk * SM_COVER_CHUNK_WORDS;
+            for (int t = 0; t * tw < SM_COVER_CHUNK_WORDS && t * tw < n_words; ++t) {
+                uint32_t any = 0;
+                for (int k = 0; k < tw && t * tw + k < n_words; ++k) any |= wds[t * tw + k];
+                n += any != 0;
+            }
+        }
+    } else if (P.pair_w > 0) {
         if (e8 == 0) {
             const int rw = cover_row_words(P.w);
             cover_walk<true>(g.bits + P.word_base + chunk * rw, P.w, 0, [&](int) { ++n; });
@@ -394,7 +405,19 @@ __global__ __launch_bounds__(256) void cover_emit_kernel(CoverGroup g) {
     if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
     const uint32_t s = g.state[P.chunk_base + chunk];
     int n = (int)(s >> 3);
-    if (P.pair_w > 0) {
+    if (P.pair_w < 0) {
+        const int tw = -P.pair_w / 32, per_chunk = SM_COVER_CHUNK_WORDS / tw;
+        const uint32_t* wds = g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS;
+        const int n_words = cover_words(P.h, P.w, P.pair_w) - chunk * SM_COVER_CHUNK_WORDS;
+        for (int t = 0; t < per_chunk && t * tw < n_words; ++t) {
+            uint32_t any = 0;
+            for (int k = 0; k < tw && t * tw + k < n_words; ++k) any |= wds[t * tw + k];
+            if (any) {
+                if (n < P.cap) P.starts[n] = (P.tag << 24) | (chunk * per_chunk + t);
+                ++n;
+            }
+        }
+    } else if (P.pair_w > 0) {
         const int rw = cover_row_words(P.w), Wp = row_stride(P.pair_w);
         cover_walk<true>(g.bits + P.word_base + chunk * rw, P.w, 0, [&](int X0) {
             const int q = (2 * chunk + 1) * Wp + 2 * X0 + 1;     // chunk = pooled row Y: image rows 2Y and 2Y + 1
@@ -411,6 +434,221 @@ __global__ __launch_bounds__(256) void cover_emit_kernel(CoverGroup g) {
             if (n < P.cap) P.starts[n] = (P.tag << 24) | (Wp + first + st);
             ++n;
         });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Grouped forms of the per-view kernels above: one launch per KIND over all levels / (level, layer) pairs of a view
+// (sm_view_masks, sm_view_lists). Same arithmetic, thread for thread; the problem tables travel as kernel arguments.
+// ---------------------------------------------------------------------------------------------------
+struct LevelMapProblem {
+    const float* E;            // [h][w] (this level's slice)
+    const float* Wt;           // or NULL
+    float* M;
+    float* pixel_weight;
+    uint8_t* passed;
+    float* m_sum;
+    int H, W;
+};
+struct LevelMapGroup {
+    LevelMapProblem p[SM_VIEW_MAX_LEVELS];
+    const float* angle_guidance;
+    const float* angle_deg;
+    float thr;
+    int h, w;
+};
+__global__ __launch_bounds__(256) void level_maps_group_kernel(LevelMapGroup g) {
+    const LevelMapProblem& P = g.p[blockIdx.y];
+    if (blockIdx.x * 256 >= P.H * P.W) return;
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int h = g.h, w = g.w, H = P.H, W = P.W;
+    float mval = 0.f;
+    if (i < H * W) {
+        const int y = i / W, x = i - y * W;
+        const int sy = nearest_src(y, h, H), sx = nearest_src(x, w, W);
+        mval = (P.E[sy * w + sx] > 0.f) ? 1.f : 0.f;
+        P.M[i] = mval;
+        if (P.pixel_weight) {
+            float pw = 1.f;
+            if (g.angle_guidance) pw = bilinear_at([&](int a, int b) { return g.angle_guidance[a * w + b]; }, y, x, h, w, H, W);
+            if (P.Wt) pw *= P.Wt[sy * w + sx];
+            P.pixel_weight[i] = pw;
+        }
+        if (P.passed) {
+            bool ps = true;
+            if (g.angle_deg) ps = bilinear_at([&](int a, int b) { return g.angle_deg[a * w + b]; }, y, x, h, w, H, W) < g.thr;
+            P.passed[i] = ps ? 1 : 0;
+        }
+    }
+    float v = mval;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = red[0] + red[1] + red[2] + red[3];
+        if (s != 0.f) atomicAdd(P.m_sum, s);
+    }
+}
+
+// mask u8 -> float (the E plane of a view without depth scaling: model/model.py:240-254 uses the plain mask)
+__global__ __launch_bounds__(256) void mask_to_float_kernel(const uint8_t* __restrict__ m, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = m[i] ? 1.f : 0.f;
+}
+
+struct LayerMaskProblem {
+    const float* M;
+    const uint8_t* passed;
+    float* planes;             // 3 padded planes
+    float* counts;
+    int H, W, hl, wl;
+};
+struct LayerMaskGroup {
+    LayerMaskProblem p[64];
+};
+__global__ __launch_bounds__(256) void layer_masks_group_kernel(LayerMaskGroup g) {
+    const LayerMaskProblem& P = g.p[blockIdx.y];
+    const int hl = P.hl, wl = P.wl;
+    if (blockIdx.x * 256 >= hl * wl) return;
+    __shared__ float red[3][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int Wp = row_stride(wl), plane = plane_size(hl, wl);
+    float a = 0.f, p = 0.f, f = 0.f;
+    if (i < hl * wl) {
+        const int y = i / wl, x = i - y * wl;
+        const int j = nearest_src(y, P.H, hl) * P.W + nearest_src(x, P.W, wl);
+        a = P.M[j];
+        const bool ps = P.passed ? P.passed[j] != 0 : true;
+        p = ps ? a : 0.f;
+        f = ps ? 0.f : a;
+        const int q = (y + 1) * Wp + x + 1;
+        P.planes[q] = a;
+        P.planes[plane + q] = p;
+        P.planes[2 * plane + q] = f;
+    }
+    float v[3] = {a, p, f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (s != 0.f) atomicAdd(P.counts + threadIdx.x, s);
+    }
+}
+
+struct FactorProblem {
+    const float* counts;       // N_all of this (level, loss layer)
+    float* factor;
+    float size;
+    int loss_layer;
+};
+struct FactorGroup {
+    FactorProblem p[64];
+    int n;
+};
+// thread k = loss layer k: the means of its levels, in table order (the order sm_level_factors sums them in)
+__global__ void level_factors_group_kernel(FactorGroup a) {
+    const int layer = threadIdx.x;
+    float s = 0.f;
+    bool any = false;
+    for (int i = 0; i < a.n; ++i)
+        if (a.p[i].loss_layer == layer) { s += *a.p[i].counts / a.p[i].size; any = true; }
+    if (!any) return;
+    for (int i = 0; i < a.n; ++i)
+        if (a.p[i].loss_layer == layer) *a.p[i].factor = (*a.p[i].counts / a.p[i].size) / s;
+}
+
+struct ResizeProblem {
+    const float* src;
+    float* dst;
+    int C, h, w, H, W;
+};
+struct ResizeGroup {
+    ResizeProblem p[16];
+};
+__global__ __launch_bounds__(256) void fmap_resize_group_kernel(ResizeGroup g) {
+    const ResizeProblem& P = g.p[blockIdx.z];
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (c >= P.C || i >= P.H * P.W) return;
+    const int y = i / P.W, x = i - y * P.W;
+    const int wp = row_stride(P.w), Wp = row_stride(P.W);
+    const float* src = P.src + (size_t)c * plane_size(P.h, P.w);
+    P.dst[(size_t)c * plane_size(P.H, P.W) + (y + 1) * Wp + x + 1] =
+        bilinear_at([&](int a, int b) { return src[(a + 1) * wp + b + 1]; }, y, x, P.h, P.w, P.H, P.W);
+}
+
+struct NeedProblem {
+    const float* need_out;
+    const float* M;            // or NULL
+    float* need_src;
+    int ho, wo, H, W, hs, ws;
+};
+struct NeedGroup {
+    NeedProblem p[SM_VIEW_MAX_LEVELS];
+    int mode;
+};
+__global__ __launch_bounds__(256) void need_step_group_kernel(NeedGroup g) {
+    const NeedProblem& P = g.p[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.hs * P.ws) return;
+    const int y = i / P.ws, x = i - y * P.ws;
+    float v = 0.f;
+    if (g.mode == 1) {
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < P.ho && xx >= 0 && xx < P.wo) v = fmaxf(v, P.need_out[yy * P.wo + xx]);
+            }
+    } else if (g.mode == 2) {
+        const int yy = y >> 1, xx = x >> 1;
+        if (yy < P.ho && xx < P.wo) v = P.need_out[yy * P.wo + xx];
+    }
+    if (P.M) v = fmaxf(v, P.M[nearest_src(y, P.H, P.hs) * P.W + nearest_src(x, P.W, P.ws)]);
+    P.need_src[i] = v > 0.f ? 1.f : 0.f;
+}
+
+// The active lists of a view: list s = the runs of its levels back to back, each padded to a multiple of `group` entries
+// with (level << 24) | 0xFFFFFF. Block s: the offsets from the covers' counts (one thread), then the copy.
+struct ConcatList {
+    const int32_t* staging;    // n_levels x staging_cap
+    int32_t* out;
+    int cap, group, staging_cap, pad;
+};
+struct ConcatGroup {
+    ConcatList l[SM_VIEW_MAX_LISTS];
+    const int32_t* counts;     // [list][level]
+    int32_t* summary;
+    int n_levels;
+};
+__global__ __launch_bounds__(256) void list_concat_kernel(ConcatGroup g) {
+    const ConcatList& L = g.l[blockIdx.x];
+    __shared__ int off[SM_VIEW_MAX_LEVELS + 1], live[SM_VIEW_MAX_LEVELS];
+    if (threadIdx.x == 0) {
+        int pos = 0;
+        for (int k = 0; k < g.n_levels; ++k) {
+            int n = g.counts[blockIdx.x * g.n_levels + k];
+            n = n > L.staging_cap ? L.staging_cap : n;          // (an overflowing cover is reported through the count)
+            live[k] = n;
+            off[k] = pos;
+            pos += n + (L.group - n % L.group) % L.group;
+        }
+        off[g.n_levels] = pos;
+        int32_t* sum = g.summary + 9 * blockIdx.x;
+        sum[0] = pos;
+        for (int k = 0; k < SM_VIEW_MAX_LEVELS; ++k) sum[1 + k] = k < g.n_levels ? g.counts[blockIdx.x * g.n_levels + k] : 0;
+    }
+    __syncthreads();
+    for (int k = 0; k < g.n_levels; ++k) {
+        const int n = live[k], end = off[k + 1] - off[k];
+        for (int i = threadIdx.x; i < end; i += 256)
+            if (off[k] + i < L.cap) L.out[off[k] + i] = i < n ? L.staging[(size_t)k * L.staging_cap + i] : ((k << 24) | 0xFFFFFF);
     }
 }
 
@@ -437,12 +675,15 @@ size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n) {
 int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t ws_bytes, void* stream) {
     if (n < 1 || n > SM_COVER_MAX || ws == nullptr || ((uintptr_t)ws & 15)) return (int)hipErrorInvalidValue;
     if (ws_bytes < sm_cover_segments_ws_bytes(problems, n)) return (int)hipErrorInvalidValue;
+    if (problems == nullptr) return (int)hipErrorInvalidValue;
     sm::CoverGroup g;
     int words = 0, chunks = 0, max_words = 0, max_chunks = 0;
     for (int i = 0; i < n; ++i) {
         const sm_cover_problem& p = problems[i];
         if (p.h < 1 || p.w < 1 || p.tag < 0 || p.tag > 127) return (int)hipErrorInvalidValue;
-        if (p.pair_w != 0 && p.pair_w / 2 != p.w) return (int)hipErrorInvalidValue;
+        if (p.pair_w > 0 && p.pair_w / 2 != p.w) return (int)hipErrorInvalidValue;
+        if (p.pair_w < 0 && ((-p.pair_w) % 64 != 0 || (SM_COVER_CHUNK_WORDS * 32) % (-p.pair_w) != 0))
+            return (int)hipErrorInvalidValue;                      // tiles of 64 .. 2048 positions that tile a chunk
         const long plane_rows = (p.pair_w > 0 ? 2l * p.h : (long)p.h) + 2;
         if (plane_rows * sm::row_stride(p.pair_w > 0 ? p.pair_w : p.w) >= 0xFFFFFFl)
             return (int)hipErrorInvalidValue;                      // a list entry holds the position in 24 bits
@@ -541,6 +782,198 @@ int sm_image_to_fmap(const float* in, int C, int h, int w, float* out, int H, in
 int sm_fmap_to_image(const float* in, int C, int H, int W, float* out, void* stream) {
     hipLaunchKernelGGL(sm::fmap_to_image_kernel, dim3((H * W + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, in, H,
                        W, sm::row_stride(W), sm::plane_size(H, W), out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_view_masks(const sm_view_masks_desc* d, void* stream) {
+    if (d == nullptr || d->n_levels < 1 || d->n_levels > SM_VIEW_MAX_LEVELS || d->n_masks < 0 || d->n_masks > 64 ||
+        d->n_resizes < 0 || d->n_resizes > 16 || d->h < 1 || d->w < 1 || d->E == nullptr)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const bool depth = d->rounded != nullptr;
+    if (depth && (d->other == nullptr || d->interp_w == nullptr || d->Wt == nullptr)) return (int)hipErrorInvalidValue;
+    const size_t hw = (size_t)d->h * d->w;
+    if (depth)
+        hipLaunchKernelGGL(sm::level_masks_kernel, dim3((unsigned)((hw + 255) / 256), d->n_levels), dim3(256), 0, st, d->rounded,
+                           d->other, d->interp_w, d->mask, d->h, d->w, d->n_levels, d->E, d->Wt);
+    else
+        hipLaunchKernelGGL(sm::mask_to_float_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, st, d->mask, d->E, (int)hw);
+    // zero the accumulators (the levels' mask sums; the masks' counts - with the factor behind them, which the factor
+    // kernel rewrites): adjacent ranges are merged, a view's tables are one or two memsets
+    char* z_lo = nullptr;
+    size_t z_len = 0;
+    auto zero = [&](void* ptr, size_t bytes) -> hipError_t {
+        char* c = static_cast<char*>(ptr);
+        if (z_lo != nullptr && c == z_lo + z_len) { z_len += bytes; return hipSuccess; }
+        hipError_t e = z_lo ? hipMemsetAsync(z_lo, 0, z_len, st) : hipSuccess;
+        z_lo = c;
+        z_len = bytes;
+        return e;
+    };
+    sm::LevelMapGroup lm;
+    int n_lm = 0, max_px = 0;
+    for (int i = 0; i < d->n_levels; ++i) {
+        const sm_view_level& L = d->levels[i];
+        if (!L.has_maps) continue;
+        if (L.M == nullptr || L.m_sum == nullptr || L.H < 1 || L.W < 1) return (int)hipErrorInvalidValue;
+        if (hipError_t e = zero(L.m_sum, sizeof(float)); e != hipSuccess) return (int)e;
+        lm.p[n_lm++] = sm::LevelMapProblem{d->E + (depth ? (size_t)i * hw : 0), depth ? d->Wt + (size_t)i * hw : nullptr, L.M,
+                                           L.pixel_weight, L.passed, L.m_sum, L.H, L.W};
+        max_px = L.H * L.W > max_px ? L.H * L.W : max_px;
+    }
+    if (n_lm == 0) return (int)hipErrorInvalidValue;
+    for (int k = 0; k < d->n_masks; ++k) {       // (before the level-maps launch: one flush for both groups when adjacent)
+        const sm_view_layer_mask& m = d->masks[k];
+        const bool with_factor = m.factor == m.counts + 3;
+        if (hipError_t e = zero(m.counts, (with_factor ? 4 : 3) * sizeof(float)); e != hipSuccess) return (int)e;
+    }
+    if (z_lo != nullptr)
+        if (hipError_t e = hipMemsetAsync(z_lo, 0, z_len, st); e != hipSuccess) return (int)e;
+    lm.angle_guidance = d->angle_guidance;
+    lm.angle_deg = d->angle_degrees;
+    lm.thr = d->angle_threshold;
+    lm.h = d->h;
+    lm.w = d->w;
+    hipLaunchKernelGGL(sm::level_maps_group_kernel, dim3((max_px + 255) / 256, n_lm), dim3(256), 0, st, lm);
+    if (d->n_masks > 0) {
+        sm::LayerMaskGroup mg;
+        sm::FactorGroup fg;
+        fg.n = d->n_masks;
+        int max_l = 0, n_loss = 0;
+        for (int k = 0; k < d->n_masks; ++k) {
+            const sm_view_layer_mask& m = d->masks[k];
+            if (m.level < 0 || m.level >= d->n_levels || !d->levels[m.level].has_maps || m.loss_layer < 0 || m.loss_layer >= 64)
+                return (int)hipErrorInvalidValue;
+            const sm_view_level& L = d->levels[m.level];
+            mg.p[k] = sm::LayerMaskProblem{L.M, L.passed, m.mask_planes, m.counts, L.H, L.W, m.hl, m.wl};
+            fg.p[k] = sm::FactorProblem{m.counts, m.factor, (float)m.hl * (float)m.wl, m.loss_layer};
+            max_l = m.hl * m.wl > max_l ? m.hl * m.wl : max_l;
+            n_loss = m.loss_layer + 1 > n_loss ? m.loss_layer + 1 : n_loss;
+        }
+        hipLaunchKernelGGL(sm::layer_masks_group_kernel, dim3((max_l + 255) / 256, d->n_masks), dim3(256), 0, st, mg);
+        hipLaunchKernelGGL(sm::level_factors_group_kernel, dim3(1), dim3(64), 0, st, fg);
+        (void)n_loss;
+    }
+    if (d->n_resizes > 0) {
+        sm::ResizeGroup rg;
+        int max_px2 = 0, max_c = 0;
+        for (int k = 0; k < d->n_resizes; ++k) {
+            const sm_view_resize& r = d->resizes[k];
+            rg.p[k] = sm::ResizeProblem{r.src, r.dst, r.C, r.h, r.w, r.H, r.W};
+            max_px2 = r.H * r.W > max_px2 ? r.H * r.W : max_px2;
+            max_c = r.C > max_c ? r.C : max_c;
+        }
+        hipLaunchKernelGGL(sm::fmap_resize_group_kernel, dim3((max_px2 + 255) / 256, max_c, d->n_resizes), dim3(256), 0, st, rg);
+    }
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+// the cover problems of a view's lists (one per list and level), in list order
+static int view_cover_problems(const sm_view_lists_desc* d, sm_cover_problem* out, int32_t* counts_dev) {
+    int n = 0;
+    for (int s = 0; s < d->n_lists; ++s) {
+        const sm_view_list& L = d->lists[s];
+        if (L.layer < 0 || L.layer >= d->n_layers || L.group < 1 || L.out == nullptr) return -1;
+        for (int g = 0; g < d->n_levels; ++g, ++n) {
+            int pair_w = 0;
+            if (L.mode == 1) {
+                if (L.pair_layer < 0 || L.pair_layer >= d->n_layers) return -1;
+                pair_w = d->lw[g][L.pair_layer];
+            } else if (L.mode == 2) {
+                pair_w = -L.bn;
+            } else if (L.mode != 0) {
+                return -1;
+            }
+            if (out) out[n] = sm_cover_problem{d->need[g][L.layer], L.staging + (size_t)g * L.staging_cap,
+                                               counts_dev ? counts_dev + n : nullptr,
+                                               d->lh[g][L.layer], d->lw[g][L.layer], g, L.staging_cap, pair_w};
+        }
+    }
+    return n;
+}
+
+static size_t view_cover_ws_bytes(const sm_view_lists_desc* d, const sm_cover_problem* probs, int n) {
+    size_t most = 0;
+    for (int i = 0; i < n; i += SM_COVER_MAX) {
+        const size_t b = sm_cover_segments_ws_bytes(probs + i, n - i < SM_COVER_MAX ? n - i : SM_COVER_MAX);
+        most = b > most ? b : most;
+    }
+    return most;
+}
+
+size_t sm_view_lists_ws_bytes(const sm_view_lists_desc* d) {
+    if (d == nullptr || d->n_lists < 0 || d->n_lists > SM_VIEW_MAX_LISTS || d->n_levels < 1 || d->n_levels > SM_VIEW_MAX_LEVELS)
+        return 0;
+    static thread_local sm_cover_problem probs[SM_VIEW_MAX_LISTS * SM_VIEW_MAX_LEVELS];
+    const int n = view_cover_problems(d, probs, nullptr);
+    if (n < 0) return 0;
+    // [cover counts: one int per problem, 256-byte aligned][cover scratch of the largest batch]
+    return (((size_t)n * 4 + 255) & ~(size_t)255) + view_cover_ws_bytes(d, probs, n) + 256;
+}
+
+int sm_view_lists(const sm_view_lists_desc* d, void* stream) {
+    if (d == nullptr || d->n_levels < 1 || d->n_levels > SM_VIEW_MAX_LEVELS || d->n_layers < 2 ||
+        d->n_layers > SM_VIEW_MAX_LAYERS || d->n_lists < 0 || d->n_lists > SM_VIEW_MAX_LISTS || d->ws == nullptr ||
+        ((uintptr_t)d->ws & 15) || d->summary == nullptr)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    // ---- need maps: the deepest layer from its mask, then one launch per node, backwards, over all levels
+    const int last = d->n_layers - 1;
+    for (int j = last; j >= 0; --j) {
+        // j == last: need[last] = mask only (mode 0). Otherwise node j (0-based) produces layer j + 1 from node_src[j]:
+        // need[src] = step(need[j + 1]); handled when we reach layer j + 1's producer below.
+        sm::NeedGroup ng;
+        int max_px = 0;
+        int src_layer, mode;
+        if (j == last) {
+            src_layer = last;
+            mode = 0;
+        } else {
+            src_layer = d->node_src[j];
+            mode = d->node_is_pool[j] ? 2 : 1;
+            if (src_layer < 0 || src_layer > j) return (int)hipErrorInvalidValue;
+        }
+        for (int g = 0; g < d->n_levels; ++g) {
+            const int out_layer = j + 1;
+            ng.p[g] = sm::NeedProblem{mode == 0 ? nullptr : d->need[g][out_layer], d->injected[src_layer] ? d->M[g] : nullptr,
+                                      d->need[g][src_layer], mode == 0 ? 0 : d->lh[g][out_layer],
+                                      mode == 0 ? 0 : d->lw[g][out_layer], d->H[g], d->W[g], d->lh[g][src_layer],
+                                      d->lw[g][src_layer]};
+            if (ng.p[g].need_src == nullptr || (mode != 0 && ng.p[g].need_out == nullptr)) return (int)hipErrorInvalidValue;
+            const int px = d->lh[g][src_layer] * d->lw[g][src_layer];
+            max_px = px > max_px ? px : max_px;
+        }
+        ng.mode = mode;
+        hipLaunchKernelGGL(sm::need_step_group_kernel, dim3((max_px + 255) / 256, d->n_levels), dim3(256), 0, st, ng);
+    }
+    if (d->n_lists == 0) {
+        SM_LAUNCH_CHECK();
+        return 0;
+    }
+    // ---- covers of every (list, level), in batches of 64 maps, then one concatenation launch
+    static thread_local sm_cover_problem probs[SM_VIEW_MAX_LISTS * SM_VIEW_MAX_LEVELS];
+    int32_t* counts_dev = static_cast<int32_t*>(d->ws);
+    const int n = view_cover_problems(d, probs, counts_dev);
+    if (n < 0) return (int)hipErrorInvalidValue;
+    const size_t counts_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+    const size_t cover_bytes = view_cover_ws_bytes(d, probs, n);
+    if (d->ws_bytes < counts_bytes + cover_bytes) return (int)hipErrorInvalidValue;
+    void* cover_ws = static_cast<char*>(d->ws) + counts_bytes;
+    for (int i = 0; i < n; i += SM_COVER_MAX) {
+        const int nb = n - i < SM_COVER_MAX ? n - i : SM_COVER_MAX;
+        if (int e = sm_cover_segments(probs + i, nb, cover_ws, cover_bytes, stream)) return e;
+    }
+    sm::ConcatGroup cg;
+    cg.summary = d->summary;
+    cg.counts = counts_dev;
+    cg.n_levels = d->n_levels;
+    for (int s = 0; s < d->n_lists; ++s) {
+        const sm_view_list& L = d->lists[s];
+        cg.l[s] = sm::ConcatList{L.staging, L.out, L.cap, L.group, L.staging_cap, 0};
+    }
+    hipLaunchKernelGGL(sm::list_concat_kernel, dim3(d->n_lists), dim3(256), 0, st, cg);
     SM_LAUNCH_CHECK();
     return 0;
 }

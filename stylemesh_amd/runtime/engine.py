@@ -161,6 +161,17 @@ class StepEngine:
         self._wslot = 0            # slot set_view is writing (differs from _slot while the next view is being prepared)
         self._prepared = None      # (view key, slot, per-view attributes, done event) of a view prepared ahead
         self._prepare_request = None   # (batch, ready event): prepare_view to run after the next begin_step
+        self._pending_view = None      # viewplan.PendingView: a view whose read-back has not been waited for yet
+        self._view_plans = {}          # (slot, view shape, active levels) -> viewplan.ViewPlan
+        self._content_graphs, self._content_warm = {}, {}   # captured content-target passes, per content size
+        # step programs (runtime/program.py): a small step's library calls recorded once per view slot and replayed with
+        # one call. STYLEMESH_STEP_PROGRAM: 1 (default) / 0 / verify (every step runs recorded and is compared with the table)
+        self.step_programs = os.environ.get("STYLEMESH_STEP_PROGRAM", "1")
+        self._programs, self._prog_warm = {}, {}
+        self._prog_run = None          # (program, key) whose update segment the coming optimizer_step replays
+        self._prog_rec = None          # (recorder, key, index of the first update call) of a step being recorded
+        self.program_replays = 0       # diagnostics
+        self.fast_view = os.environ.get("STYLEMESH_FAST_VIEW", "1") != "0"
         self._plans = [None, None]       # scatter plan per slot
         self._slot_released = [None, None]   # event: the steps that read this slot's constants have been enqueued
         self._prep_stream = None
@@ -307,11 +318,11 @@ class StepEngine:
                 f = b.act[layer]
                 self._gram_scratch((f.C, lv.index, layer), ops.gram_workspace_slabs(f.C, f.H, f.W))
 
-    def _step_begin(self):
+    def _step_begin(self, reg=None):
         """Head of a training step, ONE launch: the regulariser loss of the current texture (from the sums of squares the
         previous update left, before this step's update overwrites them) and the zero fill of everything the step
-        accumulates into. Returns ``loss_tensors()`` with this step's ``tex_reg``."""
-        reg = torch.empty(1, device=self.device)
+        accumulates into. Returns ``loss_tensors()`` with this step's ``tex_reg`` (in ``reg``, a device float)."""
+        reg = torch.empty(1, device=self.device) if reg is None else reg
         if self._can_graph():   # the captured step carries its own fills
             ops.step_begin(self.sumsq, self._reg_loss_coef_dev, reg, None, None)
             return {"content": self.loss_buf[0:1], "style": self.loss_buf[1:2], "tex_reg": reg}
@@ -392,7 +403,7 @@ class StepEngine:
         self._mark_allocs = n
 
     VIEW_ATTRS = ("view", "view_consts", "view_tiles", "view_sig", "_scatter_plan", "_scatter_levels", "view_key",
-                  "_last_batch", "_view_flags", "_other_flags", "_union_flags", "_pending_grad_zero")
+                  "_last_batch", "_view_flags", "_other_flags", "_union_flags", "_pending_grad_zero", "_pending_view")
 
     @staticmethod
     def _batch_key(batch):
@@ -423,7 +434,7 @@ class StepEngine:
         self._scatter_plan = self._plans[slot]
         try:
             with torch.cuda.stream(st):
-                self._set_view_body(batch, None)
+                self._set_view_body(batch, None, defer=True)
                 done = torch.cuda.Event()
                 done.record(st)
             self._plans[slot] = self._scatter_plan
@@ -455,6 +466,7 @@ class StepEngine:
                 setattr(self, a, v)
             self._last_batch = batch
             self._slot = self._wslot = slot
+            self._finish_pending_view(batch)      # (the read-back of a view prepared ahead is waited for HERE)
         else:
             if prep is not None:            # a prepared view that is not the one asked for: let its launches finish first
                 main.wait_event(prep[3])    # (they share scratch with a build on this stream)
@@ -478,12 +490,171 @@ class StepEngine:
             ops.flags_or(self.touched, self._view_flags)
             self._other_flags = None   # ever-touched and not in this view: built on first use
 
-    def _set_view_body(self, batch, reducer=None):
+    def _fast_view_ok(self):
+        """The grouped per-view path (``runtime/viewplan.py``: two library calls instead of ~60 per UV level) covers the
+        default configuration; the A/B switches of the list format and dense passes keep the call-per-layer path."""
+        return (self.fast_view and self.sparse_tiles and self.deepest is not None
+                and os.environ.get("STYLEMESH_SEGMENT_LISTS", "1") != "0"
+                and os.environ.get("STYLEMESH_SEGMENT_STARTS", "free") == "free")
+
+    def _set_view_fast(self, batch, reducer=None, defer=False, active_override=None, collective=True):
+        """``_set_view_body`` through ``viewplan.ViewPlan``: same buffers, same results, two grouped library calls.
+        ``defer``: leave the read-back pending (``_finish_pending_view`` waits for it - a view prepared one ahead: at the
+        swap). ``active_override``: the levels to treat as non-empty (second pass after an empty level was found)."""
+        from .viewplan import PendingView, ViewPlan
+        cfg, dev = self.cfg, self.device
+        self._mark("start")
+        self._pending_grad_zero = None
+        rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
+        if rgb.shape[0] != 1:
+            raise ValueError("batch size 1 only (the reference's masked_features indexing requires it too)")
+        h, w = rgb.shape[2:]
+        n_levels = len(uv_map)
+        if n_levels > self.MAX_UV_LEVELS:
+            raise ValueError(f"{n_levels} UV levels: at most {self.MAX_UV_LEVELS} are supported (per-level operand bounds)")
+
+        fixed = self.use_graphs     # a captured step reads the view's inputs at fixed addresses
+
+        def stage(name, src, dt=torch.float32):
+            """The input where the kernels can read it: the batch's own tensor when it already is a contiguous device
+            tensor of the right type (the batch object is kept alive with the view), else a copy in a persistent buffer."""
+            if src.dtype == torch.bool and dt == torch.uint8:
+                src = src.view(torch.uint8)      # (same bytes: 0 / 1)
+            if not fixed and src.is_cuda and src.dtype == dt and src.is_contiguous() and src.data_ptr() % 16 == 0:
+                return src
+            dst = self._persist((name, tuple(src.shape), dt), lambda: torch.empty(src.shape, dtype=dt, device=dev))
+            dst.copy_(src, non_blocking=True)
+            return dst
+        mask_u8 = stage("mask", mask[0], torch.uint8)
+        ag, adeg = stage("ag", angle_guidance[0, 0]), stage("adeg", angle_degrees[0, 0])
+        rgb_dev = stage("rgb", rgb[0])
+        r64 = o64 = iw = None
+        if cfg.use_depth_scaling:
+            r64, o64 = stage("rounded", rounded[0, 0], torch.int64), stage("other", other[0, 0], torch.int64)
+            iw = stage("interp_w", interp_w[0, 0])
+        fixed = True       # the UV grids are read by every STEP (sampling, scatter plan): fixed addresses per slot, so that
+        grids = [stage(f"grid{i}", uv[0]) for i, uv in enumerate(uv_map)]   # a recorded step serves every view of the slot
+        level_hw = tuple(tuple(g.shape[:2]) for g in grids)
+        maps_levels = list(range(n_levels)) if cfg.use_depth_scaling else [n_levels - 1]
+        active = list(maps_levels) if active_override is None else list(active_override)
+        if len({level_hw[a] for a in active}) != len(active):
+            raise ValueError("two UV levels of the same resolution are not supported")
+        pk = (self._wslot, h, w, level_hw, tuple(active), ops.CONV_MODE, tuple(self.injected))
+        plan = self._view_plans.get(pk)
+        if plan is None:
+            plan = self._view_plans[pk] = ViewPlan(self, self._wslot, h, w, level_hw, maps_levels, active)
+        self._mark("stage+plan")
+        # content target: VGG features of the captured image at its own resolution (losses :294); resized per level inside
+        # sm_view_masks
+        if plan.content_bufs is not None:
+            ops.image_to_fmap(rgb_dev, plan.content_bufs.act["img"])
+            self._content_pass(plan.content_bufs)
+        plan.launch_masks(mask_u8, ag, adeg, r64, o64, iw)
+        levels = []
+        for i, rec in enumerate(plan.levels):
+            lv = _ViewLevel()
+            lv.grid, lv.H, lv.W, lv.index = grids[i], rec["H"], rec["W"], i
+            lv.active = i in active
+            for k in ("M", "pixel_weight", "passed"):
+                if k in rec:
+                    setattr(lv, k, rec[k])
+            if lv.active:
+                lv.masks, lv.counts, lv.factor = rec["masks"], rec["counts"], rec["factor"]
+                if "content_target" in rec:
+                    lv.content_target = rec["content_target"]
+            levels.append(lv)
+        self._mark("masks")
+        plan.launch_lists()
+        self._mark("lists")
+        self.view, self.view_consts = levels, plan.consts
+        self.view_tiles, self.view_sig = None, None
+        act = [lv for lv in levels if lv.active]
+        count_dev = None
+        if collective:        # (a second pass after an empty level keeps the union the first pass exchanged)
+            self._union_flags = None
+        if reducer is not None and collective:
+            flags = self.touch_flags(reducer.chunk_log2, levels)
+            count_dev = reducer.new_view_begin(flags)      # collective; flags = the union over the ranks, in place
+            self._union_flags = flags
+        if plan.lists_desc is not None and act:
+            from . import vgg as _vgg
+            skip = set(_vgg.POOL_OUTPUT) if (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2") else set()
+            self._pending_grad_zero = [g.buf for lv in act
+                                       for name, g in self._level_bufs(lv.H, lv.W).grad.items() if name not in skip]
+        self._scatter_levels = None
+        if self.planned_scatter and act:
+            if self._scatter_plan is None:
+                self._scatter_plan = ops.ScatterPlan(self.grads, self.arena.g)
+            self._scatter_plan.build([lv.grid for lv in act], [lv.pixel_weight for lv in act])
+            self._scatter_levels = [lv.index for lv in act]
+        self._mark("scatter_plan")
+        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
+        self._last_batch = batch
+        if self.touched is not None:
+            self._view_flags = self._persist(("view_flags", self.touched.numel()), lambda: torch.zeros_like(self.touched))
+            self._view_flags.zero_()
+            for lv in act:   # the SAMPLED footprint (no pixel weights), see _set_view_body
+                ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, None, self._view_flags, self.touched_log2)
+        self._pending_view = PendingView(plan, plan.read_back(), count_dev)
+        self._pending_view.reducer = reducer if count_dev is not None else None
+        self._mark("flags+readback")
+        if not defer:
+            self._finish_pending_view(batch)
+
+    def _content_pass(self, cb):
+        """The content target's VGG pass (losses :294): a dense forward over buffers that never move - after one eager run
+        it is captured as a hipGraph and replayed (one launch instead of ~22: 0.4 ms of host time per view change)."""
+        key = (cb.H, cb.W, ops.CONV_MODE)
+        g = self._content_graphs.get(key)
+        if (g is None and (os.environ.get("STYLEMESH_CONTENT_GRAPH", "1") == "0" or torch.cuda.is_current_stream_capturing()
+                           or (ops.CONV_TIMER is not None and ops.CONV_TIMER.enabled))):
+            return self.vgg.forward(cb)
+        if g is None:
+            if self._content_warm.get(key, 0) < 1:
+                self._content_warm[key] = 1
+                return self.vgg.forward(cb)
+            cur = torch.cuda.current_stream()
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.device)
+            cap.wait_stream(cur)
+            with torch.cuda.graph(g, stream=cap):
+                self.vgg.forward(cb)
+            cur.wait_stream(cap)
+            self._content_graphs[key] = g
+        g.replay()
+
+    def _finish_pending_view(self, batch):
+        """Wait for the read-back of the current view's preparation and apply what depends on it: the lists' lengths
+        (grid sizes), the reducer's chunk count, and the empty-level filter (model/model.py:256-257) - a level whose mask
+        turned out empty (rare) is dropped by a second, synchronous pass without it."""
+        pend, self._pending_view = self._pending_view, None
+        if pend is None:
+            return
+        tiles, msums = pend.finish()
+        plan = pend.plan
+        if pend.reducer is not None:
+            pend.reducer.new_view_end(int(pend.reducer_count))
+        empty = [a for a in plan.active if not msums[a] > 0]
+        if empty:
+            keep = [a for a in plan.active if a not in empty]
+            self._wslot = self._slot
+            self._set_view_fast(batch, pend.reducer, defer=False, active_override=keep, collective=False)
+            return
+        self.view_tiles = tiles
+        act = [lv for lv in self.view if lv.active]
+        self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in act),
+                         None if tiles is None else tuple(v[0].numel() for v in tiles.values()))
+        self._mark("finish")
+
+    def _set_view_body(self, batch, reducer=None, defer=False):
         """Per-view constants of ``batch``. ``reducer`` (multi-GPU, a ``SparseGradReducer``; only when the per-view
         collective is due at this schedule position, see ``begin_step``): the max-all-reduce of the touch flags and the
         device-side compaction of the exchange's chunk list are enqueued here, and the list's length rides the ONE host
         read-back of this function - a view change costs no additional synchronisation on N > 1."""
+        if self._fast_view_ok():
+            return self._set_view_fast(batch, reducer, defer)
         cfg = self.cfg
+        self._pending_view = None
         self._mark("start")
         self._pending_grad_zero = None
         rgb, _, _, _, _, rounded, other, interp_w, idx, uv_map, mask, angle_guidance, angle_degrees = batch
@@ -1074,6 +1245,24 @@ class StepEngine:
     def optimizer_step(self, world_size: int = 1):
         """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""
         self.step_count += 1
+        run, self._prog_run = self._prog_run, None
+        if run is not None and world_size == 1:          # the update segment of the program step_compute replayed
+            prog = run[0]
+            self._program_patch_update(prog)
+            import ctypes as C
+            from . import hip as _hip
+            rc = _hip.lib.sm_call_replay(C.byref(prog.arr, prog.n_compute * C.sizeof(_hip.Call)), prog.n - prog.n_compute,
+                                         _hip.stream(), C.byref(prog._failed))
+            if rc != 0:
+                raise RuntimeError(f"libstylemesh_hip: replayed update call failed with HIP error code {rc}")
+            self._grad_dirty = False
+            return
+        try:
+            self._optimizer_step_eager(world_size)
+        finally:
+            self._prog_end_recording(discard=(world_size != 1))
+
+    def _optimizer_step_eager(self, world_size):
         if self._can_graph():
             # The step-dependent scalars live ON THE DEVICE: a captured one-thread kernel advances {lr, step} and
             # writes {lr / bc1, 1 / sqrt(bc2)} for the update that follows it in the same graph. (Sending them through
@@ -1149,7 +1338,7 @@ class StepEngine:
         ev.record(main)
         st.wait_event(ev)
         with torch.cuda.stream(st):
-            self.sumsq.zero_()
+            ops.zero_floats(self.sumsq)
             # (no gradient pointer: these chunks hold a zero data-term gradient - nothing scatters into them during
             # this view and their last update zeroed them - so the launch moves 6 instead of 8 streams)
             ops.adam_fused(self.arena.p, None if self.early_update_skips_grad else self.arena.g, self.arena.m,
@@ -1168,7 +1357,7 @@ class StepEngine:
                            self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
                            dev_hyper=dev_hyper, touched=self._view_flags, touched_log2=self.touched_log2)
             return
-        self.sumsq.zero_()
+        ops.zero_floats(self.sumsq)
         if dev_hyper is not None:
             ops.adam_hyper_step(self._hyper_state, dev_hyper)
         touched, tl2 = self._touched_arg()
@@ -1241,7 +1430,29 @@ class StepEngine:
         req, self._prepare_request = self._prepare_request, None
         if req is not None and reducer is None:
             self.prepare_view(*req)
-        losses = self._step_begin()    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
+        out = torch.empty(3, device=self.device)    # this step's [content, style, tex_reg]: stays valid for the caller
+        self._prog_end_recording(discard=True)      # (a recording whose optimizer_step never came)
+        self._prog_run = None
+        key = self._program_key(reducer)
+        if key is not None:
+            prog = self._programs.get(key)
+            if prog is not None and self.step_programs != "verify":
+                return self._program_compute(prog, key, out)
+            if prog is not None or self._prog_warm.get(key, 0) >= 2:      # steady state: record this step
+                from .program import Recorder
+                rec = Recorder()
+                self._prog_rec = [rec, key, None, out]
+                ops.lib = rec
+            else:
+                self._prog_warm[key] = self._prog_warm.get(key, 0) + 1
+        try:
+            return self._step_compute_eager(out, reducer, exchange)
+        except BaseException:
+            self._prog_end_recording(discard=True)
+            raise
+
+    def _step_compute_eager(self, out, reducer, exchange):
+        losses = self._step_begin(out[2:3])    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         pipelined = reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph()
         if not pipelined:
             if self._can_graph() or self.early_update_at == "head":
@@ -1253,11 +1464,133 @@ class StepEngine:
             self._adam_early()
         # content / style of loss_tensors() are views of the accumulators the NEXT step zeroes: hand out this step's
         # values (one 2-float copy), so that a caller may read them any number of steps later
-        snap = self.loss_buf.clone()
-        losses["content"], losses["style"] = snap[0:1], snap[1:2]
+        ops.copy_floats(out, self.loss_buf, 2)
+        losses["content"], losses["style"] = out[0:1], out[1:2]
         if exchange and reducer is not None and not pipelined:
             self._timed("exchange", lambda: reducer(self.arena.g))
+        if self._prog_rec is not None:
+            self._prog_rec[2] = len(self._prog_rec[0].calls)      # the optimizer's calls follow
         return losses
+
+    # ------------------------------------------------------------------ step programs
+    def _program_key(self, reducer):
+        """None when this step cannot be a replayed program; else what a program's validity depends on. Programs serve the
+        SMALL steps (one 256 x 341 level: 1.1 ms of GPU work against 0.65 - 1.1 ms of interpreter + ctypes time for its
+        ~70 launches), which run on one stream: no side streams, no split update (``_overlap_pays``), no graphs, no
+        per-launch timers, one rank."""
+        if self.step_programs == "0" or reducer is not None or self.use_graphs or self.view is None or self.overlap_style:
+            return None
+        if (ops.CONV_TIMER is not None and ops.CONV_TIMER.enabled) or getattr(self, "phase_timer", None) is not None:
+            return None
+        if torch.cuda.is_current_stream_capturing() or self._pending_view is not None:
+            return None
+        active = [lv for lv in self.view if lv.active]
+        if not active or self.deepest is None or self._overlap_pays(active):
+            return None
+        grouped = (self.group_losses and float(self.cfg.loss_weights.get("style", 0.0)) != 0.0 and ops.GRAM_MODE == "split2"
+                   and self.cfg.gram_mode != "average")
+        if len(active) > 1 and not grouped:      # (per-level loss streams)
+            return None
+        empties = None if self.view_tiles is None else frozenset(k for k, v in self.view_tiles.items() if v[0].numel() == 0)
+        plan = self._scatter_plan if (self.planned_scatter and self._scatter_levels == [lv.index for lv in active]) else None
+        return (self._slot, tuple((lv.index, lv.H, lv.W) for lv in active), empties, ops.CONV_MODE, ops.GRAM_MODE,
+                None if plan is None else (id(plan), plan.sorted_in), self.sparse_update,
+                None if self.touched is None else self.touched.data_ptr(), self.cfg.gram_mode, self.sparse_tiles,
+                tuple(sorted(self.cfg.loss_weights.items())))
+
+    def _prog_end_recording(self, discard=False):
+        """Take the recorder off ``ops.lib``; unless ``discard``, turn what it noted into this key's program (or, in
+        verify mode, compare it with the program that exists)."""
+        rec_state, self._prog_rec = self._prog_rec, None
+        if rec_state is None:
+            return
+        from . import hip as _hip
+        ops.lib = _hip.lib
+        rec, key, n_compute, out = rec_state
+        if discard or n_compute is None:
+            return
+        if rec.problem is not None:
+            self._prog_warm[key] = -(1 << 30)          # never again for this key
+            return
+        from .program import StepProgram
+        prog = StepProgram(rec)
+        prog.n_compute = n_compute
+        self._program_patch_points(prog)
+        old = self._programs.get(key)
+        if old is not None and self.step_programs == "verify":
+            # the table as it would have been replayed for THIS step against what the step really issued
+            self._program_patch_step(old, out, advance=False)
+            self._program_patch_update(old)
+            a, b = old.words(), prog.words()
+            if a != b:
+                bad = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+                raise RuntimeError(f"step program diverged from the step at call {bad}: "
+                                   f"{a[bad] if bad < len(a) else None} vs {b[bad] if bad < len(b) else None}")
+            self.program_verified = getattr(self, "program_verified", 0) + 1
+            return
+        prog.view_id = id(self.view_tiles)
+        self._programs[key] = prog
+
+    def _program_patch_points(self, prog):
+        """Which argument words of a recorded step change from step to step / view to view."""
+        sb = prog.find("sm_step_begin")
+        cp = [i for i in prog.find("sm_copy_floats") if i < prog.n_compute]
+        if len(sb) != 1 or not cp:
+            raise RuntimeError("a recorded step must hold exactly one sm_step_begin and the copy of the loss pair")
+        prog.i_begin, prog.i_copy = sb[0], cp[-1]
+        prog.i_adam = [i for i in prog.find("sm_adam_fused") if i >= prog.n_compute]
+        prog.i_hist = prog.find("sm_style_loss") if self.cfg.gram_mode == "average" else []
+        # active lists: (call, index of the length word, list key) wherever a list's pointer is followed by its length
+        prog.lists = []
+        if self.view_tiles is not None:
+            by_ptr = {}
+            for k, (lst, _) in self.view_tiles.items():
+                if lst.numel():
+                    by_ptr.setdefault(lst.data_ptr(), (k, lst.numel()))
+            for i in range(prog.n):
+                c = prog.arr[i]
+                for j in range(c.n_args - 2):
+                    hit = by_ptr.get(c.args[j])
+                    if hit is not None and c.args[j + 1] == hit[1]:
+                        prog.lists.append((i, j + 1, hit[0]))
+
+    def _program_patch_step(self, prog, out, advance=True):
+        """The words of the compute segment that belong to THIS step."""
+        prog.patch(prog.i_begin, 3, out.data_ptr() + 8)
+        prog.patch(prog.i_copy, 0, out.data_ptr())
+        if prog.view_id != id(self.view_tiles):          # a new view in this slot: its lists' lengths
+            for i, j, k in prog.lists:
+                prog.patch(i, j, self.view_tiles[k][0].numel())
+            prog.view_id = id(self.view_tiles)
+        for n, i in enumerate(prog.i_hist):               # gram_mode 'average': the history ring's position
+            layer = self.cfg.style_layers[n]
+            cnt = self._hist[layer][1] - (0 if advance else 1)
+            prog.patch(i, 14, min(cnt, 9))
+            prog.patch(i, 15, cnt % 9)
+            if advance:
+                self._hist[layer][1] = cnt + 1
+
+    def _program_patch_update(self, prog):
+        from .program import double_word, float_word
+        step = self.step_count
+        for i in prog.i_adam:
+            prog.patch(i, 8, float_word(self.lr))
+            prog.patch(i, 12, double_word(1.0 - 0.9 ** step))
+            prog.patch(i, 13, double_word(1.0 - 0.999 ** step))
+
+    def _program_compute(self, prog, key, out):
+        """``step_compute`` of a step whose program exists: patch, replay the compute segment with one library call."""
+        self._program_patch_step(prog, out)
+        from . import hip as _hip
+        import ctypes as C
+        rc = _hip.lib.sm_call_replay(prog.arr, prog.n_compute, _hip.stream(), C.byref(prog._failed))
+        if rc != 0:
+            raise RuntimeError(f"libstylemesh_hip: replayed call {prog._failed.value} ({prog.names[prog._failed.value]}) "
+                               f"failed with HIP error code {rc}")
+        self._grad_dirty = True
+        self._prog_run = (prog, key)
+        self.program_replays += 1
+        return {"content": out[0:1], "style": out[1:2], "tex_reg": out[2:3]}
 
     def training_step(self, batch, world_size: int = 1, reducer=None, new_view=None, next_batch=None):
         """zero_grad -> forward_with_loss -> backward -> Adam, Lightning's automatic-optimisation order.

@@ -81,6 +81,14 @@ SIGNATURES = {
     "sm_tile_flags": [_vp, _i, _i, _i, _vp, _vp],
     "sm_cover_segments_ws_bytes": [_vp, _i],
     "sm_cover_segments": [_vp, _i, _vp, _sz, _vp],
+    "sm_call_id": [C.c_char_p],
+    "sm_call_n_args": [_i],
+    "sm_call_replay": [_vp, _i, _vp, _vp],
+    "sm_copy_floats": [_vp, _vp, _sz, _vp],
+    "sm_zero_floats": [_vp, _sz, _vp],
+    "sm_view_masks": [_vp, _vp],
+    "sm_view_lists_ws_bytes": [_vp],
+    "sm_view_lists": [_vp, _vp],
     "sm_fmap_resize_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_image_to_fmap": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
     "sm_fmap_to_image": [_vp, _i, _i, _i, _vp, _vp],
@@ -106,6 +114,15 @@ SIGNATURES = {
     "sm_comm_info": [_vp, _vp],
     "sm_device_link": [_i, _i, _vp, _vp],
 }
+
+
+# entry points that are pure host functions (sizes, layout constants, ids): no stream, nothing to replay
+PURE_HOST = {"sm_fmap_row_stride", "sm_fmap_plane", "sm_abi_version", "sm_sizeof_problem", "sm_tex_scatter_plan_temp_bytes",
+             "sm_tex_scatter_plan_cross_bytes", "sm_amax_floats", "sm_conv_tile_positions", "sm_conv_split_tile_positions",
+             "sm_conv_split2_tile_positions", "sm_plane_tile_positions", "sm_gram_num_slabs", "sm_gram_workspace_slabs",
+             "sm_gram_split_num_slabs", "sm_gram_backward_split_ws_bytes", "sm_reproject_blocks", "sm_flags_compact_ws_ints",
+             "sm_comm_unique_id_bytes", "sm_cover_segments_ws_bytes", "sm_view_lists_ws_bytes", "sm_call_id",
+             "sm_call_n_args", "sm_device_link"}
 
 
 class ConvProblem(C.Structure):
@@ -143,6 +160,61 @@ class CoverProblem(C.Structure):
     """sm_cover_problem of include/stylemesh_hip.h"""
     _fields_ = [("need", C.c_void_p), ("starts", C.c_void_p), ("count", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
                 ("tag", C.c_int), ("cap", C.c_int), ("pair_w", C.c_int)]
+
+
+VIEW_MAX_LEVELS, VIEW_MAX_LAYERS, VIEW_MAX_LISTS = 8, 24, 48
+
+
+class ViewLevel(C.Structure):
+    """sm_view_level of include/stylemesh_hip.h"""
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("has_maps", C.c_int), ("M", C.c_void_p), ("pixel_weight", C.c_void_p),
+                ("passed", C.c_void_p), ("m_sum", C.c_void_p)]
+
+
+class ViewLayerMask(C.Structure):
+    """sm_view_layer_mask"""
+    _fields_ = [("level", C.c_int), ("loss_layer", C.c_int), ("hl", C.c_int), ("wl", C.c_int), ("mask_planes", C.c_void_p),
+                ("counts", C.c_void_p), ("factor", C.c_void_p)]
+
+
+class ViewResize(C.Structure):
+    """sm_view_resize"""
+    _fields_ = [("src", C.c_void_p), ("C", C.c_int), ("h", C.c_int), ("w", C.c_int), ("dst", C.c_void_p), ("H", C.c_int),
+                ("W", C.c_int)]
+
+
+class ViewMasksDesc(C.Structure):
+    """sm_view_masks_desc"""
+    _fields_ = [("mask", C.c_void_p), ("angle_guidance", C.c_void_p), ("angle_degrees", C.c_void_p), ("rounded", C.c_void_p),
+                ("other", C.c_void_p), ("interp_w", C.c_void_p), ("h", C.c_int), ("w", C.c_int), ("angle_threshold", C.c_float),
+                ("E", C.c_void_p), ("Wt", C.c_void_p), ("n_levels", C.c_int), ("levels", ViewLevel * VIEW_MAX_LEVELS),
+                ("n_masks", C.c_int), ("masks", C.POINTER(ViewLayerMask)), ("n_resizes", C.c_int),
+                ("resizes", C.POINTER(ViewResize))]
+
+
+class ViewList(C.Structure):
+    """sm_view_list"""
+    _fields_ = [("layer", C.c_int), ("mode", C.c_int), ("bn", C.c_int), ("pair_layer", C.c_int), ("group", C.c_int),
+                ("out", C.c_void_p), ("cap", C.c_int), ("staging", C.c_void_p), ("staging_cap", C.c_int)]
+
+
+class ViewListsDesc(C.Structure):
+    """sm_view_lists_desc"""
+    _fields_ = [("n_levels", C.c_int), ("M", C.c_void_p * VIEW_MAX_LEVELS), ("H", C.c_int * VIEW_MAX_LEVELS),
+                ("W", C.c_int * VIEW_MAX_LEVELS), ("n_layers", C.c_int), ("node_is_pool", C.c_int * VIEW_MAX_LAYERS),
+                ("node_src", C.c_int * VIEW_MAX_LAYERS), ("injected", C.c_int * VIEW_MAX_LAYERS),
+                ("need", (C.c_void_p * VIEW_MAX_LAYERS) * VIEW_MAX_LEVELS), ("lh", (C.c_int * VIEW_MAX_LAYERS) * VIEW_MAX_LEVELS),
+                ("lw", (C.c_int * VIEW_MAX_LAYERS) * VIEW_MAX_LEVELS), ("n_lists", C.c_int), ("lists", C.POINTER(ViewList)),
+                ("summary", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+CALL_MAX_ARGS = 24
+
+
+class Call(C.Structure):
+    """sm_call of include/stylemesh_hip.h"""
+    _fields_ = [("fn", C.c_int), ("n_args", C.c_int), ("skip", C.c_int), ("reserved", C.c_int),
+                ("args", C.c_uint64 * CALL_MAX_ARGS)]
 
 
 class PlaneProblem(C.Structure):

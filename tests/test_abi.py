@@ -36,7 +36,8 @@ def test_problem_struct_layouts_match_the_library():
     """The ctypes mirrors of the header's problem structs have the sizes the library was compiled with."""
     from stylemesh_amd.runtime import hip
     for which, kind in enumerate((hip.ConvProblem, hip.PlaneProblem, hip.GramProblem, hip.StyleProblem, hip.GramBwdProblem,
-                                  hip.CoverProblem)):
+                                  hip.CoverProblem, hip.ViewMasksDesc, hip.ViewLayerMask, hip.ViewResize,
+                                  hip.ViewListsDesc, hip.ViewList, hip.Call)):
         assert hip.lib.sm_sizeof_problem(which) == ctypes.sizeof(kind), kind.__name__
     assert hip.lib.sm_sizeof_problem(99) == -1
 

@@ -128,6 +128,99 @@ def test_cover_segments_respects_the_capacity():
     assert np.array_equal(starts.cpu().numpy(), ref[:10]) and guard.numel() == 10
 
 
+def _views_multi(seeds, view_hw=(48, 64), level_hw=((24, 32), (36, 48), (48, 64))):
+    from stylemesh_amd.data import synthetic as S
+    room = S.BoxRoom((12.0, 9.0, 3.0))
+    dev = torch.device("cuda")
+    out = []
+    for s in seeds:
+        v = S.make_view(s, view_hw=view_hw, level_hw=list(level_hw), level_heights=[h for h, _ in level_hw],
+                        min_pyramid_depth=0.25, room=room)
+        out.append(tuple([u.to(dev) for u in x] if isinstance(x, list) else (x.to(dev) if torch.is_tensor(x) and i != 8 else x)
+                         for i, x in enumerate(v)))
+    return out
+
+
+@pytest.mark.parametrize("flags", [dict(mode="multi", angle=True, depth=True, thr=30.0),
+                                   dict(mode="single", angle=False, depth=False, thr=3000.0),
+                                   dict(mode="multi", angle=True, depth=False, thr=30.0)])
+@pytest.mark.parametrize("conv_mode", ["split2", "f32"])
+def test_grouped_view_preparation_equals_the_call_per_layer_path(flags, conv_mode, monkeypatch):
+    """``viewplan.ViewPlan`` (sm_view_masks + sm_view_lists) against ``_set_view_body``'s call-per-layer path: the same
+    level maps, layer masks, counts, factors, content targets and - entry for entry - the same active lists."""
+    require_gpu()
+    from stylemesh_amd.data import synthetic as S
+    from stylemesh_amd.runtime import ops
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    monkeypatch.setattr(ops, "CONV_MODE", conv_mode)
+    monkeypatch.setattr(ops, "GRAM_MODE", conv_mode)
+    views = _views_multi((2, 6, 9, 0))
+
+    def engine(fast):
+        cfg = EngineConfig(tex_w=512, tex_h=512, hierarchical=True, n_layers=4, style_weights=[1000., 1000., 10., 10., 1000.],
+                           angle_threshold=flags["thr"], style_pyramid_mode=flags["mode"], use_angle_weight=flags["angle"],
+                           use_depth_scaling=flags["depth"], loss_weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3},
+                           learning_rate=1.0)
+        e = StepEngine(cfg, S.seeded_vgg_state(0))
+        e.set_style_image(S.style_image(1, 96, 80))
+        e.fast_view = fast
+        return e
+    a, b = engine(True), engine(False)
+    for v in views:
+        a.set_view(v)
+        b.set_view(v)
+        assert a._pending_view is None and a.view_tiles is not None
+        assert [lv.active for lv in a.view] == [lv.active for lv in b.view]
+        assert set(a.view_tiles) == set(b.view_tiles)
+        for key in b.view_tiles:
+            la, fa = a.view_tiles[key]
+            lb, fb = b.view_tiles[key]
+            assert torch.equal(la, lb), key
+            assert abs(fa - fb) < 1e-12, key
+        assert torch.equal(a.view_consts, b.view_consts)
+        for la, lb in zip(a.view, b.view):
+            if not lb.active:
+                continue
+            assert torch.equal(la.M, lb.M) and torch.equal(la.passed, lb.passed)
+            if lb.pixel_weight is not None:
+                assert torch.equal(la.pixel_weight, lb.pixel_weight)
+            for layer in b.loss_layers:
+                assert torch.equal(la.masks[layer].planes, lb.masks[layer].planes), layer
+            for layer in b.cfg.content_layers:
+                assert torch.equal(la.content_target[layer].planes, lb.content_target[layer].planes)
+        # and a training step on top of it gives the same losses
+        np.testing.assert_allclose(a.losses(a.training_step(v))["total"], b.losses(b.training_step(v))["total"], rtol=1e-5)
+    # (not bit for bit: the Gram kernels add their position ranges with fp32 atomics, two runs of ONE path differ too)
+    err = (a.arena.p - b.arena.p).abs()
+    assert float((err > 1e-4).float().mean()) < 5e-3, float(err.max())
+
+
+def test_empty_level_found_at_the_read_back_is_dropped(monkeypatch):
+    """A level whose mask is empty (model/model.py:256-257) is only known after the read-back: the grouped path redoes
+    the view without it, as the call-per-layer path does."""
+    require_gpu()
+    from stylemesh_amd.data import synthetic as S
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    v = list(_views_multi((2,))[0])
+    # send every pixel to depth level 2: levels 0 and 1 end up empty
+    v[5] = torch.full_like(v[5], 2)
+    v[6] = torch.full_like(v[6], 2)
+    v = tuple(v)
+    res = []
+    for fast in (True, False):
+        cfg = EngineConfig(tex_w=256, tex_h=256, hierarchical=True, n_layers=4, style_weights=[1000., 1000., 10., 10., 1000.],
+                           angle_threshold=30.0, style_pyramid_mode="multi", loss_weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3})
+        e = StepEngine(cfg, S.seeded_vgg_state(0))
+        e.set_style_image(S.style_image(1, 96, 80))
+        e.fast_view = fast
+        res.append((e, e.losses(e.training_step(v))))
+    (a, la), (b, lb) = res
+    assert [lv.active for lv in a.view] == [lv.active for lv in b.view] == [False, False, True]
+    np.testing.assert_allclose(la["total"], lb["total"], rtol=1e-5)
+    err = (a.arena.p - b.arena.p).abs()
+    assert float((err > 1e-4).float().mean()) < 5e-3, float(err.max())
+
+
 def _dip_engine(n_layers=1):
     from stylemesh_amd.data import synthetic as S
     from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
@@ -187,3 +280,97 @@ def test_step_compute_twice_without_optimizer_step_raises():
         pytest.skip("the split update did not run on this view (nothing outside the view has been touched yet)")
     with pytest.raises(RuntimeError, match="optimizer_step"):
         eng.step_compute(v)
+
+
+PROGRAM_CASES = {
+    "only2D": dict(mode="single", angle=False, depth=False, thr=3000.0, gram_mode="current", n_layers=4, rep=5,
+                   weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3}),
+    "with_angle": dict(mode="multi", angle=True, depth=False, thr=30.0, gram_mode="current", n_layers=4, rep=5,
+                       weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3}),
+    "dip": dict(mode="single", angle=False, depth=False, thr=3000.0, gram_mode="average", n_layers=1, rep=1,
+                weights={"content": 7e1, "style": 1e-3, "tex_reg": 0.0}),
+}
+
+
+def _program_engine(c, programs):
+    from stylemesh_amd.data import synthetic as S
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    cfg = EngineConfig(tex_w=512, tex_h=512, hierarchical=True, n_layers=c["n_layers"], style_weights=[1000., 1000., 10., 10., 1000.],
+                       angle_threshold=c["thr"], style_pyramid_mode=c["mode"], gram_mode=c["gram_mode"],
+                       use_angle_weight=c["angle"], use_depth_scaling=c["depth"], loss_weights=dict(c["weights"]),
+                       learning_rate=1.0, decay_step_size=3)
+    e = StepEngine(cfg, S.seeded_vgg_state(0))
+    e.set_style_image(S.style_image(1, 96, 80))
+    e.overlap_min_pixels = 1 << 30       # a small step: one stream, no split update - the regime programs serve
+    e.step_programs = programs
+    return e
+
+
+@pytest.mark.parametrize("name", list(PROGRAM_CASES))
+@pytest.mark.parametrize("conv_mode", ["split2", "f32"])
+def test_replayed_step_program_equals_the_eager_step(name, conv_mode, monkeypatch):
+    """``sm_call_replay`` of a recorded step (runtime/program.py) against the same schedule issued call by call: same
+    losses at every step, same texture - over view changes (new list lengths in both view slots), the optimizer's
+    changing scalars, StepLR epochs and, for the dip flags, the Gram history's ring position. A third engine runs in
+    'verify' mode: every step is recorded again and compared WORD BY WORD with what the program would have issued."""
+    require_gpu()
+    from stylemesh_amd.runtime import ops
+    monkeypatch.setattr(ops, "CONV_MODE", conv_mode)
+    monkeypatch.setattr(ops, "GRAM_MODE", conv_mode)
+    c = PROGRAM_CASES[name]
+    views = _small_views((0, 2, 6, 7, 9, 11, 12, 14))
+    rep = c["rep"]
+    n_steps = 40 if rep > 1 else 30
+    sched = [views[(i // rep) % len(views)] for i in range(n_steps)]
+    a, b, v = _program_engine(c, "1"), _program_engine(c, "0"), _program_engine(c, "verify")
+    worst = worst_tex = 0.0
+    for i, batch in enumerate(sched):
+        if i == n_steps // 2:
+            for e in (a, b, v):
+                e.end_epoch(); e.end_epoch(); e.end_epoch()           # StepLR: the learning rate drops
+        nxt = sched[i + 1] if (rep == 1 and i + 1 < n_steps) else None
+        if rep > 1 and i % rep == 1 and i - 1 + rep < n_steps:
+            for e in (a, b, v):
+                e.prepare_view(sched[i - 1 + rep])
+        # LOCK-STEP: every step starts from the eager engine's state (free-running engines at lr 1 drift apart chaotically
+        # - two eager runs of this schedule differ by 5e-3 in the loss after 40 steps), so each step's own result is compared
+        for e in (a, v):
+            for dst, src in ((e.arena.p, b.arena.p), (e.arena.m, b.arena.m), (e.arena.v, b.arena.v), (e.sumsq, b.sumsq)):
+                dst.copy_(src)
+            if e.touched is not None:
+                e.touched.copy_(b.touched)
+        la = a.losses(a.training_step(batch, next_batch=nxt))
+        lb = b.losses(b.training_step(batch, next_batch=nxt))
+        v.training_step(batch, next_batch=nxt)
+        worst = max(worst, abs(la["total"] - lb["total"]) / abs(lb["total"]))
+        np.testing.assert_allclose(la["total"], lb["total"], rtol=1e-5, err_msg=f"step {i}")
+        err = (a.arena.p - b.arena.p).abs()
+        frac = float((err > 2e-3).float().mean())
+        worst_tex = max(worst_tex, frac)
+        assert frac < 0.01, (i, frac, float(err.max()))
+    print(f"\n[{name} {conv_mode}] lock-step: worst loss deviation replayed vs eager {worst:.2e}, worst fraction of texels "
+          f"beyond 2e-3 after a step {worst_tex:.2e}, replays {a.program_replays}, verified {getattr(v, 'program_verified', 0)}")
+    assert a.program_replays >= n_steps // 2, a.program_replays
+    assert b.program_replays == 0 and getattr(v, "program_verified", 0) >= n_steps // 3
+    assert a.step_count == b.step_count == n_steps
+
+
+def test_step_program_through_step_compute_and_optimizer_step():
+    """The Lightning-shaped caller closes the step itself (``FusedTextureAdam.step`` -> ``optimizer_step``): the program's
+    two segments are replayed by the two calls."""
+    require_gpu()
+    c = PROGRAM_CASES["only2D"]
+    views = _small_views((0, 2))
+    a, b = _program_engine(c, "1"), _program_engine(c, "0")
+    for i in range(12):
+        batch = views[i // 6]
+        for dst, src in ((a.arena.p, b.arena.p), (a.arena.m, b.arena.m), (a.arena.v, b.arena.v), (a.sumsq, b.sumsq)):
+            dst.copy_(src)             # lock-step (see the test above)
+        if a.touched is not None:
+            a.touched.copy_(b.touched)
+        la = a.step_compute(batch)
+        a.optimizer_step()
+        lb = b.step_compute(batch)
+        b.optimizer_step()
+        np.testing.assert_allclose(a.losses(la)["total"], b.losses(lb)["total"], rtol=1e-5)
+    assert a.program_replays >= 6
