@@ -409,7 +409,7 @@ class StepEngine:
     def _batch_key(batch):
         return int(batch[8][0]) if torch.is_tensor(batch[8]) else batch[8]
 
-    def prepare_view(self, batch, ready_event=None):
+    def prepare_view(self, batch, ready_event=None, urgent=False):
         """Compute the per-view constants of the NEXT view ahead of its first step, on a side stream, into the other
         buffer slot, while the current view's steps run: ``set_view`` of that view then only waits for an event and swaps
         the slot in. A view change costs 1.6 ms (single level) to 4.6 ms (four levels) of GPU work plus a host read-back
@@ -425,6 +425,15 @@ class StepEngine:
             self._prep_stream = self._new_side_stream()
         slot = 1 - self._slot
         st = self._prep_stream
+        if urgent and os.environ.get("STYLEMESH_URGENT_PREPARE", "1") != "0":
+            # The view is needed by the very NEXT step (index_repeat 1): its read-back must arrive while the current step
+            # still runs, or the GPU idles while the host enqueues the next one. On a stream of the trunk's priority the
+            # preparation's small kernels are dispatched beside the step's instead of behind them.
+            if getattr(self, "_prep_stream_hi", None) is None:
+                self._prep_stream_hi = torch.cuda.Stream(device=self.device, priority=-1)
+            st = self._prep_stream_hi
+            if getattr(self, "_prep_last", None) is not None:
+                st.wait_event(self._prep_last)       # (the two preparation streams share scratch)
         if self._slot_released[slot] is not None:      # the steps of the view that used this slot are behind this point
             st.wait_event(self._slot_released[slot])
         if ready_event is not None:
@@ -438,6 +447,7 @@ class StepEngine:
                 done = torch.cuda.Event()
                 done.record(st)
             self._plans[slot] = self._scatter_plan
+            self._prep_last = done
             self._prepared = (key, slot, {a: getattr(self, a, None) for a in self.VIEW_ATTRS}, done)
         finally:
             self._wslot = self._slot
@@ -900,7 +910,10 @@ class StepEngine:
             #     right after their layer's forward conv;
             #   * the other style layers fork when the forward pass is done, deepest first - the order the backward pass
             #     needs them in.
-            grouped = self.group_losses and style_on and ops.GRAM_MODE == "split2" and cfg.gram_mode != "average"
+            # (gram_mode 'average' keeps ONE history per style layer that the levels' Grams enter one after the other,
+            # content_and_style_losses.py:319-323: the grouped launch serves it for a single level - every dip script)
+            grouped = (self.group_losses and style_on and ops.GRAM_MODE == "split2"
+                       and (cfg.gram_mode != "average" or len(active) == 1))
             self._gram_fused = {}   # style layers whose Gram backward this step's data-gradient convs take (EPI_GRAM)
             # (only for steps long enough to pay for the extra events and stream switches on the host: a single
             # 256 x 341 level is host-bound, its step 3 % slower with them)
@@ -1081,8 +1094,12 @@ class StepEngine:
                         ws = self._gram_bwd_ws[key] = torch.empty(ops.gram_backward_ws_bytes(f.C), dtype=torch.uint8,
                                                                   device=self.device)
                     fwd.append(ops.gram_problem(f, m0, m1, S0, S1, af))
-                    sty.append(ops.style_problem(S0, S1, counts, lv.factor[layer], targets, term_mask, skip, weight, f.C,
-                                                 D0, D1, ad))
+                    sp = ops.style_problem(S0, S1, counts, lv.factor[layer], targets, term_mask, skip, weight, f.C, D0, D1, ad)
+                    if cfg.gram_mode == "average":     # the layer's ring of 9 detached previous Grams (position set per step)
+                        if layer not in self._hist:
+                            self._hist[layer] = [torch.zeros(9, f.C, f.C, device=self.device), 0]
+                        sp.history = self._hist[layer][0].data_ptr()
+                    sty.append(sp)
                     # the deepest layer's gradient starts the backward pass: its bound is recorded here (unless a
                     # content term also writes that buffer)
                     rec = layer == self.deepest and layer not in cfg.content_layers and ops.CONV_MODE == "split2"
@@ -1102,8 +1119,19 @@ class StepEngine:
         assert all(k in self._gram_clean for k in keys), "Gram slabs must be zero on entry"
         ops.gram_masked_grouped(fwd)
         self._gram_clean.difference_update(keys)
+        if cfg.gram_mode == "average":
+            self._advance_history(sty, layers)
         ops.style_loss_grouped(sty, self.loss_buf[1:2])
         ops.gram_backward_grouped(bwd)
+
+    def _advance_history(self, sty, layers, advance=True):
+        """gram_mode 'average', one level: this step's position in every style layer's history ring, written into the
+        (cached, host-side) problem table the grouped style-loss launch reads."""
+        for p, layer in zip(sty, layers):
+            cnt = self._hist[layer][1] - (0 if advance else 1)
+            p.hist_len, p.hist_slot = min(cnt, 9), cnt % 9
+            if advance:
+                self._hist[layer][1] = cnt + 1
 
     def _inject_losses(self, lv, b, w_style, w_content, keep=None, only_layers=None, am=None):
         """Loss values into ``loss_buf`` and loss gradients w.r.t. the VGG activations into ``b.grad`` (the deepest
@@ -1428,8 +1456,10 @@ class StepEngine:
                                "disables the split)")
         self.begin_step(batch, reducer, new_view)
         req, self._prepare_request = self._prepare_request, None
+        self._steps_on_view = getattr(self, "_steps_on_view", 0) + 1
         if req is not None and reducer is None:
-            self.prepare_view(*req)
+            # (urgent: the schedule changes the view every step - the view before this one lasted a single step)
+            self.prepare_view(*req, urgent=getattr(self, "_last_view_steps", 0) == 1)
         out = torch.empty(3, device=self.device)    # this step's [content, style, tex_reg]: stays valid for the caller
         self._prog_end_recording(discard=True)      # (a recording whose optimizer_step never came)
         self._prog_run = None
@@ -1488,7 +1518,7 @@ class StepEngine:
         if not active or self.deepest is None or self._overlap_pays(active):
             return None
         grouped = (self.group_losses and float(self.cfg.loss_weights.get("style", 0.0)) != 0.0 and ops.GRAM_MODE == "split2"
-                   and self.cfg.gram_mode != "average")
+                   and (self.cfg.gram_mode != "average" or len(active) == 1))
         if len(active) > 1 and not grouped:      # (per-level loss streams)
             return None
         empties = None if self.view_tiles is None else frozenset(k for k, v in self.view_tiles.items() if v[0].numel() == 0)
@@ -1540,6 +1570,10 @@ class StepEngine:
         prog.i_begin, prog.i_copy = sb[0], cp[-1]
         prog.i_adam = [i for i in prog.find("sm_adam_fused") if i >= prog.n_compute]
         prog.i_hist = prog.find("sm_style_loss") if self.cfg.gram_mode == "average" else []
+        # (grouped loss phase: the ring positions are fields of the style-loss launch's problem table - a host array the
+        # program keeps and the library reads at replay time)
+        prog.hist_tables = [(prog.host[(i, 0)], prog.word(i, 1)) for i in prog.find("sm_style_loss_grouped")
+                            if self.cfg.gram_mode == "average" and (i, 0) in prog.host]
         # active lists: (call, index of the length word, list key) wherever a list's pointer is followed by its length
         prog.lists = []
         if self.view_tiles is not None:
@@ -1562,6 +1596,17 @@ class StepEngine:
             for i, j, k in prog.lists:
                 prog.patch(i, j, self.view_tiles[k][0].numel())
             prog.view_id = id(self.view_tiles)
+        for table, n_prob in prog.hist_tables:
+            # one level: problem k of a launch = style layer k of the launch's layers; every style layer is in one launch
+            done = getattr(prog, "_hist_layers", None)
+            if done is None:
+                starts, k0 = [], 0
+                for t, n in prog.hist_tables:
+                    starts.append(k0)
+                    k0 += n
+                order = self._program_hist_order()
+                prog._hist_layers = done = {id(t): order[s0:s0 + n] for (t, n), s0 in zip(prog.hist_tables, starts)}
+            self._advance_history([table[k] for k in range(n_prob)], done[id(table)], advance)
         for n, i in enumerate(prog.i_hist):               # gram_mode 'average': the history ring's position
             layer = self.cfg.style_layers[n]
             cnt = self._hist[layer][1] - (0 if advance else 1)
@@ -1569,6 +1614,11 @@ class StepEngine:
             prog.patch(i, 15, cnt % 9)
             if advance:
                 self._hist[layer][1] = cnt + 1
+
+    def _program_hist_order(self):
+        """Style layers in the order the grouped loss phase of a single-stream step launches their branches."""
+        cfg = self.cfg
+        return [l for l in cfg.style_layers]
 
     def _program_patch_update(self, prog):
         from .program import double_word, float_word
@@ -1636,6 +1686,7 @@ class StepEngine:
         if changed:
             import time
             t0 = time.perf_counter()
+            self._last_view_steps, self._steps_on_view = getattr(self, "_steps_on_view", 0), 0
             self.set_view(batch, reducer if in_set_view else None)
             self.set_view_host_s = getattr(self, "set_view_host_s", 0.0) + time.perf_counter() - t0   # diagnostics
             self.set_view_calls = getattr(self, "set_view_calls", 0) + 1
