@@ -54,6 +54,8 @@ def resolve_vgg_path(path: str) -> str:
 
 
 def main(args):
+    from ..runtime.hostcpu import limit_host_threads
+    limit_host_threads()      # (the visible core count is not what the container may use: see runtime/hostcpu.py)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)

@@ -140,6 +140,9 @@ class MiniTrainer:
             pass
         model.world_size = self.world_size
         self._model = model
+        if self.device != "cpu":
+            from .runtime.hostcpu import limit_host_threads
+            limit_host_threads()
         if hasattr(model, "_ensure_engine"):
             model.fused_backward_done = True   # training_step's gradients are final: no autograd pass over its scalar
         if hasattr(model, "to") and self.device != "cpu":
