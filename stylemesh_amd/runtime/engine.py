@@ -1524,7 +1524,8 @@ class StepEngine:
         empties = None if self.view_tiles is None else frozenset(k for k, v in self.view_tiles.items() if v[0].numel() == 0)
         plan = self._scatter_plan if (self.planned_scatter and self._scatter_levels == [lv.index for lv in active]) else None
         return (self._slot, tuple((lv.index, lv.H, lv.W) for lv in active), empties, ops.CONV_MODE, ops.GRAM_MODE,
-                None if plan is None else (id(plan), plan.sorted_in), self.sparse_update,
+                None if plan is None else (id(plan), plan.sorted_in, plan.generation, plan.n_entries), self.sparse_update,
+                None if self._gram_arena is None else self._gram_arena.data_ptr(),
                 None if self.touched is None else self.touched.data_ptr(), self.cfg.gram_mode, self.sparse_tiles,
                 tuple(sorted(self.cfg.loss_weights.items())))
 

@@ -147,6 +147,9 @@ class ScatterPlan:
         self.lh = hip.int_array([l.shape[1] for l in grad_layers])
         self.n_entries = 0
         self.bufs = None
+        self.capacity = 0
+        self.packed = None
+        self.generation = 0      # bumped whenever a buffer moves
         self.sorted_in = 0
         self.level_hw = None
 
@@ -155,15 +158,22 @@ class ScatterPlan:
         dev = self.arena.device
         hw = [(g.shape[-3], g.shape[-2]) for g in grids]
         n = 4 * len(self.grad_layers) * sum(h * w for h, w in hw)
-        if self.bufs is None or self.n_entries != n:
+        # GROW-ONLY buffers: the views of a scene do not all populate the same UV levels, so n changes from view to view.
+        # Re-allocating on every change would move the buffers under everything that holds their addresses (a recorded
+        # step program, runtime/program.py) - and did: a replayed scatter wrote its chunk sums into freed memory.
+        if self.bufs is None or self.capacity < n:
             tb = lib.sm_tex_scatter_plan_temp_bytes(n, self.key_bits)
             self.bufs = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
                          torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.int64, device=dev),
                          torch.empty(max(tb, 16), dtype=torch.uint8, device=dev),
                          torch.empty(lib.sm_tex_scatter_plan_cross_bytes(n), dtype=torch.uint8, device=dev))
-            self.n_entries = n
-        if self.level_hw != hw:
-            self.packed = torch.empty(4 * sum(hip.plane(h, w) for h, w in hw), device=dev)
+            self.capacity = n
+            self.generation += 1
+        self.n_entries = n
+        planes = 4 * sum(hip.plane(h, w) for h, w in hw)
+        if self.packed is None or self.packed.numel() < planes:
+            self.packed = torch.empty(planes, device=dev)
+            self.generation += 1
         self.level_hw = hw
         k0, k1, v0, v1, tmp, cross = self.bufs
         which = C.c_int(0)

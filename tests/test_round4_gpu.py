@@ -289,6 +289,10 @@ PROGRAM_CASES = {
                        weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3}),
     "dip": dict(mode="single", angle=False, depth=False, thr=3000.0, gram_mode="average", n_layers=1, rep=1,
                 weights={"content": 7e1, "style": 1e-3, "tex_reg": 0.0}),
+    # several UV levels whose ACTIVE set changes from view to view (an empty level is dropped): programs of different level
+    # sets alternate in one slot, and every buffer whose size follows the level set must stay where it was recorded
+    "multi_level": dict(mode="multi", angle=True, depth=True, thr=30.0, gram_mode="current", n_layers=4, rep=3, levels=True,
+                        weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3}),
 }
 
 
@@ -318,7 +322,16 @@ def test_replayed_step_program_equals_the_eager_step(name, conv_mode, monkeypatc
     monkeypatch.setattr(ops, "CONV_MODE", conv_mode)
     monkeypatch.setattr(ops, "GRAM_MODE", conv_mode)
     c = PROGRAM_CASES[name]
-    views = _small_views((0, 2, 6, 7, 9, 11, 12, 14))
+    if c.get("levels"):
+        views = []
+        for k, v in enumerate(_views_multi((0, 2, 6, 7, 9, 11, 12, 14))):
+            if k % 3 == 1:       # every third view: all pixels on depth level 2 - levels 0 and 1 are empty
+                v = list(v)
+                v[5], v[6] = torch.full_like(v[5], 2), torch.full_like(v[6], 2)
+                v = tuple(v)
+            views.append(v)
+    else:
+        views = _small_views((0, 2, 6, 7, 9, 11, 12, 14))
     rep = c["rep"]
     n_steps = 40 if rep > 1 else 30
     sched = [views[(i // rep) % len(views)] for i in range(n_steps)]

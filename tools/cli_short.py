@@ -7,6 +7,10 @@ import run_schedule as RS
 from stylemesh_amd.model import optimize as OPT
 
 if __name__ == "__main__":
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get("DUMP_AFTER"):
+        faulthandler.dump_traceback_later(int(os.environ["DUMP_AFTER"]), exit=True)
     wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
     views = int(sys.argv[2]) if len(sys.argv) > 2 else 41
     epochs = sys.argv[3] if len(sys.argv) > 3 else "2"
