@@ -275,6 +275,24 @@ __device__ __forceinline__ float block_sum(float v) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+#ifndef SM_ADAM_UNROLL
+#define SM_ADAM_UNROLL 1        // tiles whose loads are in flight together. Measured in round 4 (profiles/r04/
+                                // adam_variants.txt, 66.8 M floats, dense / 40 % / 16 % flagged): U = 1 432 / 199 / 78 us
+                                // (4.34 TB/s dense), U = 2 450 / 198 / 83, U = 4 443 / 226 / 98, U = 8 587 / 329 / 158,
+                                // U = 4 + non-temporal stores 429 / 211 / 96: the 8-stream update is not latency-bound -
+                                // more loads in flight per thread only cost occupancy; it stays at 1
+#endif
+#ifndef SM_ADAM_NT
+#define SM_ADAM_NT 0            // 1: non-temporal stores of p / m / v / zeroed g (A/B switch)
+#endif
+__device__ __forceinline__ void adam_store4(float* dst, const float* src) {
+#if SM_ADAM_NT
+    __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst));
+#else
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+#endif
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, Segs segs, float lr_over_bc1,
@@ -291,88 +309,110 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     // A block walks tiles_per_block consecutive tiles of 1024 elements and keeps sum(p^2) of the segment it is in in
     // registers: one atomic per block and segment instead of one per tile - tens of thousands of atomics on the same
     // few addresses serialise (~2 ns each) and cost more than the kernel's HBM time.
+    // Round 4: the walk can go U tiles at a time - first the U flags, then the 4 U vector loads, then the arithmetic and
+    // the stores tile by tile, in the same order as before (bit-identical sums). Built to test whether the update is
+    // bound by loads in flight: it is not (see SM_ADAM_UNROLL) - U stays 1.
+    constexpr int U = SM_ADAM_UNROLL;
     const size_t tile0 = (size_t)blockIdx.x * tiles_per_block;
     int k_cur = seg_of(segs, tile0 * 1024);
     float sq = 0.f;
-    for (int t = 0; t < tiles_per_block; ++t) {
-    const size_t tile = tile0 + t;
-    if (tile * 1024 >= n) break;
-    const size_t i0 = (tile * 256 + threadIdx.x) * 4;
-    // Ever-touched chunks (zero-initialised textures): a texel no view has ever reached has p = g = m = v = 0, so its
-    // regulariser gradient, its update and its contribution to sum(p^2) are exactly zero - the chunk is skipped
-    // without being read. (A chunk is 2^touched_log2 >= 4 floats: a thread's four elements share one flag.)
-    const bool live = !ADAM || touched == nullptr || (i0 < n && touched[i0 >> touched_log2] != 0);
-    // a tile almost always lies inside one segment (k_blk); elements of a tile that straddles a boundary and belong
-    // to another segment are added one by one.
-    const int k_blk = seg_of(segs, tile * 1024);
-    if (k_blk != k_cur) {   // block-uniform
-        if (sumsq) {
-            __syncthreads();
-            const float s = block_sum(sq);
-            if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_cur, s);
+    for (int t0 = 0; t0 < tiles_per_block; t0 += U) {
+        size_t i0s[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t tile = tile0 + t0 + u;
+            i0s[u] = (tile * 256 + threadIdx.x) * 4;
+            const bool in = t0 + u < tiles_per_block && i0s[u] < n;
+            // Ever-touched chunks (zero-initialised textures): a texel no view has ever reached has p = g = m = v = 0, so
+            // its regulariser gradient, its update and its contribution to sum(p^2) are exactly zero - the chunk is
+            // skipped without being read. (A chunk is 2^touched_log2 >= 4 floats: a thread's four elements share one flag.)
+            act[u] = in && (!ADAM || touched == nullptr || touched[i0s[u] >> touched_log2] != 0);
         }
-        sq = 0.f;
-        k_cur = k_blk;
-    }
-    if (i0 < n && live) {
-        const bool full = i0 + 4 <= n;
-        float pv[4], gv[4], mv[4], vv[4];
-        if (full) {
-            *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
-            if (ADAM) {
-                // g == NULL: the data-term gradient is known to be zero wherever this launch walks (the early half of
-                // the split update) - neither read nor zeroed: 6 instead of 8 streams
-                *reinterpret_cast<float4*>(gv) = g ? *reinterpret_cast<const float4*>(g + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
-                *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
-            }
-        } else {
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = i0 + j < n;
-                pv[j] = ok ? p[i0 + j] : 0.f;
+        float pv[U][4], gv[U][4], mv[U][4], vv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i0 = i0s[u];
+            if (!act[u]) continue;
+            if (i0 + 4 <= n) {
+                *reinterpret_cast<float4*>(pv[u]) = *reinterpret_cast<const float4*>(p + i0);
                 if (ADAM) {
-                    gv[j] = (ok && g) ? g[i0 + j] : 0.f;
-                    mv[j] = ok ? m[i0 + j] : 0.f;
-                    vv[j] = ok ? v[i0 + j] : 0.f;
+                    // g == NULL: the data-term gradient is known to be zero wherever this launch walks (the early half
+                    // of the split update) - neither read nor zeroed: 6 instead of 8 streams
+                    *reinterpret_cast<float4*>(gv[u]) = g ? *reinterpret_cast<const float4*>(g + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(mv[u]) = *reinterpret_cast<const float4*>(m + i0);
+                    *reinterpret_cast<float4*>(vv[u]) = *reinterpret_cast<const float4*>(v + i0);
+                }
+            } else {
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = i0 + j < n;
+                    pv[u][j] = ok ? p[i0 + j] : 0.f;
+                    if (ADAM) {
+                        gv[u][j] = (ok && g) ? g[i0 + j] : 0.f;
+                        mv[u][j] = ok ? m[i0 + j] : 0.f;
+                        vv[u][j] = ok ? v[i0 + j] : 0.f;
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = seg_of(segs, i0 + j);
-            float x = pv[j];
-            if (ADAM) {
-                const float gr = fmaf(gv[j], grad_scale, segs.reg[k] * x);  // data term (+ mean over ranks) + reg
-                mv[j] = mv[j] + (gr - mv[j]) * one_minus_beta1;             // exp_avg.lerp_(grad, 1 - beta1)
-                vv[j] = vv[j] * beta2 + (gr * gr) * one_minus_beta2;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-                const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
-                x = x - lr_over_bc1 * (mv[j] / denom);
+        for (int u = 0; u < U; ++u) {
+            const size_t tile = tile0 + t0 + u;
+            if (t0 + u >= tiles_per_block || tile * 1024 >= n) break;      // block-uniform
+            const size_t i0 = i0s[u];
+            // a tile almost always lies inside one segment (k_blk); elements of a tile that straddles a boundary and
+            // belong to another segment are added one by one.
+            const int k_blk = seg_of(segs, tile * 1024);
+            if (k_blk != k_cur) {   // block-uniform
+                if (sumsq) {
+                    __syncthreads();
+                    const float s = block_sum(sq);
+                    if (threadIdx.x == 0 && s != 0.f) atomicAdd(sumsq + k_cur, s);
+                }
+                sq = 0.f;
+                k_cur = k_blk;
             }
-            x = fminf(hi, fmaxf(x, lo));  // the clamp the next forward would start with
-            pv[j] = x;
-            if (sumsq && i0 + j < n) {
-                if (k == k_blk) sq += x * x;
-                else atomicAdd(sumsq + k, x * x);
-            }
-        }
-        if (full) {
-            *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
-            if (ADAM) {
-                *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
-                *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vv);
-                if (zero_grad && g) *reinterpret_cast<float4*>(g + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            for (int j = 0; j < 4 && i0 + j < n; ++j) {
-                p[i0 + j] = pv[j];
+            if (!act[u]) continue;
+            const bool full = i0 + 4 <= n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = seg_of(segs, i0 + j);
+                float x = pv[u][j];
                 if (ADAM) {
-                    m[i0 + j] = mv[j];
-                    v[i0 + j] = vv[j];
-                    if (zero_grad && g) g[i0 + j] = 0.f;
+                    const float gr = fmaf(gv[u][j], grad_scale, segs.reg[k] * x);  // data term (+ mean over ranks) + reg
+                    mv[u][j] = mv[u][j] + (gr - mv[u][j]) * one_minus_beta1;       // exp_avg.lerp_(grad, 1 - beta1)
+                    vv[u][j] = vv[u][j] * beta2 + (gr * gr) * one_minus_beta2;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+                    const float denom = sqrtf(vv[u][j]) * inv_sqrt_bc2 + eps;
+                    x = x - lr_over_bc1 * (mv[u][j] / denom);
+                }
+                x = fminf(hi, fmaxf(x, lo));  // the clamp the next forward would start with
+                pv[u][j] = x;
+                if (sumsq && i0 + j < n) {
+                    if (k == k_blk) sq += x * x;
+                    else atomicAdd(sumsq + k, x * x);
+                }
+            }
+            if (full) {
+                adam_store4(p + i0, pv[u]);
+                if (ADAM) {
+                    adam_store4(m + i0, mv[u]);
+                    adam_store4(v + i0, vv[u]);
+                    if (zero_grad && g) {
+                        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                        adam_store4(g + i0, z);
+                    }
+                }
+            } else {
+                for (int j = 0; j < 4 && i0 + j < n; ++j) {
+                    p[i0 + j] = pv[u][j];
+                    if (ADAM) {
+                        m[i0 + j] = mv[u][j];
+                        v[i0 + j] = vv[u][j];
+                        if (zero_grad && g) g[i0 + j] = 0.f;
+                    }
                 }
             }
         }
-    }
     }   // tiles
     if (sumsq) {
         __syncthreads();

@@ -11,7 +11,7 @@ mkdir -p build/ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wall -Wno-unused-function "$@" \
   -c stylemesh_amd/csrc/$file.hip -o build/ab/${file}_$tag.o
 objs=()
-for f in conv texture gram prep comm eval raster scatter_plan exchange; do
+for f in conv texture gram prep comm eval raster scatter_plan exchange replay; do
   if [ $f = $file ]; then objs+=(build/ab/${file}_$tag.o); else objs+=(build/$f.o); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/lib_$tag.so "${objs[@]}" -L/opt/rocm/lib -lrccl
