@@ -1,0 +1,44 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): the evidence set of a build for one workload -> gpurun_out/<tag>/ :
+# default bench line, rocprofv3 kernel stats + launch classes + one step's timeline, and the PMC passes (HBM traffic;
+# c3: matrix-pipe occupancy too). The PMC passes run the step on ONE stream (side streams / split update off: counter
+# collection serialises dispatches, and with several streams a c3 pass did not finish in 25 minutes) under a timeout.
+# Usage: profile_round4.sh <tag> [workload=c3] [steps of the PMC runs=3]
+set -u
+export TMPDIR=/tmp
+TAG=${1:-r04}; WL=${2:-c3}; PSTEPS=${3:-3}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+python bench.py --workload $WL > $OUT/${WL}_bench_full.json 2> $OUT/${WL}_bench_full.err
+tail -c 400 $OUT/${WL}_bench_full.json; echo
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 > $OUT/prof.log 2>&1
+cd $R
+cp $OUT/prof/run_kernel_stats.csv $OUT/${WL}_kernel_stats.csv
+python3 tools/conv_trace_split.py $OUT/prof/run_kernel_trace.csv $OUT/${WL}_conv_launch_classes.csv $([ "$WL" = "c2" ] && echo 1000000 || echo 100) > /dev/null
+python3 tools/step_timeline.py $OUT/prof/run_kernel_trace.csv 6 > $OUT/${WL}_step_timeline.txt
+rm -rf $OUT/prof
+export STYLEMESH_SIDE_STREAMS=0 STYLEMESH_SPLIT_UPDATE=0
+rm -rf gpurun_out/traffic gpurun_out/pmc_bench
+mkdir -p gpurun_out/traffic gpurun_out/pmc_bench
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/traffic/$c.log 2>&1
+  echo "pmc $c rc=$?"
+done
+cd $R
+python3 tools/summarize_pmc.py gpurun_out/traffic $OUT/${WL}_pmc_traffic_summary.csv
+MODE=$(python3 -c "from stylemesh_amd.runtime import ops; print(ops.CONV_MODE)" 2>/dev/null | tail -1)
+python3 tools/traffic_json.py $OUT/${WL}_pmc_traffic_summary.csv $WL $MODE $OUT/conv_traffic_${WL}_${MODE}.json $((PSTEPS + 1)) | tail -4
+if [ "$WL" = "c3" ]; then
+  cd /tmp
+  for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+    timeout 420 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$tag -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/pmc_bench/$tag.log 2>&1
+    echo "pmc $tag rc=$?"
+  done
+  cd $R
+  python3 tools/summarize_pmc.py gpurun_out/pmc_bench $OUT/${WL}_pmc_mfma_summary.csv
+fi
+rm -rf gpurun_out/traffic gpurun_out/pmc_bench
+ls $OUT
