@@ -101,7 +101,9 @@ def cpu_baseline(wl, view_cpu, steps):
     import stylemesh_oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     env = os.environ.get("STYLEMESH_CPU_THREADS")
-    counts = [int(env)] if env else sorted({max(1, min(avail, c)) for c in (32, 64)})
+    from stylemesh_amd.runtime.hostcpu import effective_cpus
+    quota = effective_cpus()      # what the container may really use (cgroup cpu.max), e.g. 16 of 256 visible threads
+    counts = [int(env)] if env else sorted({max(1, min(avail, c)) for c in (32, int(quota))})
     cfg = O.OracleConfig(hierarchical=True, style_weights=STYLE_WEIGHTS, angle_threshold=wl["thr"], style_pyramid_mode=wl["mode"], gram_mode=wl.get("gram_mode", "current"),
                          use_angle_weight=wl["angle"], use_depth_scaling=wl["depth"],
                          loss_weights=dict(wl.get("loss_weights", LOSS_WEIGHTS)), learning_rate=1.0,
@@ -127,7 +129,7 @@ def cpu_baseline(wl, view_cpu, steps):
         if best is None or rate > best["value"]:
             best = {"value": rate, "unit": "views/s", "cores": threads, "kind": "port", "sample": sample}
     best["thread_counts_tried"] = tried
-    best["host_cpu"] = f"{cpu_model_string()} ({avail} hardware threads available)"
+    best["host_cpu"] = f"{cpu_model_string()} ({avail} hardware threads visible, CPU quota of the container {quota:g})"
     return best
 
 
@@ -462,7 +464,11 @@ def run(args):
     roofline = None
     if timer is not None:
         n_timed = len([i for i in range(args.steps) if i % args.timer_every == 0])
-        n_all, ms_all, flops_all = timer.summary()
+        n_all = ms_all = flops_all = 0.0      # every conv launch (the HBM-bound kernels carry 'hbm:' tags of their own)
+        for t_ in ("f32", "split", "split2"):
+            n_, ms_, fl_ = timer.summary(t_)
+            n_all, ms_all, flops_all = n_all + n_, ms_all + ms_, flops_all + fl_
+        n_all = int(n_all)
         # the dominant kernel: the bf16x3-split conv when the engine runs in split mode, else the fp32-MFMA conv
         tag = ops.CONV_MODE if ops.CONV_MODE in ("split", "split2") else "f32"
         n, ms, flops = timer.summary(tag)
@@ -495,6 +501,24 @@ def run(args):
                                           "algorithmic_gflop_per_step": round(flops_all / n_timed / 1e9, 1),
                                           "share_of_step_time": round(ms_all * 1e-3 / n_timed / (dt / args.steps), 3)}}
 
+    roofline_hbm = None
+    if timer is not None:
+        # the step's HBM-bound kernels, event-timed in the same sampled steps: algorithmic bytes / time against the
+        # measured device copy rate (6.29 TB/s: profiles/r02; the nominal HBM3E peak is 8 TB/s)
+        shares = {"adam_closing(x flagged share)": None if eng._view_flags is None else float((eng._view_flags != 0).float().mean()),
+                  "adam_early(x flagged share)": None if not eng._other_flags else float((eng._other_flags[1] != 0).float().mean())}
+        roofline_hbm = {"copy_rate_TBps": 6.29, "peak_TBps": 8.0, "kernels": {}}
+        for tag in sorted({r[3] for r in timer.records if str(r[3]).startswith("hbm:")}):
+            n_l, ms_l, bytes_l = timer.summary(tag)
+            name = tag[4:]
+            share = shares.get(name, 1.0)
+            if share is None or n_l == 0:
+                continue
+            tbps = bytes_l * share / (ms_l * 1e-3) / 1e12
+            roofline_hbm["kernels"][name] = {"launches_timed": n_l, "avg_us": round(1e3 * ms_l / n_l, 1),
+                                            "algorithmic_MB_per_launch": round(bytes_l * share / n_l / 1e6, 1),
+                                            "TBps": round(tbps, 2), "frac_of_copy_rate": round(tbps / 6.29, 3),
+                                            **({"flagged_share_last_view": round(share, 4)} if name in shares else {})}
     if rank == 0:
         value = world * args.steps / dt
         lw = wl.get("loss_weights", LOSS_WEIGHTS)
@@ -537,7 +561,7 @@ def run(args):
                                   "steps": 7 * wl["index_repeat"] * 273,
                                   "projected_wall_clock_s": round(7 * wl["index_repeat"] * 273 / (value / world), 1),
                                   "note": "fixed schedule of one scene / measured views per second per scene"},
-               "roofline": roofline, "losses_last_step": {k: round(v, 3) for k, v in losses.items()},
+               "roofline": roofline, "roofline_hbm": roofline_hbm, "losses_last_step": {k: round(v, 3) for k, v in losses.items()},
                "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
                                 "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
                                         "zero-initialised texture); the fraction grows with the views of the scene"},

@@ -168,6 +168,7 @@ class StepEngine:
         # one call. STYLEMESH_STEP_PROGRAM: 1 (default) / 0 / verify (every step runs recorded and is compared with the table)
         self.step_programs = os.environ.get("STYLEMESH_STEP_PROGRAM", "1")
         self._programs, self._prog_warm = {}, {}
+        self.view_serial = 0           # bumped whenever a view becomes current (programs re-patch their list lengths)
         self._prog_run = None          # (program, key) whose update segment the coming optimizer_step replays
         self._prog_rec = None          # (recorder, key, index of the first update call) of a step being recorded
         self.program_replays = 0       # diagnostics
@@ -493,6 +494,7 @@ class StepEngine:
     def _activate_view(self):
         """Side effects of a view becoming current that must be ordered with the STEPS (main stream): gradient planes
         zeroed outside the new view's active tiles, its chunks OR-ed into the ever-touched flags."""
+        self.view_serial += 1
         if self._pending_grad_zero:
             torch._foreach_zero_(self._pending_grad_zero)
         self._pending_grad_zero = None
@@ -1559,7 +1561,9 @@ class StepEngine:
                                    f"{a[bad] if bad < len(a) else None} vs {b[bad] if bad < len(b) else None}")
             self.program_verified = getattr(self, "program_verified", 0) + 1
             return
-        prog.view_id = id(self.view_tiles)
+        prog.view_id = self.view_serial
+        if len(self._programs) >= 32:            # (slots x level sets x empty-list sets of a scene: a handful; bounded anyway)
+            self._programs.pop(next(iter(self._programs)))
         self._programs[key] = prog
 
     def _program_patch_points(self, prog):
@@ -1593,10 +1597,10 @@ class StepEngine:
         """The words of the compute segment that belong to THIS step."""
         prog.patch(prog.i_begin, 3, out.data_ptr() + 8)
         prog.patch(prog.i_copy, 0, out.data_ptr())
-        if prog.view_id != id(self.view_tiles):          # a new view in this slot: its lists' lengths
+        if prog.view_id != self.view_serial:             # a new view in this slot: its lists' lengths
             for i, j, k in prog.lists:
                 prog.patch(i, j, self.view_tiles[k][0].numel())
-            prog.view_id = id(self.view_tiles)
+            prog.view_id = self.view_serial
         for table, n_prob in prog.hist_tables:
             # one level: problem k of a launch = style layer k of the launch's layers; every style layer is in one launch
             done = getattr(prog, "_hist_layers", None)

@@ -387,3 +387,42 @@ def test_step_program_through_step_compute_and_optimizer_step():
         b.optimizer_step()
         np.testing.assert_allclose(a.losses(la)["total"], b.losses(lb)["total"], rtol=1e-5)
     assert a.program_replays >= 6
+
+
+@pytest.mark.parametrize("depth", [True, False])
+def test_level_masks_and_weights_match_the_oracle(depth):
+    """The per-view mask / weight kernels against the ORACLE's restatement of model/model.py:188-254 (since
+    round 3 the class mirror and the fused engine share these kernels, so their agreement proves nothing about them).
+    ``M`` must equal the oracle's level mask exactly; ``pixel_weight`` = (depth-interpolation weight) x (bilinear angle
+    guidance) within fp32 rounding."""
+    require_gpu()
+    import torch.nn.functional as F
+    import stylemesh_oracle as O
+    from stylemesh_amd.data import synthetic as S
+    from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+    level_hw = ((24, 32), (36, 48), (48, 64))
+    room = S.BoxRoom((12.0, 9.0, 3.0))
+    cfg = EngineConfig(tex_w=256, tex_h=256, hierarchical=True, n_layers=4, style_weights=[1000., 1000., 10., 10., 1000.],
+                       angle_threshold=30.0, style_pyramid_mode="multi", use_angle_weight=True, use_depth_scaling=depth,
+                       loss_weights={"content": 7e1, "style": 1e-4, "tex_reg": 5e3})
+    eng = StepEngine(cfg, S.seeded_vgg_state(0))
+    eng.set_style_image(S.style_image(1, 96, 80))
+    ocfg = O.OracleConfig(hierarchical=True, angle_threshold=30.0, style_pyramid_mode="multi", use_angle_weight=True,
+                          use_depth_scaling=depth)
+    for seed in (2, 6, 9):
+        v = S.make_view(seed, view_hw=(48, 64), level_hw=list(level_hw), level_heights=[h for h, _ in level_hw],
+                        min_pyramid_depth=0.25, room=room)
+        masks, weights = O.level_masks_and_weights(v, list(level_hw), ocfg)
+        dev = tuple([u.cuda() for u in x] if isinstance(x, list) else (x.cuda() if torch.is_tensor(x) and i != 8 else x)
+                    for i, x in enumerate(v))
+        eng.set_view(dev)
+        for lv in eng.view:
+            if not hasattr(lv, "M"):
+                continue
+            i = lv.index
+            assert torch.equal(lv.M.cpu(), masks[i][0, 0]), (seed, i)
+            ag = F.interpolate(v[11], level_hw[i], mode="bilinear")[0, 0]          # model/model.py:195-199
+            want = ag * (weights[i][0, 0] if depth else 1.0)
+            np.testing.assert_allclose(lv.pixel_weight.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+            deg = F.interpolate(v[12], level_hw[i], mode="bilinear")[0, 0]
+            assert torch.equal(lv.passed.cpu() != 0, deg < 30.0) or float(((lv.passed.cpu() != 0) != (deg < 30.0)).float().mean()) < 1e-3
