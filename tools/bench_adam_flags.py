@@ -25,3 +25,22 @@ for frac in (1.0, 0.4, 0.16, 0.05, 0.0):
         fl = blocks.repeat_interleave(run)[:nch].to(torch.int32).contiguous()
         t = timed(lambda: ops.adam_fused(p, g, m, v, seg, reg, 1.0, 3, sumsq_out=ssq, touched=fl, touched_log2=6))
         print(f"{frac:4.0%} flagged, runs of {run:4d} chunks: {t:7.1f} us   ({float(fl.float().mean()) * n * 28 / t / 1e6:5.2f} TB/s of flagged traffic)")
+
+# the flags of a REAL view (the bench's c3 views): the closing update walks the view's own chunks, the early half the rest
+if os.environ.get("REAL_FLAGS", "1") == "1":
+    import bench as B
+    from stylemesh_amd.data import synthetic as S
+    from stylemesh_amd.runtime.engine import StepEngine
+    wl = B.WORKLOADS["c3"]
+    eng = StepEngine(B.engine_config(wl), S.seeded_vgg_state(0))
+    eng.set_style_image(S.style_image(1, *B.STYLE_HW))
+    views = [B.to_device(v, "cuda") for v in B.make_views(wl, [0, 2, 6])]
+    for v in views:
+        eng.training_step(v)
+    a = eng.arena
+    for name, fl in (("view's own chunks (closing update)", eng._view_flags), ("ever-touched minus the view (early half)", eng._other_flags[1] if eng._other_flags else None)):
+        if fl is None:
+            continue
+        share = float((fl != 0).float().mean())
+        t = timed(lambda: ops.adam_fused(a.p, a.g, a.m, a.v, a.seg_end, eng.reg_coef, 1.0, 3, sumsq_out=eng.sumsq, touched=fl, touched_log2=6))
+        print(f"real c3 view, {name}: {share:5.1%} flagged: {t:7.1f} us ({share * a.n * 28 / t / 1e6:5.2f} TB/s of flagged traffic)")
