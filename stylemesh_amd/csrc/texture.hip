@@ -283,7 +283,8 @@ __device__ __forceinline__ float block_sum(float v) {
                                 // more loads in flight per thread only cost occupancy; it stays at 1
 #endif
 #ifndef SM_ADAM_STRIDED
-#define SM_ADAM_STRIDED 1       // 1: block b walks tiles b, b + G, b + 2 G, ... (G = blocks) instead of 16 consecutive ones
+#define SM_ADAM_STRIDED 2       // block b walks tiles b, b + G, b + 2 G, ... (G = blocks) instead of 16 consecutive ones:
+                                // 0 never, 1 always, 2 for the DENSE update only (measured, profiles/r04/adam_strided.txt)
 #endif
 #ifndef SM_ADAM_NT
 #define SM_ADAM_NT 0            // 1: non-temporal stores of p / m / v / zeroed g (A/B switch)
@@ -316,16 +317,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     // the stores tile by tile, in the same order as before (bit-identical sums). Built to test whether the update is
     // bound by loads in flight: it is not (see SM_ADAM_UNROLL) - U stays 1.
     constexpr int U = SM_ADAM_UNROLL;
-    // Which tiles a block walks: a view's footprint is a few blobs of the arena - with 16 CONSECUTIVE tiles per block the
-    // flagged work of the closing update sits in a fifth of the blocks, each streaming its tiles one after the other
-    // (few loads in flight per CU): 220 us in situ for 20 % of the arena, against 78 us for evenly spread flags. Strided
-    // tiles give every block the same share of every blob; a block's tiles still ascend, so the segment (texture layer)
-    // of its running sum changes at most n_layers - 1 times.
-#if SM_ADAM_STRIDED
-    const size_t tile0 = blockIdx.x, tile_step = gridDim.x;
-#else
-    const size_t tile0 = (size_t)blockIdx.x * tiles_per_block, tile_step = 1;
-#endif
+    // Which tiles a block walks. Strided (block b: tiles b, b + G, ...; still ascending, so the running sum's segment
+    // changes at most n_layers - 1 times) keeps all blocks of the chip on the same stretch of the arena: the DENSE update
+    // runs 433 -> 370 us (4.3 -> 5.1 TB/s) and synthetic long runs of flagged chunks 96 -> 71 us. A real view's flags are
+    // fragmented at the chunk level, and there 16 consecutive tiles per block are faster (closing update in situ
+    // 146-152 against 171 us, c3 step 185.4 against 184.5 views/s): strided for the dense update only.
+    const bool strided = SM_ADAM_STRIDED == 1 || (SM_ADAM_STRIDED == 2 && (!ADAM || touched == nullptr));
+    const size_t tile0 = strided ? (size_t)blockIdx.x : (size_t)blockIdx.x * tiles_per_block;
+    const size_t tile_step = strided ? (size_t)gridDim.x : 1;
     int k_cur = seg_of(segs, tile0 * 1024);
     float sq = 0.f;
     for (int t0 = 0; t0 < tiles_per_block; t0 += U) {
