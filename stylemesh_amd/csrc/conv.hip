@@ -376,6 +376,9 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 #ifndef SM_SPLIT2_SLOTS
 #define SM_SPLIT2_SLOTS 1
 #endif
+#ifndef SM_CONV_SPLIT_PENALTY_DEFAULT
+#define SM_CONV_SPLIT_PENALTY_DEFAULT 3.f   // measured (profiles/r04/split_penalty_ab.txt): c3 +0.4 %, c2 +0.6 % at 2-4, c2 -5 % at 8
+#endif
     // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
     constexpr int SLOTS = SM_NUM_CU * ((SPLIT && NP == 2) ? SM_SPLIT2_SLOTS : 1);
     a.n_whole = tiles / SLOTS * SLOTS;
@@ -386,9 +389,13 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)rem * BM * BN)});
         // cost of the tail in units of one whole tile; every unit pays ~1 chunk of fixed prologue / epilogue time
         float best = (chunks + 1.f) / chunks;   // S = 1: one more full round
+        // a split tail costs a second launch (the reduce / epilogue pass: 9-13 us + the slabs' round trip) whatever it
+        // saves: SM_CONV_SPLIT_PENALTY / chunks tile times (a tile takes ~3.6 us per K-chunk: 3.3 ~ 12 us; 0 = rounds 1-3)
+        static const float penalty = getenv("SM_CONV_SPLIT_PENALTY") ? (float)atof(getenv("SM_CONV_SPLIT_PENALTY")) : SM_CONV_SPLIT_PENALTY_DEFAULT;
+        const float second_pass = penalty / chunks;
         for (int S = 2; S <= max_s; ++S) {
             const int cps = (chunks + S - 1) / S, S_eff = (chunks + cps - 1) / cps;
-            const float cost = (float)((rem * S_eff + SLOTS - 1) / SLOTS) * (cps + 1.f) / chunks;
+            const float cost = (float)((rem * S_eff + SLOTS - 1) / SLOTS) * (cps + 1.f) / chunks + second_pass;
             if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
         }
     }
