@@ -45,6 +45,48 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int W, int H) {
 
 struct __attribute__((aligned(4))) pair4 { float x, y; };   // two adjacent floats at 4-byte alignment
 
+#ifndef SM_TEX_FWD_BATCH
+#define SM_TEX_FWD_BATCH 1      // 1: the gathers of up to four texture layers are issued together, branch-free (round 4)
+#endif
+// Layers l0 .. l0 + NB - 1 of one pixel with ALL their 6 NB tap loads in flight at once. The loop below issues a layer's
+// six gathers, waits, and only then computes the next layer's addresses: four dependent memory round trips per pixel for
+// the hierarchical texture. Branch-free: at the right / bottom border the east / south weights are exactly 0 (the
+// source index is clamped to W - 1 / H - 1), so the pair is loaded one texel to the left / the north row again and the
+// zero-weight products are added - the same sums as the branching form (a zero may change its sign).
+template <int NB>
+__device__ __forceinline__ void tex_sample_layers(const TexLayers& L, int l0, float2 g, float& acc0, float& acc1, float& acc2) {
+    pair4 a[NB][3], b[NB][3];
+    Taps t[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int W = L.w[l0 + k], H = L.h[l0 + k];
+        t[k] = make_taps(g.x, g.y, W, H);
+        const float* p = L.p[l0 + k] + (size_t)t[k].y0 * W + t[k].x0 - (t[k].x1_in ? 0 : 1);
+        const size_t cs = (size_t)W * H;
+        const int dy = t[k].y1_in ? W : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[k][c] = *reinterpret_cast<const pair4*>(p + c * cs);
+            b[k][c] = *reinterpret_cast<const pair4*>(p + c * cs + dy);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float west = t[k].x1_in ? a[k][c].x : a[k][c].y, swest = t[k].x1_in ? b[k][c].x : b[k][c].y;
+            v[c] = west * t[k].nw;
+            v[c] += a[k][c].y * t[k].ne;
+            v[c] += swest * t[k].sw;
+            v[c] += b[k][c].y * t[k].se;
+        }
+        acc0 += v[0];
+        acc1 += v[1];
+        acc2 += v[2];
+    }
+}
+
 __device__ __forceinline__ void tex_sample_fwd_body(const TexLayers& L, const float2* __restrict__ grid, int h, int w,
                                                     float* __restrict__ out, int Wp, int plane, int block_x) {
     const int i = block_x * 256 + threadIdx.x;
@@ -52,7 +94,17 @@ __device__ __forceinline__ void tex_sample_fwd_body(const TexLayers& L, const fl
     const int y = i / w, x = i - y * w;
     const float2 g = grid[i];
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    for (int l = 0; l < L.n; ++l) {
+    int l_first = 0;
+#if SM_TEX_FWD_BATCH
+    bool wide = true;                 // (a 1-texel-wide layer has no texel to the left of its border)
+    for (int l = 0; l < L.n; ++l) wide = wide && L.w[l] >= 2;
+    if (wide) {
+        for (; l_first + 4 <= L.n; l_first += 4) tex_sample_layers<4>(L, l_first, g, acc0, acc1, acc2);
+        if (l_first + 2 <= L.n) { tex_sample_layers<2>(L, l_first, g, acc0, acc1, acc2); l_first += 2; }
+        if (l_first + 1 <= L.n) { tex_sample_layers<1>(L, l_first, g, acc0, acc1, acc2); l_first += 1; }
+    }
+#endif
+    for (int l = l_first; l < L.n; ++l) {
         const int W = L.w[l], H = L.h[l];
         const Taps t = make_taps(g.x, g.y, W, H);
         const float* p = L.p[l] + (size_t)t.y0 * W + t.x0;

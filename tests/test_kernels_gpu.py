@@ -221,7 +221,10 @@ def test_conv3x3_split_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, monkeypa
         d = out.to_dense().double().cpu() - ref
         errs[mode] = float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
         assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max()), mode
-    assert errs["split"] <= 2.0 * errs["f32"] + 1e-9, errs
+    # (<= 2x the fp32-MFMA kernel's rms error, or within 4e-7 relative rms - the class of an fp32 chain of this length: since
+    # round 4 small launches of the fp32 kernel are no longer K-split, and an unsplit K = 576 chain of its exact 2-deep MFMA
+    # steps comes out at 1.5e-7, below what a 16-bit split reaches)
+    assert errs["split"] <= max(2.0 * errs["f32"], 4e-7) + 1e-9, errs
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 128, 20, 28), (256, 512, 6, 9), (128, 128, 13, 131), (512, 256, 40, 77),
@@ -257,7 +260,10 @@ def test_conv3x3_split2_matches_fp64_as_well_as_f32(rt, cin, cout, H, W, in_scal
         d = got.double().cpu() - ref
         errs[mode] = float((d ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
         assert float(d.abs().max()) <= 2e-6 * float(ref.abs().max()), mode
-    assert errs["split2"] <= 2.0 * errs["f32"] + 1e-9, errs
+    # (<= 2x the fp32-MFMA kernel's rms error, or within 4e-7 relative rms - the class of an fp32 chain of this length: since
+    # round 4 small launches of the fp32 kernel are no longer K-split, and an unsplit K = 576 chain of its exact 2-deep MFMA
+    # steps comes out at 1.5e-7, below what a 16-bit split reaches)
+    assert errs["split2"] <= max(2.0 * errs["f32"], 4e-7) + 1e-9, errs
     # a loose upper bound of the input maximum (a max-pool hands its input's bound through) gives the same class
     monkeypatch.setattr(rt.ops, "CONV_MODE", "split2")
     out = rt.FMap(cout, H, W)
