@@ -840,7 +840,7 @@ int sm_view_masks(const sm_view_masks_desc* d, void* stream) {
         sm::LayerMaskGroup mg;
         sm::FactorGroup fg;
         fg.n = d->n_masks;
-        int max_l = 0, n_loss = 0;
+        int max_l = 0;
         for (int k = 0; k < d->n_masks; ++k) {
             const sm_view_layer_mask& m = d->masks[k];
             if (m.level < 0 || m.level >= d->n_levels || !d->levels[m.level].has_maps || m.loss_layer < 0 || m.loss_layer >= 64)
@@ -849,11 +849,9 @@ int sm_view_masks(const sm_view_masks_desc* d, void* stream) {
             mg.p[k] = sm::LayerMaskProblem{L.M, L.passed, m.mask_planes, m.counts, L.H, L.W, m.hl, m.wl};
             fg.p[k] = sm::FactorProblem{m.counts, m.factor, (float)m.hl * (float)m.wl, m.loss_layer};
             max_l = m.hl * m.wl > max_l ? m.hl * m.wl : max_l;
-            n_loss = m.loss_layer + 1 > n_loss ? m.loss_layer + 1 : n_loss;
         }
         hipLaunchKernelGGL(sm::layer_masks_group_kernel, dim3((max_l + 255) / 256, d->n_masks), dim3(256), 0, st, mg);
         hipLaunchKernelGGL(sm::level_factors_group_kernel, dim3(1), dim3(64), 0, st, fg);
-        (void)n_loss;
     }
     if (d->n_resizes > 0) {
         sm::ResizeGroup rg;

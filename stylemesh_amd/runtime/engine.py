@@ -627,7 +627,10 @@ class StepEngine:
                 return self.vgg.forward(cb)
             cur = torch.cuda.current_stream()
             g = torch.cuda.CUDAGraph()
+            # (the capture stream stays alive with the graph: the captured convs use the split-K scratch keyed by its
+            # handle - ops.splitk_workspace -, and a later stream that inherited the handle would share that scratch)
             cap = torch.cuda.Stream(device=self.device)
+            self._content_cap_streams = getattr(self, "_content_cap_streams", []) + [cap]
             cap.wait_stream(cur)
             with torch.cuda.graph(g, stream=cap):
                 self.vgg.forward(cb)

@@ -18,7 +18,6 @@ allows (a view prepared one ahead: at the swap).
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 import torch
 
@@ -75,8 +74,6 @@ class ViewPlan:
         self.level_hw, self.maps_levels, self.active = list(level_hw), list(maps_levels), list(active_levels)
         n_levels = len(level_hw)
         depth = bool(cfg.use_depth_scaling)
-        self.keep = []        # everything the descriptors point to
-
         assert eng._wslot == slot, "a plan is built while its slot is the one being written"
 
         def persist(key, factory):
