@@ -365,6 +365,22 @@ def main():
 
 
 def run(args):
+    """One rank. Standard output carries ONE line - the result -, so everything else a rank's libraries write there (RCCL
+    prints a version banner on stdout when a communicator comes up) is sent to standard error for the duration of the run."""
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = _run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(out_fd, 1)
+        os.close(out_fd)
+    if line is not None:
+        print(line, flush=True)
+
+
+def _run(args):
     wl = WORKLOADS[args.workload]
 
     rank = int(os.environ.get("RANK", 0))
@@ -519,6 +535,7 @@ def run(args):
                                             "algorithmic_MB_per_launch": round(bytes_l * share / n_l / 1e6, 1),
                                             "TBps": round(tbps, 2), "frac_of_copy_rate": round(tbps / 6.29, 3),
                                             **({"flagged_share_last_view": round(share, 4)} if name in shares else {})}
+    line = None
     if rank == 0:
         value = world * args.steps / dt
         lw = wl.get("loss_weights", LOSS_WEIGHTS)
@@ -584,11 +601,12 @@ def run(args):
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if world > 1:
         if comm is not None and hasattr(comm, "destroy"):
             comm.destroy()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":
