@@ -120,6 +120,9 @@ class _ViewLevel:
 
 class StepEngine:
     MAX_UV_LEVELS = 8   # per-(level, style layer) bounds of the derivative matrices are laid out for this many levels
+    N_SLOTS = 2         # buffer sets of per-view constants: the current view + the views prepared ahead. (3 = TWO views in
+                        # preparation, measured on the dip schedule in round 4: 663 views/s either way - that schedule is
+                        # bound by the ~210 kernel dispatches of a step + a preparation, not by a wait for the read-back)
 
     def __init__(self, cfg: EngineConfig, vgg_state: dict, device="cuda", random_init=False):
         cfg.validate()
@@ -159,8 +162,8 @@ class StepEngine:
         self._pbuf = {}            # persistent per-view buffers (fixed addresses), keyed (slot, name)
         self._slot = 0             # slot of the CURRENT view's constants
         self._wslot = 0            # slot set_view is writing (differs from _slot while the next view is being prepared)
-        self._prepared = None      # (view key, slot, per-view attributes, done event) of a view prepared ahead
-        self._prepare_request = None   # (batch, ready event): prepare_view to run after the next begin_step
+        self._prepared = []        # views prepared ahead, next first: (view key, slot, per-view attributes, done event)
+        self._prepare_request = []     # [(batch, ready event)]: prepare_view calls to run after the next begin_step
         self._pending_view = None      # viewplan.PendingView: a view whose read-back has not been waited for yet
         self._view_plans = {}          # (slot, view shape, active levels) -> viewplan.ViewPlan
         self._content_graphs, self._content_warm = {}, {}   # captured content-target passes, per content size
@@ -173,8 +176,8 @@ class StepEngine:
         self._prog_rec = None          # (recorder, key, index of the first update call) of a step being recorded
         self.program_replays = 0       # diagnostics
         self.fast_view = os.environ.get("STYLEMESH_FAST_VIEW", "1") != "0"
-        self._plans = [None, None]       # scatter plan per slot
-        self._slot_released = [None, None]   # event: the steps that read this slot's constants have been enqueued
+        self._plans = [None] * self.N_SLOTS       # scatter plan per slot
+        self._slot_released = [None] * self.N_SLOTS   # event: the steps that read this slot's constants have been enqueued
         self._prep_stream = None
         self._pending_grad_zero = None
         self.prepare_ahead = os.environ.get("STYLEMESH_PREPARE_AHEAD", "1") != "0"
@@ -420,11 +423,16 @@ class StepEngine:
         if not self.prepare_ahead or self.use_graphs or self.targets is None or self.view is None:
             return False
         key = self._batch_key(batch)
-        if key == self.view_key or (self._prepared is not None and self._prepared[0] == key):
+        if key == self.view_key or any(p[0] == key for p in self._prepared):
+            return False
+        # a free slot: not the current view's, not one a prepared view waits in
+        busy = {self._slot} | {p[1] for p in self._prepared}
+        free = [k for k in range(self.N_SLOTS) if k not in busy]
+        if not free:
             return False
         if self._prep_stream is None:
             self._prep_stream = self._new_side_stream()
-        slot = 1 - self._slot
+        slot = free[0]
         st = self._prep_stream
         if urgent and os.environ.get("STYLEMESH_URGENT_PREPARE", "1") != "0":
             # The view is needed by the very NEXT step (index_repeat 1): its read-back must arrive while the current step
@@ -449,7 +457,7 @@ class StepEngine:
                 done.record(st)
             self._plans[slot] = self._scatter_plan
             self._prep_last = done
-            self._prepared = (key, slot, {a: getattr(self, a, None) for a in self.VIEW_ATTRS}, done)
+            self._prepared.append((key, slot, {a: getattr(self, a, None) for a in self.VIEW_ATTRS}, done))
         finally:
             self._wslot = self._slot
             for a, v in current.items():
@@ -459,18 +467,17 @@ class StepEngine:
     def drop_prepared(self):
         """Forget a view prepared ahead (or asked for) that will not be the next one - an epoch cut short, a schedule that
         changed: its launches are ordered before whatever the current stream does next, its slot is free again."""
-        prep, self._prepared, self._prepare_request = self._prepared, None, None
-        if prep is not None:
+        preps, self._prepared, self._prepare_request = self._prepared, [], []
+        for prep in preps:
             torch.cuda.current_stream().wait_event(prep[3])
 
     def set_view(self, batch, reducer=None):
         """Make ``batch`` the current view: swap in the constants ``prepare_view`` computed ahead if they are this
         view's, else compute them now on the current stream (``_set_view_body``)."""
         main = torch.cuda.current_stream()
-        prep, self._prepared = self._prepared, None
         old_slot = self._slot
-        if prep is not None and reducer is None and prep[0] == self._batch_key(batch):
-            key, slot, attrs, done = prep
+        if self._prepared and reducer is None and self._prepared[0][0] == self._batch_key(batch):
+            key, slot, attrs, done = self._prepared.pop(0)
             self.prepared_swaps = getattr(self, "prepared_swaps", 0) + 1   # diagnostics
             main.wait_event(done)
             for a, v in attrs.items():
@@ -479,8 +486,9 @@ class StepEngine:
             self._slot = self._wslot = slot
             self._finish_pending_view(batch)      # (the read-back of a view prepared ahead is waited for HERE)
         else:
-            if prep is not None:            # a prepared view that is not the one asked for: let its launches finish first
+            for prep in self._prepared:     # prepared views that are not the one asked for: let their launches finish first
                 main.wait_event(prep[3])    # (they share scratch with a build on this stream)
+            self._prepared = []
             self._scatter_plan = self._plans[self._slot]
             self._wslot = self._slot
             self._set_view_body(batch, reducer)
@@ -1445,7 +1453,7 @@ class StepEngine:
         before it has been swapped in: a caller that learns about view i + 1 BEFORE it steps view i (index_repeat 1: every
         step is the first of its view - ``RepeatingSampler`` of data/abstract_dataset.py:498-512 with the dip scripts'
         ``--index_repeat 1``) leaves the request here instead of calling ``prepare_view`` too early."""
-        self._prepare_request = (batch, ready_event)
+        self._prepare_request.append((batch, ready_event))
 
     def step_compute(self, batch, reducer=None, new_view=None, exchange=True):
         """Everything of a training step BEFORE the optimizer: per-view work, the step head (regulariser loss of the
@@ -1460,11 +1468,12 @@ class StepEngine:
                                "split update needs exactly one optimizer_step per step (STYLEMESH_SPLIT_UPDATE=0 "
                                "disables the split)")
         self.begin_step(batch, reducer, new_view)
-        req, self._prepare_request = self._prepare_request, None
+        reqs, self._prepare_request = self._prepare_request, []
         self._steps_on_view = getattr(self, "_steps_on_view", 0) + 1
-        if req is not None and reducer is None:
-            # (urgent: the schedule changes the view every step - the view before this one lasted a single step)
-            self.prepare_view(*req, urgent=getattr(self, "_last_view_steps", 0) == 1)
+        if reducer is None:
+            for req in reqs:
+                # (urgent: the schedule changes the view every step - the view before this one lasted a single step)
+                self.prepare_view(*req, urgent=getattr(self, "_last_view_steps", 0) == 1)
         out = torch.empty(3, device=self.device)    # this step's [content, style, tex_reg]: stays valid for the caller
         self._prog_end_recording(discard=True)      # (a recording whose optimizer_step never came)
         self._prog_run = None
@@ -1656,7 +1665,9 @@ class StepEngine:
         per-view constants are prepared beside this step (``request_prepare``). Returns this step's losses as device
         tensors that stay valid."""
         if next_batch is not None:
-            self.request_prepare(next_batch)
+            # one upcoming view, or a list of them in schedule order (index_repeat 1: the next two)
+            for nb in (next_batch if isinstance(next_batch, list) else [next_batch]):
+                self.request_prepare(nb)
         losses = self.step_compute(batch, reducer, new_view)
         if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
             self._timed("exchange+update", lambda: self.exchange_and_update(world_size, reducer))

@@ -253,7 +253,7 @@ def test_a_new_view_every_step_prepared_one_ahead_equals_unprepared():
     a, b = _dip_engine(), _dip_engine()
     b.prepare_ahead = False
     for k, v in enumerate(views):
-        nxt = views[k + 1] if k + 1 < len(views) else None
+        nxt = [views[j] for j in (k + 1, k + 2) if j < len(views)] or None      # two views in preparation (three slots)
         la = a.losses(a.training_step(v, next_batch=nxt))
         lb = b.losses(b.training_step(v))
         np.testing.assert_allclose(la["total"], lb["total"], rtol=1e-5)
@@ -341,7 +341,7 @@ def test_replayed_step_program_equals_the_eager_step(name, conv_mode, monkeypatc
         if i == n_steps // 2:
             for e in (a, b, v):
                 e.end_epoch(); e.end_epoch(); e.end_epoch()           # StepLR: the learning rate drops
-        nxt = sched[i + 1] if (rep == 1 and i + 1 < n_steps) else None
+        nxt = ([sched[j] for j in (i + 1, i + 2) if j < n_steps] or None) if rep == 1 else None
         if rep > 1 and i % rep == 1 and i - 1 + rep < n_steps:
             for e in (a, b, v):
                 e.prepare_view(sched[i - 1 + rep])
