@@ -1541,7 +1541,10 @@ class StepEngine:
                 None if plan is None else (id(plan), plan.sorted_in, plan.generation, plan.n_entries), self.sparse_update,
                 None if self._gram_arena is None else self._gram_arena.data_ptr(),
                 None if self.touched is None else self.touched.data_ptr(), self.cfg.gram_mode, self.sparse_tiles,
-                tuple(sorted(self.cfg.loss_weights.items())))
+                tuple(sorted(self.cfg.loss_weights.items())),
+                # host-side state the step's first launches depend on (is there anything to zero, does the scatter add or
+                # store): a replayed step leaves it as an eager one does, so in a steady run these never change
+                self._gram_arena is not None and len(self._gram_clean) != len(self._gram), self._grad_dirty)
 
     def _prog_end_recording(self, discard=False):
         """Take the recorder off ``ops.lib``; unless ``discard``, turn what it noted into this key's program (or, in
