@@ -98,6 +98,9 @@ __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2]
 //           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
 //           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
 //           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
+#ifndef SM_SPLIT2_PAIR_ROWS
+#define SM_SPLIT2_PAIR_ROWS 1  // forward convs with the pooling epilogue: the lower segment of a pair re-uses the upper one's rows
+#endif
 #ifndef SM_SPLIT2_RING6
 #define SM_SPLIT2_RING6 0      // fp16x2: six LDS slots (two whole chunks), ONE barrier per chunk instead of three
 #endif
@@ -299,6 +302,29 @@ void conv3x3_split_kernel(ConvArgs a) {
         par_ = ok_ ? ((((y_) & 1) << 1) | ((x_) & 1)) : -1;                                              \
     }
     const int h_dst = (h_kg * BNP + h_seg * SEGP + 32 + h_which) * 8 + h_c;   // in bf16 elements (+ part * 2 * BNP * 8)
+    // PAIRS (round 4): a forward conv with the pooling epilogue takes its segments in vertical pairs - entries 2k, 2k + 1 =
+    // the same 32 columns of image rows 2Y and 2Y + 1 - so slice ky of the LOWER segment holds the input row that slice
+    // ky + 1 of the UPPER one holds. The lower segment's slices 0 and 1 are therefore not staged at all: its fragments for
+    // taps ky = 0, 1 are read from the upper segment's slices 1, 2 (complete whenever the lower one's would be: the three
+    // slices of a chunk are published before its first tap, and a ring slot is only re-used after the taps that read it,
+    // see SM_NEXT_SLOT). Four staged rows per pair and chunk instead of six - the 64-row tile spends twice the staging
+    // per MFMA of the 128-row tile, and staging is what bounds it. Bit-identical: the same input
+    // values go through the same conversion. Slices 0 / 1 are staged with a mapping of their own over the UPPER segments:
+    // one unit per thread for BN = 256 (instead of two); for BN = 128 half the threads convert and store.
+    constexpr bool PAIRS = NP == 2 && !UNPOOL && (FLAGS & SM_EPI_POOL) != 0 && SM_SPLIT_BSETS == 1 && !SM_SPLIT2_RING6 &&
+                           SM_SPLIT2_PAIR_ROWS;
+    const int a_kg = BN == 256 ? (tid >> 7) : ((tid >> 6) & 1);
+    const int a_px = BN == 256 ? (tid & 127) : (tid & 63);
+    const bool a_active = BN == 256 || tid < 128;
+    int a_src = 0, a_dst = 0;
+    if constexpr (PAIRS) {
+        int q_seg = qs[0];
+#pragma unroll
+        for (int k = 1; k < SEG / 2; ++k)
+            if ((a_px >> 5) == k) q_seg = qs[2 * k];
+        a_src = (a_kg * 8 * P.plane + q_seg + (a_px & 31)) * 4;
+        a_dst = a_kg * BNP + (2 * (a_px >> 5)) * SEGP + (a_px & 31);
+    }
     // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
     // the MFMA time to hide the same fetch latency behind: its ring is deeper
     constexpr int AD = NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
@@ -340,12 +366,17 @@ void conv3x3_split_kernel(ConvArgs a) {
         rhc[set_] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, (off_ + h_kg * up_plane) * 4, (chunk_) * 2 * up_plane * 4, 0); \
     } else {                                                                                             \
         const int so_ = ((chunk_) * KC * P.plane + (ky_) * P.Wp) * 4;                                    \
-        _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                   \
+        if (PAIRS && (ky_) < 2) {   /* the upper segments only (unconditional loads: see the note at the loop) */ \
             _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                \
-                rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src[u], so_ + c * P.plane * 4, 0)); \
+                rbs[set_][0][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, a_src, so_ + c * P.plane * 4, 0)); \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u)                                               \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c)                                            \
+                    rbs[set_][u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, b_src[u], so_ + c * P.plane * 4, 0)); \
+        }                                                                                                \
         rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0)); \
     }
-#define SM_STORE_B(set_, slot_)                                                                          \
+#define SM_STORE_B(set_, slot_, ky_)                                                                     \
     if constexpr (NP == 3) {                                                                             \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
         _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
@@ -373,6 +404,18 @@ void conv3x3_split_kernel(ConvArgs a) {
                     rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
             rhs[set_] = ((int)((rhc[set_] >> (4 * h_c)) & 15u) == rhp[set_]) ? rhs[set_] : 0.f;          \
         }                                                                                                \
+        if (PAIRS && (ky_) < 2) {                                                                        \
+            f16x8 vh, vl;                                                                                \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
+                const float xs_ = __builtin_amdgcn_fmed3f(rbs[set_][0][c] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP); \
+                const _Float16 h_ = (_Float16)xs_;                                                       \
+                vh[c] = h_; vl[c] = (_Float16)(xs_ - (float)h_);                                         \
+            }                                                                                            \
+            if (a_active) {                                                                              \
+                d_[a_dst] = __builtin_bit_cast(f32x4, vh);                                               \
+                d_[a_dst + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                     \
+            }                                                                                            \
+        } else {                                                                                         \
         _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
             f16x8 vh, vl;                                                                                \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
@@ -382,6 +425,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             }                                                                                            \
             d_[b_dst[u]] = __builtin_bit_cast(f32x4, vh);                                                \
             d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
+        }                                                                                                \
         }                                                                                                \
         const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
         const _Float16 h_ = (_Float16)xs_;                                                               \
@@ -396,6 +440,18 @@ void conv3x3_split_kernel(ConvArgs a) {
             _Pragma("unroll") for (int i = 0; i < NJ; ++i)                                               \
                 dst_[i][s] = bf_[s * 2 * BNP + i * SEGP];                                                \
     }
+    // PAIRS: n-tile i of a wave is segment wn / 32 + i, and wn / 32 is even - odd i = the LOWER segment of a pair, whose
+    // taps ky = 0, 1 read the upper segment's (i - 1) slice ky + 1 (slot_up_)
+#define SM_READ_B_KY(dst_, slot_, slot_up_, ky_, kx_)                                                    \
+    if (PAIRS && (ky_) < 2) {                                                                            \
+        const f32x4* bf_ = b_frag + (slot_) * SLICE + (kx_);                                             \
+        const f32x4* bu_ = b_frag + (slot_up_) * SLICE + (kx_);                                          \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                   \
+            _Pragma("unroll") for (int i = 0; i < NJ; ++i)                                               \
+                dst_[i][s] = (i & 1) ? bu_[s * 2 * BNP + (i - 1) * SEGP] : bf_[s * 2 * BNP + i * SEGP];  \
+    } else {                                                                                             \
+        SM_READ_B(dst_, slot_, kx_)                                                                      \
+    }
 
     SM_TS(0)
     // prologue: the first AD weight stages into the register ring, chunk ch_begin's three slices into slots 0..2
@@ -405,7 +461,7 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) SM_LOAD_B(ky, ky, ch_begin);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) SM_STORE_B(ky, ky);
+        for (int ky = 0; ky < 3; ++ky) SM_STORE_B(ky, ky, ky);
     }
     {
         const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
@@ -426,7 +482,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     const f32x4* b_frag = Bs + lhi * BNP + (wn / 32) * SEGP + l31;   // n-tile i of the wave = segment wn / 32 + i
     f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 bf16 / fp16)
 #if SM_SPLIT_PREFETCH_B
-    SM_READ_B(fb, 0, 0)
+    SM_READ_B_KY(fb, 0, 1, 0, 0)
 #endif
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         // Every load below is issued UNCONDITIONALLY (the last chunk re-reads its own data instead of the next
@@ -443,12 +499,12 @@ void conv3x3_split_kernel(ConvArgs a) {
             if (ch == ch_begin && tap == 0) { SM_READ_B(fb_next, 0, 1) }
 #elif SM_SPLIT_PREFETCH_B
             if (tap < 8) {
-                SM_READ_B(fb_next, SM_CUR_SLOT((tap + 1) / 3), (tap + 1) % 3)
+                SM_READ_B_KY(fb_next, SM_CUR_SLOT((tap + 1) / 3), SM_CUR_SLOT((tap + 1) / 3 + 1), (tap + 1) / 3, (tap + 1) % 3)
             } else {
-                SM_READ_B(fb_next, SM_NEXT_SLOT(0), 0)
+                SM_READ_B_KY(fb_next, SM_NEXT_SLOT(0), SM_NEXT_SLOT(1), 0, 0)
             }
 #else
-            SM_READ_B(fb, SM_CUR_SLOT(ky), kx)
+            SM_READ_B_KY(fb, SM_CUR_SLOT(ky), SM_CUR_SLOT(ky + 1), ky, kx)
 #endif
 #if SM_SPLIT_PIN_READS
             // keep the fragment reads HERE, a full stage ahead of their use: left alone, the scheduler sinks them to the
@@ -517,7 +573,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
             if constexpr (SM_SPLIT_BSETS == 1) {
 #ifndef SM_ABL_NOB
-                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky)); }
+                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky), ky); }
 #endif
                 // six slots: the next chunk is written into the other half of the ring, which nobody reads after the
                 // barrier at the end of tap 7 of the previous chunk (tap 8 already prefetches from the new half): that
@@ -536,7 +592,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 }
             } else {
                 if (kx == 1) {   // slice ky of the next chunk out of its register set, the chunk after that into it
-                    SM_STORE_B(ky, SM_NEXT_SLOT(ky));
+                    SM_STORE_B(ky, SM_NEXT_SLOT(ky), ky);
                     SM_LOAD_B(ky, ky, ch_next2);
                 }
                 if (RING6 ? tap == 7 : kx == 2) __syncthreads();
@@ -562,6 +618,7 @@ void conv3x3_split_kernel(ConvArgs a) {
 #undef SM_LOAD_B
 #undef SM_STORE_B
 #undef SM_READ_B
+#undef SM_READ_B_KY
 
     // ---- epilogue (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31,
     //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
