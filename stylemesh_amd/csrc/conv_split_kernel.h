@@ -98,6 +98,9 @@ __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2]
 //           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
 //           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
 //           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
+#ifndef SM_ABL_NOSEL
+#define SM_ABL_NOSEL 0          // 1 (ablation build, timing only): the un-pooling input without its argmax selection
+#endif
 #ifndef SM_SPLIT2_PAIR_ROWS
 #define SM_SPLIT2_PAIR_ROWS 1  // forward convs with the pooling epilogue: the lower segment of a pair re-uses the upper one's rows
 #endif
@@ -398,7 +401,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         e_[h_dst + 4 * BNP * 8] = l;                                                                     \
     } else {                                                                                             \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
-        if constexpr (UNPOOL) {   /* gradient only at the window element that held the maximum */       \
+        if constexpr (UNPOOL && !SM_ABL_NOSEL) {   /* gradient only at the window element that held the maximum */ \
             _Pragma("unroll") for (int u = 0; u < NU; ++u)                                               \
                 _Pragma("unroll") for (int c = 0; c < 8; ++c)                                            \
                     rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
@@ -704,7 +707,11 @@ void conv3x3_split_kernel(ConvArgs a) {
     // epilogue adds its masked Gram backward, sum_k m_k(q) (D_k F)(q), F = the gate operand - C / 16 sixteen-channel steps
     // per mask on the matrix cores for each of the wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
     // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
+#ifdef SM_ABL_NOGRAM   // (ablation build, timing only)
+    constexpr bool GRAM = false;
+#else
     constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
+#endif
     float g_fscale = 1.f, g_oscale = 1.f;
     if constexpr (GRAM) {
         static_assert(NP == 2 && MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
@@ -714,6 +721,94 @@ void conv3x3_split_kernel(ConvArgs a) {
         conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
         g_oscale = inv_f * inv_d;
     }
+    // Round 4: the operand F is staged ONCE per block through the (now idle) slice ring - 64 channels at a time, already
+    // scaled and split, in the main loop's unit format [part][k-group][position] - instead of being loaded and converted
+    // by every wave that shares the positions (2 of 4 waves on the 64 x 256 tile, all 4 on the 128 x 128 one) in a
+    // load -> convert -> MFMA chain per 32 channels; the derivative matrices' fragments are fetched once per k-step for the
+    // wave's NJ column tiles, whose NJ accumulators take the MFMAs interleaved. Per column tile the products arrive in the
+    // order they always did (chunk, mask, k-step): the sums keep their bits.
+    f32x16 accg[GRAM ? NJ : 1];
+    if constexpr (GRAM) {
+        constexpr int PH = BM / 64;             // phases of 64 channels (the ring holds 2 parts x 8 k-groups x BN units)
+        constexpr int GU = 8 * BN / 256;        // staging units (k-group, position) per thread and phase
+        static_assert(2 * 8 * BN <= conv_split_slots(NP, BM) * SLICE, "a phase of the Gram operand fits the slice ring");
+        f32x4* Gs = smem4;
+        float mk[NJ][2];
+        bool anyk[NJ][2], alive_j[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+            int q_seg = qs[0];
+            alive_j[nj] = live[0];
+#pragma unroll
+            for (int k = 1; k < SEG; ++k)
+                if (wn / 32 + nj == k) { q_seg = qs[k]; alive_j[nj] = live[k]; }
+            const int q = q_seg + l31;
+            const bool valid = alive_j[nj] && q < q_end;
+            const int qc = valid ? q : q_seg;                          // (lanes past the plane's end load a valid address)
+            mk[nj][0] = valid ? P.gram_mask0[qc] : 0.f;
+            mk[nj][1] = (valid && P.gram_mask1) ? P.gram_mask1[qc] : 0.f;
+            anyk[nj][0] = __ballot(mk[nj][0] != 0.f) != 0ull;
+            anyk[nj][1] = __ballot(mk[nj][1] != 0.f) != 0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accg[nj][r] = 0.f;
+        }
+        // staging unit u of this thread: position tid % BN of the block, k-group tid / BN + u * (256 / BN)
+        const int g_pos = tid & (BN - 1);
+        int g_q = qs[0];
+#pragma unroll
+        for (int k = 1; k < SEG; ++k)
+            if ((g_pos >> 5) == k) g_q = qs[k];
+        g_q += g_pos & 31;
+        if (g_q >= q_end) g_q -= g_pos & 31;                           // (as above: a valid address, masked to zero later)
+        const f32x4* gp = P.gram_p + lhi * BM + wm + l31;            // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
+        const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph) {
+            __syncthreads();                                           // the ring's (the previous phase's) last readers are through
+            {
+                float rb[GU][8];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int kg = tid / BN + u * (256 / BN);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        rb[u][c] = P.gate[(size_t)(ph * 64 + kg * 8 + c) * P.plane + g_q];
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int kg = tid / BN + u * (256 / BN);
+                    f32x4 vh, vl;
+                    conv_gram_split(rb[u], g_fscale, vh, vl);
+                    Gs[kg * BN + g_pos] = vh;
+                    Gs[(8 + kg) * BN + g_pos] = vl;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int chunk = 0; chunk < 2; ++chunk)                    // 32 channels
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int t = (ph * 2 + chunk) * 2 + ks;       // k-step of 16 channels
+                        const f32x4* gk = k == 0 ? gp : gp1;
+                        f32x4 fa[2];
+                        fa[0] = gk[(t * 4 + 0) * BM];
+                        fa[1] = gk[(t * 4 + 2) * BM];
+#pragma unroll
+                        for (int nj = 0; nj < NJ; ++nj) {
+                            if (!alive_j[nj] || !anyk[nj][k]) continue;   // (wave-uniform)
+                            const f32x4* gf = Gs + ((chunk * 2 + ks) * 2 + lhi) * BN + wn + nj * 32 + l31;
+                            const bool keep = mk[nj][k] != 0.f;
+                            f32x4 fb[2];
+                            fb[0] = keep ? gf[0] : zero4;
+                            fb[1] = keep ? gf[8 * BN] : zero4;
+                            conv_gram_mfma(accg[nj], fa, fb);
+                        }
+                    }
+        }
+    }
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         int q_seg = qs[0];
@@ -722,44 +817,6 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int k = 1; k < SEG; ++k)
             if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
         const int q = q_seg + l31;
-        f32x16 accg;
-        if constexpr (GRAM) {
-            if (!alive) continue;                                    // (wave-uniform: a padding segment)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accg[r] = 0.f;
-            const bool valid = q < q_end;
-            const int qc = valid ? q : q_seg;                          // (lanes past the plane's end load a valid address)
-            const float mk0 = valid ? P.gram_mask0[qc] : 0.f;
-            const float mk1 = (valid && P.gram_mask1) ? P.gram_mask1[qc] : 0.f;
-            const bool any0 = __ballot(mk0 != 0.f) != 0ull, any1 = __ballot(mk1 != 0.f) != 0ull;
-            if (any0 || any1) {
-                const f32x4* gp = P.gram_p + lhi * BM + wm + l31;    // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
-                const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
-#pragma unroll
-                for (int chunk = 0; chunk < BM / 32; ++chunk) {
-                    float rb[2][8];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            rb[ks][c] = P.gate[(size_t)(chunk * 32 + ks * 16 + lhi * 8 + c) * P.plane + qc];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if (k == 0 ? !any0 : !any1) continue;          // (wave-uniform)
-                        const float sm_ = ((k == 0 ? mk0 : mk1) != 0.f) ? g_fscale : 0.f;
-                        const f32x4* gk = k == 0 ? gp : gp1;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            f32x4 fa[2], fb[2];
-                            fa[0] = gk[((chunk * 2 + ks) * 4 + 0) * BM];
-                            fa[1] = gk[((chunk * 2 + ks) * 4 + 2) * BM];
-                            conv_gram_split(rb[ks], sm_, fb[0], fb[1]);
-                            conv_gram_mfma(accg, fa, fb);
-                        }
-                    }
-                }
-            }
-        }
         if (!alive || q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
@@ -780,7 +837,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 if (NP == 2) v *= out_scale;
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += prev[r];
-                if constexpr (GRAM) v += accg[r] * g_oscale;
+                if constexpr (GRAM) v += accg[nj][r] * g_oscale;
                 if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
                 v = inside ? v : 0.f;
                 P.out[o] = v;
