@@ -80,6 +80,9 @@ __device__ __forceinline__ void conv_gram_split(const float (&x)[8], float sm, f
     vh = __builtin_bit_cast(f32x4, h);
     vl = __builtin_bit_cast(f32x4, l);
 }
+__device__ __forceinline__ unsigned Gs_gate_byte(const f32x4* smem, int index, int unit_offset) {
+    return reinterpret_cast<const unsigned char*>(smem + unit_offset)[index];
+}
 __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2], const f32x4 (&fb)[2]) {
 #define SM_H(x_) __builtin_bit_cast(cg_f16x8, x_)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
@@ -731,8 +734,14 @@ void conv3x3_split_kernel(ConvArgs a) {
     if constexpr (GRAM) {
         constexpr int PH = BM / 64;             // phases of 64 channels (the ring holds 2 parts x 8 k-groups x BN units)
         constexpr int GU = 8 * BN / 256;        // staging units (k-group, position) per thread and phase
-        static_assert(2 * 8 * BN <= conv_split_slots(NP, BM) * SLICE, "a phase of the Gram operand fits the slice ring");
+        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= conv_split_slots(NP, BM) * SLICE * 16,
+                      "a phase of the Gram operand + the gate bits of all channels fit the slice ring");
         f32x4* Gs = smem4;
+        // F is also the ReLU gate of this launch's output: the staging threads - which hold the raw values - leave one bit
+        // per (channel, position), x > 0, behind the operand (byte [channel / 8][position]); the store loop below reads its
+        // gate from there instead of loading the layer a second time (conv1_2's data gradient moved 1.27 GB, a third of it
+        // this second read)
+        unsigned char* Gb = reinterpret_cast<unsigned char*>(smem4 + 2 * 8 * BN);
         float mk[NJ][2];
         bool anyk[NJ][2], alive_j[NJ];
 #pragma unroll
@@ -782,6 +791,10 @@ void conv3x3_split_kernel(ConvArgs a) {
                     conv_gram_split(rb[u], g_fscale, vh, vl);
                     Gs[kg * BN + g_pos] = vh;
                     Gs[(8 + kg) * BN + g_pos] = vl;
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) bits |= (rb[u][c] > 0.f ? 1u : 0u) << c;
+                    Gb[(ph * 8 + kg) * BN + g_pos] = (unsigned char)bits;
                 }
             }
             __syncthreads();
@@ -828,7 +841,15 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
                 if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
-                if (FLAGS & SM_EPI_RELU_MASK) gate[r] = P.gate[o];
+                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
+            }
+            if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned b8 = Gs_gate_byte(smem4, (wm / 8 + g) * BN + wn + nj * 32 + l31, 2 * 8 * BN);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gate[4 * g + k] = ((b8 >> (4 * lhi + k)) & 1u) ? 1.f : 0.f;
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
