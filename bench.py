@@ -530,8 +530,16 @@ def _run(args):
             share = shares.get(name, 1.0)
             if share is None or n_l == 0:
                 continue
+            extra = {}
+            plan = getattr(eng, "_scatter_plan", None)
+            if name == "scatter" and plan is not None and plan.level_hw is not None:
+                # entries without weight sort to the tail and are skipped: only the live ones move bytes
+                live = plan.live_share()
+                pack = sum(h * w for h, w in plan.level_hw) * 28.0 * n_l
+                bytes_l = pack + (bytes_l - pack) * live
+                extra = {"live_entries_last_view": round(live, 4)}
             tbps = bytes_l * share / (ms_l * 1e-3) / 1e12
-            roofline_hbm["kernels"][name] = {"launches_timed": n_l, "avg_us": round(1e3 * ms_l / n_l, 1),
+            roofline_hbm["kernels"][name] = {"launches_timed": n_l, "avg_us": round(1e3 * ms_l / n_l, 1), **extra,
                                             "algorithmic_MB_per_launch": round(bytes_l * share / n_l / 1e6, 1),
                                             "TBps": round(tbps, 2), "frac_of_copy_rate": round(tbps / 6.29, 3),
                                             **({"flagged_share_last_view": round(share, 4)} if name in shares else {})}

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(const unsigned* __r
     const int lane = threadIdx.x & 63;
     const size_t base = (((size_t)blockIdx.x * 256 + threadIdx.x) >> 6) * (64 * U);   // first entry of this wave
     if (base >= n) return;
+    // sorted: the invalid entries (taps without weight: ~a third of a c3 view's list) are the tail - a wave whose first
+    // entry is one of them has nothing to do and leaves on one wave-uniform load instead of streaming its keys and values
+    if (keys[base] == invalid) return;
     unsigned key[U], kprev[U], knext[U];
     unsigned long long val[U];
 #pragma unroll

@@ -199,13 +199,21 @@ class ScatterPlan:
                                           pcross, self.key_bits, C.byref(which), hip.stream()), "sm_tex_scatter_plan")
         self.sorted_in = which.value
 
+    def live_share(self) -> float:
+        """Share of the current view's entries that carry weight (the others sort to the tail and are skipped). Synchronises:
+        for reports, not for the step."""
+        invalid = 0xffffffff if self.key_bits == 32 else (1 << self.key_bits) - 1
+        keys = self.bufs[self.sorted_in][:self.n_entries]
+        signed = invalid - (1 << 32) if invalid >= (1 << 31) else invalid        # (the key buffers are int32 tensors)
+        return float((keys != signed).float().mean())
+
     def scatter(self, grad_imgs, accumulate=True):
         """``grad_imgs``: the levels' image-gradient FMaps, in the order of ``build``. Adds into the gradient arena;
         ``accumulate=False`` when the arena is known to be zero (texels are then stored without being read)."""
         assert self.level_hw is not None and [(g.H, g.W) for g in grad_imgs] == self.level_hw
         keys, vals = self.bufs[self.sorted_in], self.bufs[2 + self.sorted_in]
-        # algorithmic bytes (upper bound: every entry live): key + value + the pixel's packed gradient per entry, the
-        # image gradients packed once (3 planes read, 16 B per pixel written)
+        # algorithmic bytes (upper bound: every entry live - bench.py scales the entry term by ``live_share()``): key + value
+        # + the pixel's packed gradient per entry, the image gradients packed once (3 planes read, 16 B per pixel written)
         nbytes = self.n_entries * (4 + 8 + 16) + sum(h * w for h, w in self.level_hw) * 28
         _hbm_timed("scatter", nbytes, lambda: hip.check(
             lib.sm_tex_scatter_planned(ptr(keys), ptr(vals), self.n_entries, hip.ptr_array(grad_imgs),
