@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box: alternate variant libraries over the c3 bench (200-step many-views leg), two rounds (temporary A/B tool).
+# On the GPU box: alternate variant libraries over the c3 bench (200-step many-views leg), two rounds.
 R=$GRAFT_REPO_ROOT
 for round in 1 2; do
 for t in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: per variant library, rocprofv3 kernel stats of a short c3 bench run; prints the average duration of every
-# split conv kernel variant (temporary A/B tool).
+# split conv kernel variant.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for t in "$@"; do
