@@ -169,16 +169,27 @@ class ScanNetSingleSceneDataModule:
         n_train = int(self.split[0] * n)
         self.train_indices, self.val_indices = list(range(n_train)), list(range(n_train, n))
 
+    def _decode_worker(self):
+        """The persistent decode process(es) of all epochs (re-started if an epoch was abandoned)."""
+        from ..runtime.distributed import DecodeProcess
+        if self.prefetch <= 0:
+            return None
+        if getattr(self, "_worker", None) is None or not self._worker.alive() or self._worker.busy:
+            if getattr(self, "_worker", None) is not None:
+                self._worker.close()
+            self._worker = DecodeProcess(self.train_dataset.__getitem__, depth=self.prefetch,
+                                         n_workers=self.decode_workers)
+        return self._worker
+
+    def warm_start(self):
+        """Start the decode processes NOW (a spawned interpreter needs ~1 s to import its modules): called by the CLI
+        before it builds the model, so that the first view is decoded while the training process still sets itself up
+        instead of the first step waiting for it."""
+        self._decode_worker()
+
     def train_dataloader(self):
-        from ..runtime.distributed import DecodeProcess, scheduled_batches   # equal step counts + lock-step view changes
-        worker = None
-        if self.prefetch > 0:   # one persistent decode process for all epochs (re-started if an epoch was abandoned)
-            if getattr(self, "_worker", None) is None or not self._worker.alive() or self._worker.busy:
-                if getattr(self, "_worker", None) is not None:
-                    self._worker.close()
-                self._worker = DecodeProcess(self.train_dataset.__getitem__, depth=self.prefetch,
-                                             n_workers=self.decode_workers)
-            worker = self._worker
+        from ..runtime.distributed import scheduled_batches   # equal step counts + lock-step view changes
+        worker = self._decode_worker()
         return scheduled_batches(self.train_dataset.__getitem__, self.train_indices, self.rank, self.world_size,
                                  self.index_repeat, repeat=self.sampler_mode == "repeat", prefetch=self.prefetch,
                                  worker=worker)

@@ -97,6 +97,8 @@ def main(args):
         raise ValueError(f"Unsupported dataset: {args.dataset}")
     dm.prepare_data()
     dm.setup()
+    if hasattr(dm, "warm_start"):
+        dm.warm_start()       # (the decode processes import their modules while the model is being built)
 
     if args.loss_weights:
         args.loss_weights = {l[0]: float(l[1]) for l in args.loss_weights}

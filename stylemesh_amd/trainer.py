@@ -182,6 +182,12 @@ class MiniTrainer:
         if os.environ.get("STYLEMESH_SWITCH_INTERVAL"):   # experiment: interpreter-lock hand-over interval (seconds)
             import sys
             sys.setswitchinterval(float(os.environ["STYLEMESH_SWITCH_INTERVAL"]))
+        if hasattr(datamodule, "warm_start"):
+            datamodule.warm_start()              # decode processes up before anything waits for them
+        if hasattr(model, "_ensure_engine") and self.device != "cpu" and torch.cuda.is_available():
+            # the fused engine (weight packing, style targets: ~0.3 s) is built here, beside the loader's start-up,
+            # instead of inside the first training step behind the first view
+            model._ensure_engine(torch.device(self.device))
         optimizers, schedulers = model.configure_optimizers()
         opt, sched = optimizers[0], (schedulers[0] if schedulers else None)
         if hasattr(opt, "world_size"):

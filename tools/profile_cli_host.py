@@ -27,5 +27,5 @@ if __name__ == "__main__":
     pr.disable()
     print(f"wall {time.time() - t0:.1f} s")
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "28")))
     print(s.getvalue()[:6000])
