@@ -54,6 +54,13 @@ def resolve_vgg_path(path: str) -> str:
 
 
 def main(args):
+    import time as _time
+    _t0 = _time.time()
+    _timing = os.environ.get("STYLEMESH_MAIN_TIMING") == "1"
+
+    def _mark(what):
+        if _timing:
+            print(f"[main +{_time.time() - _t0:6.2f} s] {what}", flush=True)
     from ..runtime.hostcpu import limit_host_threads
     limit_host_threads()      # (the visible core count is not what the container may use: see runtime/hostcpu.py)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -95,10 +102,13 @@ def main(args):
                                               decode_workers=max(1, min(args.num_workers, 4)))
     else:
         raise ValueError(f"Unsupported dataset: {args.dataset}")
+    _mark("datamodule built")
     dm.prepare_data()
     dm.setup()
+    _mark("datamodule set up")
     if hasattr(dm, "warm_start"):
         dm.warm_start()       # (the decode processes import their modules while the model is being built)
+    _mark("decode processes started")
 
     if args.loss_weights:
         args.loss_weights = {l[0]: float(l[1]) for l in args.loss_weights}
@@ -123,7 +133,9 @@ def main(args):
     model.grad_reducer = make_sparse_grad_reducer(comm, world)
 
     trainer = MiniTrainer(max_epochs=args.max_epochs, logger=logger, device=device, rank=rank, world_size=world)
+    _mark("model built")
     trainer.fit(model, dm)
+    _mark("fit done")
     if world > 1:
         if hasattr(comm, "destroy"):
             comm.destroy()

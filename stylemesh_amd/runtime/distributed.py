@@ -172,6 +172,14 @@ def _decode_main(get_view, tasks, results):
         os.nice(10)      # the training process's launch loop and its wake-ups from device syncs come first
     except OSError:
         pass
+    if get_view is None:
+        # the decoder arrives as the first message: a process started under 'spawn' receives its arguments through a pipe
+        # the parent WRITES SYNCHRONOUSLY - beyond the pipe's 64 KB (a 276-view dataset's file lists pickle to 100 KB) the
+        # parent's start() blocks until the child has imported its modules (0.8 s per worker, measured); a queue's
+        # feeder thread writes in the background instead
+        get_view = tasks.get()
+        if get_view is None:
+            return
     while True:
         order = tasks.get()
         if order is None:
@@ -202,7 +210,7 @@ class DecodeProcess:
         self.n = max(1, n_workers)
         self.tasks = [ctx.Queue() for _ in range(self.n)]
         self.results = [ctx.Queue(maxsize=max(1, depth)) for _ in range(self.n)]
-        self.procs = [ctx.Process(target=_decode_main, args=(get_view, self.tasks[k], self.results[k]), daemon=True,
+        self.procs = [ctx.Process(target=_decode_main, args=(None, self.tasks[k], self.results[k]), daemon=True,
                                   name=f"stylemesh-view-decode-{k}") for k in range(self.n)]
         # the decoders are single-threaded by construction (numpy indexing, PIL, small torch ops): keep their math
         # libraries from spinning up one thread per VISIBLE core (256 on the GPU boxes, under a 16-CPU quota)
@@ -211,6 +219,8 @@ class DecodeProcess:
         try:
             for p in self.procs:
                 p.start()
+            for q in self.tasks:
+                q.put(get_view)       # (see _decode_main: not through the start-up pipe)
         finally:
             for k, v in saved.items():
                 if v is None:

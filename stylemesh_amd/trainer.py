@@ -182,6 +182,7 @@ class MiniTrainer:
         if os.environ.get("STYLEMESH_SWITCH_INTERVAL"):   # experiment: interpreter-lock hand-over interval (seconds)
             import sys
             sys.setswitchinterval(float(os.environ["STYLEMESH_SWITCH_INTERVAL"]))
+        t0 = time.time()                         # (the schedule's clock: engine set-up and loader start-up included)
         if hasattr(datamodule, "warm_start"):
             datamodule.warm_start()              # decode processes up before anything waits for them
         if hasattr(model, "_ensure_engine") and self.device != "cpu" and torch.cuda.is_available():
@@ -192,7 +193,6 @@ class MiniTrainer:
         opt, sched = optimizers[0], (schedulers[0] if schedulers else None)
         if hasattr(opt, "world_size"):
             opt.world_size = self.world_size
-        t0 = time.time()
         def now():
             if self.device != "cpu" and torch.cuda.is_available():
                 torch.cuda.synchronize()
