@@ -354,7 +354,12 @@ __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict_
 }
 
 // SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false>
+// KG = 2 (fp16x2 kernel, launches of at most one tile per CU): blocks of two wave groups that split the block's K range
+// between them (conv_split_kernel.h) - chosen below, never by the caller.
+#ifndef SM_CONV_KG2_DEFAULT
+#define SM_CONV_KG2_DEFAULT 0   // measured (profiles/r05/kg2_c2_layers.txt): -8 % on the one-level layers - the groups run in lock-step
+#endif
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false, int KG = 1>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -366,9 +371,15 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     if (SPLIT && a.tile_list && n_list % (BN / 32) != 0) return (int)hipErrorInvalidValue;
     a.n_tiles = a.tile_list ? (SPLIT ? n_list / (BN / 32) : n_list) : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
-    constexpr size_t lds = SPLIT ? conv_split_lds_bytes(BM, BN, NP)
+    constexpr size_t lds = SPLIT ? KG * conv_split_lds_bytes(BM, BN, NP)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
+    if constexpr (SPLIT && NP == 2 && KG == 1 && (FLAGS & SM_EPI_GRAM) == 0) {
+        // small grids (<= one tile per CU): 512-thread blocks of two wave groups; SM_CONV_KG=1 keeps the 4-wave blocks (A/B)
+        static const bool kg2 = getenv("SM_CONV_KG") ? atoi(getenv("SM_CONV_KG")) == 2 : SM_CONV_KG2_DEFAULT != 0;
+        if (kg2 && tiles <= SM_NUM_CU && chunks % 2 == 0)
+            return launch_conv<BM, BN, KC, WGM, WGN, FLAGS, SPLIT, NP, UNPOOL, 2>(a0, n_list, ws_floats, s);
+    }
     // Full rounds of one tile per resident block slot run whole; the tail of `rem` tiles is split along K so that
     // it becomes about one more (short) round of rem * splits small units. Pick the split count that minimises the
     // tail's duration ceil(rem * S / slots) / S, each split keeping >= 2 K-chunks. (The split kernel keeps two
@@ -385,6 +396,25 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     a.splits = 1;
     a.chunks_per_split = chunks;
     int rem = tiles - a.n_whole;
+    if constexpr (KG == 2) {
+        // tiles <= CUs: all of them whole (S = 1) or all of them split S ways. A unit of cps chunks takes its groups
+        // cps / 2 chunk times + ~1 of prologue / exchange / epilogue; a split launch pays the second pass on top
+        // (SM_CONV_SPLIT_PENALTY, in the same unit). Every unit's chunk count stays even (cps even, chunks even).
+        static const float penalty = getenv("SM_CONV_SPLIT_PENALTY") ? (float)atof(getenv("SM_CONV_SPLIT_PENALTY")) : SM_CONV_SPLIT_PENALTY_DEFAULT;
+        a.n_whole = tiles;
+        rem = 0;
+        float best = chunks * 0.5f + 1.f;
+        if (a.ws != nullptr && chunks >= 4) {
+            const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)tiles * BM * BN)});
+            for (int S = 2; S <= max_s; ++S) {
+                const int cps = ((chunks + S - 1) / S + 1) & ~1, S_eff = (chunks + cps - 1) / cps;
+                if (S_eff < 2) continue;
+                const float cost = (float)((tiles * S_eff + SM_NUM_CU - 1) / SM_NUM_CU) * (cps * 0.5f + 1.f) + penalty;
+                if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
+            }
+        }
+        if (a.splits > 1) { a.n_whole = 0; rem = tiles; }
+    } else
     if (a.ws != nullptr && rem > 0 && chunks >= 4) {
         const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)rem * BM * BN)});
         // cost of the tail in units of one whole tile; every unit pays ~1 chunk of fixed prologue / epilogue time
@@ -404,8 +434,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         if (force_s > 0 && a.ws != nullptr && tiles - tiles / SLOTS * SLOTS > 0) {
             a.n_whole = tiles / SLOTS * SLOTS;
             rem = tiles - a.n_whole;
-            const int S = std::max(1, std::min({force_s, chunks, (int)(ws_floats / ((size_t)rem * BM * BN))}));
-            a.chunks_per_split = (chunks + S - 1) / S;
+            const int S = std::max(1, std::min({force_s, chunks / KG, (int)(ws_floats / ((size_t)rem * BM * BN))}));
+            a.chunks_per_split = ((chunks + S - 1) / S + KG - 1) / KG * KG;
             a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
         }
     }
@@ -414,15 +444,15 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && !UNPOOL) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL, NP, UNPOOL>
-                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL>;
+        auto k = (stamp && !UNPOOL) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL, NP, UNPOOL, KG>
+                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             attr_done = true;
         }
-        hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256 * KG), lds, s, a);
     } else {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>), dim3(a.n_whole + rem * a.splits),
                            dim3(256), lds, s, a);

@@ -101,11 +101,17 @@ __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2]
 //           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
 //           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
 //           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
+#ifndef SM_ABL_NOCVT
+#define SM_ABL_NOCVT 0          // 1 (ablation build, timing only): activations staged without the fp32 -> fp16-pair conversion
+#endif
 #ifndef SM_ABL_NOSEL
 #define SM_ABL_NOSEL 0          // 1 (ablation build, timing only): the un-pooling input without its argmax selection
 #endif
 #ifndef SM_SPLIT2_PAIR_ROWS
 #define SM_SPLIT2_PAIR_ROWS 1  // forward convs with the pooling epilogue: the lower segment of a pair re-uses the upper one's rows
+#endif
+#ifndef SM_SPLIT2_ILV
+#define SM_SPLIT2_ILV 0        // experiment: 1 = no scheduling fence below a stage's MFMAs; 2 = tail instructions dealt between the MFMAs
 #endif
 #ifndef SM_SPLIT2_RING6
 #define SM_SPLIT2_RING6 0      // fp16x2: six LDS slots (two whole chunks), ONE barrier per chunk instead of three
@@ -148,12 +154,25 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
 constexpr int conv_split_waves(int BM, int BN, int NP) {
     return BM == 256 ? 1 : (BM == 64 && BN == 128) ? SM_SPLIT_WAVES64 : NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES;
 }
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false>
-__global__ __launch_bounds__(256)
+// KG (round 5) = wave GROUPS per block. KG = 2: a block is 512 threads = two groups of four waves; both compute the SAME
+// output tile, group g over half g of the block's K-chunks, each with a slice ring and weight registers of its own (the
+// groups only meet at the stages' barriers), and exchange accumulator halves through LDS before the epilogue, which each
+// group runs for half of the wave's column tiles. For launches of <= one block per CU (every layer of a one-level view:
+// 12 - 172 tiles): a lone 4-wave block is latency-bound - one wave per SIMD cannot cover its own load / convert / store
+// stage tail with MFMAs (a stage takes ~800 cycles against ~475 per block when two blocks share a CU) - and getting the
+// second wave per SIMD from MORE global K-splits doubles the partial slabs instead.
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
 void conv3x3_split_kernel(ConvArgs a) {
     static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
-    static_assert(!UNPOOL || (NP == 2 && SM_SPLIT_BSETS == 1), "the unpool input exists for the fp16x2 kernel");
+    static_assert(KG == 1 || (KG == 2 && NP == 2 && conv_split_waves(BM, BN, NP) == 2 && !(FLAGS & SM_EPI_GRAM)),
+                  "two wave groups: the fp16x2 kernel at two waves per SIMD, without the Gram epilogue");
+    static_assert(KG == 1 || !SM_SPLIT2_RING6, "two wave groups: the four-slot ring (a barrier at the end of every chunk)");
+    static_assert(!UNPOOL || NP == 2, "the unpool input exists for the fp16x2 kernel");
+    // activation register sets: 1 = a slice is loaded two stages before it is converted; 3 = one set per ky slice, loaded a
+    // whole chunk (nine stages) ahead. (the un-pooling input and the pair rows keep one set)
+    constexpr int BSETS = (UNPOOL || ((FLAGS & SM_EPI_POOL) != 0 && NP == 2 && SM_SPLIT2_PAIR_ROWS)) ? 1 : SM_SPLIT_BSETS;
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
@@ -170,9 +189,10 @@ void conv3x3_split_kernel(ConvArgs a) {
     constexpr int BNP = SEG * SEGP;       // staged positions per slice
     constexpr int SLICE = 2 * NP * BNP;   // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
-    f32x4* Bs = smem4;                    // [4 slots][SLICE]
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);        // wave group (wave-uniform)
+    f32x4* Bs = smem4 + grp * (conv_split_slots(NP, BM) * SLICE);   // [4 slots][SLICE] of this group
 
-    const int tid = threadIdx.x;
+    const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread / wave index INSIDE the group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l31 = lane & 31;
@@ -181,7 +201,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int wn = (wave % WGN) * (32 * NJ);
 #define SM_TS(slot_)                                                                                     \
     if (STAMP && lane == 0) {                                                                            \
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)blockIdx.x * 4 + wave) * 64 + (slot_)] = \
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)(blockIdx.x * KG + grp) * 4 + wave) * 64 + (slot_)] = \
             __builtin_readcyclecounter();                                                                \
     }
 
@@ -220,8 +240,13 @@ void conv3x3_split_kernel(ConvArgs a) {
         }
     }
     const int n_chunks = a.Cin_pad / KC;
-    const int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
-    const int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
+    int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
+    int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
+    if constexpr (KG == 2) {   // (the host keeps every unit's chunk count even: both groups run the same number of stages)
+        const int half = (ch_end - ch_begin) >> 1;
+        ch_begin += grp * half;
+        ch_end = ch_begin + half;
+    }
     const int m0 = m_tile * BM;
 
     const float amax_seen = split < 0 ? amax_peek(a.amax_out) : 0.f;   // whole tiles record their output's bound
@@ -317,7 +342,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     // per MFMA of the 128-row tile, and staging is what bounds it. Bit-identical: the same input
     // values go through the same conversion. Slices 0 / 1 are staged with a mapping of their own over the UPPER segments:
     // one unit per thread for BN = 256 (instead of two); for BN = 128 half the threads convert and store.
-    constexpr bool PAIRS = NP == 2 && !UNPOOL && (FLAGS & SM_EPI_POOL) != 0 && SM_SPLIT_BSETS == 1 && !SM_SPLIT2_RING6 &&
+    constexpr bool PAIRS = NP == 2 && !UNPOOL && (FLAGS & SM_EPI_POOL) != 0 && BSETS == 1 && !SM_SPLIT2_RING6 &&
                            SM_SPLIT2_PAIR_ROWS;
     const int a_kg = BN == 256 ? (tid >> 7) : ((tid >> 6) & 1);
     const int a_px = BN == 256 ? (tid & 127) : (tid & 63);
@@ -410,6 +435,14 @@ void conv3x3_split_kernel(ConvArgs a) {
                     rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
             rhs[set_] = ((int)((rhc[set_] >> (4 * h_c)) & 15u) == rhp[set_]) ? rhs[set_] : 0.f;          \
         }                                                                                                \
+        if constexpr (SM_ABL_NOCVT) {   /* (ablation, timing only: raw bits instead of the scaled fp16 pairs) */ \
+            _Pragma("unroll") for (int u = 0; u < ((PAIRS && (ky_) < 2) ? 1 : NU); ++u) {               \
+                f32x4 vh = {rbs[set_][u][0], rbs[set_][u][1], rbs[set_][u][2], rbs[set_][u][3]};         \
+                f32x4 vl = {rbs[set_][u][4], rbs[set_][u][5], rbs[set_][u][6], rbs[set_][u][7]};         \
+                if (PAIRS && (ky_) < 2) { if (a_active) { d_[a_dst] = vh; d_[a_dst + 2 * BNP] = vl; } }  \
+                else { d_[b_dst[u]] = vh; d_[b_dst[u] + 2 * BNP] = vl; }                                 \
+            }                                                                                            \
+        } else                                                                                           \
         if (PAIRS && (ky_) < 2) {                                                                        \
             f16x8 vh, vl;                                                                                \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
@@ -471,7 +504,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
     {
         const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
-        if constexpr (SM_SPLIT_BSETS == 1) {
+        if constexpr (BSETS == 1) {
             SM_LOAD_B(0, 0, ch1);      // stored at the end of tap 1 of the first chunk
         } else {
 #pragma unroll
@@ -490,6 +523,22 @@ void conv3x3_split_kernel(ConvArgs a) {
 #if SM_SPLIT_PREFETCH_B
     SM_READ_B_KY(fb, 0, 1, 0, 0)
 #endif
+    // SM_SPLIT2_ILV = 2 (experiment): a stage's instruction stream is dictated - the next stage's fragment reads first, then
+    // its MFMAs with the tail's instructions dealt between them (a lone wave per SIMD cannot hide a tail that FOLLOWS
+    // its MFMAs): per MFMA `valu_` VALU instructions (the convert-and-store stage) or one vector-memory load
+#if SM_SPLIT2_ILV == 2
+#define SM_ILV_PIPE(valu_)                                                                               \
+    if constexpr (NP == 2) {                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, NJ * NP, 0);                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < MI * NJ * 3; ++g_) {                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+            if ((valu_) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (valu_), 0);                    \
+            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
+        }                                                                                                \
+    }
+#else
+#define SM_ILV_PIPE(valu_)
+#endif
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         // Every load below is issued UNCONDITIONALLY (the last chunk re-reads its own data instead of the next
         // chunk's): a load under `if (more)` makes the compiler's waitcnt pass assume the no-load path at the join,
@@ -501,6 +550,9 @@ void conv3x3_split_kernel(ConvArgs a) {
             const int ky = tap / 3, kx = tap % 3;
             // the next stage's activation fragments are read under this stage's MFMAs (its slice is complete: slices
             // are written a full barrier before their first use)
+#if SM_SPLIT2_ILV == 2
+            __builtin_amdgcn_sched_barrier(0);   // a scheduling region = one stage
+#endif
 #if defined(SM_ABL_NOREAD)
             if (ch == ch_begin && tap == 0) { SM_READ_B(fb_next, 0, 1) }
 #elif SM_SPLIT_PREFETCH_B
@@ -558,7 +610,9 @@ void conv3x3_split_kernel(ConvArgs a) {
 #undef SM_PRODUCT
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
+#if SM_SPLIT2_ILV == 0
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if (STAMP && ch - ch_begin == 1) SM_TS(32 + tap)      // this stage's MFMAs are issued
 #if SM_SPLIT_TAIL_PRIO
             __builtin_amdgcn_s_setprio(SM_SPLIT_TAIL_PRIO);   // the load / convert / store tail outranks the partner's MFMAs
@@ -577,9 +631,10 @@ void conv3x3_split_kernel(ConvArgs a) {
             // tap 3 ky - 1. The slice is loaded at the end of tap 3 ky - 1 (for ky = 0: tap 8 of the previous chunk),
             // converted and written at the end of tap 3 ky + 1 - a stage WITHOUT a barrier, so that the conversion does
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
-            if constexpr (SM_SPLIT_BSETS == 1) {
+            if constexpr (BSETS == 1) {
 #ifndef SM_ABL_NOB
-                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky), ky); }
+                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky), ky); SM_ILV_PIPE(6 * NU) }
+                if (kx == 0) { SM_ILV_PIPE(0) }
 #endif
                 // six slots: the next chunk is written into the other half of the ring, which nobody reads after the
                 // barrier at the end of tap 7 of the previous chunk (tap 8 already prefetches from the new half): that
@@ -593,6 +648,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         SM_LOAD_B(0, 0, ch_next2);
                     }
 #endif
+                    SM_ILV_PIPE(0)
                     if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
                     if (!RING6) __syncthreads();
                 }
@@ -625,19 +681,67 @@ void conv3x3_split_kernel(ConvArgs a) {
 #undef SM_STORE_B
 #undef SM_READ_B
 #undef SM_READ_B_KY
+#undef SM_ILV_PIPE
+
+    // ---- KG = 2: the two groups' partial sums meet. Wave w of group g keeps column tiles [g NJ/2, (g + 1) NJ/2) of its
+    // 32 MI x 32 NJ tile and hands the other half to wave w of the other group through the (now idle) slice rings; both
+    // form group 0's sum + group 1's sum - one fixed order, deterministic - and each runs the epilogue for the tiles it
+    // kept, in acc[.][0 .. NJ/2). (The loop's last barrier is behind every fragment read of the rings.)
+    constexpr int NJE = NJ / KG;          // column tiles per wave in the epilogue
+    const int nj0 = grp * NJE;            // first of them
+    if constexpr (KG == 2) {
+        static_assert(NJ % 2 == 0 && NJE % 2 == 0, "whole segment pairs per group");
+        static_assert((size_t)8 * MI * NJE * 16 * 64 * 4 <= 2 * conv_split_lds_bytes(BM, BN, NP), "exchange fits the two rings");
+        float* X = reinterpret_cast<float*>(smem4);
+        float* mine = X + (size_t)((grp * 4 + wave) * (MI * NJE * 16)) * 64 + lane;
+        const float* theirs = X + (size_t)(((1 - grp) * 4 + wave) * (MI * NJE * 16)) * 64 + lane;
+        if (grp == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NJE; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((mi * NJE + j) * 16 + r) * 64] = acc[mi][NJE + j][r];
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NJE; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((mi * NJE + j) * 16 + r) * 64] = acc[mi][j][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NJE; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][j][r] = acc[mi][j][r] + theirs[((mi * NJE + j) * 16 + r) * 64];
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NJE; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][j][r] = theirs[((mi * NJE + j) * 16 + r) * 64] + acc[mi][NJE + j][r];
+        }
+        SM_TS(50)
+    }
 
     // ---- epilogue (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31,
-    //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); column tile nj0 + j of the wave is in acc[.][j]
     if (split >= 0) {
         float* wt = a.ws + ((size_t)(tile - a.n_whole) * a.splits + split) * (BM * BN);
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
+        for (int j = 0; j < NJE; ++j)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + nj * 32 + l31] =
-                        NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r];   // power of two: exact
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + (nj0 + j) * 32 + l31] =
+                        NP == 2 ? acc[mi][j][r] * out_scale : acc[mi][j][r];   // power of two: exact
+        SM_TS(51)
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
@@ -661,12 +765,12 @@ void conv3x3_split_kernel(ConvArgs a) {
         static_assert(FLAGS == (SM_EPI_BIAS_RELU | SM_EPI_POOL) && NJ % 2 == 0, "forward epilogue, segment pairs per wave");
         const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
 #pragma unroll
-        for (int pj = 0; pj < NJ; pj += 2) {
+        for (int pj = 0; pj < NJE; pj += 2) {
             int q_seg = qs[0];
             bool alive = live[0];
 #pragma unroll
             for (int k = 1; k < SEG; ++k)
-                if (wn / 32 + pj == k) { q_seg = qs[k]; alive = live[k]; }
+                if (wn / 32 + nj0 + pj == k) { q_seg = qs[k]; alive = live[k]; }
             if (!alive) continue;                                  // (wave-uniform: a padding pair)
             const int q = q_seg + l31;                             // this lane's position in the upper row
             const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
@@ -823,12 +927,12 @@ void conv3x3_split_kernel(ConvArgs a) {
         }
     }
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
+    for (int nj = 0; nj < NJE; ++nj) {   // (KG = 2: column tile nj0 + nj of the wave, held in acc[.][nj])
         int q_seg = qs[0];
         bool alive = live[0];
 #pragma unroll
         for (int k = 1; k < SEG; ++k)
-            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
+            if (wn / 32 + nj0 + nj == k) { q_seg = qs[k]; alive = live[k]; }
         const int q = q_seg + l31;
         if (!alive || q >= q_end) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
