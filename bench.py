@@ -152,6 +152,7 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
                           new_view=(i % rep == 0), next_batch=upcoming(i))
     for i in range(args.warmup):
         step(i)
+    eng.finish_pending()
     ops.CONV_TIMER = timer
     if getattr(eng, "phase_timer", None) is not None:
         eng.phase_timer.enabled = True
@@ -161,6 +162,7 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
         if timer is not None:
             timer.enabled = (i - args.warmup) % args.timer_every == 0
         step(i)
+    eng.finish_pending()   # (pair images: steps the device invalidated are repeated inside the timed region)
     barrier()
     dt = time.perf_counter() - t0
     ops.CONV_TIMER = None
@@ -590,7 +592,11 @@ def _run(args):
                "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
                                 "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
                                         "zero-initialised texture); the fraction grows with the views of the scene"},
-               "exchange": exchange_report(eng, comm, reducer, args) if sharded else None}
+               "exchange": exchange_report(eng, comm, reducer, args) if sharded else None,
+               # pair images: steps whose VGG tensors were stored as fp16 pairs under predicted
+               # scales; "invalid" = invalidated on the device (a tensor outgrew its scale), "repeated" = made up for -
+               # inside the timed region when they fell into it
+               "pair_images": dict(eng.pair_stats, enabled=bool(eng.pair_images), headroom=eng.pair_headroom)}
         if world > 1:
             out["per_rank_views_per_s"] = [round(args.steps / t, 3) for t in per_rank_dt]
             out["ranks_consistent"] = ranks_consistent

@@ -123,7 +123,7 @@ int sm_tex_scatter_planned(const uint32_t* keys, const uint64_t* vals, size_t n_
  * grad_scale multiplies the data-term gradient first (1/R after an all-reduce over R ranks).
  * bias_corr1 = 1-beta1^t and bias_corr2 = 1-beta2^t are computed by the caller in double; the betas are
  * doubles because torch derives the fp32 constants 1-beta from Python doubles.
- * dev_hyper (optional, device, 2 floats): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2)}
+ * dev_hyper (optional, device, 3 floats - ABI 9): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2), valid}
  * from it instead of the scalar arguments, so a captured launch (hipGraph) can be replayed across steps
  * (sm_adam_hyper_step maintains it on the device).
  * touched (optional, device, one int32 per 2^touched_chunk_log2 floats of the arena, log2 in [2, 24]): chunks whose
@@ -141,10 +141,12 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
 
 /* Device-side step counter of the fused update for hipGraph replay (torch.optim.Adam's state['step'] and the
  * bias corrections of model/model.py:387-395's optimizer): state = {lr, step} (device, 2 doubles). Adds 1 to the
- * step and writes dev_hyper = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} (2 floats, computed in double as
+ * step and writes dev_hyper = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step), 1} (3 floats, computed in double as
  * torch does). Captured together with sm_adam_fused(dev_hyper=...), every replay advances one step with no
- * step-dependent value crossing from the host. */
-int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream);
+ * step-dependent value crossing from the host. guard (ABI 9, optional, device int32 - sm_pair_check's status): when
+ * *guard == 0 the step count stays and dev_hyper[2] = 0: sm_adam_fused(dev_hyper) then leaves p, m, v as they are
+ * (sum(p^2) is still taken, the gradient still zeroed) - the step is repeated by the caller. */
+int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, const int32_t* guard, void* stream);
 
 /* Head of a training step in ONE launch: *reg_out = sum_l coef[l] * sumsq[l] (the regulariser loss `tex_reg` of the
  * current texture from the per-layer sums of squares the previous sm_adam_fused left; model/model.py:387-395), and a
@@ -214,6 +216,9 @@ typedef struct {
     const float* gram_mask1;
     const float* gram_amax_feat;
     const float* gram_amax_d;
+    /* ABI 9, sm_conv3x3_grouped_pair with SM_EPI_ADD (NULL elsewhere): the addend is read from these fp32 planes
+     * [Cout][plane(H, W)] instead of from `out` - required when the output is stored as pairs. */
+    const float* addend;
 } sm_conv_problem;
 /* "amax" bounds. An amax argument is a DEVICE array of sm_amax_floats() floats (64 slots, 256 bytes apart), zeroed by
  * the caller before the first launch that records into it; its VALUE is the maximum over the slots. Writers atomically
@@ -259,6 +264,32 @@ int sm_conv_split2_tile_positions(int Cout);
 int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
                               const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
                               float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream);
+/* PAIR IMAGES (ABI 9; stylemesh_amd/csrc/conv_split_kernel.h). A feature map may be stored as packed fp16 pairs - one
+ * 32-bit word per element, h | l << 16 with h = fp16(x s), l = fp16(x s - h): the two operand parts the fp16x2 kernels
+ * otherwise build from the fp32 value every time they stage it (that conversion was 13.5 % of a four-level step). Same
+ * [C][plane] addressing and size, zero word = zero. The power-of-two scale s must be fixed BEFORE the producer runs:
+ *   sm_pair_roll   table[i] = {s, 1 / s} for every entry i of an amax book (n_entries arrays of sm_amax_floats() floats,
+ *                  back to back) from the bound the book holds - what the PREVIOUS step recorded - times `headroom`
+ *                  (>= 1; the engine uses 4): s maps headroom x bound into [2^14, 2^15); no bound yet: {1, 1};
+ *   sm_conv3x3_grouped_pair  = sm_conv3x3_grouped_split2 with pair_in / pair_out / pair_gate: device pointers to the
+ *                  {s, 1 / s} of the input / output / gate tensor, NULL = that tensor is fp32 planes (pair_in NULL:
+ *                  amax_in gives the operand scale as before). Outputs saturate at +-65000 / s. amax_out records the
+ *                  fp32 bound as always. SM_EPI_ADD with pair_out needs sm_conv_problem::addend;
+ *   sm_pair_check  after the step's last producer: status[0] = 1 if for every listed entry bound x s is in [2^9, 65000]
+ *                  (nothing saturated, at most 2^5 of precision head-room given away; an all-zero tensor always passes)
+ *                  else 0, status[1] += 1 per failed check, status[2] += 1 per check, status[3] = first failing entry
+ *                  or -1. sm_adam_hyper_step(guard = status) then marks the update invalid and sm_adam_fused leaves
+ *                  p, m, v untouched (gradient zeroed): the caller repeats the step - with scales from the bounds the
+ *                  failed attempt recorded.
+ * Results equal the fp32-plane path's bit for bit whenever the table's scales equal the scales that path derives from
+ * the exact bounds (same pairs, same product order); with head-room the pairs of elements more than 2^16 below the
+ * tensor's maximum lose low bits of l earlier (absolute error <= 2^-36 of the maximum instead of 2^-40). */
+int sm_pair_roll(const float* amax_book, int n_entries, float headroom, float* table, void* stream);
+int sm_pair_check(const float* amax_book, const float* table, const int32_t* entries, int n, int32_t* status, void* stream);
+int sm_conv3x3_grouped_pair(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
+                            const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
+                            float* ws, size_t ws_floats, const float* amax_in, float* amax_out, const float* pair_in,
+                            const float* pair_out, const float* pair_gate, void* stream);
 /* max |x| over a feature map [C][plane(H,W)], max-ed into the amax array like the convolutions' amax_out: the operand
  * bound of sm_conv3x3_grouped_split2 for tensors no convolution produced (the deepest loss layer's gradient). */
 int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream);
@@ -357,6 +388,8 @@ typedef struct {
     float* S1;
     const float* amax_feat; /* amax array: bound of max |feat| */
     int C, H, W;
+    const float* pair_feat; /* ABI 9, optional: feat holds packed fp16 PAIRS (sm_conv3x3_grouped_pair: pair_out) under the
+                             * device {scale, 1 / scale} given here; amax_feat is then not read */
 } sm_gram_problem;
 int sm_gram_masked_split2_grouped(const sm_gram_problem* problems, int n_problems, void* stream);
 
@@ -429,6 +462,7 @@ typedef struct {
     const float* amax_d;
     float* amax_out;        /* optional amax array: records max |dfeat| (see sm_conv3x3_grouped: amax_out) */
     int C, H, W, relu_gate;
+    const float* pair_feat; /* ABI 9, optional: as sm_gram_problem::pair_feat (dfeat stays fp32) */
 } sm_gram_bwd_problem;
 int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream);
 

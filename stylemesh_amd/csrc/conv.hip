@@ -268,18 +268,41 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
             for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
             const int co = m0 + row;
             const size_t o = (size_t)co * P.plane + q;
-            f32x4 prev, gate;
-            if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>(P.out + o);
-            if (FLAGS & SM_EPI_RELU_MASK) gate = *reinterpret_cast<const f32x4*>(P.gate + o);
+            f32x4 prev;
+            bool open[4] = {true, true, true, true};
+            if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>((P.addend ? P.addend : P.out) + o);
+            if (FLAGS & SM_EPI_RELU_MASK) {
+                // gate planes as pair images (conv_split_kernel.h): x > 0 <=> word != 0
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const u32x4_ gw = *reinterpret_cast<const u32x4_*>(P.gate + o);
+                // (the element goes through a scalar first: __builtin_bit_cast applied to a vector ELEMENT reads element 0
+                // for every index on this compiler)
+                const bool gate_pair = a.pair_gate != nullptr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned w = gw[j];
+                    const float f = __builtin_bit_cast(float, w);
+                    open[j] = gate_pair ? w != 0u : f > 0.f;
+                }
+            }
             const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x = v[j];
                 if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
                 if (FLAGS & SM_EPI_ADD) x += prev[j];
-                if (FLAGS & SM_EPI_RELU_MASK) x = (gate[j] > 0.f) ? x : 0.f;
+                if (FLAGS & SM_EPI_RELU_MASK) x = open[j] ? x : 0.f;
                 v[j] = interior(q + j, P.H, P.W, P.Wp) ? x : 0.f;
                 m = fmaxf(m, fabsf(v[j]));
+            }
+            if (a.pair_out != nullptr) {
+                const float ps = a.pair_out[0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = v[j];
+                    const unsigned w = pair_encode(x, ps);
+                    v[j] = __builtin_bit_cast(float, w);
+                }
             }
             *reinterpret_cast<f32x4*>(P.out + o) = v;
         }
@@ -330,7 +353,8 @@ __global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
         if (v10 > m) { m = v10; code = 2u; }
         if (v11 > m) { m = v11; code = 3u; }
         if (!(m > 0.f)) code = 4u;
-        if (ok) P.pool_out[(size_t)(m_tile * BM + row) * plane_o + qo] = m;
+        if (ok) P.pool_out[(size_t)(m_tile * BM + row) * plane_o + qo] =
+            a.pair_out != nullptr ? __builtin_bit_cast(float, pair_encode(m, a.pair_out[0])) : m;
     }
     unsigned word = code << (4 * c);
     word |= (unsigned)__shfl_xor((int)word, 1, 64);
@@ -353,13 +377,52 @@ __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict_
     record_amax(amax_out, m, seen);
 }
 
+// ---- pair images (conv_split_kernel.h): the scale table of a step and its verification
+// table[i] = {s, 1 / s}: the power of two that maps headroom x (the bound entry i of the amax book holds - what the
+// PREVIOUS step recorded) into [2^14, 2^15); an entry without a bound yet gets {1, 1}. One wave per entry.
+__global__ __launch_bounds__(64) void pair_roll_kernel(const float* __restrict__ book, float headroom, float* __restrict__ table) {
+    const float v = amax_read(book + (size_t)blockIdx.x * (SM_AMAX_SLOTS * SM_AMAX_STRIDE));
+    float inv;
+    const float s = pow2_scale_for(v * headroom, inv);
+    if (threadIdx.x == 0) {
+        table[2 * blockIdx.x] = s;
+        table[2 * blockIdx.x + 1] = inv;
+    }
+}
+// The step stored entry list[k] as pairs under table[.]: valid if nothing saturated (bound x s <= 65000) and the
+// operands kept their precision (bound x s >= 2^9: at most 2^5 below the ideal window - an absolute error floor of
+// 2^-34 of the tensor's maximum instead of 2^-39; an all-zero tensor is fine under any scale). status[0] = 1 / 0 (this
+// step), status[1] += 1 per invalid step, status[2] += 1 per check, status[3] = first failing entry of this step or -1.
+__global__ __launch_bounds__(64) void pair_check_kernel(const float* __restrict__ book, const float* __restrict__ table,
+                                                        const int* __restrict__ list, int n, int* __restrict__ status) {
+    int bad = -1;
+    for (int k = 0; k < n; ++k) {
+        const int i = list[k];
+        const float am = amax_read(book + (size_t)i * (SM_AMAX_SLOTS * SM_AMAX_STRIDE));
+        const float v = am * table[2 * i];
+        const int ex = (int)((__builtin_bit_cast(unsigned, am) >> 23) & 0xff);
+        const bool unscalable = ex < 16 || ex > 250;   // pow2_scale_for gives up on such a bound: scale 1 is all there is
+        if (!(v <= SM_F16_CLAMP) || (v != 0.f && v < 512.f && !(unscalable && table[2 * i] == 1.f))) bad = bad < 0 ? i : bad;
+    }
+    if (threadIdx.x == 0) {
+        status[0] = bad < 0 ? 1 : 0;
+        status[1] += bad < 0 ? 0 : 1;
+        status[2] += 1;
+        status[3] = bad;
+    }
+}
+
 // SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
 // KG = 2 (fp16x2 kernel, launches of at most one tile per CU): blocks of two wave groups that split the block's K range
 // between them (conv_split_kernel.h) - chosen below, never by the caller.
 #ifndef SM_CONV_KG2_DEFAULT
 #define SM_CONV_KG2_DEFAULT 0   // measured (profiles/r05/kg2_c2_layers.txt): -8 % on the one-level layers - the groups run in lock-step
 #endif
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false, int KG = 1>
+#ifndef SM_CONV_KG2_BUILD
+#define SM_CONV_KG2_BUILD 0   // 1: compile the two-wave-group variants (selected with SM_CONV_KG=2)
+#endif
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false, int KG = 1,
+          bool PIN = false>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -374,7 +437,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     constexpr size_t lds = SPLIT ? KG * conv_split_lds_bytes(BM, BN, NP)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
-    if constexpr (SPLIT && NP == 2 && KG == 1 && (FLAGS & SM_EPI_GRAM) == 0) {
+    if constexpr (SM_CONV_KG2_BUILD && SPLIT && NP == 2 && KG == 1 && !PIN && (FLAGS & SM_EPI_GRAM) == 0) {
         // small grids (<= one tile per CU): 512-thread blocks of two wave groups; SM_CONV_KG=1 keeps the 4-wave blocks (A/B)
         static const bool kg2 = getenv("SM_CONV_KG") ? atoi(getenv("SM_CONV_KG")) == 2 : SM_CONV_KG2_DEFAULT != 0;
         if (kg2 && tiles <= SM_NUM_CU && chunks % 2 == 0)
@@ -444,8 +507,8 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && !UNPOOL) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL, NP, UNPOOL, KG>
-                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG>;
+        auto k = (stamp && !UNPOOL && !PIN) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !PIN, NP, UNPOOL, KG, PIN>
+                                            : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG, PIN>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -474,7 +537,7 @@ static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, 
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true>(a, n_list, ws_floats, s);
 }
 
-template <int FLAGS, bool UNPOOL = false>
+template <int FLAGS, bool UNPOOL = false, bool PIN = false>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
 #if SM_SPLIT2_BN256
     // 64 output channels: 64 x 256 tiles (the same 12 MFMAs per stage and wave as the 128-row tile), waves 2 x 2 with
@@ -484,15 +547,15 @@ static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats,
 #define SM_SPLIT2_W64GM 2
 #endif
     if (a.Cout % 128 != 0)
-        return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
+        return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 #else
-    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 #endif
 #if SM_SPLIT2_BM256
     // one wave per SIMD with a 64 x 128 wave tile (128 accumulator registers): 24 MFMAs per stage and wave
-    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
+    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 #endif
-    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -837,7 +900,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 8; }
+int sm_abi_version(void) { return 9; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
@@ -850,31 +913,40 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
     }
 }
 
-static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
+}  // extern "C"
+template <bool PIN>
+static int conv_dispatch_flags_split2_t(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
         if (flags == (SM_EPI_RELU_MASK | SM_EPI_GRAM)) {   // + the Gram backward of the 64-channel output layer; whole tiles only
             a.ws = nullptr;
             if (a.Cout == 64)
-                return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+                return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true, 1, PIN>(a, n_list, 0, s);
             if (a.Cout == 128)   // (four waves of 32 rows: the 128-row tile holds all channels of its positions)
-                return sm::launch_conv<128, 128, 16, 4, 1, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true>(a, n_list, 0, s);
+                return sm::launch_conv<128, 128, 16, 4, 1, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true, 1, PIN>(a, n_list, 0, s);
             return (int)hipErrorInvalidValue;
         }
         switch (flags) {
-            case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);
-            case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true, PIN>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true, PIN>(a, n_list, ws_floats, s);
             default: return (int)hipErrorInvalidValue;
         }
     }
     switch (flags) {
-        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
-        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU | SM_EPI_POOL>(a, n_list, ws_floats, s);
-        case 0: return sm::dispatch_conv_split2<0>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
-        case SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_ADD>(a, n_list, ws_floats, s);
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU, false, PIN>(a, n_list, ws_floats, s);
+        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU | SM_EPI_POOL, false, PIN>(a, n_list, ws_floats, s);
+        case 0: return sm::dispatch_conv_split2<0, false, PIN>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, false, PIN>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, false, PIN>(a, n_list, ws_floats, s);
+        case SM_EPI_ADD:
+            if constexpr (!PIN) return sm::dispatch_conv_split2<SM_EPI_ADD>(a, n_list, ws_floats, s);
+            return (int)hipErrorInvalidValue;
         default: return (int)hipErrorInvalidValue;
     }
+}
+extern "C" {
+static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
+    return a.pair_in != nullptr ? conv_dispatch_flags_split2_t<true>(a, n_list, flags, ws_floats, unpool, s)
+                                : conv_dispatch_flags_split2_t<false>(a, n_list, flags, ws_floats, unpool, s);
 }
 
 static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
@@ -895,6 +967,21 @@ int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W), n = H * Wp;
     hipLaunchKernelGGL(sm::fmap_amax_kernel, dim3(std::min(8, (n / 4 + 255) / 256), C), dim3(256), 0, (hipStream_t)stream,
                        planes, plane, Wp, (H + 1) * Wp, amax_out);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_pair_roll(const float* amax_book, int n_entries, float headroom, float* table, void* stream) {
+    if (n_entries < 1 || !(headroom >= 1.f)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sm::pair_roll_kernel, dim3(n_entries), dim3(64), 0, (hipStream_t)stream, amax_book, headroom, table);
+    SM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sm_pair_check(const float* amax_book, const float* table, const int32_t* entries, int n, int32_t* status, void* stream) {
+    if (n < 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sm::pair_check_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_book, table,
+                       reinterpret_cast<const int*>(entries), n, reinterpret_cast<int*>(status));
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -963,6 +1050,52 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
     a.amax_in = amax_in;
     a.amax_out = amax_out;
     a.w_scale_inv = w_scale_inv;
+    if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
+    return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
+}
+
+int sm_conv3x3_grouped_pair(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
+                            const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
+                            float* ws, size_t ws_floats, const float* amax_in, float* amax_out, const float* pair_in,
+                            const float* pair_out, const float* pair_gate, void* stream) {
+    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
+    if (Cout % 64 != 0 || Cin % 16 != 0 || !(w_scale_inv > 0.f)) return (int)hipErrorInvalidValue;
+    if (amax_in == nullptr && pair_in == nullptr) return (int)hipErrorInvalidValue;   // one of them carries the input's scale
+    sm::ConvArgs a{};
+    int unpool = 0;
+    for (int g = 0; g < n_problems; ++g) {
+        unpool += problems[g].unpool_code != nullptr;
+        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].unpool_code,
+                                 problems[g].H, problems[g].W, sm::row_stride(problems[g].W),
+                                 sm::plane_size(problems[g].H, problems[g].W), problems[g].pool_out, problems[g].pool_code,
+                                 reinterpret_cast<const sm::f32x4*>(problems[g].gram_ws), problems[g].gram_mask0,
+                                 problems[g].gram_mask1, problems[g].gram_amax_feat, problems[g].gram_amax_d,
+                                 problems[g].addend};
+        if ((flags & SM_EPI_GRAM) != 0 && (problems[g].gram_ws == nullptr || problems[g].gram_mask0 == nullptr ||
+                                          problems[g].gram_amax_feat == nullptr || problems[g].gram_amax_d == nullptr ||
+                                          problems[g].gate == nullptr || problems[g].unpool_code == nullptr))
+            return (int)hipErrorInvalidValue;
+        if ((flags & SM_EPI_POOL) != 0 && (problems[g].pool_out == nullptr || problems[g].pool_code == nullptr ||
+                                          problems[g].H < 2 || problems[g].W < 2))
+            return (int)hipErrorInvalidValue;
+        // a pair output cannot be its own fp32 addend
+        if ((flags & SM_EPI_ADD) != 0 && pair_out != nullptr && problems[g].addend == nullptr) return (int)hipErrorInvalidValue;
+    }
+    if ((flags & SM_EPI_POOL) != 0 && (tile_list == nullptr || bias == nullptr || unpool != 0)) return (int)hipErrorInvalidValue;
+    a.n_problems = n_problems;
+    a.wt = reinterpret_cast<const float*>(wt2);
+    a.bias = bias;
+    a.Cin_pad = Cin;
+    a.Cout = Cout;
+    a.ws = ws;
+    a.splits = 1;
+    a.tile_list = tile_list;
+    a.amax_in = amax_in;
+    a.amax_out = amax_out;
+    a.w_scale_inv = w_scale_inv;
+    a.pair_in = pair_in;
+    a.pair_out = pair_out;
+    a.pair_gate = pair_gate;
     if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
     return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
 }

@@ -31,6 +31,9 @@ struct ConvProblem {
     const float* gram_mask1;
     const float* gram_amax_feat;
     const float* gram_amax_d;
+    // SM_EPI_ADD, optional: the addend is read from these fp32 planes instead of from `out` (pair images: `out` holds
+    // packed pairs, the loss kernels keep writing their gradients as fp32)
+    const float* addend;
 };
 
 struct ConvArgs {
@@ -61,6 +64,12 @@ struct ConvArgs {
     const float* amax_in;
     float* amax_out;
     float w_scale_inv;
+    // Pair images (fp16x2 kernel; conv_split_kernel.h): device {scale, 1 / scale} of the tensor, NULL = fp32 planes.
+    // pair_in: the input planes hold packed fp16 pairs (amax_in is not read); pair_out: outputs (out / pool_out) are
+    // stored as pairs; pair_gate: the gate planes are pairs.
+    const float* pair_in;
+    const float* pair_out;
+    const float* pair_gate;
 };
 
 constexpr int SM_NUM_CU = 256;

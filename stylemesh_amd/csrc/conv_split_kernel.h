@@ -139,6 +139,30 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
     return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);    // 2^(141 - ex)
 }
 
+// ---- pair images (round 5). A feature map may be stored as PACKED fp16 PAIRS instead of fp32: word = h | l << 16 with
+// h = fp16(x s), l = fp16(x s - h) - exactly the two operand parts the fp16x2 kernels build from an fp32 value while
+// they stage it, so a consumer only un-packs (two byte permutes per channel pair instead of mul / clamp / cvt / cvt /
+// sub / cvt per element: that conversion was 13.5 % of a four-level step, profiles/r05/staging_ablation_c2_c3.txt).
+// Same 4 bytes per element, same [C][plane] addressing, zero word = zero. The power-of-two scale s must be known BEFORE
+// the producer runs: it is derived from the bound the PREVIOUS step recorded for the tensor, with head-room
+// (sm_pair_scales); sm_pair_check compares the bound this step recorded with it and invalidates the step on overflow
+// (values beyond the fp16 range saturate at +-65000 s^-1; the engine skips the update and repeats the step).
+__device__ __forceinline__ unsigned pair_encode(float v, float s) {
+    const float xs = __builtin_amdgcn_fmed3f(v * s, -SM_F16_CLAMP, SM_F16_CLAMP);
+    const _Float16 h = (_Float16)xs;
+    const _Float16 l = (_Float16)(xs - (float)h);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+// eight pair words (channels c .. c + 7 of one position) -> the h unit and the l unit (8 fp16 each)
+__device__ __forceinline__ void pair_units(const float (&w)[8], f32x4& vh, f32x4& vl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned a = __builtin_bit_cast(unsigned, w[2 * k + 1]), b = __builtin_bit_cast(unsigned, w[2 * k]);
+        vh[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x05040100u));
+        vl[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x07060302u));
+    }
+}
+
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 // the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
 #ifndef SM_SPLIT_BSETS
@@ -161,11 +185,14 @@ constexpr int conv_split_waves(int BM, int BN, int NP) {
 // 12 - 172 tiles): a lone 4-wave block is latency-bound - one wave per SIMD cannot cover its own load / convert / store
 // stage tail with MFMAs (a stage takes ~800 cycles against ~475 per block when two blocks share a CU) - and getting the
 // second wave per SIMD from MORE global K-splits doubles the partial slabs instead.
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false, int KG = 1>
+// PIN (round 5): the input planes hold packed fp16 pairs (above): staging un-packs instead of converting.
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false, int KG = 1,
+          bool PIN = false>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
 void conv3x3_split_kernel(ConvArgs a) {
     static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
+    static_assert(!PIN || NP == 2, "pair images are the fp16x2 kernel's operand format");
     static_assert(KG == 1 || (KG == 2 && NP == 2 && conv_split_waves(BM, BN, NP) == 2 && !(FLAGS & SM_EPI_GRAM)),
                   "two wave groups: the fp16x2 kernel at two waves per SIMD, without the Gram epilogue");
     static_assert(KG == 1 || !SM_SPLIT2_RING6, "two wave groups: the four-slot ring (a barrier at the end of every chunk)");
@@ -271,11 +298,17 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int a_stage_bytes = 2 * NP * a.Cout * 16;   // bytes per (tap, chunk) stage
     // NP = 2: operand scale from the producer's recorded max |x| (one vector load of the bound's slots per wave)
     float in_scale = 1.f, out_scale = 1.f;
-    if (NP == 2) {
+    if constexpr (PIN) {
+        out_scale = a.pair_in[1] * a.w_scale_inv;          // {scale, 1 / scale} of the stored pairs
+    } else if (NP == 2) {
         float inv;
         in_scale = pow2_scale_for(a.amax_in ? amax_read(a.amax_in) : 1.f, inv);
         out_scale = inv * a.w_scale_inv;
     }
+    // outputs as pairs (fp16x2 kernel; wave-uniform), the ReLU gate planes as pairs (x > 0 <=> word != 0)
+    const bool pout = NP == 2 && a.pair_out != nullptr;
+    const float po_scale = pout ? a.pair_out[0] : 1.f;
+    const bool gate_pair = NP == 2 && a.pair_gate != nullptr;
     // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
     // k-group at stride `plane`; the 2 remaining halo positions x 2 k-groups x 8 channels = 32 single elements are
     // fetched one per lane (every half-wave does the same 32: identical values to identical addresses)
@@ -435,6 +468,20 @@ void conv3x3_split_kernel(ConvArgs a) {
                     rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
             rhs[set_] = ((int)((rhc[set_] >> (4 * h_c)) & 15u) == rhp[set_]) ? rhs[set_] : 0.f;          \
         }                                                                                                \
+        if constexpr (PIN) {   /* stored pairs: un-pack (a stale word of an unlisted tile is still a finite pair) */ \
+            if (PAIRS && (ky_) < 2) {                                                                    \
+                f32x4 vh, vl;                                                                            \
+                pair_units(rbs[set_][0], vh, vl);                                                        \
+                if (a_active) { d_[a_dst] = vh; d_[a_dst + 2 * BNP] = vl; }                              \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                         \
+                    f32x4 vh, vl;                                                                        \
+                    pair_units(rbs[set_][u], vh, vl);                                                    \
+                    d_[b_dst[u]] = vh;                                                                   \
+                    d_[b_dst[u] + 2 * BNP] = vl;                                                         \
+                }                                                                                        \
+            }                                                                                            \
+        } else                                                                                           \
         if constexpr (SM_ABL_NOCVT) {   /* (ablation, timing only: raw bits instead of the scaled fp16 pairs) */ \
             _Pragma("unroll") for (int u = 0; u < ((PAIRS && (ky_) < 2) ? 1 : NU); ++u) {               \
                 f32x4 vh = {rbs[set_][u][0], rbs[set_][u][1], rbs[set_][u][2], rbs[set_][u][3]};         \
@@ -466,11 +513,18 @@ void conv3x3_split_kernel(ConvArgs a) {
             d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
         }                                                                                                \
         }                                                                                                \
+        if constexpr (PIN) {                                                                             \
+            const unsigned w_ = __builtin_bit_cast(unsigned, rhs[set_]);                                 \
+            unsigned short* e_ = reinterpret_cast<unsigned short*>(d_);                                  \
+            e_[h_dst] = (unsigned short)(w_ & 0xffffu);                                                  \
+            e_[h_dst + 2 * BNP * 8] = (unsigned short)(w_ >> 16);                                        \
+        } else {                                                                                         \
         const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
         const _Float16 h_ = (_Float16)xs_;                                                               \
         _Float16* e_ = reinterpret_cast<_Float16*>(d_);                                                  \
         e_[h_dst] = h_;                                                                                  \
         e_[h_dst + 2 * BNP * 8] = (_Float16)(xs_ - (float)h_);                                           \
+        }                                                                                                \
     }
 #define SM_READ_B(dst_, slot_, kx_)                                                                      \
     {                                                                                                    \
@@ -797,7 +851,8 @@ void conv3x3_split_kernel(ConvArgs a) {
                     if (bp > m) { m = bp; c = 3u; }
                     if (!(m > 0.f)) c = 4u;
                     vmax = ok ? fmaxf(vmax, m) : vmax;         // (bound of the POOLED map: what the next conv reads)
-                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] = m;
+                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] =
+                        pout ? __builtin_bit_cast(float, pair_encode(m, po_scale)) : m;
                     codes[r >> 2] |= c << (4 * ((r & 3) + 4 * lhi));
                 }
 #pragma unroll
@@ -825,6 +880,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                       "the Gram term replaces the addend of a data gradient whose row tile holds all C = BM channels");
         float inv_f, inv_d;
         g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
+        if (gate_pair) inv_f = a.pair_gate[1];   // F = the gate planes, stored as pairs under their own scale
         conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
         g_oscale = inv_f * inv_d;
     }
@@ -892,12 +948,14 @@ void conv3x3_split_kernel(ConvArgs a) {
                 for (int u = 0; u < GU; ++u) {
                     const int kg = tid / BN + u * (256 / BN);
                     f32x4 vh, vl;
-                    conv_gram_split(rb[u], g_fscale, vh, vl);
+                    if (gate_pair) pair_units(rb[u], vh, vl);
+                    else conv_gram_split(rb[u], g_fscale, vh, vl);
                     Gs[kg * BN + g_pos] = vh;
                     Gs[(8 + kg) * BN + g_pos] = vl;
                     unsigned bits = 0u;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) bits |= (rb[u][c] > 0.f ? 1u : 0u) << c;
+                    for (int c = 0; c < 8; ++c)
+                        bits |= ((gate_pair ? __builtin_bit_cast(unsigned, rb[u][c]) != 0u : rb[u][c] > 0.f) ? 1u : 0u) << c;
                     Gb[(ph * 8 + kg) * BN + g_pos] = (unsigned char)bits;
                 }
             }
@@ -944,8 +1002,11 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
-                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
+                if (FLAGS & SM_EPI_ADD) prev[r] = P.addend ? P.addend[o] : P.out[o];
+                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) {
+                    const float gv = P.gate[o];
+                    gate[r] = gate_pair ? (__builtin_bit_cast(unsigned, gv) != 0u ? 1.f : 0.f) : gv;
+                }
             }
             if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
 #pragma unroll
@@ -965,7 +1026,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 if constexpr (GRAM) v += accg[nj][r] * g_oscale;
                 if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
                 v = inside ? v : 0.f;
-                P.out[o] = v;
+                P.out[o] = pout ? __builtin_bit_cast(float, pair_encode(v, po_scale)) : v;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         }

@@ -113,6 +113,28 @@ __device__ __forceinline__ void masked_parts(const float (&x)[8], const float (&
     }
 }
 
+// PAIR (round 5; conv_split_kernel.h "pair images"): eight stored fp16 pairs (word = h | l << 16) x eight per-position
+// factors (non-zero: keep, 0: masked out) -> the h unit and the l unit - two byte permutes per pair of words instead of
+// the conversion above. The pairs ARE what split2x8_scaled would build from the fp32 values under the same scale.
+__device__ __forceinline__ void masked_pair_units(const float (&w)[8], const float (&sm)[8], f32x4& vh, f32x4& vl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned a = sm[2 * k + 1] != 0.f ? __builtin_bit_cast(unsigned, w[2 * k + 1]) : 0u;
+        const unsigned b = sm[2 * k] != 0.f ? __builtin_bit_cast(unsigned, w[2 * k]) : 0u;
+        vh[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x05040100u));
+        vl[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x07060302u));
+    }
+}
+template <int NP, bool PAIR>
+__device__ __forceinline__ void masked_operand(const float (&x)[8], const float (&sm)[8], f32x4 (&v)[NP]) {
+    if constexpr (PAIR) {
+        static_assert(NP == 2, "stored pairs are fp16x2 operands");
+        masked_pair_units(x, sm, v[0], v[1]);
+    } else {
+        masked_parts<NP>(x, sm, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // D [C][C] fp32 (symmetric) -> MFMA A-fragment image [C/16 chunks][3 parts][2 k-groups][C rows][8] bf16
 // ---------------------------------------------------------------------------------------------------
@@ -191,6 +213,7 @@ struct GramBwdProb {
     const float* amax_d;
     float* amax_out;          // optional: records max |dF| (the operand bound of the conv that consumes dfeat)
     int C, plane, q_begin, q_end, relu_gate, n_ptiles;
+    const float* pair_feat;   // PAIR kernels: {scale, 1 / scale} of the stored pairs of feat
 };
 struct GramBwdGroup {
     GramBwdProb p[GRAM_MAX_GROUP];
@@ -198,7 +221,7 @@ struct GramBwdGroup {
     int n;
 };
 
-template <int MI, int NP>
+template <int MI, int NP, bool PAIR = false>
 __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const int block_x, const int block_y) {
     const float* __restrict__ feat = G.feat;
     const float* __restrict__ mask0 = G.mask0;
@@ -218,6 +241,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
     if (NP == 2) {
         float inv_f, inv_d;
         f_scale = gram_pow2_scale(amax_read(amax_feat), inv_f);
+        if constexpr (PAIR) inv_f = G.pair_feat[1];
         gram_pow2_scale(amax_read(amax_d), inv_d);
         out_scale = inv_f * inv_d;
     }
@@ -281,7 +305,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         _Pragma("unroll") for (int c = 0; c < 8; ++c) sm_[c] = (mv_ != 0.f) ? f_scale : 0.f; \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
             f32x4 v_[NP];                                                                   \
-            masked_parts<NP>(rb[set_][ks], sm_, v_);                                        \
+            masked_operand<NP, PAIR>(rb[set_][ks], sm_, v_);                                \
             f32x4* d_ = &Bs[buf_][ks * 2 * NP * BN + b_kg * BN + b_px];                     \
             _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * BN] = v_[part]; \
         }                                                                                   \
@@ -337,7 +361,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         for (int r = 0; r < 16; ++r) {
             float v = acc[0][nj][r];
             if (NP == 2) v *= out_scale;
-            if (RELU_GATE) v = (gate[r] > 0.f) ? v : 0.f;
+            if (RELU_GATE) v = (PAIR ? __builtin_bit_cast(unsigned, gate[r]) != 0u : gate[r] > 0.f) ? v : 0.f;
             side_store(v, dfeat + o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane);
             vmax = fmaxf(vmax, fabsf(v));
         }
@@ -350,19 +374,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
     const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
     int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
-    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, nullptr, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0};
+    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, nullptr, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0, nullptr};
     gram_backward_body<MI, NP>(G, blockIdx.x, blockIdx.y);
 }
 
 // GROUPED: one launch over the (level, layer) problems of one row-tile class; block -> (problem, position tile, row tile)
-template <int MI, int NP>
+template <int MI, int NP, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2, MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2))) void gram_backward_group_kernel(GramBwdGroup G) {
     int g = 0;
     for (int i = 1; i < G.n; ++i)
         if ((int)blockIdx.x >= G.first_block[i]) g = i;
     const GramBwdProb P = G.p[g];
     const int local = blockIdx.x - G.first_block[g];
-    gram_backward_body<MI, NP>(P, local % P.n_ptiles, local / P.n_ptiles);
+    gram_backward_body<MI, NP, PAIR>(P, local % P.n_ptiles, local / P.n_ptiles);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -386,6 +410,7 @@ struct GramProb {
     float* S1;
     const float* amax_feat;   // NP = 2 only
     int C, plane, q_begin, q_end, qb, n_ranges;
+    const float* pair_feat;   // PAIR kernels: {scale, 1 / scale} of the stored pairs of feat
 };
 struct GramGroup {
     GramProb p[GRAM_MAX_GROUP];
@@ -405,7 +430,7 @@ constexpr size_t gram_group_lds_bytes(int MI, int NP, bool diag_only = false) {
 
 // MI = 1 (126 VGPRs): four blocks per CU when every problem of the launch is a single diagonal tile (C = 64: the Bt
 // half of the LDS image is not allocated then) - a block keeps ~one 16 KB stage in flight, a CU needs ~50 KB
-template <int MI, int NP>
+template <int MI, int NP, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4 : 2, MI == 1 ? 4 : 2))) void gram_group_kernel(GramGroup G) {
     constexpr int TS = 64 * MI;                 // tile size (channels)
     constexpr int KS = gram_ks(MI);             // MFMA K-steps per stage
@@ -442,7 +467,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4
     float f_scale = 1.f, out_scale = 1.f;
     if (NP == 2) {
         float inv;
-        f_scale = gram_pow2_scale(amax_read(P.amax_feat), inv);
+        if constexpr (PAIR) {
+            f_scale = 1.f;   // (only its being non-zero matters: the masks select stored pairs)
+            inv = P.pair_feat[1];
+        } else {
+            f_scale = gram_pow2_scale(amax_read(P.amax_feat), inv);
+        }
         out_scale = inv * inv;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -532,11 +562,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4
     {                                                                                                   \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
             f32x4 v_[NP];                                                                               \
-            masked_parts<NP>(rA[set_][r], rM[set_], v_);                                                \
+            masked_operand<NP, PAIR>(rA[set_][r], rM[set_], v_);                                        \
             f32x4* d_ = As + (buf_) * BUF + u_dst + r * CP;                                             \
             _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[part * PART] = v_[part];         \
             if constexpr (!DIAG) {                                                                                \
-                masked_parts<NP>(rB[set_][r], rM[set_], v_);                                            \
+                masked_operand<NP, PAIR>(rB[set_][r], rM[set_], v_);                                    \
                 f32x4* e_ = Bt + (buf_) * BUF + u_dst + r * CP;                                         \
                 _Pragma("unroll") for (int part = 0; part < NP; ++part) e_[part * PART] = v_[part];     \
             }                                                                                           \

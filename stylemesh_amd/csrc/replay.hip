@@ -70,7 +70,8 @@ const Entry ENTRIES[] = {
     SM_ENTRY(sm_gram_masked), SM_ENTRY(sm_gram_masked_split), SM_ENTRY(sm_gram_masked_split_acc),
     SM_ENTRY(sm_gram_masked_split2_grouped), SM_ENTRY(sm_style_loss), SM_ENTRY(sm_gram_backward),
     SM_ENTRY(sm_gram_backward_split), SM_ENTRY(sm_style_loss_grouped), SM_ENTRY(sm_gram_backward_split2_grouped),
-    SM_ENTRY(sm_mse_masked), SM_ENTRY(sm_copy_floats), SM_ENTRY(sm_zero_floats),
+    SM_ENTRY(sm_mse_masked), SM_ENTRY(sm_copy_floats), SM_ENTRY(sm_zero_floats), SM_ENTRY(sm_conv3x3_grouped_pair),
+    SM_ENTRY(sm_pair_roll), SM_ENTRY(sm_pair_check),
 };
 constexpr int N_ENTRIES = (int)(sizeof(ENTRIES) / sizeof(ENTRIES[0]));
 

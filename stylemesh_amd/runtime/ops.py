@@ -273,11 +273,28 @@ def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.
                           ptr(sumsq_out), ptr(dev_hyper), ptr(touched), touched_log2, hip.stream()), "sm_adam_fused"))
 
 
-def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999):
-    """``state``: device float64 [lr, step]; advances the step and writes the two step-dependent scalars of the
-    fused update into ``dev_hyper`` (device float32 [2]) - on the device, so the launch can live in a hipGraph."""
-    assert state.dtype == torch.float64 and state.numel() == 2 and dev_hyper.dtype == torch.float32
-    hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), hip.stream()), "sm_adam_hyper_step")
+def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999, guard=None):
+    """``state``: device float64 [lr, step]; advances the step and writes the step-dependent scalars of the fused update
+    into ``dev_hyper`` (device float32 [3]: lr / bc1, 1 / sqrt(bc2), valid = 1) - on the device, so the launch can live
+    in a hipGraph. ``guard`` (device int32, ``pair_check``'s status): 0 there leaves the step where it is and marks the
+    update invalid (``adam_fused(dev_hyper=...)`` then changes nothing but the gradient, which it zeroes)."""
+    assert state.dtype == torch.float64 and state.numel() == 2 and dev_hyper.dtype == torch.float32 and dev_hyper.numel() >= 3
+    assert guard is None or guard.dtype == torch.int32
+    hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), ptr(guard), hip.stream()), "sm_adam_hyper_step")
+
+
+def pair_roll(book, n_entries: int, headroom: float, table):
+    """``table[i] = {s, 1 / s}`` of every entry of an amax book from the bounds it holds (the previous step's) times
+    ``headroom``: the scales this step's pair images are stored under (include/stylemesh_hip.h, PAIR IMAGES)."""
+    assert book.numel() >= n_entries * AMAX_FLOATS and table.numel() >= 2 * n_entries and table.dtype == torch.float32
+    hip.check(lib.sm_pair_roll(ptr(book), n_entries, float(headroom), ptr(table), hip.stream()), "sm_pair_roll")
+
+
+def pair_check(book, table, entries, status):
+    """``status[0] = 1`` if every listed entry's bound (recorded by this step) fits the scale it was stored under, else 0
+    (``status``: device int32 [4], see sm_pair_check)."""
+    assert entries.dtype == torch.int32 and status.dtype == torch.int32 and status.numel() >= 4
+    hip.check(lib.sm_pair_check(ptr(book), ptr(table), ptr(entries), entries.numel(), ptr(status), hip.stream()), "sm_pair_check")
 
 
 def step_begin(sumsq, coef, reg_out, zero_a, zero_b=None):
@@ -401,7 +418,7 @@ def conv_list_format(cin_pad: int, cout: int):
 
 
 def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
-                    wt2=None, amax_in=None, amax_out=None):
+                    wt2=None, amax_in=None, amax_out=None, pair_in=None, pair_out=None, pair_gate=None, addends=None):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code[, pooled, pool_code]]), ...]
     (FMaps; with a ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel
     takes the pool's backward on the fly, see ``maxpool_fwd_grouped``; with ``flags & EPI_POOL`` - 'split2' mode, a
@@ -413,7 +430,10 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
     ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
     ``amax_in`` (device float: upper bound of max |input|). ``amax_out`` (device float, caller-zeroed, any mode):
-    receives max |output| of the launch."""
+    receives max |output| of the launch.
+    Pair images ('split2' mode; include/stylemesh_hip.h): ``pair_in`` / ``pair_out`` / ``pair_gate`` = device {scale,
+    1 / scale} of the input / output / gate tensor when its planes hold packed fp16 pairs (None: fp32 planes);
+    ``addends``: per problem the fp32 FMap ``EPI_ADD`` reads instead of ``out`` (required with ``pair_out``)."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
     if tile_list is not None and tile_list.numel() == 0:
         return
@@ -438,7 +458,8 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         gws, gm0, gm1, gaf, gad = gram if gram is not None else (None,) * 5
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code),
                                  None if pooled is None else pooled.ptr, ptr(pool_code),
-                                 ptr(gws), ptr(gm0), ptr(gm1), ptr(gaf), ptr(gad))
+                                 ptr(gws), ptr(gm0), ptr(gm1), ptr(gaf), ptr(gad),
+                                 None if addends is None else addends[i].ptr)
         cin_true = 3 if cin_pad == 4 else cin_pad
         flops += 2.0 * 9 * cin_true * cout * out.H * out.W
         # algorithmic HBM bytes: input read once, output written once (pooled: a quarter + 1/2 byte of codes per element),
@@ -448,12 +469,20 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
             streams = cout * (0.25 + 0.125 / 4)
         nbytes += 4.0 * streams * out.H * out.W + (4.0 if code is None else 4.5) * cin_true * inp.H * inp.W
 
-    use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
+    pair = pair_in is not None or pair_out is not None or pair_gate is not None or addends is not None
+    use_split2 = wt2 is not None and (amax_in is not None or pair_in is not None) and CONV_MODE == "split2"
     use_split = wt3 is not None and CONV_MODE == "split"
+    assert not pair or use_split2, "pair images are the fp16x2 kernel's format"
 
     def run():
         ws = splitk_workspace(wt.device)
         n_list = 0 if tile_list is None else tile_list.numel()
+        if pair:
+            hip.check(lib.sm_conv3x3_grouped_pair(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
+                                                  flags, ptr(tile_list), n_list, ptr(ws), ws.numel(), ptr(amax_in),
+                                                  ptr(amax_out), ptr(pair_in), ptr(pair_out), ptr(pair_gate),
+                                                  hip.stream()), "sm_conv3x3_grouped_pair")
+            return
         if use_split2:
             hip.check(lib.sm_conv3x3_grouped_split2(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
                                                     flags, ptr(tile_list), n_list, ptr(ws), ws.numel(), ptr(amax_in),
@@ -581,9 +610,11 @@ def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False, amax_feat=Non
     return n
 
 
-def gram_problem(feat: FMap, mask0, mask1, S0, S1, amax_feat) -> "hip.GramProblem":
-    """One entry of ``gram_masked_grouped`` (pointers only: valid while the tensors live)."""
-    return hip.GramProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), ptr(amax_feat), feat.C, feat.H, feat.W)
+def gram_problem(feat: FMap, mask0, mask1, S0, S1, amax_feat, pair_feat=None) -> "hip.GramProblem":
+    """One entry of ``gram_masked_grouped`` (pointers only: valid while the tensors live). ``pair_feat``: device {scale,
+    1 / scale} when ``feat`` holds packed fp16 pairs."""
+    return hip.GramProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), ptr(amax_feat), feat.C, feat.H, feat.W,
+                           ptr(pair_feat))
 
 
 def gram_problem_array(problems):
@@ -615,14 +646,14 @@ def style_problem(S0, S1, counts, factor, targets, term_mask, skip_if_empty, wei
 
 
 def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate,
-                     amax_out=None) -> "hip.GramBwdProblem":
+                     amax_out=None, pair_feat=None) -> "hip.GramBwdProblem":
     """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own;
     ``amax_out`` (optional amax bound): max |dfeat| is max-ed into it. ``dfeat`` None: only the operand images of D0 / D1
     are written into ``ws`` (a conv launch with ``EPI_GRAM`` consumes them)."""
     assert ws.numel() >= lib.sm_gram_backward_split_ws_bytes(feat.C)
     return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), None if dfeat is None else dfeat.ptr,
                               ptr(ws), ptr(amax_feat),
-                              ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate))
+                              ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate), ptr(pair_feat))
 
 
 def gram_backward_ws_bytes(C: int) -> int:

@@ -95,6 +95,41 @@ class AmaxBook:
         self.buf.zero_()
 
 
+class PairCtx:
+    """Pair images of a grouped pass (include/stylemesh_hip.h, PAIR IMAGES): which VGG tensors are stored as packed fp16
+    pairs by their producer, and under which scales. ``table``: {scale, 1 / scale} per entry of ``book`` (``ops.pair_roll``
+    of the previous step's bounds). Kept as fp32 planes: the image, relu1_1 (written / read by the first layer's VALU
+    kernels), the content layers (the masked MSE reads them), the gradient of relu1_1 (read by conv1_1's data gradient)
+    and the gradient the loss kernels write for the deepest layer; the gradients the loss kernels write for the other
+    injected layers stay fp32 ADDEND planes (``grad[layer]``) - the data-gradient conv stores its pair output beside them
+    (``gradp[layer]``)."""
+
+    def __init__(self, table: torch.Tensor, book: AmaxBook, fp32_acts, start_layer: str):
+        self.table, self.book = table, book
+        self.fp32_acts = set(fp32_acts) | {"img", "r11"}
+        self.start = start_layer
+        self.used = set()          # book indices of the tensors stored as pairs by this pass (ops.pair_check's list)
+
+    def _entry(self, name, producer=False):
+        i = self.book.idx[name]
+        if producer:
+            self.used.add(i)
+        return self.table[2 * i:2 * i + 2]
+
+    def act(self, layer, producer=False):
+        """scale entry of activation tensor ``layer`` (a conv or a pool output), None: fp32 planes"""
+        base = POOL_INPUT.get(layer, layer)
+        if layer in self.fp32_acts or base in self.fp32_acts:
+            return None
+        return self._entry("a:" + base, producer)
+
+    def grad(self, layer, producer=False):
+        """scale entry of the gradient planes of ``layer`` (as ``AmaxBook.grad_bound``), None: fp32 planes"""
+        if layer in ("r11", "img", self.start):
+            return None
+        return self._entry("g:" + POOL_OUTPUT.get(layer, layer), producer)
+
+
 def _amax_on():
     return ops.CONV_MODE == "split2" or ops.GRAM_MODE == "split2"
 
@@ -120,6 +155,13 @@ class LevelBuffers:
                 if kind == "pool":   # argmax codes of the pool (fused pool backward of the fp16x2 data-gradient convs)
                     self.code[out] = torch.zeros(cout // 8 * self.act[out].plane, dtype=torch.int32, device=device)
         self.amax = AmaxBook(device)   # bounds of this buffer set's tensors (single-level passes)
+        self.gradp = {}                # pair images: the data-gradient convs' outputs of layers whose grad[.] is an fp32 addend
+
+    def pair_grad(self, layer) -> FMap:
+        if layer not in self.gradp:
+            g = self.grad[layer]
+            self.gradp[layer] = FMap(g.C, g.H, g.W, g.buf.device)
+        return self.gradp[layer]
 
     def nbytes(self):
         return sum(f.buf.numel() * 4 for f in list(self.act.values()) + list(self.grad.values()))
@@ -158,7 +200,7 @@ class VGGNet:
                             amax_in=None if am is None or src == "img" else am.act_bound(src),
                             amax_out=None if am is None else am["a:" + out])
 
-    def forward_group(self, bufs, tiles=None, on_layer=None, amax: AmaxBook | None = None):
+    def forward_group(self, bufs, tiles=None, on_layer=None, amax: AmaxBook | None = None, pair: PairCtx | None = None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
         weights), which fills the chip where a single small level cannot. ``tiles``: optional active-tile
         lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed).
@@ -169,9 +211,16 @@ class VGGNet:
         assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
         pooled_by_conv = set()   # pools whose output the conv below them has already written (EPI_POOL)
         for kind, src, out, _, _ in NODES[:last + 1]:
+            pkw = {}
+            if pair is not None and kind != "pool" and src != "img":
+                # pair images: input / output stored as fp16 pairs where the context says so (the pooled map a conv with
+                # the pooling epilogue writes carries the bound - and the scale - of the pre-pool layer ``out``)
+                pkw = dict(pair_in=pair.act(src), pair_out=pair.act(out, producer=True))
             if kind == "pool":
                 if out in pooled_by_conv:
                     continue
+                if pair is not None:
+                    raise RuntimeError("pair images need the pooling epilogues (STYLEMESH_FUSE_POOL_FWD, active lists)")
                 fused = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(out in b.code for b in bufs)
                 ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
                                         tiles[("pool", out)][0] if tiles else None,
@@ -183,7 +232,7 @@ class VGGNet:
                                     self.wf[kind], self.bias[kind], hip.EPI_BIAS_RELU | hip.EPI_POOL, tl, frac,
                                     self.wf3[kind], self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out])
+                                    None if am is None else am["a:" + out], **pkw)
                 pooled_by_conv.add(po)
                 if on_layer is not None:
                     on_layer(out)
@@ -195,12 +244,13 @@ class VGGNet:
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
                                     hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind], self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out])
+                                    None if am is None else am["a:" + out], **pkw)
                 if on_layer is not None:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
     def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None,
-                       amax: AmaxBook | None = None, start_bound_recorded=False, gram_terms=None):
+                       amax: AmaxBook | None = None, start_bound_recorded=False, gram_terms=None,
+                       pair: PairCtx | None = None):
         """``backward`` for several levels at once (same injected layers on every level). ``amax``: as in
         ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here unless
         the loss kernels recorded it themselves (``start_bound_recorded``)."""
@@ -211,6 +261,13 @@ class VGGNet:
                 ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         fuse = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(b.code for b in bufs)
         unpool = None   # fused pool backward: name of the pooled map whose gradient the next conv un-pools on the fly
+
+        def gin(b, layer):
+            # the planes that hold the gradient of ``layer``: with pair images an injected layer's final gradient is the
+            # conv's pair output beside the fp32 addend the loss kernels wrote
+            return b.gradp[layer] if (pair is not None and layer in b.gradp and layer != start_layer) else b.grad[layer]
+        if pair is not None and not fuse:
+            raise RuntimeError("pair images need the fused pool backward (argmax codes)")
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if before_layer is not None and kind != "pool":
                 before_layer(src)      # the injected gradient of ``src`` is about to be consumed
@@ -227,9 +284,10 @@ class VGGNet:
                                              tiles[("img", "d")][0] if tiles else None)
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
-                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
+                pkw = {} if pair is None else dict(pair_in=pair.grad(out), pair_out=pair.grad(src, producer=True))
+                ops.conv3x3_grouped([(gin(b, out), b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
                                     self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src])
+                                    None if am is None else am["g:" + src], **pkw)
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
@@ -240,16 +298,23 @@ class VGGNet:
                     if unpool is None or len(gt) != len(bufs) or ops.CONV_MODE != "split2":
                         raise RuntimeError(f"{kind}: a fused Gram backward needs the un-pooling fp16x2 data gradient")
                     flags = hip.EPI_RELU_MASK | hip.EPI_GRAM
+                pkw, dst = {}, [b.grad[src] for b in bufs]
+                if pair is not None:
+                    pkw = dict(pair_in=pair.grad(out), pair_out=pair.grad(src, producer=True), pair_gate=pair.act(src))
+                    if (flags & hip.EPI_ADD) and pkw["pair_out"] is not None:
+                        # the loss kernels' fp32 gradient stays in grad[src] as the addend, the sum is stored as pairs
+                        pkw["addends"] = dst
+                        dst = [b.pair_grad(src) for b in bufs]
                 if unpool is not None:
-                    probs = [(b.grad[unpool], b.grad[src], b.act[src], b.code[unpool]) for b in bufs]
+                    probs = [(b.grad[unpool], d, b.act[src], b.code[unpool]) for b, d in zip(bufs, dst)]
                     if gt is not None:
                         probs = [p + (None, None, g) for p, g in zip(probs, gt)]
                     unpool = None
                 else:
-                    probs = [(b.grad[out], b.grad[src], b.act[src]) for b in bufs]
+                    probs = [(gin(b, out), d, b.act[src]) for b, d in zip(bufs, dst)]
                 ops.conv3x3_grouped(probs, self.wd[kind], None, flags,
                                     tl, frac, self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src])
+                                    None if am is None else am["g:" + src], **pkw)
             assert unpool is None or kind == "pool", "a fused pool backward must be consumed by the conv below it"
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
