@@ -206,7 +206,20 @@ def exchange_report(eng, comm, reducer, args):
         rep["rccl"] = comm.info()          # ranks RCCL saw, its version, link type of this rank's device to the others
     else:
         rep["process_group"] = {"backend": str(comm.get_backend()), "nranks": comm.get_world_size()}
-    rep["pipelined"] = bool(eng.pipeline_exchange)
+    rep["pipelined"] = bool(eng.use_pipelined_exchange(reducer))
+    rep["pipelined_policy"] = {True: "forced on", False: "forced off"}.get(
+        eng.pipeline_exchange, f"auto: from {eng.pipeline_min_bytes >> 20} MB of flagged chunks on")
+    # DESIGN.md section 6's cost model beside the measurement, so that a driver-run scaling record checks itself:
+    # t(N) = 2 (N - 1) / N * B / (L(N) * 76.8 GB/s * eta) + 2 B / 4 TB/s, L(N) = N - 1 xGMI links per GPU (point-to-point
+    # mesh, 153.6 GB/s per link = 76.8 per direction), eta = the fraction RCCL realises on tens-of-MB messages (0.7
+    # assumed), B = the bytes exchanged per step; the second term = gather + scatter of the flagged chunks
+    nb, N = rep["bytes_per_step"], args.gpus
+    if nb and N > 1:
+        model = lambda eta: 1e3 * (2.0 * (N - 1) / N * nb / ((N - 1) * 76.8e9 * eta) + 2.0 * nb / 4e12)
+        rep["model"] = {"formula": "2(N-1)/N * B / ((N-1) * 76.8 GB/s * eta) + 2 B / 4 TB/s", "B_bytes": nb, "N": N,
+                        "predicted_exchange_ms": {"eta_0.6": round(model(0.6), 3), "eta_0.7": round(model(0.7), 3),
+                                                  "eta_0.8": round(model(0.8), 3)},
+                        "note": "xGMI figures: only meaningful for the own-RCCL communicator on separate GPUs"}
     t = getattr(eng, "phase_timer", None)
     if t is not None:
         for tag, key in (("exchange", "exchange_ms"), ("update", "update_ms"), ("exchange+update", "exchange_update_ms")):
@@ -359,10 +372,10 @@ def main():
     args = parse_args()
     from stylemesh_amd import launch
     if launch.needs_launch(args.gpus, os.environ):
-        # plain `python bench.py --gpus N`: N fresh rank processes, decided before this process touches the GPU
-        # (torch.cuda.device_count() does not initialise HIP on this image); the parent relays rank 0's JSON line
+        # plain `python bench.py --gpus N`: N fresh rank processes, decided before this process touches the GPU (the
+        # devices are counted from the KFD topology in sysfs, not through the runtime); the parent relays rank 0's line
         sys.exit(launch.launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
-                               device_count=torch.cuda.device_count, timeout_s=args.launch_timeout))
+                               device_count=launch.kfd_gpu_count, timeout_s=args.launch_timeout))
     run(args)
 
 
@@ -424,7 +437,8 @@ def _run(args):
     eng.use_graphs = args.graphs
     eng.sparse_tiles = not args.dense
     eng.overlap_style = args.overlap_style
-    eng.pipeline_exchange = args.pipeline_exchange or os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0") == "1"
+    if args.pipeline_exchange:
+        eng.pipeline_exchange = True      # (else the engine's default: pipelined from STYLEMESH_PIPELINE_MIN_MB flagged bytes on)
     eng.planned_scatter = not args.atomic_scatter
     eng.sparse_update = not args.dense_adam
 
@@ -556,7 +570,7 @@ def _run(args):
                 ", RCCL all-reduce of the 267 MB texture gradient per step" if args.dense_allreduce else
                 f", RCCL all-reduce of the view-touched chunks of the texture gradient per step "
                 f"({reducer.last_bytes / 1e6:.1f} of {4 * eng.arena.n / 1e6:.0f} MB on the last step)"
-                + (f", in {reducer.n_pieces} pieces overlapped with the update" if eng.pipeline_exchange else ""))
+                + (f", in {reducer.n_pieces} pieces overlapped with the update" if eng.use_pipelined_exchange(reducer) else ""))
         else:
             parallelism = "views sharded over 1 rank(s)"
         out = {"metric": "views/sec (fwd+bwd into 4096^2 texture)" if wl["tex"] == 4096 else

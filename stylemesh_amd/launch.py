@@ -112,9 +112,34 @@ def run_ranks(plans, timeout_s=None, out=None, err=None, poll_s=0.2, grace_s=10.
     return worst_rc([p.returncode for p in procs])
 
 
+def kfd_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs of this node counted WITHOUT the HIP / HSA runtime (the launcher's parent must not open /dev/kfd before it
+    starts the ranks; ``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount`` on ROCm builds without amdsmi,
+    ADVICE r4): KFD topology nodes with SIMDs (CPU nodes report ``simd_count 0``), narrowed by ``HIP_VISIBLE_DEVICES`` /
+    ``ROCR_VISIBLE_DEVICES``. 0 without a KFD; None when the topology cannot be read (the ranks then refuse by themselves)."""
+    env = os.environ if env is None else env
+    try:
+        n = 0
+        for node in sorted(os.listdir(topology)):
+            with open(os.path.join(topology, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except FileNotFoundError:
+        return 0         # no KFD: no AMD GPU on this node
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch(n_gpus: int, argv, env=None, device_count=None, backend=None, timeout_s=None, out=None, err=None) -> int:
-    """The parent's whole job. ``device_count``: callable or int (``torch.cuda.device_count`` does not initialise the GPU
-    on this image; it is only called here, in the parent, to refuse early with ONE clear message)."""
+    """The parent's whole job. ``device_count``: callable or int, only used here, in the parent, to refuse early with ONE
+    clear message - ``kfd_gpu_count`` by default in bench.py: it reads sysfs and never touches the runtime (None: no
+    check, every rank refuses on its own when it finds fewer devices than ranks)."""
     env = dict(os.environ if env is None else env)
     backend = backend or env.get("STYLEMESH_DIST_BACKEND", "nccl")
     n_dev = device_count() if callable(device_count) else device_count

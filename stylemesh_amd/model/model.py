@@ -63,7 +63,7 @@ class FusedTextureAdam:
         eng.cfg.learning_rate = self.param_groups[0]["lr"]
         eng.cfg.decay_gamma, eng.epoch = 1.0, 0    # the scheduler owns the learning rate
         reducer = getattr(self.module, "grad_reducer", None)
-        if reducer is not None and eng.pipeline_exchange and hasattr(reducer, "pipelined") and not eng._can_graph():
+        if eng.use_pipelined_exchange(reducer):
             # STYLEMESH_PIPELINE_EXCHANGE=1: ``step_compute`` left the gradient un-exchanged - all-reduce it in pieces,
             # the update of each arena range issued as its sums arrive (``StepEngine.exchange_and_update``)
             eng.exchange_and_update(self.world_size, reducer)

@@ -180,6 +180,9 @@ def _decode_main(get_view, tasks, results):
         get_view = tasks.get()
         if get_view is None:
             return
+        if isinstance(get_view, (bytes, bytearray)):
+            import pickle
+            get_view = pickle.loads(get_view)
     while True:
         order = tasks.get()
         if order is None:
@@ -217,10 +220,15 @@ class DecodeProcess:
         saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
         os.environ.update({k: "1" for k in saved})
         try:
+            # pickled HERE, in the caller: a decoder that cannot be pickled raises now instead of leaving a traceback in
+            # the queue's feeder thread and a child that waits for its first message forever; the bytes still
+            # travel through the queue (see _decode_main: not through the start-up pipe)
+            from multiprocessing.reduction import ForkingPickler
+            payload = bytes(ForkingPickler.dumps(get_view))
             for p in self.procs:
                 p.start()
             for q in self.tasks:
-                q.put(get_view)       # (see _decode_main: not through the start-up pipe)
+                q.put(payload)
         finally:
             for k, v in saved.items():
                 if v is None:

@@ -193,7 +193,10 @@ class StepEngine:
         self.group_losses = True       # fp16x2 mode: the loss phase as grouped launches over all levels and layers
         # style layers whose branch runs on a side stream beside the conv trunk (grouped loss phase only)
         self.side_style_layers = tuple(x for x in os.environ.get("STYLEMESH_SIDE_STYLE", "r11").split(",") if x)
+        # (inline: the SAME launch sequence - fused Gram epilogues included - issued on the trunk's stream: what the PMC
+        # passes profile, since counter collection serialises dispatches)
         self.side_streams = os.environ.get("STYLEMESH_SIDE_STREAMS", "1") != "0"
+        self.side_inline = os.environ.get("STYLEMESH_SIDE_STREAMS", "1") == "inline"
         # WHERE in the forward pass the HBM-bound side work is forked (a conv output's name; 'head' = before the texture
         # sampling). The split update's early half and the early style branches (relu1_1: Gram kernels over the largest
         # planes) stream HBM at 3-4 TB/s: beside the head of the step - texture sampling, conv1_1, conv1_2, all
@@ -219,7 +222,12 @@ class StepEngine:
         self._lv_streams = []
         # N > 1, opt-in: all-reduce the gradient in pieces and update each arena range as soon as its sums arrive
         # (functionally verified over gloo; not yet timed under RCCL, so the plain exchange-then-update is the default)
-        self.pipeline_exchange = os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0") == "1"
+        # ... round 5: by DEFAULT whenever the ranks' views flag at least STYLEMESH_PIPELINE_MIN_MB (32) megabytes of the
+        # arena - where the exchange is long enough for the update of the early pieces to hide behind the later ones;
+        # STYLEMESH_PIPELINE_EXCHANGE=1 / 0 forces / forbids it. Same arithmetic either way (update by ranges:
+        # test_adam_fused_by_ranges_equals_one_launch; 2-rank bit-identity: tests/test_round5_gpu.py)
+        self.pipeline_exchange = {"1": True, "0": False}.get(os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "auto"), "auto")
+        self.pipeline_min_bytes = int(float(os.environ.get("STYLEMESH_PIPELINE_MIN_MB", "32")) * (1 << 20))
         self.view_tiles = None
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
@@ -245,7 +253,6 @@ class StepEngine:
         self._other_flags = None       # touched & ~view
         self._adam_early_done = None   # event: the update of the other chunks (issued at the head of the step) is done
         self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
-        self.early_update_skips_grad = os.environ.get("STYLEMESH_EARLY_UPDATE_READS_GRAD", "0") != "1"
         self._gram_fused = {}
         # Pair images (round 5; include/stylemesh_hip.h "PAIR IMAGES", runtime/vgg.py:PairCtx): in the multi-level steps
         # (grouped loss phase on side streams, one rank) the VGG activations / gradients are stored as packed fp16 pairs by
@@ -270,8 +277,8 @@ class StepEngine:
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
     def _new_side_stream(self):
-        """Side streams carry work with slack (style branches joined many kernels later, the early half of the update);
-        STYLEMESH_SIDE_PRIORITY=low asks the hardware queues to dispatch the main stream's workgroups first."""
+        """Side streams carry work with slack (style branches joined many kernels later, the early half of the update), at
+        normal priority - the trunk's stream is the high-priority one (``trunk_stream``)."""
         n_cus = int(os.environ.get("STYLEMESH_SIDE_CUS", "0"))
         if n_cus > 0:   # a queue confined to n_cus compute units (n_cus / 8 of every XCD): see sm_stream_create_cu_subset
             import ctypes
@@ -279,9 +286,6 @@ class StepEngine:
             with torch.cuda.device(self.device):
                 ops.hip.check(ops.hip.lib.sm_stream_create_cu_subset(n_cus, ctypes.byref(out)), "sm_stream_create_cu_subset")
             return torch.cuda.ExternalStream(out.value, device=self.device)
-        if os.environ.get("STYLEMESH_SIDE_PRIORITY", "") == "low":
-            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-            return torch.cuda.Stream(device=self.device, priority=lo)
         return torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ texture access
@@ -465,7 +469,7 @@ class StepEngine:
             self._prep_stream = self._new_side_stream()
         slot = free[0]
         st = self._prep_stream
-        if urgent and os.environ.get("STYLEMESH_URGENT_PREPARE", "1") != "0":
+        if urgent:
             # The view is needed by the very NEXT step (index_repeat 1): its read-back must arrive while the current step
             # still runs, or the GPU idles while the host enqueues the next one. On a stream of the trunk's priority the
             # preparation's small kernels are dispatched beside the step's instead of behind them.
@@ -499,6 +503,9 @@ class StepEngine:
         """Forget a view prepared ahead (or asked for) that will not be the next one - an epoch cut short, a schedule that
         changed: its launches are ordered before whatever the current stream does next, its slot is free again."""
         preps, self._prepared, self._prepare_request = self._prepared, [], []
+        # the preparation kernels read the batch's own tensors (no staging copies): keep every dropped view referenced
+        # until its launches have completed (ADVICE r4)
+        self._dropped = [d for d in getattr(self, "_dropped", []) if not d[3].query()] + preps
         for prep in preps:
             torch.cuda.current_stream().wait_event(prep[3])
 
@@ -980,6 +987,9 @@ class StepEngine:
                 last_early = max(early, key=depth_of) if early else None
 
                 def on_side(work, done_layers):
+                    if self.side_inline:
+                        work()
+                        return
                     ev = torch.cuda.Event()
                     ev.record(main)
                     st.wait_event(ev)
@@ -1439,6 +1449,12 @@ class StepEngine:
                 raise RuntimeError(f"libstylemesh_hip: replayed update call failed with HIP error code {rc}")
             self._grad_dirty = False
             return
+        from . import hip as _hip
+        if self._prog_rec is not None:
+            if world_size == 1 and ops.lib is _hip.lib:
+                ops.lib = self._prog_rec[0]         # the update segment of the step being recorded
+            else:
+                self._prog_end_recording(discard=True)
         try:
             self._optimizer_step_eager(world_size)
         finally:
@@ -1530,7 +1546,7 @@ class StepEngine:
                 ops.zero_floats(self.sumsq)
             # (no gradient pointer: these chunks hold a zero data-term gradient - nothing scatters into them during
             # this view and their last update zeroed them - so the launch moves 6 instead of 8 streams)
-            ops.adam_fused(self.arena.p, None if self.early_update_skips_grad else self.arena.g, self.arena.m,
+            ops.adam_fused(self.arena.p, None, self.arena.m,
                            self.arena.v, self.arena.seg_end, self.reg_coef,
                            self.lr, self.step_count + 1, grad_scale=1.0, sumsq_out=self.sumsq, dev_hyper=dev_hyper,
                            touched=self._other_flags[1], touched_log2=self.touched_log2)
@@ -1556,6 +1572,20 @@ class StepEngine:
         ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
                        self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
                        dev_hyper=dev_hyper, touched=touched, touched_log2=tl2)
+
+    def use_pipelined_exchange(self, reducer) -> bool:
+        """Multi-GPU tail of the step as pipelined exchange + update? (identical on every rank: it depends on the
+        reducer's chunk count - the all-reduced union of the ranks' footprints - and on configuration only)"""
+        if reducer is None or not hasattr(reducer, "pipelined") or self._can_graph() or self.pipeline_exchange is False:
+            return False
+        if self.pipeline_exchange is True:
+            return True
+        n_idx = getattr(reducer, "n_idx", None)
+        if n_idx is None:
+            return False
+        dense = getattr(reducer, "fraction", 0.0) > getattr(reducer, "dense_above", 1.0)
+        nbytes = 4 * self.arena.n if dense else 4 * n_idx * reducer.chunk
+        return nbytes >= self.pipeline_min_bytes
 
     def exchange_and_update(self, world_size: int, reducer):
         """Multi-GPU tail of the step: gradient exchange overlapped with the fused update (``reducer.pipelined``:
@@ -1646,25 +1676,35 @@ class StepEngine:
             prog = self._programs.get(key)
             if prog is not None and self.step_programs != "verify":
                 return self._program_compute(prog, key, out)
-            if prog is not None or self._prog_warm.get(key, 0) >= 2:      # steady state: record this step
+            from . import hip as _hip
+            if (prog is not None or self._prog_warm.get(key, 0) >= 2) and ops.lib is _hip.lib:
+                # steady state: record this step. The recorder stands in for the module-global ``ops.lib`` ONLY while this
+                # engine's own calls are being issued: from here to the end of ``step_compute`` and again inside
+                # ``optimizer_step`` - never across the caller's code in between (a hook that renders the texture, a
+                # validation pass, a second engine's step would otherwise land in this engine's program). An
+                # engine that finds another recorder installed does not record.
                 from .program import Recorder
                 rec = Recorder()
                 self._prog_rec = [rec, key, None, out]
                 ops.lib = rec
-            else:
+            elif prog is None:
                 self._prog_warm[key] = self._prog_warm.get(key, 0) + 1
         try:
             return self._step_compute_eager(out, reducer, exchange)
         except BaseException:
             self._prog_end_recording(discard=True)
             raise
+        finally:
+            if self._prog_rec is not None:          # paused until optimizer_step
+                from . import hip as _hip
+                ops.lib = _hip.lib
 
     def _step_compute_eager(self, out, reducer, exchange):
         self._join_early()
         if self._pair_step:
             self._pair_begin()
         losses = self._step_begin(out[2:3])    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
-        pipelined = reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph()
+        pipelined = self.use_pipelined_exchange(reducer)
         if not pipelined:
             if (self._can_graph() or self.early_update_at == "head") and not self._pair_step:
                 self._adam_early()
@@ -1704,7 +1744,9 @@ class StepEngine:
             return None
         empties = None if self.view_tiles is None else frozenset(k for k, v in self.view_tiles.items() if v[0].numel() == 0)
         plan = self._scatter_plan if (self.planned_scatter and self._scatter_levels == [lv.index for lv in active]) else None
-        return (self._slot, tuple((lv.index, lv.H, lv.W) for lv in active), empties, ops.CONV_MODE, ops.GRAM_MODE,
+        # (the launch stream: recorded words hold per-stream scratch - the split-K slabs, the Gram-backward workspace -
+        # and every buffer a recorded call touches must be grow-never or part of this key)
+        return (self._slot, ops.hip.stream(), tuple((lv.index, lv.H, lv.W) for lv in active), empties, ops.CONV_MODE, ops.GRAM_MODE,
                 None if plan is None else (id(plan), plan.sorted_in, plan.generation, plan.n_entries), self.sparse_update,
                 None if self._gram_arena is None else self._gram_arena.data_ptr(),
                 None if self.touched is None else self.touched.data_ptr(), self.cfg.gram_mode, self.sparse_tiles,
@@ -1720,9 +1762,14 @@ class StepEngine:
         if rec_state is None:
             return
         from . import hip as _hip
-        ops.lib = _hip.lib
         rec, key, n_compute, out = rec_state
+        if ops.lib is rec:
+            ops.lib = _hip.lib
         if discard or n_compute is None:
+            return
+        if not any(c[0] == "sm_adam_fused" for c in rec.calls[n_compute:]):
+            # an update segment without the fused update would be replayed as "no update at all": never store it
+            self._prog_warm[key] = -(1 << 30)
             return
         if rec.problem is not None:
             self._prog_warm[key] = -(1 << 30)          # never again for this key
@@ -1839,7 +1886,7 @@ class StepEngine:
             for nb in (next_batch if isinstance(next_batch, list) else [next_batch]):
                 self.request_prepare(nb)
         losses = self.step_compute(batch, reducer, new_view)
-        if reducer is not None and self.pipeline_exchange and hasattr(reducer, "pipelined") and not self._can_graph():
+        if self.use_pipelined_exchange(reducer):
             self._timed("exchange+update", lambda: self.exchange_and_update(world_size, reducer))
             return losses
         self._timed("update", lambda: self.optimizer_step(world_size))

@@ -107,8 +107,7 @@ class MiniTrainer:
         upcoming = getattr(batch, "upcoming", None)
         # (also at a view's FIRST step - with index_repeat 1 there is no other: the module's hook leaves a request that the
         # engine serves once this batch's own view has become current, ``StepEngine.request_prepare``)
-        if (upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None
-                and os.environ.get("STYLEMESH_UPLOAD_AHEAD", "1") != "0"):
+        if upcoming is not None and torch.cuda.is_available() and getattr(self, "_ahead", None) is None:
             nxt = upcoming()
             if nxt is not None and nxt[0] is not batch[0]:
                 if not hasattr(self, "_copy_stream"):
@@ -162,26 +161,6 @@ class MiniTrainer:
                 torch.cuda.set_stream(caller_stream)
 
     def _fit(self, model, datamodule):
-        sampler = None
-        if os.environ.get("STYLEMESH_SAMPLE") == "1":   # diagnostics: where does the training thread sit? (2 ms sampling)
-            import collections
-            import sys
-            import threading
-            main_id, hist, stop = threading.get_ident(), collections.Counter(), threading.Event()
-
-            def sample():
-                while not stop.wait(0.002):
-                    f = sys._current_frames().get(main_id)
-                    chain = []
-                    while f is not None and len(chain) < 4:
-                        chain.append(f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}:{f.f_code.co_name}")
-                        f = f.f_back
-                    hist[" <- ".join(chain)] += 1
-            sampler = (threading.Thread(target=sample, daemon=True), hist, stop)
-            sampler[0].start()
-        if os.environ.get("STYLEMESH_SWITCH_INTERVAL"):   # experiment: interpreter-lock hand-over interval (seconds)
-            import sys
-            sys.setswitchinterval(float(os.environ["STYLEMESH_SWITCH_INTERVAL"]))
         t0 = time.time()                         # (the schedule's clock: engine set-up and loader start-up included)
         if hasattr(datamodule, "warm_start"):
             datamodule.warm_start()              # decode processes up before anything waits for them
@@ -272,11 +251,6 @@ class MiniTrainer:
             IMAGE_WRITER.wait()
         except ImportError:
             pass
-        if sampler is not None:
-            sampler[2].set()
-            tot = sum(sampler[1].values())
-            for k, v in sampler[1].most_common(14):
-                print(f"sample {100.0 * v / tot:5.1f} %  {k}")
         if self.progress and self.rank == 0:
             print(f"fit: {time.time() - t0:.1f} s")
             if getattr(self, "host_seconds", None) and os.environ.get("STYLEMESH_TRAINER_TIMING") == "1":

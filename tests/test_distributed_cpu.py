@@ -325,3 +325,50 @@ def test_view_prefetcher_order_peek_errors_and_early_close():
     ahead = list(D.scheduled_batches(get, range(5), 1, 2, index_repeat=2, prefetch=2))
     assert [(b[8], b.new_view) for b in ahead] == plain and all(callable(b.upcoming) for b in ahead)
     assert ahead[0][0] is ahead[1][0]           # repeats of a view share the decoded tensors
+
+
+def _eight_rank_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = D.make_sparse_grad_reducer(dist, world)            # the product's chunk size (64 floats) and 0.75 threshold
+    n_chunks, chunk = 4096, red.chunk
+    g = torch.Generator().manual_seed(7 + rank)
+    out = {}
+    # three "views" per rank: per-rank footprints of 3 %, 12 % and 22 % of the arena - the unions over eight ranks land
+    # below, near and ABOVE the dense-fallback threshold
+    for view, share in enumerate((0.03, 0.12, 0.22)):
+        start = int(torch.randint(0, n_chunks, (1,), generator=g))
+        touched = torch.zeros(n_chunks, dtype=torch.bool)
+        touched[(start + torch.arange(int(share * n_chunks))) % n_chunks] = True      # a blob, as a view's footprint is
+        flags = touched.to(torch.int32)
+        red.new_view(flags)
+        arena = torch.zeros(n_chunks, chunk)
+        arena[touched] = torch.randn(int(touched.sum()), chunk, generator=g)
+        arena = arena.reshape(-1)
+        dense = arena.clone()
+        dist.all_reduce(dense)
+        red(arena)
+        out[view] = (arena.clone(), dense, red.fraction, red.last_bytes, bool(red._sparse(arena.numel())))
+    torch.save(out, os.path.join(out_dir, f"eight{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sparse_grad_reducer_at_eight_ranks_crosses_the_dense_fallback(tmp_path):
+    """the reducer at the world size of the node - the union of eight footprints grows past the 0.75
+    threshold and the exchange switches to the dense all-reduce on EVERY rank at the same view; sums equal the plain
+    all-reduce in both regimes, bytes follow the union."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_eight_rank_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    res = [torch.load(tmp_path / f"eight{r}.pt") for r in range(8)]
+    fr = [res[0][v][2] for v in range(3)]
+    assert fr[0] < fr[1] < fr[2] and fr[0] < 0.3 and fr[2] > 0.75, fr
+    for v in range(3):
+        mine, dense, frac, nbytes, sparse = res[0][v]
+        # (eight summands: the ring adds a chunk's contributions in an order that depends on the buffer's length - equal to
+        # rounding against the dense all-reduce, and IDENTICAL on every rank, which is what the update relies on)
+        assert torch.allclose(mine, dense, rtol=1e-5, atol=1e-6) and torch.equal(mine != 0, dense != 0)
+        for r in res[1:]:
+            assert torch.equal(r[v][0], mine) and r[v][2] == frac and r[v][3] == nbytes and r[v][4] == sparse
+        assert sparse == (frac <= 0.75)
+        assert nbytes == (int(round(frac * 4096)) * 64 * 4 if sparse else 4096 * 64 * 4)

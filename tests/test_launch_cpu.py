@@ -97,3 +97,20 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
         return
     assert r.returncode == launch.RC_NO_DEVICES, (r.returncode, r.stderr[-400:])
     assert "one rank per GPU" in r.stderr and r.stdout == ""
+
+
+def test_gpus_are_counted_from_the_kfd_topology_without_the_runtime(tmp_path):
+    """The launcher's parent counts devices from sysfs (``torch.cuda.device_count()`` may open /dev/kfd): KFD
+    nodes with SIMDs, narrowed by the visibility variables; no KFD = 0 GPUs; an unreadable topology = no check."""
+    topo = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):      # two CPU nodes, three GPUs
+        d = topo / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert launch.kfd_gpu_count(str(topo), env={}) == 3
+    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert launch.kfd_gpu_count(str(topo), env={"ROCR_VISIBLE_DEVICES": ""}) == 0
+    assert launch.kfd_gpu_count(str(tmp_path / "absent"), env={}) == 0
+    (topo / "5").mkdir()
+    (topo / "5" / "properties").write_text("simd_count not-a-number\n")
+    assert launch.kfd_gpu_count(str(topo), env={}) is None

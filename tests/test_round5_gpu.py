@@ -373,3 +373,75 @@ def test_pair_image_step_equals_the_fp32_plane_step_and_an_invalid_step_leaves_n
     assert eng.step_count == ref.step_count == 3
     err = (eng.arena.p - ref.arena.p).abs()
     assert float((err > 2e-3).float().mean()) <= 0.01 and float(err.max()) <= 0.3, (float(err.max()), float((err > 2e-3).float().mean()))
+
+
+def test_step_program_recording_is_scoped_to_the_engines_own_calls():
+    """the recorder stands in for the module-global ``ops.lib`` only while ONE engine issues its own
+    calls. Two engines whose steps interleave (a.compute, b.compute, b.update, a.update) and a caller that launches
+    library work between ``step_compute`` and ``optimizer_step`` (a hook rendering the texture) must each get programs
+    with their own update segment - every step still takes its Adam update and equals the unrecorded engines' step."""
+    require_gpu()
+    import numpy as np
+    import test_round4_gpu as R4
+    from stylemesh_amd.runtime import hip, ops
+    c = R4.PROGRAM_CASES["only2D"]
+    views = R4._small_views((0, 2))
+    a, b = R4._program_engine(c, "1"), R4._program_engine(c, "1")
+    ra, rb = R4._program_engine(c, "0"), R4._program_engine(c, "0")
+    scratch = torch.zeros(64, device="cuda")
+    for i in range(14):
+        batch = views[i // 7]
+        for e, r in ((a, ra), (b, rb)):
+            for dst, src in ((e.arena.p, r.arena.p), (e.arena.m, r.arena.m), (e.arena.v, r.arena.v), (e.sumsq, r.sumsq)):
+                dst.copy_(src)             # lock-step with the unrecorded twins
+            if e.touched is not None:
+                e.touched.copy_(r.touched)
+        la = a.step_compute(batch)
+        assert ops.lib is hip.lib          # paused between the two halves of a's step
+        ops.zero_floats(scratch)           # a caller's own library call: must not enter anybody's program
+        lb = b.step_compute(batch)
+        b.optimizer_step()
+        a.optimizer_step()
+        assert ops.lib is hip.lib
+        lra = ra.step_compute(batch)
+        ra.optimizer_step()
+        lrb = rb.step_compute(batch)
+        rb.optimizer_step()
+        np.testing.assert_allclose(a.losses(la)["total"], ra.losses(lra)["total"], rtol=1e-5)
+        np.testing.assert_allclose(b.losses(lb)["total"], rb.losses(lrb)["total"], rtol=1e-5)
+        for e, r in ((a, ra), (b, rb)):
+            err = (e.arena.p - r.arena.p).abs()
+            assert float((err > 2e-3).float().mean()) < 0.01, (i, float(err.max()))
+        assert float((a.arena.p - ra.arena.p).abs().max()) < 0.3
+    for e in (a, b):
+        assert e.program_replays >= 4, e.program_replays
+        for prog in e._programs.values():
+            assert "sm_zero_floats" not in prog.names[prog.n_compute:] or prog.names.count("sm_adam_fused") >= 1
+            assert any(n == "sm_adam_fused" for n in prog.names[prog.n_compute:])
+
+
+def test_two_rank_pipelined_exchange_equals_exchange_then_update_bit_for_bit():
+    """the pipelined exchange + update - round 5's default from 32 MB of flagged chunks on - against
+    the all-reduce followed by one fused update, from the same state and the same local gradients on two ranks (one
+    device, gloo): p, m, v, the zeroed gradient and sum(p^2) identical to the bit, identical across the ranks; the policy
+    answers the same on every rank."""
+    require_gpu()
+    import os
+    import tempfile
+    import test_round2_gpu as R2
+    from conftest import REPO
+    with tempfile.TemporaryDirectory() as tmp:
+        r = R2._launch_ranks([os.path.join(REPO, "tests", "two_rank_worker.py"), "pipelined", tmp], 2,
+                             {"STYLEMESH_TEST_BACKEND": "gloo"}, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        r0, r1 = (torch.load(os.path.join(tmp, f"rank{k}.pt")) for k in (0, 1))
+    assert len(r0["steps"]) >= 2
+    for s0, s1 in zip(r0["steps"], r1["steps"]):
+        (plain0, pipe0), (plain1, pipe1) = s0, s1
+        for a, b, c in zip(plain0[:4], pipe0[:4], plain1[:4]):
+            assert torch.equal(a, b) and torch.equal(a, c)
+        assert float(plain0[1].abs().max()) == 0.0 and float(plain0[0].abs().max()) > 0
+        # (sum(p^2) is added with atomics, per range in the pipelined form: equal to rounding)
+        assert torch.allclose(plain0[4], pipe0[4], rtol=1e-5) and torch.allclose(plain0[4], plain1[4], rtol=1e-5)
+    for r in (r0, r1):
+        assert r["auto_small"] is False and r["auto_large"] is True

@@ -3,6 +3,7 @@
     two_rank_worker.py g8 <out_dir>        mean-gradient step of golden G8 with the HIP gradients
     two_rank_worker.py trainer <out_dir>   MiniTrainer epoch over 5 train views (odd) with index_repeat 2
     two_rank_worker.py dense_vs_sparse <out_dir>   zero-initialised texture, 6 steps, dense and sparse reducer
+    two_rank_worker.py pipelined <out_dir>  pipelined exchange + update against exchange-then-update, same state
 
 STYLEMESH_TEST_BACKEND=nccl: one GPU per rank, exchange over the product's own RCCL communicator;
 gloo: both ranks on cuda:0, exchange through torch.distributed's gloo backend (1-GPU boxes)."""
@@ -112,6 +113,50 @@ def main():
             torch.cuda.synchronize()
             out[kind] = {"p": eng.arena.p.cpu().clone(), "g": eng.arena.g.cpu().clone(), "m": eng.arena.m.cpu().clone(),
                          "dense_update": eng.touched is None}
+        torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    elif mode == "pipelined":
+        # the pipelined exchange + update (the default from STYLEMESH_PIPELINE_MIN_MB of flagged chunks
+        # on) against exchange-then-update, from the SAME state and the SAME local gradients: bit-identical p, m, v.
+        from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+        cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
+                           angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
+                           use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
+                           learning_rate=1, decay_gamma=0.1, decay_step_size=1)
+        eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
+        eng.load_texture(init)
+        eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
+        red = D.make_sparse_grad_reducer(comm, world)
+        out = {"auto_small": None, "auto_large": None, "steps": []}
+        seeds = D.shard_views(MULTIVIEW_SEEDS, rank, world)
+        for k, seed in enumerate(seeds):
+            batch = S.make_view(seed, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                                min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+            eng.set_view(batch)
+            red.new_view(eng.touch_flags(red.chunk_log2))
+            eng.forward_backward()
+            torch.cuda.synchronize()
+            state = [t.clone() for t in (eng.arena.p, eng.arena.g, eng.arena.m, eng.arena.v, eng.sumsq)]
+            count = eng.step_count
+            res = []
+            for pipe in (False, True):
+                for dst, src in zip((eng.arena.p, eng.arena.g, eng.arena.m, eng.arena.v, eng.sumsq), state):
+                    dst.copy_(src)
+                eng.step_count = count
+                eng._grad_dirty = True
+                if pipe:
+                    eng.exchange_and_update(world, red)
+                else:
+                    red(eng.arena.g)
+                    eng.optimizer_step(world)
+                torch.cuda.synchronize()
+                res.append([t.cpu().clone() for t in (eng.arena.p, eng.arena.g, eng.arena.m, eng.arena.v, eng.sumsq)])
+            out["steps"].append(res)
+            # the policy: the same answer on every rank, on for large exchanges only
+            eng.pipeline_exchange, eng.pipeline_min_bytes = "auto", 1 << 40
+            small = eng.use_pipelined_exchange(red)
+            eng.pipeline_min_bytes = 1
+            large = eng.use_pipelined_exchange(red)
+            out["auto_small"], out["auto_large"] = small, large
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     else:
         raise SystemExit(f"unknown mode {mode}")

@@ -109,8 +109,6 @@ def main():
     t0 = time.time()
     r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True)
     wall = time.time() - t0
-    if os.environ.get("STYLEMESH_SAMPLE") == "1":
-        print("\n".join(l for l in r.stdout.splitlines() if l.startswith("sample ")), file=sys.stderr)
     print("\n".join(l for l in r.stdout.splitlines() if l.startswith(("epoch ", "fit:", "loader:", "set_view:", "host ms"))),
           file=sys.stderr)
     if r.returncode != 0:
