@@ -418,6 +418,9 @@ __global__ __launch_bounds__(64) void pair_check_kernel(const float* __restrict_
 #ifndef SM_CONV_KG2_DEFAULT
 #define SM_CONV_KG2_DEFAULT 0   // measured (profiles/r05/kg2_c2_layers.txt): -8 % on the one-level layers - the groups run in lock-step
 #endif
+#ifndef SM_CONV_SMALL_BM64_DEFAULT
+#define SM_CONV_SMALL_BM64_DEFAULT 0   // (tiles of 128 x 128 up to which a launch takes 64 x 128 tiles; 0 = never)
+#endif
 #ifndef SM_CONV_KG2_BUILD
 #define SM_CONV_KG2_BUILD 0   // 1: compile the two-wave-group variants (selected with SM_CONV_KG=2)
 #endif
@@ -450,11 +453,15 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 #ifndef SM_SPLIT2_SLOTS
 #define SM_SPLIT2_SLOTS 1
 #endif
+#ifndef SM_SMALL_SLOTS
+#define SM_SMALL_SLOTS 3
+#endif
 #ifndef SM_CONV_SPLIT_PENALTY_DEFAULT
 #define SM_CONV_SPLIT_PENALTY_DEFAULT 3.f   // measured (profiles/r04/split_penalty_ab.txt): c3 +0.4 %, c2 +0.6 % at 2-4, c2 -5 % at 8
 #endif
     // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
-    constexpr int SLOTS = SM_NUM_CU * ((SPLIT && NP == 2) ? SM_SPLIT2_SLOTS : 1);
+    // (64 x 128 tiles - the small-grid choice of round 5, dispatch_conv_split2 - are sized for three blocks per CU)
+    constexpr int SLOTS = SM_NUM_CU * ((SPLIT && NP == 2) ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
     a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;
@@ -555,6 +562,20 @@ static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats,
     // one wave per SIMD with a 64 x 128 wave tile (128 accumulator registers): 24 MFMAs per stage and wave
     if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 #endif
+    // Small grids (round 5; a one-level view: 12 - 172 tiles of 128 x 128 on 256 CUs): a lone 128 x 128 block per CU is
+    // bound by the LATENCY of its own pipeline, not by its MFMAs (without any MFMA the c2 layers still take 78 % of their
+    // time: profiles/r05/c2_layer_ablation.txt). 64 x 128 tiles double the blocks, three of them share a CU (34.8 KB of LDS,
+    // 129 VGPRs) and cover each other's stalls; the K-split count is chosen for 3 x 256 slots.
+    {
+        static const int small = getenv("SM_CONV_SMALL_BM64") ? atoi(getenv("SM_CONV_SMALL_BM64")) : SM_CONV_SMALL_BM64_DEFAULT;
+        if (small && (FLAGS & SM_EPI_GRAM) == 0) {
+            long long ntile = 0;
+            if (a.tile_list) ntile = n_list / 4;
+            else for (int g = 0; g < a.n_problems; ++g) ntile += (a.p[g].H * a.p[g].Wp + 127) / 128;
+            if (ntile * (a.Cout / 128) <= small)
+                return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
+        }
+    }
     return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
 }
 

@@ -31,6 +31,8 @@ SWITCHES = {
     "SM_CONV_FORCE_SPLITS": ("(unset)", "experiment", "(C library) force the tail's K-split count (tools/bench_c2_layers.py sweeps)"),
     "SM_CONV_KG": ("1", "experiment", "(C library, needs -DSM_CONV_KG2_BUILD=1) 2 = 512-thread blocks of two wave groups for small "
                    "grids: -8 % on the one-level layers (profiles/r05/kg2_c2_layers.txt)"),
+    "SM_CONV_SMALL_BM64": ("0", "experiment", "(C library) launches of up to N 128 x 128 tiles take 64 x 128 tiles, three blocks per CU: "
+                           "no effect on the one-level layers (profiles/r05/c2_layer_ablation.txt)"),
     "SM_CONV_STAMP": ("(unset)", "diagnostic", "(C library) the conv build that writes s_memtime stage stamps (tools/ts_split.py, ts_small.py)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),
     # ---- step structure
