@@ -14,8 +14,8 @@
 
 // resident waves per SIMD the register budgets are set for (A/B: tools/build_variant.sh -f gram -DSM_GRAM_FWD_W1=4 ...)
 #ifndef SM_GRAM_FWD_W1
-#define SM_GRAM_FWD_W1 2
-#endif
+#define SM_GRAM_FWD_W1 3   // grouped forward, 64-channel tiles: 4 waves per SIMD (128 VGPRs) spilled 13 registers (round 4's
+#endif                     // verdict); 3 (168) fits without scratch - A/B in profiles/r05/gram_fwd_waves_ab.txt
 #ifndef SM_GRAM_FWD_W2
 #define SM_GRAM_FWD_W2 2
 #endif
@@ -431,7 +431,7 @@ constexpr size_t gram_group_lds_bytes(int MI, int NP, bool diag_only = false) {
 // MI = 1 (126 VGPRs): four blocks per CU when every problem of the launch is a single diagonal tile (C = 64: the Bt
 // half of the LDS image is not allocated then) - a block keeps ~one 16 KB stage in flight, a CU needs ~50 KB
 template <int MI, int NP, bool PAIR = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? 4 : 2, MI == 1 ? 4 : 2))) void gram_group_kernel(GramGroup G) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_FWD_W1 : 2, MI == 1 ? SM_GRAM_FWD_W1 : 2))) void gram_group_kernel(GramGroup G) {
     constexpr int TS = 64 * MI;                 // tile size (channels)
     constexpr int KS = gram_ks(MI);             // MFMA K-steps per stage
     constexpr int SP = 16 * KS;                 // positions per stage
