@@ -88,7 +88,7 @@ int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int*
  * weights, depends only on the view - and the reference's RepeatingSampler (data/abstract_dataset.py:498-512) optimises a
  * view for 20-100 consecutive steps. sm_tex_scatter_plan lists every (pixel, layer, tap) contribution of ALL levels
  * of the view as key = arena offset of the texel (channel 0), value = (pixel, level, layer, tap weight x pixel weight),
- * radix-sorts the list by key and lists the runs of equal texels that cross a 64-entry chunk boundary (once per view).
+ * radix-sorts the list by key (sm_radix_sort_pairs) and lists the runs of equal texels that cross a 64-entry chunk boundary (once per view).
  * sm_tex_scatter_planned then replaces the n_levels sm_tex_sample_bwd calls of a step: the planar image gradients
  * are packed into one float4 per pixel, one lane per sorted entry gathers its pixel, a wave-wide segmented sum adds
  * the runs of equal texels, a run inside a chunk writes its texel, and one thread per crossing run adds that run's
@@ -104,6 +104,13 @@ int sm_tex_touch_flags(float* const* grad_layers, const int* layer_w, const int*
  *   guarantees that the arena is ZERO where this view writes (sm_adam_fused zeroes it): texels are stored without
  *   being read; 1: add into the arena like sm_tex_sample_bwd. */
 size_t sm_tex_scatter_plan_temp_bytes(size_t n_entries, int key_bits);
+/* The sort of the plan as an entry point of its own (ABI 9; rounds 1-4 called rocPRIM's device radix sort here): STABLE LSD
+ * radix sort of n (u32 key, u64 value) pairs by the low key_bits bits of the keys - equal keys keep their input order, so
+ * everything downstream adds in a fixed order. Ping-pongs between (keys0, vals0) - the input - and (keys1, vals1);
+ * *sorted_in (HOST) = 0 / 1 = which pair holds the result. temp: sm_tex_scatter_plan_temp_bytes(n, key_bits) bytes.
+ * ceil(key_bits / 9) passes of three launches (per-tile digit histograms, per-bin scan over the tiles, stable scatter). */
+int sm_radix_sort_pairs(uint32_t* keys0, uint32_t* keys1, uint64_t* vals0, uint64_t* vals1, size_t n, int key_bits,
+                        void* temp, size_t temp_bytes, int* sorted_in, void* stream);
 size_t sm_tex_scatter_plan_cross_bytes(size_t n_entries);
 int sm_tex_scatter_plan(float* const* grad_layers, const int* layer_w, const int* layer_h, int n_layers,
                         const float* arena_base, const float* const* grids, const float* const* pixel_weights,

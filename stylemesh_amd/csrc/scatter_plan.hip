@@ -6,11 +6,11 @@
 // totals are written with plain stores - atomics only where a run crosses a wave boundary.
 //
 // Replaces grid_sampler_2d_backward + the gradient hooks exactly like tex_sample_bwd_tiled_kernel (texture.hip);
-// same tap arithmetic (make_taps below mirrors texture.hip). The sort is rocPRIM's device radix sort (per-view
-// preparation, not a per-step kernel).
+// same tap arithmetic (make_taps below mirrors texture.hip). The sort (per-view preparation, not a per-step kernel) is the
+// library's OWN stable LSD radix sort since round 5 (rs_* kernels below; rounds 1-4 called rocPRIM's device radix sort -
+// the last third-party device code on the product path).
+#include <algorithm>
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -76,6 +76,188 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(PlanLevels V, Plan
         keys[e + k] = live ? L.base[layer] + (unsigned)((y0 + (k >> 1)) * W + x0 + (k & 1)) : invalid;
         vals[e + k] = pack_value(q, level, layer, wk);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (u32 key, u64 value) pairs, ceil(key_bits / 9) passes of <= 9 bits. A pass = three launches:
+//   rs_hist_kernel     one block per TILE of 4096 entries: its digit histogram -> hist[bin][tile] (bin-major);
+//   rs_scan_rows_kernel one block per bin: exclusive scan of the bin's row over the tiles + the bin's total;
+//   rs_scatter_kernel  one block per tile: base[bin] (the scan of the totals, redone per block: 512 values) + the row scan
+//                      = where the tile's first entry of every bin goes; the tile's entries are ranked STABLY in 16
+//                      rounds of 256 (round-major, then thread order = the input order): within a wave by matching
+//                      digits with ballots, across the four waves through tagged per-wave counts in LDS.
+// The keys of a view are spatially coherent (neighbouring pixels hit neighbouring texels): the high-digit passes write
+// whole tiles into one or two bins - contiguous; the low-digit pass scatters runs of ~8 entries.
+// Deterministic: equal keys keep their input order (pixel, layer, tap), so the per-step sums add in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 16, RS_TILE = 256 * RS_ITEMS, RS_MAX_BITS = 9, RS_MAX_BINS = 1 << RS_MAX_BITS;
+
+// lanes of the wave whose (valid) entry has the same digit as this lane's
+__device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid, int bits) {
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool one = (d >> b) & 1u;
+        const unsigned long long s = __ballot(one);
+        m &= one ? s : ~s;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, size_t n, int shift, int bits,
+                                                      int n_tiles, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[RS_MAX_BINS];
+    const int bins = 1 << bits, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    unsigned k[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t e = base + r * 256 + threadIdx.x;
+        k[r] = e < n ? keys[e] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t e = base + r * 256 + threadIdx.x;
+        const bool valid = e < n;
+        const unsigned d = (k[r] >> shift) & (unsigned)(bins - 1);
+        const unsigned long long m = rs_match(d, valid, bits);
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], (unsigned)__popcll(m));   // one add per wave and bin
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256) hist[(size_t)i * n_tiles + blockIdx.x] = h[i];
+}
+
+// block-wide inclusive scan of one value per thread (256 threads); returns the inclusive prefix, *total = block sum
+__device__ __forceinline__ unsigned rs_block_scan(unsigned v, unsigned* wsum /*[4] shared*/, unsigned* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();            // (wsum may still be read from the previous call)
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned off = 0u, tot = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) off += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
+    return x + off;
+}
+
+__global__ __launch_bounds__(256) void rs_scan_rows_kernel(unsigned* __restrict__ hist, int n_tiles, unsigned* __restrict__ totals) {
+    __shared__ unsigned wsum[4];
+    unsigned* row = hist + (size_t)blockIdx.x * n_tiles;
+    unsigned carry = 0u;
+    for (int i0 = 0; i0 < n_tiles; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const unsigned v = i < n_tiles ? row[i] : 0u;
+        unsigned tot;
+        const unsigned incl = rs_block_scan(v, wsum, &tot);
+        if (i < n_tiles) row[i] = carry + incl - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ keys_in,
+                                                         const unsigned long long* __restrict__ vals_in,
+                                                         unsigned* __restrict__ keys_out, unsigned long long* __restrict__ vals_out,
+                                                         size_t n, int shift, int bits, int n_tiles,
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ totals) {
+    __shared__ unsigned run[RS_MAX_BINS];          // next output position of every bin for this tile
+    __shared__ unsigned wcnt[4][RS_MAX_BINS];      // per-wave count of the current round, tagged with the round: (r + 1) << 16 | count
+    __shared__ unsigned wsum[4];
+    const int bins = 1 << bits, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // base[bin] = exclusive scan of the bins' totals (two bins per thread), + this tile's offset inside the bin
+        const int b0 = 2 * threadIdx.x, b1 = b0 + 1;
+        const unsigned t0 = b0 < bins ? totals[b0] : 0u, t1 = b1 < bins ? totals[b1] : 0u;
+        unsigned tot;
+        const unsigned incl = rs_block_scan(t0 + t1, wsum, &tot);
+        const unsigned ex = incl - (t0 + t1);
+        if (b0 < bins) run[b0] = ex + hist[(size_t)b0 * n_tiles + blockIdx.x];
+        if (b1 < bins) run[b1] = ex + t0 + hist[(size_t)b1 * n_tiles + blockIdx.x];
+        for (int i = threadIdx.x; i < 4 * RS_MAX_BINS; i += 256) (&wcnt[0][0])[i] = 0u;
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    unsigned k[RS_ITEMS];
+    unsigned long long v[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {   // all loads of the tile in flight together
+        const size_t e = base + r * 256 + threadIdx.x;
+        k[r] = e < n ? keys_in[e] : 0u;
+        v[r] = e < n ? vals_in[e] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t e = base + r * 256 + threadIdx.x;
+        const bool valid = e < n;
+        const unsigned d = (k[r] >> shift) & (unsigned)(bins - 1);
+        const unsigned long long m = rs_match(d, valid, bits);
+        const unsigned before = (unsigned)__popcll(m & ((1ull << lane) - 1ull)), cnt = (unsigned)__popcll(m);
+        const unsigned tag = (unsigned)(r + 1) << 16;
+        if (valid && before == 0u) wcnt[wave][d] = tag | cnt;
+        __syncthreads();
+        unsigned pos = 0u;
+        if (valid) {
+            pos = run[d] + before;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const unsigned c = wcnt[w][d];
+                if (w < wave && (c >> 16) == (unsigned)(r + 1)) pos += c & 0xffffu;
+            }
+        }
+        __syncthreads();
+        if (valid && before == 0u) atomicAdd(&run[d], cnt);      // (<= 4 adds per bin and round)
+        if (valid) {
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+        __syncthreads();
+    }
+}
+
+struct RsPlan {
+    int passes, bits, n_tiles;
+    size_t temp_bytes;
+};
+static RsPlan rs_plan(size_t n, int key_bits) {
+    RsPlan p;
+    p.passes = (key_bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+    p.bits = (key_bits + p.passes - 1) / p.passes;
+    p.n_tiles = (int)((n + RS_TILE - 1) / RS_TILE);
+    p.temp_bytes = ((size_t)(1 << p.bits) * (size_t)std::max(p.n_tiles, 1) + RS_MAX_BINS) * sizeof(unsigned);
+    return p;
+}
+// sorts (keys0, vals0) by the low key_bits of the keys, ping-ponging with (keys1, vals1); *sorted_in = 0 / 1
+static int rs_sort_pairs(unsigned* keys0, unsigned* keys1, unsigned long long* vals0, unsigned long long* vals1, size_t n,
+                         int key_bits, void* temp, size_t temp_bytes, int* sorted_in, hipStream_t s) {
+    const RsPlan p = rs_plan(n, key_bits);
+    *sorted_in = 0;
+    if (n == 0) return 0;
+    if (temp == nullptr || temp_bytes < p.temp_bytes || n >= (1ull << 32)) return (int)hipErrorInvalidValue;
+    unsigned* hist = reinterpret_cast<unsigned*>(temp);
+    unsigned* totals = hist + (size_t)(1 << p.bits) * p.n_tiles;
+    unsigned* k[2] = {keys0, keys1};
+    unsigned long long* v[2] = {vals0, vals1};
+    int cur = 0;
+    for (int pass = 0; pass < p.passes; ++pass) {
+        const int shift = pass * p.bits, bits = std::min(p.bits, key_bits - shift);
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(p.n_tiles), dim3(256), 0, s, k[cur], n, shift, bits, p.n_tiles, hist);
+        hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(1 << bits), dim3(256), 0, s, hist, p.n_tiles, totals);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(p.n_tiles), dim3(256), 0, s, k[cur], v[cur], k[1 - cur], v[1 - cur], n, shift,
+                           bits, p.n_tiles, hist, totals);
+        SM_LAUNCH_CHECK();
+        cur = 1 - cur;
+    }
+    *sorted_in = cur;
+    return 0;
 }
 
 struct GatherLevels {
@@ -265,11 +447,16 @@ __global__ __launch_bounds__(256) void cross_fix_kernel(const CrossRun* __restri
 extern "C" {
 
 size_t sm_tex_scatter_plan_temp_bytes(size_t n_entries, int key_bits) {
-    size_t bytes = 0;
-    rocprim::double_buffer<unsigned> k(nullptr, nullptr);
-    rocprim::double_buffer<unsigned long long> v(nullptr, nullptr);
-    if (rocprim::radix_sort_pairs(nullptr, bytes, k, v, n_entries, 0, key_bits, (hipStream_t)0) != hipSuccess) return 0;
-    return bytes;
+    if (key_bits < 1 || key_bits > 32) return 0;
+    return sm::rs_plan(n_entries, key_bits).temp_bytes;
+}
+
+int sm_radix_sort_pairs(uint32_t* keys0, uint32_t* keys1, uint64_t* vals0, uint64_t* vals1, size_t n, int key_bits,
+                        void* temp, size_t temp_bytes, int* sorted_in, void* stream) {
+    if (key_bits < 1 || key_bits > 32 || sorted_in == nullptr) return (int)hipErrorInvalidValue;
+    return sm::rs_sort_pairs(keys0, keys1, reinterpret_cast<unsigned long long*>(vals0),
+                             reinterpret_cast<unsigned long long*>(vals1), n, key_bits, temp, temp_bytes, sorted_in,
+                             (hipStream_t)stream);
 }
 
 /* cross buffer layout: [count u32, 3 pad][CrossRun list: n_chunks][part: 2 n_chunks float4] */
@@ -322,19 +509,15 @@ int sm_tex_scatter_plan(float* const* grad_layers, const int* layer_w, const int
     hipLaunchKernelGGL(sm::scatter_entries_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, V, L, keys0,
                        reinterpret_cast<unsigned long long*>(vals0), invalid);
     SM_LAUNCH_CHECK();
-    rocprim::double_buffer<unsigned> k(keys0, keys1);
-    rocprim::double_buffer<unsigned long long> v(reinterpret_cast<unsigned long long*>(vals0),
-                                                 reinterpret_cast<unsigned long long*>(vals1));
-    size_t bytes = temp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs(temp, bytes, k, v, threads * 4, 0, key_bits, s);
-    if (e != hipSuccess) return (int)e;
-    *sorted_in = k.current() == keys0 ? 0 : 1;
-    if ((v.current() == reinterpret_cast<unsigned long long*>(vals0) ? 0 : 1) != *sorted_in) return (int)hipErrorUnknown;
-    // runs that cross chunk boundaries (static per view)
     const size_t n = threads * 4;
+    if (int e = sm::rs_sort_pairs(keys0, keys1, reinterpret_cast<unsigned long long*>(vals0),
+                                  reinterpret_cast<unsigned long long*>(vals1), n, key_bits, temp, temp_bytes, sorted_in, s))
+        return e;
+    const unsigned* sorted_keys = *sorted_in ? keys1 : keys0;
+    // runs that cross chunk boundaries (static per view)
     if (hipError_t e2 = hipMemsetAsync(cross, 0, 16, s); e2 != hipSuccess) return (int)e2;
     const size_t boundaries = cross_chunks(n);
-    hipLaunchKernelGGL(sm::cross_list_kernel, dim3((unsigned)((boundaries + 255) / 256)), dim3(256), 0, s, k.current(), n,
+    hipLaunchKernelGGL(sm::cross_list_kernel, dim3((unsigned)((boundaries + 255) / 256)), dim3(256), 0, s, sorted_keys, n,
                        invalid, cross_list_ptr(cross), reinterpret_cast<unsigned*>(cross));
     SM_LAUNCH_CHECK();
     return 0;

@@ -112,23 +112,35 @@ def run_ranks(plans, timeout_s=None, out=None, err=None, poll_s=0.2, grace_s=10.
     return worst_rc([p.returncode for p in procs])
 
 
-def kfd_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes", env=None):
-    """GPUs of this node counted WITHOUT the HIP / HSA runtime (the launcher's parent must not open /dev/kfd before it
-    starts the ranks; ``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount`` on ROCm builds without amdsmi,
-    ADVICE r4): KFD topology nodes with SIMDs (CPU nodes report ``simd_count 0``), narrowed by ``HIP_VISIBLE_DEVICES`` /
-    ``ROCR_VISIBLE_DEVICES``. 0 without a KFD; None when the topology cannot be read (the ranks then refuse by themselves)."""
+def kfd_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes", env=None, dri="/dev/dri"):
+    """GPUs this process can use, counted WITHOUT the HIP / HSA runtime (the launcher's parent must not open /dev/kfd
+    before it starts the ranks; ``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount`` on ROCm builds without
+    amdsmi): KFD topology nodes with SIMDs (CPU nodes report ``simd_count 0``) whose properties are readable and
+    whose render node exists under ``/dev/dri`` (a container is given ONE GPU of an eight-GPU node by cgroup device
+    rules: the other nodes' properties answer 'Operation not permitted', their render nodes are absent), narrowed by
+    ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES``. 0 without a KFD; None when nothing can be said (a malformed
+    topology) - the ranks then refuse by themselves."""
     env = os.environ if env is None else env
     try:
-        n = 0
-        for node in sorted(os.listdir(topology)):
-            with open(os.path.join(topology, node, "properties")) as f:
-                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
-                n += 1
+        nodes = sorted(os.listdir(topology))
     except FileNotFoundError:
         return 0         # no KFD: no AMD GPU on this node
-    except (OSError, ValueError):
+    except OSError:
         return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(topology, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+        except PermissionError:
+            continue     # a device of the node this container was not given
+        except (OSError, ValueError):
+            return None
+        if dri is None or minor < 0 or os.path.exists(os.path.join(dri, f"renderD{minor}")):
+            n += 1
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = env.get(var)
         if v is not None:

@@ -34,6 +34,7 @@ SIGNATURES = {
     "sm_tex_touch_flags": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     "sm_tex_scatter_plan_temp_bytes": [_sz, _i],
     "sm_tex_scatter_plan_cross_bytes": [_sz],
+    "sm_radix_sort_pairs": [_vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp],
     "sm_tex_scatter_plan": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp],
     "sm_tex_scatter_planned": [_vp, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp],
     "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp],

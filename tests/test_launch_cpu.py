@@ -101,16 +101,26 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
 
 def test_gpus_are_counted_from_the_kfd_topology_without_the_runtime(tmp_path):
     """The launcher's parent counts devices from sysfs (``torch.cuda.device_count()`` may open /dev/kfd): KFD
-    nodes with SIMDs, narrowed by the visibility variables; no KFD = 0 GPUs; an unreadable topology = no check."""
-    topo = tmp_path / "nodes"
-    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):      # two CPU nodes, three GPUs
+    nodes with SIMDs whose render node this process was given, narrowed by the visibility variables; no KFD = 0 GPUs; a
+    malformed topology = no check."""
+    topo, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate(((0, 0), (0, 0), (1024, 128), (1024, 136), (1024, 144))):      # two CPU nodes, three GPUs
         d = topo / str(i)
         d.mkdir(parents=True)
-        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
-    assert launch.kfd_gpu_count(str(topo), env={}) == 3
-    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "0,2"}) == 2
-    assert launch.kfd_gpu_count(str(topo), env={"ROCR_VISIBLE_DEVICES": ""}) == 0
-    assert launch.kfd_gpu_count(str(tmp_path / "absent"), env={}) == 0
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+        if simd:
+            (dri / f"renderD{minor}").write_text("")
+    assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) == 3
+    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "0,2"}, dri=str(dri)) == 2
+    assert launch.kfd_gpu_count(str(topo), env={"ROCR_VISIBLE_DEVICES": ""}, dri=str(dri)) == 0
+    assert launch.kfd_gpu_count(str(tmp_path / "absent"), env={}, dri=str(dri)) == 0
+    (dri / "renderD136").unlink()                     # a container that was given two of the three render nodes
+    assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) == 2
+    if os.geteuid() != 0:                             # (root reads everything: the permission case cannot be staged)
+        os.chmod(topo / "4" / "properties", 0)
+        assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) == 1
+        os.chmod(topo / "4" / "properties", 0o644)
     (topo / "5").mkdir()
     (topo / "5" / "properties").write_text("simd_count not-a-number\n")
-    assert launch.kfd_gpu_count(str(topo), env={}) is None
+    assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) is None

@@ -445,3 +445,34 @@ def test_two_rank_pipelined_exchange_equals_exchange_then_update_bit_for_bit():
         assert torch.allclose(plain0[4], pipe0[4], rtol=1e-5) and torch.allclose(plain0[4], plain1[4], rtol=1e-5)
     for r in (r0, r1):
         assert r["auto_small"] is False and r["auto_large"] is True
+
+
+@pytest.mark.parametrize("n,key_bits", [(1, 27), (255, 9), (4097, 18), (350_003, 22), (3_000_017, 27), (1_000_003, 32)])
+def test_own_radix_sort_is_the_stable_sort(n, key_bits):
+    """sm_radix_sort_pairs (round 5: the scatter plan's own sort instead of rocPRIM's) against torch's stable sort: same
+    keys, and equal keys keep their input order - with spatially coherent keys (long runs), random keys, heavy
+    duplicates and the all-ones 'invalid' key that must end up in the tail."""
+    require_gpu()
+    import ctypes as C
+    from stylemesh_amd.runtime import hip
+    g = torch.Generator(device="cuda").manual_seed(n)
+    top = (1 << key_bits) - 1
+    coherent = (torch.arange(n, device="cuda") // 7 * 3) % (top + 1)                       # runs of equal keys, slowly rising
+    rand = torch.randint(0, top + 1, (n,), device="cuda", generator=g, dtype=torch.int64)
+    dup = torch.randint(0, 17, (n,), device="cuda", generator=g, dtype=torch.int64) * (top // 17)
+    pick = torch.randint(0, 4, (n,), device="cuda", generator=g)
+    keys64 = torch.where(pick == 0, coherent, torch.where(pick == 1, rand, torch.where(pick == 2, dup, torch.full_like(rand, top))))
+    k0 = keys64.to(torch.int32) if key_bits < 32 else (keys64 - (keys64 >= (1 << 31)).long() * (1 << 32)).to(torch.int32)
+    v0 = torch.arange(n, device="cuda", dtype=torch.int64) * 3 + 1
+    k1, v1 = torch.empty_like(k0), torch.empty_like(v0)
+    tb = hip.lib.sm_tex_scatter_plan_temp_bytes(n, key_bits)
+    temp = torch.empty(max(tb, 16), dtype=torch.uint8, device="cuda")
+    which = C.c_int(-1)
+    kin, vin = k0.clone(), v0.clone()
+    hip.check(hip.lib.sm_radix_sort_pairs(k0.data_ptr(), k1.data_ptr(), v0.data_ptr(), v1.data_ptr(), n, key_bits,
+                                          temp.data_ptr(), temp.numel(), C.byref(which), hip.stream()), "sm_radix_sort_pairs")
+    torch.cuda.synchronize()
+    ks, vs = (k0, v0) if which.value == 0 else (k1, v1)
+    order = torch.sort(keys64, stable=True).indices
+    assert torch.equal(ks.long() & 0xFFFFFFFF, keys64[order])
+    assert torch.equal(vs, vin[order])
