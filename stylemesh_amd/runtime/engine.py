@@ -123,6 +123,8 @@ class StepEngine:
     N_SLOTS = 2         # buffer sets of per-view constants: the current view + the views prepared ahead. (3 = TWO views in
                         # preparation, measured on the dip schedule in round 4: 663 views/s either way - that schedule is
                         # bound by the ~210 kernel dispatches of a step + a preparation, not by a wait for the read-back)
+    _pair_pending = ()  # pair-image bookkeeping (set per instance in __init__): nothing outstanding on an engine whose
+    _pair_failed = 0    # kernels are stubbed (tests/test_distributed_cpu.py builds one without __init__)
 
     def __init__(self, cfg: EngineConfig, vgg_state: dict, device="cuda", random_init=False):
         cfg.validate()
