@@ -43,6 +43,10 @@ extern "C" {
                             * Gram backward of the output layer (sm_conv_problem::gram_*), computed in the epilogue   (dgrad)    */
 #define SM_EPI_POOL 8      /* with SM_EPI_BIAS_RELU, sm_conv3x3_grouped_split2 only: store the 2x2 max-pooled map and the
                             * pool's argmax codes (sm_conv_problem::pool_out / pool_code) INSTEAD of out     (forward)  */
+#define SM_LIST_QUADS 32   /* (ABI 10; not an epilogue) sm_conv3x3_grouped_split2 with Cout = 64, Cin % 64 == 0 and a tile list
+                            * whose every four entries are a QUAD - the same 32 columns of four consecutive rows: q, q + Wp,
+                            * q + 2 Wp, q + 3 Wp (sm_cover_problem::quad) - takes the resident-input kernel: the block stages
+                            * its (4 + 2) x 34 input positions of 64 channels once. Same results, bit for bit. */
 
 /* ---- layout helpers (host, pure functions) -------------------------------------------------------- */
 int sm_fmap_row_stride(int W);        /* Wp */

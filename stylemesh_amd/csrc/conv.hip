@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) void pair_check_kernel(const float* __restrict_
 #define SM_CONV_KG2_BUILD 0   // 1: compile the two-wave-group variants (selected with SM_CONV_KG=2)
 #endif
 template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false, int KG = 1,
-          bool PIN = false>
+          bool PIN = false, bool RES = false>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -437,8 +437,10 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     if (SPLIT && a.tile_list && n_list % (BN / 32) != 0) return (int)hipErrorInvalidValue;
     a.n_tiles = a.tile_list ? (SPLIT ? n_list / (BN / 32) : n_list) : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
-    constexpr size_t lds = SPLIT ? KG * conv_split_lds_bytes(BM, BN, NP)
+    constexpr size_t lds = RES ? conv_resident_lds_bytes()
+                         : SPLIT ? KG * conv_split_lds_bytes(BM, BN, NP)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
+    if (RES && (a.tile_list == nullptr || a.Cin_pad % 64 != 0)) return (int)hipErrorInvalidValue;   // quads of a list; 64-channel phases
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
     if constexpr (SM_CONV_KG2_BUILD && SPLIT && NP == 2 && KG == 1 && !PIN && (FLAGS & SM_EPI_GRAM) == 0) {
         // small grids (<= one tile per CU): 512-thread blocks of two wave groups; SM_CONV_KG=1 keeps the 4-wave blocks (A/B)
@@ -509,13 +511,14 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
             a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
         }
     }
+    if (RES) a.splits = 1;                       // resident input: whole tiles only (K <= 1152: nothing to split)
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
     if constexpr (SPLIT) {
         static_assert(KC == 16, "one bf16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && !UNPOOL && !PIN) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !PIN, NP, UNPOOL, KG, PIN>
-                                            : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG, PIN>;
+        auto k = (stamp && !UNPOOL && !PIN && !RES) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !PIN && !RES, NP, UNPOOL, KG, PIN, RES>
+                                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG, PIN, RES>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -935,6 +938,31 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
 }
 
 }  // extern "C"
+// SM_LIST_QUADS: the list holds vertical quads of segments and the launch has 64 output channels - the resident-input
+// kernel (conv_split_kernel.h, RES). fp32 planes only.
+template <int FLAGS, bool UNPOOL>
+static int launch_conv_resident(sm::ConvArgs& a, int n_list, hipStream_t s) {
+    a.ws = nullptr;
+    return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, false, true>(a, n_list, 0, s);
+}
+static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool unpool, hipStream_t s) {
+    if (a.Cout != 64 || a.Cin_pad % 64 != 0 || a.tile_list == nullptr || a.pair_in || a.pair_out || a.pair_gate)
+        return (int)hipErrorInvalidValue;
+    if (unpool) {
+        switch (flags) {
+            case SM_EPI_RELU_MASK | SM_EPI_GRAM: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_GRAM, true>(a, n_list, s);
+            case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, true>(a, n_list, s);
+            case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, s);
+            default: return (int)hipErrorInvalidValue;
+        }
+    }
+    switch (flags) {
+        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return launch_conv_resident<SM_EPI_BIAS_RELU | SM_EPI_POOL, false>(a, n_list, s);
+        case SM_EPI_BIAS_RELU: return launch_conv_resident<SM_EPI_BIAS_RELU, false>(a, n_list, s);
+        case 0: return launch_conv_resident<0, false>(a, n_list, s);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
 template <bool PIN>
 static int conv_dispatch_flags_split2_t(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
@@ -966,6 +994,7 @@ static int conv_dispatch_flags_split2_t(sm::ConvArgs& a, int n_list, int flags, 
 }
 extern "C" {
 static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
+    if (flags & SM_LIST_QUADS) return conv_dispatch_resident(a, n_list, flags & ~SM_LIST_QUADS, unpool, s);
     return a.pair_in != nullptr ? conv_dispatch_flags_split2_t<true>(a, n_list, flags, ws_floats, unpool, s)
                                 : conv_dispatch_flags_split2_t<false>(a, n_list, flags, ws_floats, unpool, s);
 }

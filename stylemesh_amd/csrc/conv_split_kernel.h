@@ -186,12 +186,25 @@ constexpr int conv_split_waves(int BM, int BN, int NP) {
 // stage tail with MFMAs (a stage takes ~800 cycles against ~475 per block when two blocks share a CU) - and getting the
 // second wave per SIMD from MORE global K-splits doubles the partial slabs instead.
 // PIN (round 5): the input planes hold packed fp16 pairs (above): staging un-packs instead of converting.
+// RES (round 5): RESIDENT INPUT, for the 64-output-channel launches (conv1_2 forward / data gradient, conv2_1's data
+// gradient: K = 576 / 1152). The 64 x 256 tile stages every chunk's three ky slices for each of its eight free segments -
+// 3 x 34 / 32 = 3.2 staged positions per output position and 16 channels - and spends twice the staging per MFMA of the
+// 128-row tile. Here a tile is a QUAD: four vertically adjacent 32-position segments (list entries q, q + Wp, q + 2 Wp,
+// q + 3 Wp; sm_cover_segments quad modes), and the block stages the (4 + 2) rows x 34 positions it needs of 64 input
+// channels ONCE, already scaled and split: 6 x 34 x 64 channels x 2 parts x 2 B = 51 KB (three blocks per CU), 1.59 staged
+// positions per output position. The 36 stages of a 64-channel phase then are MFMAs, weight-fragment loads and LDS
+// fragment reads only - a tap shift (ky, kx) is the offset ky * 34 + kx - with no barrier and no conversion inside the
+// loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
+constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
+constexpr size_t conv_resident_lds_bytes() { return (size_t)(4 * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false, int KG = 1,
-          bool PIN = false>
+          bool PIN = false, bool RES = false>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
 void conv3x3_split_kernel(ConvArgs a) {
     static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
+    static_assert(!RES || (NP == 2 && BM == 64 && BN == 128 && WGM == 2 && WGN == 2 && KG == 1 && !PIN && !STAMP),
+                  "resident input: the fp16x2 kernel on 64 x 128 tiles (a quad of segments), waves 2 x 2");
     static_assert(!PIN || NP == 2, "pair images are the fp16x2 kernel's operand format");
     static_assert(KG == 1 || (KG == 2 && NP == 2 && conv_split_waves(BM, BN, NP) == 2 && !(FLAGS & SM_EPI_GRAM)),
                   "two wave groups: the fp16x2 kernel at two waves per SIMD, without the Gram epilogue");
@@ -547,6 +560,123 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
 
     SM_TS(0)
+    if constexpr (RES) {
+        constexpr int RP = SM_RES_RP;
+        constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
+        constexpr int RU = (RGRP * RP + 255) / 256;      // staging units (8 channels of one position) per thread and phase
+        f32x4* Rs = smem4;
+        // unit u = tid + 256 k: group u / RP, position u % RP = (row r, p) of the staged window; LDS position (r, p) holds
+        // input position qs[0] - 1 + p + (r - 1) Wp (row 0 / column 0 of the window = the halo above / left of segment 0)
+        int r_src[RU], r_dst[RU], r_code[UNPOOL ? RU : 1], r_par[UNPOOL ? RU : 1];
+        bool r_on[RU];
+#pragma unroll
+        for (int k = 0; k < RU; ++k) {
+            const int u = tid + 256 * k;
+            r_on[k] = u < RGRP * RP;
+            const int uu = r_on[k] ? u : tid;            // (idle units load a valid address and store nothing)
+            const int grp = uu / RP, pos = uu - grp * RP;
+            const int r = pos / SEGP, p = pos - r * SEGP;
+            r_dst[k] = ((grp >> 1) * 4 + (grp & 1)) * RP + pos;                  // + part * 2 * RP
+            if constexpr (UNPOOL) {
+                const int qc = qs[0] + p - 1 + (r - 1) * P.Wp;                   // position in the un-pooled padded plane
+                const int y = qc / P.Wp - 1, x = qc - (y + 1) * P.Wp - 1;
+                int off_;
+                SM_UP_MAP(y, x, off_, r_par[k])
+                r_src[k] = (off_ + grp * 8 * up_plane) * 4;
+                r_code[k] = (off_ + grp * up_plane) * 4;
+            } else {
+                r_src[k] = (grp * 8 * P.plane + qs[0] + p + r * P.Wp) * 4;       // bytes from the shifted base (row ky = 0)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < AD; ++t) SM_LOAD_A(t, 0);
+        // n-tile i of the wave = segment wn / 32 + i = window row wn / 32 + i + ky of tap row ky
+        const f32x4* b_frag = Rs + lhi * RP + (wn / 32) * SEGP + l31;
+        const int n_phases = a.Cin_pad / 64;
+        for (int ph = 0; ph < n_phases; ++ph) {
+            if (ph > 0) __syncthreads();                 // the previous phase's last fragment reads
+            {
+                float rb[RU][8];
+                unsigned rc[UNPOOL ? RU : 1];
+                if constexpr (UNPOOL) {
+                    const int sc_ = ph * 64 * up_plane * 4;
+#pragma unroll
+                    for (int k = 0; k < RU; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            rb[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, r_src[k], sc_ + c * up_plane * 4, 0));
+                        rc[k] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, r_code[k], ph * 8 * up_plane * 4, 0);
+                    }
+                } else {
+                    const int so_ = ph * 64 * P.plane * 4;
+#pragma unroll
+                    for (int k = 0; k < RU; ++k)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            rb[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, r_src[k], so_ + c * P.plane * 4, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < RU; ++k) {
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float v = rb[k][c];
+                        if constexpr (UNPOOL) v = ((int)((rc[k] >> (4 * c)) & 15u) == r_par[k]) ? v : 0.f;
+                        const float xs_ = __builtin_amdgcn_fmed3f(v * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);
+                        const _Float16 h_ = (_Float16)xs_;
+                        vh[c] = h_;
+                        vl[c] = (_Float16)(xs_ - (float)h_);
+                    }
+                    if (r_on[k]) {
+                        Rs[r_dst[k]] = __builtin_bit_cast(f32x4, vh);
+                        Rs[r_dst[k] + 2 * RP] = __builtin_bit_cast(f32x4, vl);
+                    }
+                }
+            }
+            __syncthreads();
+            f32x4 fb[NJ][NP], fb_next[NJ][NP];
+#pragma unroll
+            for (int s = 0; s < NP; ++s)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) fb[i][s] = b_frag[s * 2 * RP + i * SEGP];
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ch = ph * 4 + cc;
+                const int ch_next = ch + 1 < n_chunks ? ch + 1 : ch;   // (loads stay unconditional: see the ring loop)
+                const f32x4* bc = b_frag + cc * 4 * RP;
+                const f32x4* bn = b_frag + (cc < 3 ? cc + 1 : cc) * 4 * RP;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    // the next stage's fragments are read under this stage's MFMAs
+                    const f32x4* bf_ = tap < 8 ? bc + ((tap + 1) / 3) * SEGP + (tap + 1) % 3 : bn;
+#pragma unroll
+                    for (int s = 0; s < NP; ++s)
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) fb_next[i][s] = bf_[s * 2 * RP + i * SEGP];
+                    f32x4 fa[NP];
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) fa[s] = ra[tap % AD][0][s];
+#define SM_RES_PRODUCT(pa_, pb_)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                       \
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[pa_]),           \
+                                                           __builtin_bit_cast(f16x8, fb[j][pb_]), acc[0][j], 0, 0, 0);
+                    SM_RES_PRODUCT(1, 0)
+                    SM_RES_PRODUCT(0, 1)
+                    SM_RES_PRODUCT(0, 0)
+#undef SM_RES_PRODUCT
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap + AD < 9) {
+                        SM_LOAD_A(tap + AD, ch);
+                    } else {
+                        SM_LOAD_A(tap + AD - 9, ch_next);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NP; ++s)
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) fb[i][s] = fb_next[i][s];
+                }
+            }
+        }
+    } else {
     // prologue: the first AD weight stages into the register ring, chunk ch_begin's three slices into slots 0..2
 #pragma unroll
     for (int t = 0; t < AD; ++t) SM_LOAD_A(t, ch_begin);
@@ -726,6 +856,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         }
         base = RING6 ? 3 - base : (base + 3) & 3;
     }
+    }   // (ring kernel)
     SM_TS(30)
 #undef SM_CUR_SLOT
 #undef SM_NEXT_SLOT
@@ -894,7 +1025,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     if constexpr (GRAM) {
         constexpr int PH = BM / 64;             // phases of 64 channels (the ring holds 2 parts x 8 k-groups x BN units)
         constexpr int GU = 8 * BN / 256;        // staging units (k-group, position) per thread and phase
-        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= conv_split_slots(NP, BM) * SLICE * 16,
+        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= (RES ? conv_resident_lds_bytes() : (size_t)conv_split_slots(NP, BM) * SLICE * 16),
                       "a phase of the Gram operand + the gate bits of all channels fit the slice ring");
         f32x4* Gs = smem4;
         // F is also the ReLU gate of this launch's output: the staging threads - which hold the raw values - leave one bit

@@ -19,6 +19,7 @@ ABI_VERSION = 9          # sm_abi_version() of the library this binding was writ
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
 EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL, EPI_GRAM = 1, 2, 4, 8, 16
+LIST_QUADS = 32          # SM_LIST_QUADS: the tile list holds vertical quads of segments (resident-input kernel)
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 

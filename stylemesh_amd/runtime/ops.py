@@ -418,7 +418,8 @@ def conv_list_format(cin_pad: int, cout: int):
 
 
 def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
-                    wt2=None, amax_in=None, amax_out=None, pair_in=None, pair_out=None, pair_gate=None, addends=None):
+                    wt2=None, amax_in=None, amax_out=None, pair_in=None, pair_out=None, pair_gate=None, addends=None,
+                    quads=False):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code[, pooled, pool_code]]), ...]
     (FMaps; with a ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel
     takes the pool's backward on the fly, see ``maxpool_fwd_grouped``; with ``flags & EPI_POOL`` - 'split2' mode, a
@@ -433,7 +434,9 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     receives max |output| of the launch.
     Pair images ('split2' mode; include/stylemesh_hip.h): ``pair_in`` / ``pair_out`` / ``pair_gate`` = device {scale,
     1 / scale} of the input / output / gate tensor when its planes hold packed fp16 pairs (None: fp32 planes);
-    ``addends``: per problem the fp32 FMap ``EPI_ADD`` reads instead of ``out`` (required with ``pair_out``)."""
+    ``addends``: per problem the fp32 FMap ``EPI_ADD`` reads instead of ``out`` (required with ``pair_out``).
+    ``quads``: ``tile_list`` holds vertical QUADS of segments (``cover_segments`` quad modes; 'split2' mode, 64 output
+    channels, fp32 planes): the launch takes the resident-input kernel (``SM_LIST_QUADS``)."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
     if tile_list is not None and tile_list.numel() == 0:
         return
@@ -473,6 +476,7 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     use_split2 = wt2 is not None and (amax_in is not None or pair_in is not None) and CONV_MODE == "split2"
     use_split = wt3 is not None and CONV_MODE == "split"
     assert not pair or use_split2, "pair images are the fp16x2 kernel's format"
+    assert not quads or (use_split2 and not pair and tile_list is not None and cout == 64), "quad lists: fp16x2 kernel, 64 output channels"
 
     def run():
         ws = splitk_workspace(wt.device)
@@ -485,7 +489,8 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
             return
         if use_split2:
             hip.check(lib.sm_conv3x3_grouped_split2(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
-                                                    flags, ptr(tile_list), n_list, ptr(ws), ws.numel(), ptr(amax_in),
+                                                    flags | (hip.LIST_QUADS if quads else 0), ptr(tile_list), n_list,
+                                                    ptr(ws), ws.numel(), ptr(amax_in),
                                                     ptr(amax_out), hip.stream()), "sm_conv3x3_grouped_split2")
             return
         fn, w = (lib.sm_conv3x3_grouped_split, wt3) if use_split else (lib.sm_conv3x3_grouped, wt)
