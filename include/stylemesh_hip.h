@@ -548,6 +548,12 @@ typedef struct {
      * covered with runs of 16 windows starting at any window X0, and each run becomes TWO entries: the segment of
      * image row 2Y that starts at column 2 X0, then the one right below it (row 2Y + 1). */
     int pair_w;
+    /* ABI 10. 1: QUAD mode, the lists of the resident-input conv kernel (SM_LIST_QUADS) - the rows of the need map are
+     * walked in GROUPS whose bits are OR-ed: two pooled rows with pair_w > 0 (runs of 16 windows from any window X0,
+     * columns 2 X0 ...), four rows with pair_w == 0 (runs of 32 positions from any needed position X0) - and every run
+     * becomes FOUR entries: the same 32 columns of image rows 4 Y .. 4 Y + 3 (q, q + Wp, q + 2 Wp, q + 3 Wp; a row
+     * behind the last image row: (tag << 24) | 0xFFFFFF). Runs of one group are disjoint. 0: as above. */
+    int quad;
 } sm_cover_problem;
 size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n);
 int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t ws_bytes, void* stream);
@@ -608,7 +614,8 @@ typedef struct {
     int layer;                 /* index of the need map the list is built from (pair mode: the POOLED layer) */
     int mode;                  /* 0: free 32-position segments, 1: segment pairs (sm_cover_segments pair mode; the conv's
                                 * full-resolution output is layer `pair_layer`), 2: aligned tiles of `bn` positions,
-                                * entry = (level << 24) | tile (bn divides 2048) */
+                                * entry = (level << 24) | tile (bn divides 2048); ABI 10: 3 = quads over the POOLED
+                                * layer's need map (as mode 1, sm_cover_problem::quad), 4 = quads over the layer's own */
     int bn;
     int pair_layer;
     int group;                 /* every level's run is padded to a multiple of `group` entries with (level << 24) | 0xFFFFFF */

@@ -924,7 +924,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 9; }
+int sm_abi_version(void) { return 10; }
 
 static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
     switch (flags) {
@@ -942,7 +942,9 @@ static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, siz
 // kernel (conv_split_kernel.h, RES). fp32 planes only.
 template <int FLAGS, bool UNPOOL>
 static int launch_conv_resident(sm::ConvArgs& a, int n_list, hipStream_t s) {
+#ifndef SM_RES_TRACE
     a.ws = nullptr;
+#endif
     return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, false, true>(a, n_list, 0, s);
 }
 static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool unpool, hipStream_t s) {
@@ -960,6 +962,8 @@ static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool u
         case SM_EPI_BIAS_RELU | SM_EPI_POOL: return launch_conv_resident<SM_EPI_BIAS_RELU | SM_EPI_POOL, false>(a, n_list, s);
         case SM_EPI_BIAS_RELU: return launch_conv_resident<SM_EPI_BIAS_RELU, false>(a, n_list, s);
         case 0: return launch_conv_resident<0, false>(a, n_list, s);
+        case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, false>(a, n_list, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, false>(a, n_list, s);
         default: return (int)hipErrorInvalidValue;
     }
 }

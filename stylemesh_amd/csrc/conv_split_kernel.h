@@ -404,7 +404,13 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
     // weight prefetch distance in stages = ring size; slot of a stage = tap % AD. A stage of the fp16x2 variant has half
     // the MFMA time to hide the same fetch latency behind: its ring is deeper
-    constexpr int AD = NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
+#ifndef SM_RES_AD
+#define SM_RES_AD SM_SPLIT2_AD
+#endif
+#ifndef SM_RES_ABL
+#define SM_RES_ABL 0           // ablation builds (timing only): 1 = no MFMA loop, 2 = no staging, 3 = no weight loads in the loop
+#endif
+    constexpr int AD = RES ? SM_RES_AD : NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
     f32x4 ra[AD][MI][NP];
     // in-flight activation loads: SM_SPLIT_BSETS = 1: one register set, a slice is loaded two stages before it is
@@ -560,6 +566,18 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
 
     SM_TS(0)
+#ifdef SM_RES_TRACE   // (debug build: per block {start, staged, loop done, end, HW_ID, XCC_ID} into the tail of ws; tools/res_trace.py)
+#define SM_RT(slot_)                                                                                     \
+    if (RES && tid == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + (slot_)] = \
+        (long long)__builtin_amdgcn_s_memrealtime();
+    if (RES && tid == 0) {
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(63492);
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(63508);
+    }
+#else
+#define SM_RT(slot_)
+#endif
+    SM_RT(0)
     if constexpr (RES) {
         constexpr int RP = SM_RES_RP;
         constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
@@ -588,6 +606,10 @@ void conv3x3_split_kernel(ConvArgs a) {
                 r_src[k] = (grp * 8 * P.plane + qs[0] + p + r * P.Wp) * 4;       // bytes from the shifted base (row ky = 0)
             }
         }
+#ifdef SM_RES_STAGGER   // (experiment: the blocks of a CU's first round start SM_RES_STAGGER x 8 k cycles apart)
+        if (blockIdx.x < 768)
+            for (int i = 0; i < (int)((blockIdx.x >> 8) % 3) * SM_RES_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 #pragma unroll
         for (int t = 0; t < AD; ++t) SM_LOAD_A(t, 0);
         // n-tile i of the wave = segment wn / 32 + i = window row wn / 32 + i + ky of tap row ky
@@ -595,7 +617,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         const int n_phases = a.Cin_pad / 64;
         for (int ph = 0; ph < n_phases; ++ph) {
             if (ph > 0) __syncthreads();                 // the previous phase's last fragment reads
-            {
+            if (SM_RES_ABL != 2) {
                 float rb[RU][8];
                 unsigned rc[UNPOOL ? RU : 1];
                 if constexpr (UNPOOL) {
@@ -615,6 +637,11 @@ void conv3x3_split_kernel(ConvArgs a) {
                         for (int c = 0; c < 8; ++c)
                             rb[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, r_src[k], so_ + c * P.plane * 4, 0));
                 }
+                SM_RT(6)
+#ifdef SM_RES_TRACE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SM_RT(7)
+#endif
 #pragma unroll
                 for (int k = 0; k < RU; ++k) {
                     f16x8 vh, vl;
@@ -634,12 +661,13 @@ void conv3x3_split_kernel(ConvArgs a) {
                 }
             }
             __syncthreads();
+            SM_RT(1)
             f32x4 fb[NJ][NP], fb_next[NJ][NP];
 #pragma unroll
             for (int s = 0; s < NP; ++s)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) fb[i][s] = b_frag[s * 2 * RP + i * SEGP];
-            for (int cc = 0; cc < 4; ++cc) {
+            for (int cc = 0; cc < (SM_RES_ABL == 1 ? 0 : 4); ++cc) {
                 const int ch = ph * 4 + cc;
                 const int ch_next = ch + 1 < n_chunks ? ch + 1 : ch;   // (loads stay unconditional: see the ring loop)
                 const f32x4* bc = b_frag + cc * 4 * RP;
@@ -664,10 +692,12 @@ void conv3x3_split_kernel(ConvArgs a) {
                     SM_RES_PRODUCT(0, 0)
 #undef SM_RES_PRODUCT
                     __builtin_amdgcn_sched_barrier(0);
+                    if (SM_RES_ABL != 3) {
                     if (tap + AD < 9) {
                         SM_LOAD_A(tap + AD, ch);
                     } else {
                         SM_LOAD_A(tap + AD - 9, ch_next);
+                    }
                     }
 #pragma unroll
                     for (int s = 0; s < NP; ++s)
@@ -858,6 +888,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
     }   // (ring kernel)
     SM_TS(30)
+    SM_RT(2)
 #undef SM_CUR_SLOT
 #undef SM_NEXT_SLOT
 #undef SM_UP_MAP
@@ -994,6 +1025,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             }
         }
         record_amax(a.amax_out, vmax, amax_seen);
+        SM_RT(3)
         return;
     }
     // SM_EPI_GRAM: the output layer is a style layer of C = BM channels (the block's row tile holds all of them) and this
@@ -1124,6 +1156,10 @@ void conv3x3_split_kernel(ConvArgs a) {
             if (wn / 32 + nj0 + nj == k) { q_seg = qs[k]; alive = live[k]; }
         const int q = q_seg + l31;
         if (!alive || q >= q_end) continue;
+        // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
+        // continue on the first columns of the next one, which another run of the quad's next segment covers - a position
+        // stored twice, added twice under SM_EPI_ADD: a lane stays in its segment's row)
+        if (RES && q / P.Wp != q_seg / P.Wp) continue;
         const bool inside = interior(q, P.H, P.W, P.Wp);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -1164,7 +1200,9 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
     record_amax(a.amax_out, vmax, amax_seen);
     SM_TS(31)
+    SM_RT(3)
 #undef SM_TS
+#undef SM_RT
 }
 
 }  // namespace sm

@@ -265,6 +265,7 @@ struct CoverProblem {
     int32_t* count;        // out: number of segments
     int h, w, tag, cap;
     int pair_w;
+    int quad;              // 1: QUAD mode (rows of the map are walked in groups: two pooled rows / four rows, header)
     int word_base;         // first word of this map's bits in the workspace
     int chunk_base;        // first chunk of this map in the workspace's table / state arrays
 };                         // (56 bytes: 64 of them + three pointers stay below the 4 KB of kernel arguments)
@@ -278,11 +279,20 @@ struct CoverGroup {
 __host__ __device__ inline int cover_row_words(int w) { return (w + 31) / 32 + 1; }   // pair mode: + a zero word behind a row
 // words of a map's bit image (flat: the positions of rows 1 .. h of the padded plane + two zero tail words; pair: h rows
 // of cover_row_words + one word the walk may read behind the last row) and its chunks (pair: one per pooled row)
-__host__ __device__ inline int cover_words(int h, int w, int pair_w) {
-    return pair_w > 0 ? h * cover_row_words(w) + 1 : (h * row_stride(w) + 31) / 32 + 2;
+// QUAD mode (round 5, the resident-input conv kernel): a chunk = a GROUP of rows of the need map - two pooled rows over a
+// pooled need map (pair_w > 0), four rows otherwise - whose bits are OR-ed into one row image; the walk is row-local like
+// the pair mode's, and every run becomes FOUR entries: the same 32 columns of image rows 4 Y .. 4 Y + 3.
+__host__ __device__ inline int cover_group_rows(int pair_w, int quad) { return quad ? (pair_w > 0 ? 2 : 4) : 1; }
+__host__ __device__ inline int cover_rows(int h, int pair_w, int quad) {
+    const int G = cover_group_rows(pair_w, quad);
+    return (h + G - 1) / G;
 }
-__host__ __device__ inline int cover_chunks(int h, int w, int pair_w) {
-    return pair_w > 0 ? h : (h * row_stride(w) + SM_COVER_CHUNK_WORDS * 32 - 1) / (SM_COVER_CHUNK_WORDS * 32);
+__host__ __device__ inline int cover_words(int h, int w, int pair_w, int quad = 0) {
+    return (pair_w > 0 || quad) ? cover_rows(h, pair_w, quad) * cover_row_words(w) + 1 : (h * row_stride(w) + 31) / 32 + 2;
+}
+__host__ __device__ inline int cover_chunks(int h, int w, int pair_w, int quad = 0) {
+    return (pair_w > 0 || quad) ? cover_rows(h, pair_w, quad)
+                                : (h * row_stride(w) + SM_COVER_CHUNK_WORDS * 32 - 1) / (SM_COVER_CHUNK_WORDS * 32);
 }
 
 // (1) bits. One wave = 64 consecutive positions per ballot = two words; a block of 4 waves makes 64 words.
@@ -290,17 +300,19 @@ __global__ __launch_bounds__(256) void cover_pack_kernel(CoverGroup g) {
     const CoverProblem& P = g.p[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int first_word = blockIdx.x * 64 + wave * 16;
-    const int n_words = cover_words(P.h, P.w, P.pair_w);
+    const int n_words = cover_words(P.h, P.w, P.pair_w, P.quad);
     if (first_word >= n_words) return;
     const int Wp = row_stride(P.w), n_pos = P.h * Wp, rw = cover_row_words(P.w);
+    const int G = cover_group_rows(P.pair_w, P.quad);
     for (int k = 0; k < 8; ++k) {
         const int wd = first_word + 2 * k;
         if (wd >= n_words) break;
         bool bit = false;
-        if (P.pair_w > 0) {             // word wd = row wd / rw, columns (wd % rw) * 32 ...; a row is a whole number of words
+        if (P.pair_w > 0 || P.quad) {   // word wd = row (group) wd / rw, columns (wd % rw) * 32 ...; a row is a whole number of words
             const int wl = wd + (lane >> 5);
             const int Y = wl / rw, X = (wl - Y * rw) * 32 + (lane & 31);
-            bit = Y < P.h && X < P.w && P.need[(size_t)Y * P.w + X] > 0.f;
+            for (int r = 0; r < G; ++r)
+                bit = bit || (Y * G + r < P.h && X < P.w && P.need[(size_t)(Y * G + r) * P.w + X] > 0.f);
         } else {
             const int i = wd * 32 + lane;
             if (i < n_pos) {
@@ -320,7 +332,8 @@ __global__ __launch_bounds__(256) void cover_pack_kernel(CoverGroup g) {
 // segment whose first needed position lies in the chunk, returns the exit state. `words` holds the chunk's bits and at
 // least one readable word behind them. FLAT mode: segment start = first needed position rounded down to 4, next cursor =
 // start + 32. PAIR mode (n_bits = the row's width, align1): start = the first needed window itself, next cursor = + 16.
-template <bool PAIR, typename Emit>
+// (ROWQ: the flat QUAD mode - row-local like PAIR, start = the first needed position itself, next cursor = + 32)
+template <bool PAIR, bool ROWQ = false, typename Emit>
 __device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, int n_bits, int e, Emit emit) {
     int cursor = e, end = e;     // end: one past the last position covered so far (skipping zeros covers nothing)
     while (cursor < n_bits) {
@@ -330,7 +343,7 @@ __device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, in
         if (valid < 64) win &= (1ull << valid) - 1ull;
         if (win == 0) { cursor += 64 - sh; continue; }
         const int p = cursor + __builtin_ctzll(win);
-        const int st = PAIR ? p : (p & ~3);
+        const int st = (PAIR || ROWQ) ? p : (p & ~3);
         emit(st);
         cursor = end = st + (PAIR ? 16 : 32);
     }
@@ -341,9 +354,14 @@ __device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, in
 __global__ __launch_bounds__(256) void cover_table_kernel(CoverGroup g) {
     const CoverProblem& P = g.p[blockIdx.y];
     const int chunk = blockIdx.x * 32 + (threadIdx.x >> 3), e8 = threadIdx.x & 7;
-    if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
+    if (chunk >= cover_chunks(P.h, P.w, P.pair_w, P.quad)) return;
     int n = 0, ex = 0;
-    if (P.pair_w < 0) {                   // TILE mode: live tiles of -pair_w positions in this chunk (entry state unused)
+    if (P.quad && P.pair_w == 0) {        // flat QUAD mode: a row group, runs of 32 positions
+        if (e8 == 0) {
+            const int rw = cover_row_words(P.w);
+            cover_walk<false, true>(g.bits + P.word_base + chunk * rw, P.w, 0, [&](int) { ++n; });
+        }
+    } else if (P.pair_w < 0) {            // TILE mode: live tiles of -pair_w positions in this chunk (entry state unused)
         if (e8 == 0) {
             const int tw = -P.pair_w / 32;                                    // words per tile (bn >= 64) ...
             const uint32_t* wds = g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS;
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(64) void cover_scan_kernel(CoverGroup g) {
     __shared__ uint4 rows[BATCH];                    // chunk would cost ~0.5 us each)
     __shared__ uint32_t out[BATCH];
     int e8 = 0, base = 0;                            // (meaningful on thread 0 only)
-    const int n_chunks = cover_chunks(P.h, P.w, P.pair_w);
+    const int n_chunks = cover_chunks(P.h, P.w, P.pair_w, P.quad);
     for (int c0 = 0; c0 < n_chunks; c0 += BATCH) {
         const int nb = min(BATCH, n_chunks - c0);
         for (int i = threadIdx.x; i < nb; i += 64) rows[i] = tab[c0 + i];
@@ -395,17 +413,31 @@ __global__ __launch_bounds__(64) void cover_scan_kernel(CoverGroup g) {
         for (int i = threadIdx.x; i < nb; i += 64) state[c0 + i] = out[i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *P.count = P.pair_w > 0 ? 2 * base : base;
+    if (threadIdx.x == 0) *P.count = P.quad ? 4 * base : P.pair_w > 0 ? 2 * base : base;
 }
 
 // (4) every chunk once more, from its true entry state, writing its segments.
 __global__ __launch_bounds__(256) void cover_emit_kernel(CoverGroup g) {
     const CoverProblem& P = g.p[blockIdx.y];
     const int chunk = blockIdx.x * 256 + threadIdx.x;
-    if (chunk >= cover_chunks(P.h, P.w, P.pair_w)) return;
+    if (chunk >= cover_chunks(P.h, P.w, P.pair_w, P.quad)) return;
     const uint32_t s = g.state[P.chunk_base + chunk];
     int n = (int)(s >> 3);
-    if (P.pair_w < 0) {
+    if (P.quad) {
+        // chunk = image rows 4 chunk .. 4 chunk + 3 (rows behind the last image row: padding entries, which the conv's
+        // epilogue skips); H = the height of the plane the segments index
+        const bool pooled = P.pair_w > 0;
+        const int rw = cover_row_words(P.w), Wp = row_stride(pooled ? P.pair_w : P.w), H = pooled ? 2 * P.h : P.h;
+        auto emit = [&](int X0) {
+            const int q = (4 * chunk + 1) * Wp + (pooled ? 2 * X0 : X0) + 1;
+            if (4 * n + 3 < P.cap)
+                for (int i = 0; i < 4; ++i)
+                    P.starts[4 * n + i] = (P.tag << 24) | (4 * chunk + i < H ? q + i * Wp : 0xFFFFFF);
+            ++n;
+        };
+        if (pooled) cover_walk<true>(g.bits + P.word_base + chunk * rw, P.w, 0, emit);
+        else cover_walk<false, true>(g.bits + P.word_base + chunk * rw, P.w, 0, emit);
+    } else if (P.pair_w < 0) {
         const int tw = -P.pair_w / 32, per_chunk = SM_COVER_CHUNK_WORDS / tw;
         const uint32_t* wds = g.bits + P.word_base + chunk * SM_COVER_CHUNK_WORDS;
         const int n_words = cover_words(P.h, P.w, P.pair_w) - chunk * SM_COVER_CHUNK_WORDS;
@@ -657,8 +689,8 @@ __global__ __launch_bounds__(256) void list_concat_kernel(ConcatGroup g) {
 extern "C" {
 
 static void cover_extent(const sm_cover_problem& p, int* n_words, int* n_chunks) {
-    *n_words = sm::cover_words(p.h, p.w, p.pair_w);
-    *n_chunks = sm::cover_chunks(p.h, p.w, p.pair_w);
+    *n_words = sm::cover_words(p.h, p.w, p.pair_w, p.quad);
+    *n_chunks = sm::cover_chunks(p.h, p.w, p.pair_w, p.quad);
 }
 
 size_t sm_cover_segments_ws_bytes(const sm_cover_problem* problems, int n) {
@@ -690,7 +722,8 @@ int sm_cover_segments(const sm_cover_problem* problems, int n, void* ws, size_t 
         int nw, nc;
         cover_extent(p, &nw, &nc);
         if (p.pair_w > 0 && (p.w + 15) / 16 + 1 > 8191) return (int)hipErrorInvalidValue;   // 13-bit counts per chunk
-        g.p[i] = sm::CoverProblem{p.need, p.starts, p.count, p.h, p.w, p.tag, p.cap, p.pair_w, words, chunks};
+        if (p.quad != 0 && (p.quad != 1 || p.pair_w < 0 || (p.w + 31) / 32 + 1 > 8191)) return (int)hipErrorInvalidValue;
+        g.p[i] = sm::CoverProblem{p.need, p.starts, p.count, p.h, p.w, p.tag, p.cap, p.pair_w, p.quad, words, chunks};
         words += (nw + 3) & ~3;
         chunks += nc;
         max_words = nw > max_words ? nw : max_words;
@@ -881,12 +914,16 @@ static int view_cover_problems(const sm_view_lists_desc* d, sm_cover_problem* ou
                 pair_w = d->lw[g][L.pair_layer];
             } else if (L.mode == 2) {
                 pair_w = -L.bn;
-            } else if (L.mode != 0) {
+            } else if (L.mode == 3) {          // quads over the pooled layer's need map (a conv with SM_EPI_POOL)
+                if (L.pair_layer < 0 || L.pair_layer >= d->n_layers) return -1;
+                pair_w = d->lw[g][L.pair_layer];
+            } else if (L.mode != 0 && L.mode != 4) {
                 return -1;
             }
             if (out) out[n] = sm_cover_problem{d->need[g][L.layer], L.staging + (size_t)g * L.staging_cap,
                                                counts_dev ? counts_dev + n : nullptr,
-                                               d->lh[g][L.layer], d->lw[g][L.layer], g, L.staging_cap, pair_w};
+                                               d->lh[g][L.layer], d->lw[g][L.layer], g, L.staging_cap, pair_w,
+                                               (L.mode == 3 || L.mode == 4) ? 1 : 0};
         }
     }
     return n;

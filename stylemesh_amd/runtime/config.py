@@ -22,6 +22,9 @@ SWITCHES = {
                                 "(+2.8 % together, round 3); 0 = none"),
     "STYLEMESH_SEGMENT_LISTS": ("1", "tuning", "active lists of 32-position segments (+10 % on c3, round 3); 0 = whole 128-position tiles"),
     "STYLEMESH_SEGMENT_STARTS": ("free", "tuning", "segment starts on the 4-position grid (+2.5 %, round 3); grid = aligned to 32"),
+    "STYLEMESH_RESIDENT": ("1", "tuning", "round 5: the 64-output-channel conv launches (conv1_2 forward / data gradient, conv2_1's data "
+                           "gradient) take lists of vertical segment QUADS and the resident-input kernel (SM_LIST_QUADS); 0 = the "
+                           "ring kernel on 64 x 256 tiles"),
     "STYLEMESH_PAIR_IMAGES": ("0", "experiment", "round 5: VGG tensors stored as packed fp16 pairs by their producers under predicted "
                               "scales (verify-and-repeat protocol). Kernel time -3.7 %, step -3.6 % on c3: opt-in "
                               "(profiles/r05/pair_images_ab.txt)"),

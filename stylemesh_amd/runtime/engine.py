@@ -1354,6 +1354,7 @@ class StepEngine:
                     and cfg.gram_mode != "average" and self.side_streams and self._overlap_pays(active)
                     and not torch.cuda.is_current_stream_capturing() and not self._can_graph()
                     and self.view_tiles is not None and _vgg.fuse_pool_fwd()
+                    and not getattr(self.view_tiles, "quads", ())   # (quad lists feed the resident-input kernel: fp32 planes)
                     and all(("conv%s_%s" % (k[1], k[2]), "fp") in self.view_tiles for k in _vgg.PRE_POOL
                             if depth_of(k) < depth_of(self.deepest)))
 

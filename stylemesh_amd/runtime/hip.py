@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
 
-ABI_VERSION = 9          # sm_abi_version() of the library this binding was written against
+ABI_VERSION = 10         # sm_abi_version() of the library this binding was written against
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
 EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL, EPI_GRAM = 1, 2, 4, 8, 16
@@ -165,7 +165,7 @@ class GramBwdProblem(C.Structure):
 class CoverProblem(C.Structure):
     """sm_cover_problem of include/stylemesh_hip.h"""
     _fields_ = [("need", C.c_void_p), ("starts", C.c_void_p), ("count", C.c_void_p), ("h", C.c_int), ("w", C.c_int),
-                ("tag", C.c_int), ("cap", C.c_int), ("pair_w", C.c_int)]
+                ("tag", C.c_int), ("cap", C.c_int), ("pair_w", C.c_int), ("quad", C.c_int)]
 
 
 VIEW_MAX_LEVELS, VIEW_MAX_LAYERS, VIEW_MAX_LISTS = 8, 24, 48

@@ -750,18 +750,20 @@ def need_step(need_out, mode, M, need_src):
 
 
 def cover_segments(problems):
-    """``problems``: [(need [h,w] float tensor, starts int32 tensor, count int32 [1] tensor, tag[, pair_w]), ...] (<= 64): disjoint
-    32-position segments covering the needed positions of every plane, starts as (tag << 24) | q (``sm_cover_segments``)."""
+    """``problems``: [(need [h,w] float tensor, starts int32 tensor, count int32 [1] tensor, tag[, pair_w[, quad]]), ...] (<= 64):
+    disjoint 32-position segments covering the needed positions of every plane, starts as (tag << 24) | q
+    (``sm_cover_segments``). ``quad`` = 1: vertical QUADS of segments (four entries per run; the resident-input conv kernel)."""
     arr = (hip.CoverProblem * len(problems))()
     for i, prob in enumerate(problems):
         need, starts, count, tag = prob[:4]
         pair_w = prob[4] if len(prob) > 4 else 0   # > 0: PAIR mode (``need`` = need map of the pooled plane, see the header)
+        quad = prob[5] if len(prob) > 5 else 0
         h, w = need.shape
         rows, width = (2 * h + 2, pair_w) if pair_w else (h + 2, w)
         if rows * hip.row_stride(width) >= 0xFFFFFF:
             raise ValueError(f"segment list of a {rows - 2} x {width} plane: a list entry holds the position in 24 bits "
                              f"(planes up to ~16.7 M padded positions); STYLEMESH_SEGMENT_LISTS=0 lists whole tiles instead")
-        arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel(), int(pair_w))
+        arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel(), int(pair_w), int(quad))
     nbytes = lib.sm_cover_segments_ws_bytes(arr, len(problems))
     dev = problems[0][0].device
     ws = _COVER_WS.get(dev)

@@ -210,6 +210,7 @@ class VGGNet:
         am = amax if _amax_on() else None
         assert am is not None or not _amax_on(), "CONV_MODE 'split2' needs the group's AmaxBook"
         pooled_by_conv = set()   # pools whose output the conv below them has already written (EPI_POOL)
+        quads = getattr(tiles, "quads", ())   # lists of vertical segment quads: the resident-input kernel (viewplan.TileLists)
         for kind, src, out, _, _ in NODES[:last + 1]:
             pkw = {}
             if pair is not None and kind != "pool" and src != "img":
@@ -232,7 +233,7 @@ class VGGNet:
                                     self.wf[kind], self.bias[kind], hip.EPI_BIAS_RELU | hip.EPI_POOL, tl, frac,
                                     self.wf3[kind], self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out], **pkw)
+                                    None if am is None else am["a:" + out], quads=(kind, "fp") in quads, **pkw)
                 pooled_by_conv.add(po)
                 if on_layer is not None:
                     on_layer(out)
@@ -244,7 +245,7 @@ class VGGNet:
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
                                     hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind], self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out], **pkw)
+                                    None if am is None else am["a:" + out], quads=(kind, "f") in quads, **pkw)
                 if on_layer is not None:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
@@ -260,6 +261,7 @@ class VGGNet:
             for b in bufs:
                 ops.fmap_amax(b.grad[start_layer], am["g:" + start_layer])
         fuse = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(b.code for b in bufs)
+        quads = getattr(tiles, "quads", ())   # (as in forward_group)
         unpool = None   # fused pool backward: name of the pooled map whose gradient the next conv un-pools on the fly
 
         def gin(b, layer):
@@ -287,7 +289,7 @@ class VGGNet:
                 pkw = {} if pair is None else dict(pair_in=pair.grad(out), pair_out=pair.grad(src, producer=True))
                 ops.conv3x3_grouped([(gin(b, out), b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
                                     self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src], **pkw)
+                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads, **pkw)
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
@@ -314,7 +316,7 @@ class VGGNet:
                     probs = [(gin(b, out), d, b.act[src]) for b, d in zip(bufs, dst)]
                 ops.conv3x3_grouped(probs, self.wd[kind], None, flags,
                                     tl, frac, self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src], **pkw)
+                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads, **pkw)
             assert unpool is None or kind == "pool", "a fused pool backward must be consumed by the conv below it"
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):

@@ -26,10 +26,23 @@ from .fmap import FMap
 from .vgg import NODES, POOL_OUTPUT, PRE_POOL, depth_of, fuse_pool_fwd, layer_hw
 
 
-def list_jobs(deepest: str, pairs: bool):
+def resident_lists() -> bool:
+    """Do the 64-output-channel launches of the fp16x2 mode take QUAD lists (the resident-input kernel, SM_LIST_QUADS)?"""
+    import os
+    return ops.CONV_MODE == "split2" and os.environ.get("STYLEMESH_RESIDENT", "1") != "0"
+
+
+class TileLists(dict):
+    """{job key: (list tensor, live fraction)} of a view; ``quads``: the keys whose lists hold vertical quads of segments."""
+    quads = frozenset()
+
+
+def list_jobs(deepest: str, pairs: bool, resident: bool = False):
     """The step's active-list consumers in launch order: (key, layer name the list is built from, mode, bn, group,
     pair layer) - the job table of ``sparsity.build_tile_lists``. mode 0: free segments, 1: segment pairs over the POOLED
-    layer's need map, 2: aligned tiles of bn positions."""
+    layer's need map, 2: aligned tiles of bn positions; ``resident``: the launches with 64 output channels and whole
+    64-channel input phases (conv1_2 forward / data gradient, conv2_1's data gradient) take QUADS instead - mode 3 over the
+    pooled layer's need map, mode 4 over the layer's own (``sm_cover_problem::quad``), four entries per tile."""
     jobs = []
     names = {"img"} | {n[2] for n in NODES[:depth_of(deepest) + 1]}
     for kind, src, dst, cin, cout in NODES[:depth_of(deepest) + 1]:
@@ -37,14 +50,18 @@ def list_jobs(deepest: str, pairs: bool):
             jobs.append((("pool", dst), dst, 2, ops.plane_tile_positions(1), 1, None))
             continue
         bn, group = ops.conv_list_format(4 if cin == 3 else cin, cout)
+        quads_f = resident and group > 0 and cout == 64 and cin % 64 == 0
         if pairs and group > 0 and dst in PRE_POOL and POOL_OUTPUT[dst] in names:
-            jobs.append(((kind, "fp"), POOL_OUTPUT[dst], 1, 32, group, dst))
+            jobs.append(((kind, "fp"), POOL_OUTPUT[dst], 3, 32, 4, dst) if quads_f else ((kind, "fp"), POOL_OUTPUT[dst], 1, 32, group, dst))
         elif group > 0:
-            jobs.append(((kind, "f"), dst, 0, 32, group, None))
+            jobs.append(((kind, "f"), dst, 4, 32, 4, None) if quads_f else ((kind, "f"), dst, 0, 32, group, None))
         else:
             jobs.append(((kind, "f"), dst, 2, bn, 1, None))
         if src != "img":
             bn, group = ops.conv_list_format(cout, cin)
+            if resident and group > 0 and cin == 64 and cout % 64 == 0:
+                jobs.append(((kind, "b"), src, 4, 32, 4, None))
+                continue
             jobs.append(((kind, "b"), src, 0, 32, group, None) if group > 0 else ((kind, "b"), src, 2, bn, 1, None))
         else:
             jobs.append((("img", "d"), "img", 2, ops.plane_tile_positions(0), 1, None))
@@ -88,7 +105,7 @@ class ViewPlan:
         n_ll = len(eng.loss_layers)
         self.consts = eng._persist(("consts", n_levels, n_ll), lambda: torch.zeros(n_levels, n_ll, 4, device=dev))
         # ---- lists: jobs -> unique list specs ----------------------------------------------------------------
-        self.jobs = list_jobs(eng.deepest, fuse_pool_fwd())
+        self.jobs = list_jobs(eng.deepest, fuse_pool_fwd(), resident_lists() and not eng.pair_images)
         layer_names = ["img"] + [n[2] for n in NODES[:depth_of(eng.deepest) + 1]]
         self.layer_index = {n: i for i, n in enumerate(layer_names)}
         n_specs = len({(j[1], j[2], j[3], j[4], j[5]) for j in self.jobs})
@@ -199,6 +216,13 @@ class ViewPlan:
                     fh, fw = self.need[g][pair_layer].shape
                     caps.append(2 * hh * ((ww + 15) // 16 + 1) + 2)
                     n_all += (fh * hip.row_stride(fw) + 31) // 32
+                elif mode == 3:     # quads over the pooled need map: two pooled rows per group, four entries per run
+                    fh, fw = self.need[g][pair_layer].shape
+                    caps.append(4 * ((hh + 1) // 2) * ((ww + 15) // 16 + 1) + 4)
+                    n_all += (fh * hip.row_stride(fw) + 31) // 32
+                elif mode == 4:     # quads over the layer's own need map: four rows per group
+                    caps.append(4 * ((hh + 3) // 4) * ((ww + 31) // 32 + 1) + 4)
+                    n_all += (hh * hip.row_stride(ww) + 31) // 32
                 elif mode == 0:
                     caps.append(hh * hip.row_stride(ww) // 32 + 2)
                     n_all += (hh * hip.row_stride(ww) + 31) // 32
@@ -254,7 +278,8 @@ class ViewPlan:
         msums = host[9 * n_specs:9 * n_specs + len(self.level_hw)].view(torch.float32).tolist()
         tiles = None
         if self.lists_desc is not None:
-            tiles = {}
+            tiles = TileLists()
+            tiles.quads = frozenset(j[0] for j in self.jobs if j[2] in (3, 4))
             for key, layer, mode, bn, group, pair_layer in self.jobs:
                 s = self.job_spec[(layer, mode, bn, group, pair_layer)]
                 sp, row = self.specs[s], ints[s]

@@ -4,6 +4,7 @@ conv1_2 forward with the pooling epilogue, conv2_1's data gradient, conv1_2's da
 results compared bit for bit, launches timed with events. Usage: bench_resident.py [c3|c2]   (GPU box)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -11,44 +12,9 @@ from stylemesh_amd.runtime import hip, ops
 from stylemesh_amd.runtime.fmap import FMap
 
 LEVELS = {"c3": [(256, 341), (432, 576), (608, 811), (784, 1045)], "c2": [(256, 341)]}[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+from bench_resident_lib import rows_list, timed  # noqa: E402
+
 ops.CONV_MODE = "split2"
-PAD = 0xFFFFFF
-
-
-def rows_list(hws, rows, group):
-    """Dense list: per level, blocks of `rows` consecutive image rows x 32 columns, one entry per row (row-major inside a
-    block), each level padded to a multiple of `group` entries."""
-    parts = []
-    for g, (H, W) in enumerate(hws):
-        Wp = hip.row_stride(W)
-        Y = np.arange((H + rows - 1) // rows)[:, None, None] * rows
-        X = np.arange(0, W, 32)[None, :, None]
-        I = np.arange(rows)[None, None, :]
-        y = Y + I + 0 * X
-        q = (y + 1) * Wp + X + 1
-        e = np.where(y < H, (g << 24) | q, (g << 24) | PAD).reshape(-1)
-        pad = (-len(e)) % group
-        parts.append(np.concatenate([e, np.full(pad, (g << 24) | PAD)]))
-    return torch.tensor(np.concatenate(parts).astype(np.int32), device="cuda")
-
-
-def timed(fn, n=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / n
-
-
-def interior(f):
-    return f.to_dense()
-
-
 torch.manual_seed(1)
 # ---- conv1_2 forward, pooling epilogue
 hws = LEVELS
