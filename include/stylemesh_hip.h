@@ -550,7 +550,7 @@ typedef struct {
     int pair_w;
     /* ABI 10. 1: QUAD mode, the lists of the resident-input conv kernel (SM_LIST_QUADS) - the rows of the need map are
      * walked in GROUPS whose bits are OR-ed: two pooled rows with pair_w > 0 (runs of 16 windows from any window X0,
-     * columns 2 X0 ...), four rows with pair_w == 0 (runs of 32 positions from any needed position X0) - and every run
+     * columns 2 X0 ...), four rows with pair_w == 0 (runs of 32 positions from the first needed position, rounded down to even) - and every run
      * becomes FOUR entries: the same 32 columns of image rows 4 Y .. 4 Y + 3 (q, q + Wp, q + 2 Wp, q + 3 Wp; a row
      * behind the last image row: (tag << 24) | 0xFFFFFF). Runs of one group are disjoint. 0: as above. */
     int quad;

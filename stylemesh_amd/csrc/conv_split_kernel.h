@@ -581,30 +581,46 @@ void conv3x3_split_kernel(ConvArgs a) {
     if constexpr (RES) {
         constexpr int RP = SM_RES_RP;
         constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
-        constexpr int RU = (RGRP * RP + 255) / 256;      // staging units (8 channels of one position) per thread and phase
+        // Staging tasks: (group of 8 channels, window row r, block of four consecutive positions) - 8 x 6 x 9 = 432 per
+        // phase, two per thread. A task loads its four positions of each channel with ONE 16-byte load (un-pooling input:
+        // its two pooled elements with one 8-byte load + the codes of both) - the single-position units of the first
+        // version spent 3 us of a block's 7 us staging time ISSUING 56 dword loads per thread through the CU's one
+        // address unit (tools/res_trace.py) - and builds the four positions' 8-channel units in registers.
+        // Window position (r, p) holds input position qs[0] - 1 + p + (r - 1) Wp.
+        constexpr int RCB = 9, RT = RGRP * SM_RES_ROWS * RCB, RU = (RT + 255) / 256;
         f32x4* Rs = smem4;
-        // unit u = tid + 256 k: group u / RP, position u % RP = (row r, p) of the staged window; LDS position (r, p) holds
-        // input position qs[0] - 1 + p + (r - 1) Wp (row 0 / column 0 of the window = the halo above / left of segment 0)
-        int r_src[RU], r_dst[RU], r_code[UNPOOL ? RU : 1], r_par[UNPOOL ? RU : 1];
-        bool r_on[RU];
+        int r_src[RU], r_dst[RU], r_code[UNPOOL ? RU : 1], r_ypar[UNPOOL ? RU : 1];
+        bool r_on[RU], r_ok[UNPOOL ? RU : 1][2];
+        int r_p0[RU];                                    // window position of the task's element 0 (un-pooling: may be -1)
 #pragma unroll
         for (int k = 0; k < RU; ++k) {
-            const int u = tid + 256 * k;
-            r_on[k] = u < RGRP * RP;
-            const int uu = r_on[k] ? u : tid;            // (idle units load a valid address and store nothing)
-            const int grp = uu / RP, pos = uu - grp * RP;
-            const int r = pos / SEGP, p = pos - r * SEGP;
-            r_dst[k] = ((grp >> 1) * 4 + (grp & 1)) * RP + pos;                  // + part * 2 * RP
+            const int t = tid + 256 * k;
+            r_on[k] = t < RT;
+            const int tt = r_on[k] ? t : tid;            // (idle tasks load a valid address and store nothing)
+            const int grp = tt / (SM_RES_ROWS * RCB), rem = tt - grp * (SM_RES_ROWS * RCB);
+            const int r = rem / RCB, cb = rem - r * RCB;
             if constexpr (UNPOOL) {
-                const int qc = qs[0] + p - 1 + (r - 1) * P.Wp;                   // position in the un-pooled padded plane
-                const int y = qc / P.Wp - 1, x = qc - (y + 1) * P.Wp - 1;
-                int off_;
-                SM_UP_MAP(y, x, off_, r_par[k])
+                // quads of an un-pooling launch start on even columns (sm_cover_segments, flat quads) and rows 4 Y: the
+                // task = the two pooled elements under image columns x .. x + 3, x = x0 - 2 + 4 cb (even), of image row
+                // y = y0 - 1 + r; no gradient outside the pooled windows (and, row-locally, behind the row's end: only
+                // outputs nobody stores read those)
+                const int y0 = qs[0] / P.Wp - 1, x0 = qs[0] - (y0 + 1) * P.Wp - 1;   // pixel of the quad's first position
+                const int y = y0 - 1 + r, x = x0 - 2 + 4 * cb;
+                const bool yok = (unsigned)y < (unsigned)(2 * up_Ho);
+                r_ok[k][0] = yok && (unsigned)x < (unsigned)(2 * up_Wo);
+                r_ok[k][1] = yok && (unsigned)(x + 2) < (unsigned)(2 * up_Wo);
+                // (rows / columns outside the image clamp to the pooled plane's own padding: a readable address)
+                const int yp = min(max((y >> 1) + 1, 0), up_Ho + 1), xp = max((x >> 1) + 1, 0);
+                const int off_ = yp * up_Wp + xp;
                 r_src[k] = (off_ + grp * 8 * up_plane) * 4;
                 r_code[k] = (off_ + grp * up_plane) * 4;
+                r_ypar[k] = (y & 1) << 1;
+                r_p0[k] = 4 * cb - 1;
             } else {
-                r_src[k] = (grp * 8 * P.plane + qs[0] + p + r * P.Wp) * 4;       // bytes from the shifted base (row ky = 0)
+                r_p0[k] = 4 * cb;
+                r_src[k] = (grp * 8 * P.plane + qs[0] + 4 * cb + r * P.Wp) * 4;  // bytes from the shifted base (row ky = 0)
             }
+            r_dst[k] = ((grp >> 1) * 4 + (grp & 1)) * RP + r * SEGP + r_p0[k];   // + j (position in the task) + part * 2 * RP
         }
 #ifdef SM_RES_STAGGER   // (experiment: the blocks of a CU's first round start SM_RES_STAGGER x 8 k cycles apart)
         if (blockIdx.x < 768)
@@ -618,46 +634,76 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int ph = 0; ph < n_phases; ++ph) {
             if (ph > 0) __syncthreads();                 // the previous phase's last fragment reads
             if (SM_RES_ABL != 2) {
-                float rb[RU][8];
-                unsigned rc[UNPOOL ? RU : 1];
                 if constexpr (UNPOOL) {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                    f32x2_ rb[RU][8];
+                    u32x2_ rc[RU];
                     const int sc_ = ph * 64 * up_plane * 4;
 #pragma unroll
                     for (int k = 0; k < RU; ++k) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            rb[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, r_src[k], sc_ + c * up_plane * 4, 0));
-                        rc[k] = __builtin_amdgcn_raw_buffer_load_b32(code_rsrc, r_code[k], ph * 8 * up_plane * 4, 0);
+                            rb[k][c] = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(gp_rsrc, r_src[k], sc_ + c * up_plane * 4, 0));
+                        rc[k] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(code_rsrc, r_code[k], ph * 8 * up_plane * 4, 0));
                     }
+                    SM_RT(6)
+#ifdef SM_RES_TRACE
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    SM_RT(7)
+#endif
+#pragma unroll
+                    for (int k = 0; k < RU; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {            // position r_p0 + j: pooled element j >> 1, window parity (y, j & 1)
+                            const int e = j >> 1;
+                            const unsigned cw = e ? rc[k][1] : rc[k][0];
+                            const int par = r_ypar[k] | (j & 1);
+                            f16x8 vh, vl;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                float v = e ? rb[k][c][1] : rb[k][c][0];
+                                v = (r_ok[k][e] && (int)((cw >> (4 * c)) & 15u) == par) ? v : 0.f;
+                                const float xs_ = __builtin_amdgcn_fmed3f(v * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);
+                                const _Float16 h_ = (_Float16)xs_;
+                                vh[c] = h_;
+                                vl[c] = (_Float16)(xs_ - (float)h_);
+                            }
+                            if (r_on[k] && (unsigned)(r_p0[k] + j) < (unsigned)SEGP) {
+                                Rs[r_dst[k] + j] = __builtin_bit_cast(f32x4, vh);
+                                Rs[r_dst[k] + j + 2 * RP] = __builtin_bit_cast(f32x4, vl);
+                            }
+                        }
                 } else {
+                    f32x4 rb[RU][8];
                     const int so_ = ph * 64 * P.plane * 4;
 #pragma unroll
                     for (int k = 0; k < RU; ++k)
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            rb[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, r_src[k], so_ + c * P.plane * 4, 0));
-                }
-                SM_RT(6)
+                            rb[k][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, r_src[k], so_ + c * P.plane * 4, 0));
+                    SM_RT(6)
 #ifdef SM_RES_TRACE
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                SM_RT(7)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    SM_RT(7)
 #endif
 #pragma unroll
-                for (int k = 0; k < RU; ++k) {
-                    f16x8 vh, vl;
+                    for (int k = 0; k < RU; ++k)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float v = rb[k][c];
-                        if constexpr (UNPOOL) v = ((int)((rc[k] >> (4 * c)) & 15u) == r_par[k]) ? v : 0.f;
-                        const float xs_ = __builtin_amdgcn_fmed3f(v * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);
-                        const _Float16 h_ = (_Float16)xs_;
-                        vh[c] = h_;
-                        vl[c] = (_Float16)(xs_ - (float)h_);
-                    }
-                    if (r_on[k]) {
-                        Rs[r_dst[k]] = __builtin_bit_cast(f32x4, vh);
-                        Rs[r_dst[k] + 2 * RP] = __builtin_bit_cast(f32x4, vl);
-                    }
+                        for (int j = 0; j < 4; ++j) {
+                            f16x8 vh, vl;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                const float xs_ = __builtin_amdgcn_fmed3f(rb[k][c][j] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);
+                                const _Float16 h_ = (_Float16)xs_;
+                                vh[c] = h_;
+                                vl[c] = (_Float16)(xs_ - (float)h_);
+                            }
+                            if (r_on[k] && r_p0[k] + j < SEGP) {
+                                Rs[r_dst[k] + j] = __builtin_bit_cast(f32x4, vh);
+                                Rs[r_dst[k] + j + 2 * RP] = __builtin_bit_cast(f32x4, vl);
+                            }
+                        }
                 }
             }
             __syncthreads();

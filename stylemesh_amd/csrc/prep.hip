@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void cover_pack_kernel(CoverGroup g) {
 // segment whose first needed position lies in the chunk, returns the exit state. `words` holds the chunk's bits and at
 // least one readable word behind them. FLAT mode: segment start = first needed position rounded down to 4, next cursor =
 // start + 32. PAIR mode (n_bits = the row's width, align1): start = the first needed window itself, next cursor = + 16.
-// (ROWQ: the flat QUAD mode - row-local like PAIR, start = the first needed position itself, next cursor = + 32)
+// (ROWQ: the flat QUAD mode - row-local like PAIR, start = the first needed position rounded down to even, next cursor = + 32)
 template <bool PAIR, bool ROWQ = false, typename Emit>
 __device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, int n_bits, int e, Emit emit) {
     int cursor = e, end = e;     // end: one past the last position covered so far (skipping zeros covers nothing)
@@ -343,7 +343,7 @@ __device__ __forceinline__ int cover_walk(const uint32_t* __restrict__ words, in
         if (valid < 64) win &= (1ull << valid) - 1ull;
         if (win == 0) { cursor += 64 - sh; continue; }
         const int p = cursor + __builtin_ctzll(win);
-        const int st = (PAIR || ROWQ) ? p : (p & ~3);
+        const int st = PAIR ? p : ROWQ ? (p & ~1) : (p & ~3);   // (quads start on even columns: the un-pooling input's pairs)
         emit(st);
         cursor = end = st + (PAIR ? 16 : 32);
     }

@@ -38,6 +38,8 @@ def _host_quads(need, pooled, hip, tag, full_w=None):
             if len(nz) == 0:
                 break
             p = cur + int(nz[0])
+            if not pooled:
+                p &= ~1                      # flat quads start on even columns
             q = (4 * Y + 1) * Wp + (2 * p if pooled else p) + 1
             for i in range(4):
                 out.append((tag << 24) | (q + i * Wp if 4 * Y + i < H else PAD))
@@ -76,7 +78,7 @@ def test_quad_covers_equal_the_host_greedy(hw):
             q = got[k] & PAD
             assert (got[k] >> 24) == 3 and q != PAD
             y, x = q // Wp - 1, q % Wp - 1
-            assert y % 4 == 0 and 0 <= x < W
+            assert y % 4 == 0 and 0 <= x < W and x % 2 == 0
             for i in range(4):
                 e = got[k + i] & PAD
                 assert e == (q + i * Wp if y + i < H else PAD)
