@@ -568,11 +568,11 @@ void conv3x3_split_kernel(ConvArgs a) {
     SM_TS(0)
 #ifdef SM_RES_TRACE   // (debug build: per block {start, staged, loop done, end, HW_ID, XCC_ID} into the tail of ws; tools/res_trace.py)
 #define SM_RT(slot_)                                                                                     \
-    if (RES && tid == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + (slot_)] = \
+    if (RES && tid == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + (slot_)] = \
         (long long)__builtin_amdgcn_s_memrealtime();
     if (RES && tid == 0) {
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(63492);
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(63508);
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_getreg(63492);
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_getreg(63508);
     }
 #else
 #define SM_RT(slot_)
@@ -622,10 +622,6 @@ void conv3x3_split_kernel(ConvArgs a) {
             }
             r_dst[k] = ((grp >> 1) * 4 + (grp & 1)) * RP + r * SEGP + r_p0[k];   // + j (position in the task) + part * 2 * RP
         }
-#ifdef SM_RES_STAGGER   // (experiment: the blocks of a CU's first round start SM_RES_STAGGER x 8 k cycles apart)
-        if (blockIdx.x < 768)
-            for (int i = 0; i < (int)((blockIdx.x >> 8) % 3) * SM_RES_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
 #pragma unroll
         for (int t = 0; t < AD; ++t) SM_LOAD_A(t, 0);
         // n-tile i of the wave = segment wn / 32 + i = window row wn / 32 + i + ky of tap row ky
@@ -706,6 +702,10 @@ void conv3x3_split_kernel(ConvArgs a) {
                         }
                 }
             }
+#ifdef SM_RES_TRACE   // every wave's "converted and stored" time (slots 10 .. 13) and "loads arrived" (wave 3: slot 14)
+            if (lane == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 10 + wave] =
+                (long long)__builtin_amdgcn_s_memrealtime();
+#endif
             __syncthreads();
             SM_RT(1)
             f32x4 fb[NJ][NP], fb_next[NJ][NP];
@@ -1169,6 +1169,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                 }
             }
             __syncthreads();
+            SM_RT(8)
 #pragma unroll
             for (int chunk = 0; chunk < 2; ++chunk)                    // 32 channels
 #pragma unroll
@@ -1192,6 +1193,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         }
                     }
         }
+        SM_RT(9)
     }
 #pragma unroll
     for (int nj = 0; nj < NJE; ++nj) {   // (KG = 2: column tile nj0 + nj of the wave, held in acc[.][nj])
