@@ -1050,7 +1050,9 @@ void conv3x3_split_kernel(ConvArgs a) {
                     const float bv = bias4[mi][r >> 2][r & 3];
                     t = fmaxf(t + bv, 0.f);
                     b = fmaxf(b + bv, 0.f);
-                    const float tp = __shfl_xor(t, 1, 64), bp = __shfl_xor(b, 1, 64);
+                    // the window partner (lane ^ 1) through a DPP quad permute [1, 0, 3, 2] (round 5; an LDS permute before: -1 % on the launch)
+                    const float tp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
+                    const float bp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
                     // first maximum in row-major order (strict '>' scan, as max_pool2d_with_indices); 4: maximum <= 0
                     float m = t;
                     unsigned c = 0u;

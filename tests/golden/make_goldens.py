@@ -131,6 +131,25 @@ def install_stubs():
             return VC.resize_bilinear_np(np.asarray(img, dtype=np.float32), (h, w)).astype(np.asarray(img).dtype)
         return VC.resize_nearest_np(np.asarray(img), (h, w))
 
+    # The stub stands in for OpenCV (absent from this image) in the reference's data code, so fixture g7's depth / mask path
+    # is pinned only as far as this function IS cv2.resize. Known answers of cv2.resize(..., INTER_LINEAR) stated here, from
+    # its documented sampling rule - source coordinate (dst + 0.5) * in / out - 0.5, clamped to the image, two-tap linear
+    # weights, no anti-aliasing - worked by hand:
+    #   [0 10 20 30] -> 2 samples: source 0.5, 2.5                     -> 5, 25
+    #   [0 10]       -> 4 samples: source -0.25, 0.25, 0.75, 1.25       -> 0, 2.5, 7.5, 10
+    #   [0 .. 6]     -> 3 samples: source 2/3, 3, 16/3                  -> 2/3, 3, 16/3
+    #   [[0 10] [20 30]] -> 1 x 1: source (0.5, 0.5)                    -> 15;   3 x 3 -> 3 x 3: the identity
+    def _row(v, n):
+        return resize(np.asarray([v], dtype=np.float32), (n, 1))[0]
+    np.testing.assert_allclose(_row([0, 10, 20, 30], 2), [5, 25], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(_row([0, 10], 4), [0, 2.5, 7.5, 10], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(_row(list(range(7)), 3), [2 / 3, 3, 16 / 3], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(resize(np.asarray([[0, 10], [20, 30]], dtype=np.float32), (1, 1)), [[15]], rtol=0, atol=1e-5)
+    eye = np.arange(9, dtype=np.float32).reshape(3, 3)
+    np.testing.assert_array_equal(resize(eye, (3, 3)), eye)
+    # INTER_NEAREST: source index floor(dst * in / out)
+    np.testing.assert_array_equal(resize(np.asarray([[0, 1, 2, 3, 4]], dtype=np.int32), (2, 1), interpolation=0), [[0, 2]])
+
     cv2.resize = resize
     sys.modules["cv2"] = cv2
 
