@@ -508,7 +508,8 @@ def _run(args):
         products = {"split": 6, "split2": 3}.get(tag)
         peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None   # HBM bytes per conv launch from the committed PMC pass of this workload
-        for rnd in ("r04", "r03", "r02", "r01"):   # (offline: PMC runs cannot be live inside bench.py)
+        rounds = sorted((d for d in os.listdir(os.path.join(REPO, "profiles")) if d[:1] == "r" and d[1:].isdigit()), reverse=True)
+        for rnd in rounds:   # the latest committed pass (offline: PMC runs cannot be live inside bench.py)
             tf = os.path.join(REPO, "profiles", rnd, f"conv_traffic_{args.workload}_{tag}.json")
             if os.path.exists(tf):
                 traffic, traffic_src = round(json.load(open(tf))["hbm_bytes_per_launch"]), f"profiles/{rnd}/{os.path.basename(tf)}"
