@@ -341,7 +341,9 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
     assert float(amax_out.max()) == max(float(o.planes.abs().max()) for o in out)
 
 
-def test_engine_step_with_and_without_quad_lists(monkeypatch):
+@pytest.mark.parametrize("env", [{}, {"STYLEMESH_FUSE_POOL_FWD": "0"}, {"STYLEMESH_FUSE_POOL_BWD": "0"},
+                                 {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"}])
+def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
     """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses up
     to the operand scales - the quads list a few more dead positions, whose values may raise a tensor's recorded bound -
     and textures that agree in bulk after two steps (Adam at lr 1 turns last-bit gradient differences into +-lr steps)."""
@@ -352,6 +354,11 @@ def test_engine_step_with_and_without_quad_lists(monkeypatch):
     for on in ("1", "0"):
         monkeypatch.setenv("STYLEMESH_RESIDENT", on)
         monkeypatch.setenv("STYLEMESH_OVERLAP_MIN_PIXELS", "0")     # the small test view takes the side-stream path
+        for k, v in env.items():                                    # every epilogue variant the resident kernel is built for
+            monkeypatch.setenv(k, v)
+        if env.get("STYLEMESH_FUSE_POOL_BWD") == "0":               # (read once, when the module is imported)
+            from stylemesh_amd.runtime import vgg
+            monkeypatch.setattr(vgg, "FUSE_POOL_BWD", False)
         torch.manual_seed(11)
         torch.cuda.manual_seed(11)
         eng = _engine(random_init=True)
@@ -360,6 +367,8 @@ def test_engine_step_with_and_without_quad_lists(monkeypatch):
         torch.cuda.synchronize()
         quads = getattr(eng.view_tiles, "quads", frozenset())
         assert (len(quads) == 3) == (on == "1"), quads          # conv1_2 forward / data gradient, conv2_1's data gradient
+        if on == "1":
+            assert (("conv1_2", "fp") in quads) == (env.get("STYLEMESH_FUSE_POOL_FWD") != "0" and env.get("STYLEMESH_FUSE_POOL_BWD") != "0")
         res[on] = (losses, eng.arena.p.clone())
     for k in res["1"][0][0]:
         a, b = res["1"][0][0][k], res["0"][0][0][k]
