@@ -296,8 +296,8 @@ def many_views_leg(eng, wl, args, dev, barrier, good, first_seeds):
 def measured_schedule(workload):
     """The fixed schedule of one scene MEASURED on the product path (tools/run_schedule.py: directory loader, MiniTrainer,
     the CLI's flags) - a committed record of a GPU-box run, the default bench run cannot afford 4 minutes of it."""
-    for rnd in ("r04", "r03"):
-        f = os.path.join(REPO, "profiles", rnd, f"schedule_{workload}.json")
+    for rnd in sorted((d for d in os.listdir(os.path.join(REPO, "profiles")) if d[:1] == "r" and d[1:].isdigit()), reverse=True):
+        f = os.path.join(REPO, "profiles", rnd, f"schedule_{workload}.json")   # (the latest committed record)
         if os.path.exists(f):
             d = json.load(open(f))
             return {"measured_schedule_s": d.get("measured_schedule_s"), "measured_schedule_live": False, "steps": d.get("steps"),
