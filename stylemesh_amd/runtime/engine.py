@@ -852,11 +852,13 @@ class StepEngine:
             from .sparsity import build_tile_lists, need_maps
             needs = [need_maps(lv.M, lv.H, lv.W, set(self.injected), self.deepest) for lv in active]
             shapes = tuple((lv.H, lv.W) for lv in active)
-            self.view_tiles = {}
+            from .viewplan import TileLists, resident_lists
+            self.view_tiles = TileLists()
             dsts, srcs = [], []
-            lists = build_tile_lists(needs, self.deepest, msums)
+            lists = build_tile_lists(needs, self.deepest, msums, resident=resident_lists() and not self.pair_images)
             if msums is not None:
                 lists, sums_host = lists
+            self.view_tiles.quads = lists.quads
             for key, (lst, frac, cap) in lists.items():
                 # fixed-address storage (a captured graph keeps the pointer); capacity = all tiles of the launch
                 buf = self._persist(("tiles", key, shapes), lambda: torch.zeros(max(cap, 1), dtype=torch.int32, device=dev))

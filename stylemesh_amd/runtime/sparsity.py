@@ -39,8 +39,10 @@ def need_maps(M: torch.Tensor, H: int, W: int, injected, last_layer: str) -> dic
     return need
 
 
-def build_tile_lists(needs, last_layer: str, extra=None):
+def build_tile_lists(needs, last_layer: str, extra=None, resident: bool = False):
     """``needs``: one ``need_maps`` dict per level of the grouped launch (in problem order).
+    ``resident``: the launches with 64 output channels take vertical QUADS of segments (``viewplan.list_jobs``); the keys
+    of those lists are the ``quads`` attribute of the returned ``viewplan.TileLists``.
     Returns {(conv name, 'f' | 'b'): (int32 device tensor of (problem << 24) | tile, active fraction, list capacity)};
     for the split conv kernels the entries are 32-position SEGMENTS, ``ops.conv_list_format`` of them per tile.
     ``extra``: optional 1-D float device tensor that rides along in the one read-back; then returns (dict, list)."""
@@ -57,11 +59,15 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     pairs = free and fuse_pool_fwd()
 
     def cover_src(g, layer):
-        """(need map the cover runs on, pair_w, (h, w) of the plane the segments index) of a cover key."""
+        """(need map the cover runs on, pair_w, (h, w) of the plane the segments index, quad) of a cover key: a layer name
+        (free segments), ('pair', layer) / ('quadp', layer): pairs / quads over the need map of the layer's POOLED plane,
+        ('quad', layer): quads over the layer's own need map."""
+        if isinstance(layer, tuple) and layer[0] == "quad":
+            return needs[g][layer[1]], 0, tuple(needs[g][layer[1]].shape), 1
         if isinstance(layer, tuple):
             h, w = needs[g][layer[1]].shape
-            return needs[g][POOL_OUTPUT[layer[1]]], w, (h, w)
-        return needs[g][layer], 0, tuple(needs[g][layer].shape)
+            return needs[g][POOL_OUTPUT[layer[1]]], w, (h, w), int(layer[0] == "quadp")
+        return needs[g][layer], 0, tuple(needs[g][layer].shape), 0
     jobs = []            # (key, layer, bn, group): group > 0 = a SEGMENT list (bn = 32) consumed `group` entries per tile
     for kind, src, dst, cin, cout in NODES[:depth_of(last_layer) + 1]:
         if kind == "pool":
@@ -69,14 +75,19 @@ def build_tile_lists(needs, last_layer: str, extra=None):
             jobs.append((("pool", dst), dst, ops.plane_tile_positions(1), 0))
             continue
         f = fmt(4 if cin == 3 else cin, cout)
+        quads_f = resident and free and f[1] > 0 and cout == 64 and cin % 64 == 0   # (viewplan.list_jobs: the same table)
         if pairs and f[1] > 0 and dst in PRE_POOL and POOL_OUTPUT[dst] in needs[0]:
             # the conv below a pool takes the maxima in its epilogue (EPI_POOL): its segments come in vertical PAIRS
             # that cover the need map of the POOLED plane; key (conv, 'fp'), cover key ('pair', layer)
-            jobs.append(((kind, "fp"), ("pair", dst)) + f)
+            jobs.append(((kind, "fp"), ("quadp", dst), 32, 4) if quads_f else ((kind, "fp"), ("pair", dst)) + f)
         else:
-            jobs.append(((kind, "f"), dst) + f)
+            jobs.append(((kind, "f"), ("quad", dst), 32, 4) if quads_f else ((kind, "f"), dst) + f)
         if src != "img":
-            jobs.append(((kind, "b"), src) + fmt(cout, cin))
+            fb = fmt(cout, cin)
+            if resident and free and fb[1] > 0 and cin == 64 and cout % 64 == 0:
+                jobs.append(((kind, "b"), ("quad", src), 32, 4))
+            else:
+                jobs.append(((kind, "b"), src) + fb)
         else:
             jobs.append((("img", "d"), "img", ops.plane_tile_positions(0), 0))   # conv1_1's data gradient
     # --- segment jobs with FREE starts: one greedy cover per (layer, level) need map, all in one launch
@@ -86,7 +97,10 @@ def build_tile_lists(needs, last_layer: str, extra=None):
         seg_layers = sorted({layer for _, layer, _, group in jobs if group > 0}, key=str)
 
         def cap_of(g, layer):
-            nd, pair_w, (h, w) = cover_src(g, layer)
+            nd, pair_w, (h, w), quad = cover_src(g, layer)
+            if quad:
+                return (4 * ((nd.shape[0] + 1) // 2) * ((nd.shape[1] + 15) // 16 + 1) + 4 if pair_w else
+                        4 * ((nd.shape[0] + 3) // 4) * ((nd.shape[1] + 31) // 32 + 1) + 4)
             if pair_w:
                 return 2 * nd.shape[0] * ((nd.shape[1] + 15) // 16 + 1) + 2
             return h * hip.row_stride(w) // 32 + 2
@@ -98,8 +112,8 @@ def build_tile_lists(needs, last_layer: str, extra=None):
             starts = torch.empty(len(needs), caps[layer], dtype=torch.int32, device=dev)
             cover[layer] = (starts, k)
             for g in range(len(needs)):
-                nd, pair_w, _ = cover_src(g, layer)
-                cover_problems.append((nd, starts[g], counts_dev[k:k + 1], g, pair_w))
+                nd, pair_w, _, quad = cover_src(g, layer)
+                cover_problems.append((nd, starts[g], counts_dev[k:k + 1], g, pair_w, quad))
                 k += 1
         for i in range(0, len(cover_problems), 64):
             ops.cover_segments(cover_problems[i:i + 64])
@@ -143,7 +157,9 @@ def build_tile_lists(needs, last_layer: str, extra=None):
     cov_counts = [int(v) for v in both[len(bounds):len(bounds) + n_cov]]
     extra_host = both[len(bounds) + n_cov:] if extra is not None else None
     cnt = dict(zip(bounds, host))
-    out = {}
+    from .viewplan import TileLists
+    out = TileLists()
+    out.quads = frozenset(j[0] for j in jobs if isinstance(j[1], tuple) and j[1][0] in ("quad", "quadp"))
     if coarse:   # A/B: whole tiles - every live tile contributes all of its `group` segments
         for key, layer, bn, group in jobs:
             if group > 0:
