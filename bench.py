@@ -272,6 +272,29 @@ def late_epoch_leg(eng, schedule, args, wl, barrier):
                     "HIP rasteriser): the update's early half (side stream) walks all of it, the closing half the view's own chunks"}
 
 
+def resident_views_leg(eng, schedule, args, wl, barrier):
+    """A schedule that changes the view every step, from its SECOND epoch on: the per-view state of every view of the leg is
+    resident in HBM (``viewplan.ResidentView``; first visit during the untimed warm-up) and a view change copies it back
+    instead of recomputing it. Same engine, same steps, timed like the main leg."""
+    import copy
+    n_distinct = len({id(v) for v in schedule})
+    eng.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "96"))
+    a = copy.copy(args)
+    a.warmup, a.steps = max(args.warmup, n_distinct + 2), args.resident_steps
+    sched = [schedule[i % len(schedule)] for i in range(a.warmup + a.steps)]
+    h0 = eng.view_cache_hits
+    dt = timed_leg(eng, sched, a, wl, 1, None, barrier, None)
+    out = {"value": round(a.steps / dt, 3), "unit": "views/s", "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(1e3 * dt / a.steps, 3), "distinct_views": n_distinct,
+           "resident_mb_per_view": round(eng._resident_bytes / max(len(eng._resident), 1) / 2 ** 20, 2),
+           "view_changes_served_from_hbm": eng.view_cache_hits - h0,
+           "note": "every view change of the timed steps copies the view's state back from HBM (level maps, layer masks, "
+                   "content targets, active lists, sorted scatter plan, touch flags: computed at the view's first visit, in "
+                   "the warm-up) - the regime of epochs 2 .. 7 of a scene's schedule; the main leg computes every view change"}
+    eng.view_cache_gb = 0.0
+    return out
+
+
 def many_views_leg(eng, wl, args, dev, barrier, good, first_seeds):
     """The same engine and workload over ELEVEN more views (one warm-up view, then ``many_views_steps`` timed steps = ten
     views at index_repeat steps per view): the main leg's 2-3 views are the first of the camera path and happen to carry 20 % more
@@ -342,6 +365,8 @@ def parse_args(argv=None):
                     "workload with v_mfma_f32_32x32x2_f32 everywhere (reported as 'f32_mode'; 0 = skip)")
     ap.add_argument("--dense-adam", action="store_true", help="fused update over every texel instead of the chunks "
                     "some view has touched so far")
+    ap.add_argument("--resident-steps", type=int, default=200, help="N = 1, workloads that change the view every step: timed "
+                    "steps of the 'resident_views' leg (0 = skip)")
     ap.add_argument("--many-views-steps", type=int, default=200, help="N = 1: timed steps of the 'many_views' leg (the same "
                     "workload over ten more views instead of the main leg's first two or three; 0 = skip the leg)")
     ap.add_argument("--late-epoch-views", type=int, default=276, help="N = 1: views whose coverage seeds the ever-touched "
@@ -441,6 +466,10 @@ def _run(args):
         eng.pipeline_exchange = True      # (else the engine's default: pipelined from STYLEMESH_PIPELINE_MIN_MB flagged bytes on)
     eng.planned_scatter = not args.atomic_scatter
     eng.sparse_update = not args.dense_adam
+    # Every timed leg below COMPUTES each view change: the engine's resident views (a revisited view's state copied back
+    # from HBM instead of recomputed - the regime of a scene's later epochs) are switched off here and measured in a leg of
+    # their own (`resident_views`), so that no number of this line contains re-used results unless its name says so.
+    eng.view_cache_gb = 0.0
 
     # sharded: views of the scene shard over ranks - rank r takes views r, r + R, ... ; replicas: every rank has a scene
     # (a camera path) of its own; each view is repeated index_repeat times
@@ -626,6 +655,8 @@ def _run(args):
             out["many_views"] = many_views_leg(eng, wl, args, dev, barrier, good, on_dev)
         if world == 1 and args.late_epoch_views > 0 and eng.touched is not None and not args.dense_adam:
             out["late_epoch"] = late_epoch_leg(eng, schedule, args, wl, barrier)
+        if world == 1 and args.resident_steps > 0 and wl["index_repeat"] == 1:
+            out["resident_views"] = resident_views_leg(eng, schedule, args, wl, barrier)
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:

@@ -609,8 +609,10 @@ void conv3x3_split_kernel(ConvArgs a) {
                 const bool yok = (unsigned)y < (unsigned)(2 * up_Ho);
                 r_ok[k][0] = yok && (unsigned)x < (unsigned)(2 * up_Wo);
                 r_ok[k][1] = yok && (unsigned)(x + 2) < (unsigned)(2 * up_Wo);
-                // (rows / columns outside the image clamp to the pooled plane's own padding: a readable address)
-                const int yp = min(max((y >> 1) + 1, 0), up_Ho + 1), xp = max((x >> 1) + 1, 0);
+                // (rows / columns outside the image clamp into the pooled plane - its own padding row / columns: the 8-byte
+                // load of elements xp, xp + 1 stays inside the plane of every channel, and of the code image, which has no
+                // guard floats behind it)
+                const int yp = min(max((y >> 1) + 1, 0), up_Ho + 1), xp = min(max((x >> 1) + 1, 0), up_Wp - 2);
                 const int off_ = yp * up_Wp + xp;
                 r_src[k] = (off_ + grp * 8 * up_plane) * 4;
                 r_code[k] = (off_ + grp * up_plane) * 4;

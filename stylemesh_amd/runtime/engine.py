@@ -118,6 +118,31 @@ class _ViewLevel:
     pass
 
 
+class _capture:
+    """``torch.cuda.graph`` with Python's cyclic garbage collector paused: a collection INSIDE the capture region may run
+    the destructor of an unrelated, no longer referenced ``CUDAGraph`` (another engine's), whose ``hipGraphDestroy`` is an
+    error while a stream of the process captures in global mode - and ``~CUDAGraph`` turns that error into ``abort()``
+    (found when the resident views changed the moment at which collections happen in the test suite)."""
+
+    def __init__(self, g, **kw):
+        self.ctx = torch.cuda.graph(g, **kw)
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        self.ctx.__enter__()          # (collects once itself, before the capture begins)
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 class StepEngine:
     MAX_UV_LEVELS = 8   # per-(level, style layer) bounds of the derivative matrices are laid out for this many levels
     N_SLOTS = 2         # buffer sets of per-view constants: the current view + the views prepared ahead. (3 = TWO views in
@@ -231,6 +256,12 @@ class StepEngine:
         self.pipeline_exchange = {"1": True, "0": False}.get(os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "auto"), "auto")
         self.pipeline_min_bytes = int(float(os.environ.get("STYLEMESH_PIPELINE_MIN_MB", "32")) * (1 << 20))
         self.view_tiles = None
+        # Resident views (round 5; viewplan.ResidentView): the per-view state of up to view_cache_gb gigabytes of views
+        # stays in HBM after a view's first visit; a revisit copies it back into the slot's buffers instead of recomputing
+        # it. One rank, the grouped view path, no hipGraph replay. STYLEMESH_VIEW_CACHE_GB=0 switches it off.
+        self.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "96"))
+        self._resident, self._resident_bytes = {}, 0
+        self.view_cache_hits = self.view_cache_misses = 0
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
         self._gram_need = {}       # key -> slabs per mask
@@ -596,20 +627,31 @@ class StepEngine:
         grids = [stage(f"grid{i}", uv[0]) for i, uv in enumerate(uv_map)]   # a recorded step serves every view of the slot
         level_hw = tuple(tuple(g.shape[:2]) for g in grids)
         maps_levels = list(range(n_levels)) if cfg.use_depth_scaling else [n_levels - 1]
+        vkey = self._batch_key(batch)
+        res = None     # the view's resident state (a revisit), when it was kept and still fits this engine's configuration
+        if active_override is None and reducer is None and self.view_cache_gb > 0 and not self.use_graphs:
+            res = self._resident.get(vkey)
         active = list(maps_levels) if active_override is None else list(active_override)
+        if res is not None:
+            active = list(res.active)
         if len({level_hw[a] for a in active}) != len(active):
             raise ValueError("two UV levels of the same resolution are not supported")
         pk = (self._wslot, h, w, level_hw, tuple(active), ops.CONV_MODE, tuple(self.injected))
         plan = self._view_plans.get(pk)
         if plan is None:
             plan = self._view_plans[pk] = ViewPlan(self, self._wslot, h, w, level_hw, maps_levels, active)
+        if res is not None and res.plan_key != plan.cache_key:     # kept under another configuration: forget it
+            self._resident_bytes -= res.nbytes
+            del self._resident[vkey]
+            return self._set_view_fast(batch, reducer, defer, active_override, collective)
         self._mark("stage+plan")
-        # content target: VGG features of the captured image at its own resolution (losses :294); resized per level inside
-        # sm_view_masks
-        if plan.content_bufs is not None:
-            ops.image_to_fmap(rgb_dev, plan.content_bufs.act["img"])
-            self._content_pass(plan.content_bufs)
-        plan.launch_masks(mask_u8, ag, adeg, r64, o64, iw)
+        if res is None:
+            # content target: VGG features of the captured image at its own resolution (losses :294); resized per level inside
+            # sm_view_masks
+            if plan.content_bufs is not None:
+                ops.image_to_fmap(rgb_dev, plan.content_bufs.act["img"])
+                self._content_pass(plan.content_bufs)
+            plan.launch_masks(mask_u8, ag, adeg, r64, o64, iw)
         levels = []
         for i, rec in enumerate(plan.levels):
             lv = _ViewLevel()
@@ -624,7 +666,8 @@ class StepEngine:
                     lv.content_target = rec["content_target"]
             levels.append(lv)
         self._mark("masks")
-        plan.launch_lists()
+        if res is None:
+            plan.launch_lists()
         self._mark("lists")
         self.view, self.view_consts = levels, plan.consts
         self.view_tiles, self.view_sig = None, None
@@ -641,16 +684,33 @@ class StepEngine:
             skip = set(_vgg.POOL_OUTPUT) if (_vgg.FUSE_POOL_BWD and ops.CONV_MODE == "split2") else set()
             self._pending_grad_zero = [g for lv in act for g in self._grad_planes(lv.H, lv.W, skip)]
         self._scatter_levels = None
-        if self.planned_scatter and act:
-            if self._scatter_plan is None:
-                self._scatter_plan = ops.ScatterPlan(self.grads, self.arena.g)
-            self._scatter_plan.build([lv.grid for lv in act], [lv.pixel_weight for lv in act])
+        want_scatter = bool(self.planned_scatter and act)
+        if want_scatter and self._scatter_plan is None:
+            self._scatter_plan = ops.ScatterPlan(self.grads, self.arena.g)
+        if want_scatter:
             self._scatter_levels = [lv.index for lv in act]
-        self._mark("scatter_plan")
-        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
-        self._last_batch = batch
         if self.touched is not None:
             self._view_flags = self._persist(("view_flags", self.touched.numel()), lambda: torch.zeros_like(self.touched))
+        self.view_key = int(idx[0]) if torch.is_tensor(idx) else idx
+        self._last_batch = batch
+        if res is not None and (res.scatter_meta is not None) == want_scatter and res.has_flags == (self.touched is not None):
+            # a resident view: its state copied back (the plan's outputs, the sorted scatter plan, the touch flags)
+            from .viewplan import CachedPending
+            res.restore(plan, self._scatter_plan if want_scatter else None, self._view_flags)
+            self._pending_view = CachedPending(plan, res)
+            self.view_cache_hits += 1
+            self._mark("resident")
+            if not defer:
+                self._finish_pending_view(batch)
+            return
+        if res is not None:     # (kept without / with a scatter plan or flags this engine now wants / does not want)
+            self._resident_bytes -= res.nbytes
+            del self._resident[vkey]
+            return self._set_view_fast(batch, reducer, defer, active_override, collective)
+        if want_scatter:
+            self._scatter_plan.build([lv.grid for lv in act], [lv.pixel_weight for lv in act])
+        self._mark("scatter_plan")
+        if self.touched is not None:
             self._view_flags.zero_()
             for lv in act:   # the SAMPLED footprint (no pixel weights), see _set_view_body
                 ops.tex_touch_flags(self.grads, self.arena.g, lv.grid, None, self._view_flags, self.touched_log2)
@@ -679,7 +739,7 @@ class StepEngine:
             cap = torch.cuda.Stream(device=self.device)
             self._content_cap_streams = getattr(self, "_content_cap_streams", []) + [cap]
             cap.wait_stream(cur)
-            with torch.cuda.graph(g, stream=cap):
+            with _capture(g, stream=cap):
                 self.vgg.forward(cb)
             cur.wait_stream(cap)
             self._content_graphs[key] = g
@@ -706,7 +766,23 @@ class StepEngine:
         act = [lv for lv in self.view if lv.active]
         self.view_sig = (tuple((lv.index, lv.H, lv.W) for lv in act),
                          None if tiles is None else tuple(v[0].numel() for v in tiles.values()))
+        self._keep_resident(pend, batch)
         self._mark("finish")
+
+    def _keep_resident(self, pend, batch):
+        """After a view's first (computed) preparation: keep its state in HBM for the next visit, budget permitting."""
+        from .viewplan import PendingView, ResidentView
+        if (not isinstance(pend, PendingView) or pend.reducer is not None or self.view_cache_gb <= 0 or self.use_graphs
+                or self._union_flags is not None):
+            return
+        key = self._batch_key(batch)
+        if key in self._resident or self._resident_bytes >= self.view_cache_gb * (1 << 30):
+            return
+        self.view_cache_misses += 1
+        r = ResidentView(pend.plan, self._scatter_plan if self._scatter_levels is not None else None,
+                         self._view_flags if self.touched is not None else None, pend.plan.active)
+        self._resident[key] = r
+        self._resident_bytes += r.nbytes
 
     def _set_view_body(self, batch, reducer=None, defer=False):
         """Per-view constants of ``batch``. ``reducer`` (multi-GPU, a ``SparseGradReducer``; only when the per-view
@@ -1497,7 +1573,7 @@ class StepEngine:
                     self._optimizer_launch(world_size, self._hyper_dev)
                     return
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     self._optimizer_launch(world_size, self._hyper_dev)
                 self._opt_graph = (key, g)
             self._opt_graph[1].replay()
@@ -1625,7 +1701,7 @@ class StepEngine:
                 self._graph_warm[sig] = 1
                 return self.forward_backward()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 self.forward_backward()
             self._graphs[sig] = g
         g.replay()

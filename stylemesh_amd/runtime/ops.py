@@ -167,9 +167,24 @@ class ScatterPlan:
 
     def build(self, grids, pixel_weights):
         """``grids``: [h,w,2] tensors (one per level), ``pixel_weights``: [h,w] tensors or None entries."""
-        dev = self.arena.device
         hw = [(g.shape[-3], g.shape[-2]) for g in grids]
         n = 4 * len(self.grad_layers) * sum(h * w for h, w in hw)
+        self._ensure(n, hw)
+        k0, k1, v0, v1, tmp, cross = self.bufs
+        which = C.c_int(0)
+        if getattr(self, "_static_key", None) != (tuple(hw), k0.data_ptr()):   # the call's view-independent arguments, once
+            self._static_key = (tuple(hw), k0.data_ptr())
+            self._static = (hip.ptr_array(self.grad_layers), hip.int_array([h for h, _ in hw]),
+                            hip.int_array([w for _, w in hw]), ptr(k0), ptr(k1), ptr(v0), ptr(v1), ptr(tmp), tmp.numel(), ptr(cross))
+        gl, hs, ws_, pk0, pk1, pv0, pv1, ptmp, ntmp, pcross = self._static
+        hip.check(lib.sm_tex_scatter_plan(gl, self.lw, self.lh, len(self.grad_layers), ptr(self.arena), hip.ptr_array(grids),
+                                          hip.ptr_array(pixel_weights), hs, ws_, len(hw), pk0, pk1, pv0, pv1, ptmp, ntmp,
+                                          pcross, self.key_bits, C.byref(which), hip.stream()), "sm_tex_scatter_plan")
+        self.sorted_in = which.value
+
+    def _ensure(self, n, hw):
+        """Buffers for ``n`` entries over levels ``hw``."""
+        dev = self.arena.device
         # GROW-ONLY buffers: the views of a scene do not all populate the same UV levels, so n changes from view to view.
         # Re-allocating on every change would move the buffers under everything that holds their addresses (a recorded
         # step program, runtime/program.py) - and did: a replayed scatter wrote its chunk sums into freed memory.
@@ -187,17 +202,6 @@ class ScatterPlan:
             self.packed = torch.empty(planes, device=dev)
             self.generation += 1
         self.level_hw = hw
-        k0, k1, v0, v1, tmp, cross = self.bufs
-        which = C.c_int(0)
-        if getattr(self, "_static_key", None) != (tuple(hw), k0.data_ptr()):   # the call's view-independent arguments, once
-            self._static_key = (tuple(hw), k0.data_ptr())
-            self._static = (hip.ptr_array(self.grad_layers), hip.int_array([h for h, _ in hw]),
-                            hip.int_array([w for _, w in hw]), ptr(k0), ptr(k1), ptr(v0), ptr(v1), ptr(tmp), tmp.numel(), ptr(cross))
-        gl, hs, ws_, pk0, pk1, pv0, pv1, ptmp, ntmp, pcross = self._static
-        hip.check(lib.sm_tex_scatter_plan(gl, self.lw, self.lh, len(self.grad_layers), ptr(self.arena), hip.ptr_array(grids),
-                                          hip.ptr_array(pixel_weights), hs, ws_, len(hw), pk0, pk1, pv0, pv1, ptmp, ntmp,
-                                          pcross, self.key_bits, C.byref(which), hip.stream()), "sm_tex_scatter_plan")
-        self.sorted_in = which.value
 
     def live_share(self) -> float:
         """Share of the current view's entries that carry weight (the others sort to the tail and are skipped). Synchronises:
