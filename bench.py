@@ -278,7 +278,7 @@ def resident_views_leg(eng, schedule, args, wl, barrier):
     instead of recomputing it. Same engine, same steps, timed like the main leg."""
     import copy
     n_distinct = len({id(v) for v in schedule})
-    eng.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "96"))
+    eng.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "0")) or 96.0
     a = copy.copy(args)
     a.warmup, a.steps = max(args.warmup, n_distinct + 2), args.resident_steps
     sched = [schedule[i % len(schedule)] for i in range(a.warmup + a.steps)]

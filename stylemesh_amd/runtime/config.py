@@ -25,10 +25,11 @@ SWITCHES = {
     "STYLEMESH_RESIDENT": ("1", "tuning", "round 5: the 64-output-channel conv launches (conv1_2 forward / data gradient, conv2_1's data "
                            "gradient) take lists of vertical segment QUADS and the resident-input kernel (SM_LIST_QUADS); 0 = the "
                            "ring kernel on 64 x 256 tiles"),
-    "STYLEMESH_VIEW_CACHE_GB": ("96", "tuning", "round 5: HBM budget of the RESIDENT VIEWS - the per-view state (level maps, layer masks, content "
-                                "targets, active lists, sorted scatter plan, touch flags) of a view stays on the device after its first "
-                                "visit and is copied back at the next one instead of being recomputed (one rank, grouped view path); "
-                                "0 = off. bench.py switches it off for every leg but `resident_views`"),
+    "STYLEMESH_VIEW_CACHE_GB": ("0", "experiment", "round 5: HBM budget (GB) of the RESIDENT VIEWS - the per-view state (level maps, layer masks, "
+                                "content targets, active lists, sorted scatter plan, touch flags) of a view stays on the device after its "
+                                "first visit and is copied back at the next one instead of being recomputed (one rank, grouped view "
+                                "path). +7.5 % when the view changes every step and views recur (bench.py's `resident_views` leg), "
+                                "neutral on the reference's index_repeat-20 schedules (profiles/r05/resident_views.txt): opt-in"),
     "STYLEMESH_PAIR_IMAGES": ("0", "experiment", "round 5: VGG tensors stored as packed fp16 pairs by their producers under predicted "
                               "scales (verify-and-repeat protocol). Kernel time -3.7 %, step -3.6 % on c3: opt-in "
                               "(profiles/r05/pair_images_ab.txt)"),

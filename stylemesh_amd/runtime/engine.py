@@ -256,10 +256,13 @@ class StepEngine:
         self.pipeline_exchange = {"1": True, "0": False}.get(os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "auto"), "auto")
         self.pipeline_min_bytes = int(float(os.environ.get("STYLEMESH_PIPELINE_MIN_MB", "32")) * (1 << 20))
         self.view_tiles = None
-        # Resident views (round 5; viewplan.ResidentView): the per-view state of up to view_cache_gb gigabytes of views
-        # stays in HBM after a view's first visit; a revisit copies it back into the slot's buffers instead of recomputing
-        # it. One rank, the grouped view path, no hipGraph replay. STYLEMESH_VIEW_CACHE_GB=0 switches it off.
-        self.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "96"))
+        # Resident views (round 5; viewplan.ResidentView), OPT-IN (STYLEMESH_VIEW_CACHE_GB=<budget>): the per-view state of
+        # up to view_cache_gb gigabytes of views stays in HBM after a view's first visit; a revisit copies it back into the
+        # slot's buffers instead of recomputing it. One rank, the grouped view path, no hipGraph replay. Measured
+        # (profiles/r05/resident_views.txt): +7.5 % where the view changes EVERY step and views recur; neutral on the
+        # reference's multi-epoch schedules (index_repeat 20: the preparation already hides on a side stream, and the
+        # first epoch pays for the copies) - hence off by default.
+        self.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "0"))
         self._resident, self._resident_bytes = {}, 0
         self.view_cache_hits = self.view_cache_misses = 0
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
