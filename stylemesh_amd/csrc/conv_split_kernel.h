@@ -619,8 +619,12 @@ void conv3x3_split_kernel(ConvArgs a) {
                 r_ypar[k] = (y & 1) << 1;
                 r_p0[k] = 4 * cb - 1;
             } else {
+                // (window rows below the plane's bottom padding row - the quads of a level's last rows - read that row
+                // again: only outputs behind the last image row use them, and no load passes the plane's end by more than
+                // the 36 floats of its own width, whatever the level's size)
+                const int r_max = P.H + 1 - (qs[0] / P.Wp - 1);
                 r_p0[k] = 4 * cb;
-                r_src[k] = (grp * 8 * P.plane + qs[0] + 4 * cb + r * P.Wp) * 4;  // bytes from the shifted base (row ky = 0)
+                r_src[k] = (grp * 8 * P.plane + qs[0] + 4 * cb + min(r, r_max) * P.Wp) * 4;  // bytes from the shifted base (row ky = 0)
             }
             r_dst[k] = ((grp >> 1) * 4 + (grp & 1)) * RP + r * SEGP + r_p0[k];   // + j (position in the task) + part * 2 * RP
         }
