@@ -583,9 +583,10 @@ void conv3x3_split_kernel(ConvArgs a) {
         constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
         // Staging tasks: (group of 8 channels, window row r, block of four consecutive positions) - 8 x 6 x 9 = 432 per
         // phase, two per thread. A task loads its four positions of each channel with ONE 16-byte load (un-pooling input:
-        // its two pooled elements with one 8-byte load + the codes of both) - the single-position units of the first
-        // version spent 3 us of a block's 7 us staging time ISSUING 56 dword loads per thread through the CU's one
-        // address unit (tools/res_trace.py) - and builds the four positions' 8-channel units in registers.
+        // its two pooled elements with one 8-byte load + the codes of both) and builds the four positions' 8-channel units
+        // in registers. (The single-position units of the first version issued 56 dword loads per thread: 3.0 us of a
+        // block's 7 us staging time passed before the last of them was issued, 2.4 us now - tools/res_trace.py; -3 % on
+        // the launches.)
         // Window position (r, p) holds input position qs[0] - 1 + p + (r - 1) Wp.
         constexpr int RCB = 9, RT = RGRP * SM_RES_ROWS * RCB, RU = (RT + 255) / 256;
         f32x4* Rs = smem4;
