@@ -152,7 +152,6 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
                           new_view=(i % rep == 0), next_batch=upcoming(i))
     for i in range(args.warmup):
         step(i)
-    eng.finish_pending()
     ops.CONV_TIMER = timer
     if getattr(eng, "phase_timer", None) is not None:
         eng.phase_timer.enabled = True
@@ -162,7 +161,6 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
         if timer is not None:
             timer.enabled = (i - args.warmup) % args.timer_every == 0
         step(i)
-    eng.finish_pending()   # (pair images: steps the device invalidated are repeated inside the timed region)
     barrier()
     dt = time.perf_counter() - t0
     ops.CONV_TIMER = None
@@ -330,6 +328,58 @@ def measured_schedule(workload):
     return None
 
 
+def live_schedule_leg(args, wl):
+    """BASELINE's second metric UNDER THIS RUN'S CLOCK: the scene's fixed schedule - ``--schedule-epochs``
+    epochs (default: all 7) of index_repeat x 273 views - through ``python -m stylemesh_amd.model.optimize`` as a fresh
+    child process on an on-disk synthetic scene the HIP rasteriser writes first (stylemesh_amd/schedule.py). The child is
+    ended at ``--schedule-budget-s``; the epochs that finished by then are reported. Never fails the bench line: any error
+    is reported as ``live_error`` and the committed record stays the only figure."""
+    import shutil
+    import tempfile
+    from stylemesh_amd import schedule as SCH
+    epochs_full = 7
+    out = {"measured_schedule_live": False}
+    root = tempfile.mkdtemp(prefix="stylemesh_scene_")
+    try:
+        heights = [256, 432, 608, 784] if args.workload == "c3" else [256]
+        t0 = time.time()
+        SCH.write_scene(root, "scene0000_00", 276, heights)
+        torch.cuda.synchronize()
+        t_scene = time.time() - t0
+        cmd = SCH.cli_command(root, os.path.join(root, "logs"), args.workload, args.schedule_epochs, wl["index_repeat"], 4)
+        stdout, stderr, rc, wall = SCH.run_cli(cmd, deadline_s=args.schedule_budget_s)
+        epochs, loops, per_epoch = SCH.parse_epochs(stdout)
+        if not epochs:
+            out["live_error"] = f"no epoch finished (rc {rc}): {(stderr or stdout)[-400:]}"
+            return out
+        steps, secs = epochs[-1][1], epochs[-1][2]
+        per_epoch_steps = wl["index_repeat"] * 273
+        done = len(epochs)
+        out.update({
+            "measured_schedule_live": True,
+            "live_epochs": done, "live_epochs_requested": args.schedule_epochs, "live_steps": steps,
+            "live_seconds": round(secs, 1), "live_epoch_s": [e["seconds"] for e in per_epoch],
+            "live_epoch_views_per_s": [e["views_per_s"] for e in per_epoch],
+            "live_train_loop_views_per_s": [l[1] for l in loops],
+            "live_mean_views_per_s": round(steps / secs, 2),
+            "live_cli_wall_clock_s_incl_process_start_and_style_setup": round(wall, 1),
+            "live_scene_write_s": round(t_scene, 1),
+            "live_ended_by_budget": rc is None,
+            "live_source": "this run: python -m stylemesh_amd.model.optimize as a fresh child on a 276-view on-disk scene "
+                           "(HIP rasteriser), validation + texture exports included"})
+        if done >= epochs_full and steps == epochs_full * per_epoch_steps:
+            out["live_schedule_s"] = round(secs, 1)          # the WHOLE fixed schedule of one scene, measured
+        else:                                                # fewer epochs: the remaining ones at the measured epochs' mean
+            out["live_projected_schedule_s"] = round(secs / done * epochs_full, 1)
+        if rc not in (0, None):
+            out["live_error"] = f"the CLI ended with code {rc}: {stderr[-300:]}"
+    except BaseException as e:      # (a leg of a benchmark line: report, do not raise)
+        out["live_error"] = f"{type(e).__name__}: {e}"[:500]
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,8 +405,8 @@ def parse_args(argv=None):
                     "with the update of each arena range issued as its sums arrive (default: exchange, then update; "
                     "STYLEMESH_PIPELINE_EXCHANGE=1 selects it for the trainer)")
     ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
-                    "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate), 'split' "
-                    "(bf16x3-split operands, 6 partial products) or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
+                    "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate) "
+                    "or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
                     "STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event-time the conv launches of every n-th timed "
                     "step (event pairs around ~50 launches serialise the stream: timing every step costs 10-45 %% "
@@ -371,6 +421,10 @@ def parse_args(argv=None):
                     "workload over ten more views instead of the main leg's first two or three; 0 = skip the leg)")
     ap.add_argument("--late-epoch-views", type=int, default=276, help="N = 1: views whose coverage seeds the ever-touched "
                     "set of the 'late_epoch' leg (0 = skip the leg)")
+    ap.add_argument("--schedule-epochs", type=int, default=7, help="N = 1, workloads c3 / c2: epochs of the scene's fixed "
+                    "schedule run LIVE through the CLI as a child process (7 = the whole schedule, ~3 min for c3; 0 = skip)")
+    ap.add_argument("--schedule-budget-s", type=float, default=420.0, help="seconds after which the live schedule's child is "
+                    "ended (the epochs finished by then are reported)")
     ap.add_argument("--launch-timeout", type=float, default=None, help="self-launched N > 1 runs: seconds after which the "
                     "rank processes are ended (default: none)")
     return ap.parse_args(argv)
@@ -463,7 +517,7 @@ def _run(args):
     eng.sparse_tiles = not args.dense
     eng.overlap_style = args.overlap_style
     if args.pipeline_exchange:
-        eng.pipeline_exchange = True      # (else the engine's default: pipelined from STYLEMESH_PIPELINE_MIN_MB flagged bytes on)
+        eng.pipeline_exchange = True      # (else the engine's default: exchange-then-update; STYLEMESH_PIPELINE_EXCHANGE)
     eng.planned_scatter = not args.atomic_scatter
     eng.sparse_update = not args.dense_adam
     # Every timed leg below COMPUTES each view change: the engine's resident views (a revisited view's state copied back
@@ -526,15 +580,15 @@ def _run(args):
     if timer is not None:
         n_timed = len([i for i in range(args.steps) if i % args.timer_every == 0])
         n_all = ms_all = flops_all = 0.0      # every conv launch (the HBM-bound kernels carry 'hbm:' tags of their own)
-        for t_ in ("f32", "split", "split2"):
+        for t_ in ("f32", "split2"):
             n_, ms_, fl_ = timer.summary(t_)
             n_all, ms_all, flops_all = n_all + n_, ms_all + ms_, flops_all + fl_
         n_all = int(n_all)
-        # the dominant kernel: the bf16x3-split conv when the engine runs in split mode, else the fp32-MFMA conv
-        tag = ops.CONV_MODE if ops.CONV_MODE in ("split", "split2") else "f32"
+        # the dominant kernel: the fp16x2-split conv when the engine runs in split2 mode, else the fp32-MFMA conv
+        tag = "split2" if ops.CONV_MODE == "split2" else "f32"
         n, ms, flops = timer.summary(tag)
         ach = flops / (ms * 1e-3) / 1e12
-        products = {"split": 6, "split2": 3}.get(tag)
+        products = {"split2": 3}.get(tag)
         peak = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_FP32_MFMA_TFLOPS
         traffic, traffic_src = None, None   # HBM bytes per conv launch from the committed PMC pass of this workload
         rounds = sorted((d for d in os.listdir(os.path.join(REPO, "profiles")) if d[:1] == "r" and d[1:].isdigit()), reverse=True)
@@ -547,10 +601,9 @@ def _run(args):
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_live": False,
                     "traffic_unit": f"HBM bytes per launch (committed PMC pass, {traffic_src}; not measured in this run)",
                     "algorithmic_bytes_per_launch": round(timer.bytes.get(tag, 0.0) / max(n, 1)),
-                    "kernel": {"split": "conv3x3_split_kernel<NP=3> (bf16 x 3)", "split2": "conv3x3_split_kernel<NP=2> (fp16 x 2)"}
-                    .get(tag, "conv3x3_mfma_kernel"),
+                    "kernel": {"split2": "conv3x3_split_kernel (fp16 x 2)"}.get(tag, "conv3x3_mfma_kernel"),
                     "peak_basis": (f"16-bit dense MFMA peak 2500 TFLOP/s / {products} MFMA partial products per fp32 "
-                                   f"multiply-add (operands split into {'3 bf16' if tag == 'split' else '2 fp16'} parts, fp32 "
+                                   "multiply-add (operands split into 2 fp16 parts, fp32 "
                                    "accumulate); achieved = algorithmic fp32 FLOPs / time, i.e. frac = executed MFMA FLOPs "
                                    "/ 2500. A pure-MFMA loop on random operands sustains 0.72 of 2500 on this part "
                                    "(profiles/r02/mfma_rate_operand_sweep.txt)") if products else
@@ -607,11 +660,8 @@ def _run(args):
                f"views/sec (fwd+bwd into {wl['tex']}^2 texture)", "value": round(value, 3), "unit": "views/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": {"split2": "f32 (fp16x2 split multiply, fp32 accumulate)",
-                         "split": "f32 (bf16x3 split multiply, fp32 accumulate)"}.get(ops.CONV_MODE, "f32"),
-               "dtype_note": {"split": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the bf16 "
-                              "matrix cores with every fp32 operand split into 3 bf16 parts (6 partial products, fp32 accumulate)",
-                              "split2": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the fp16 "
+               "dtype": {"split2": "f32 (fp16x2 split multiply, fp32 accumulate)"}.get(ops.CONV_MODE, "f32"),
+               "dtype_note": {"split2": "all tensors, sums and the optimizer are fp32; the VGG convolutions multiply on the fp16 "
                               "matrix cores with every fp32 operand (scaled by a power of two from its tensor's recorded "
                               "max) split into 2 fp16 parts = 22 significand bits (3 partial products, fp32 accumulate) - an "
                               "emulation of the fp32 multiply, NOT native fp32: the strict-fp32 number of this run is f32_mode"}
@@ -636,11 +686,7 @@ def _run(args):
                "fused_update": {"ever_touched_fraction_of_arena": None if touched_fraction is None else round(touched_fraction, 4),
                                 "note": "the update skips 256-byte chunks no view has touched yet (exact for a "
                                         "zero-initialised texture); the fraction grows with the views of the scene"},
-               "exchange": exchange_report(eng, comm, reducer, args) if sharded else None,
-               # pair images: steps whose VGG tensors were stored as fp16 pairs under predicted
-               # scales; "invalid" = invalidated on the device (a tensor outgrew its scale), "repeated" = made up for -
-               # inside the timed region when they fell into it
-               "pair_images": dict(eng.pair_stats, enabled=bool(eng.pair_images), headroom=eng.pair_headroom)}
+               "exchange": exchange_report(eng, comm, reducer, args) if sharded else None}
         if world > 1:
             out["per_rank_views_per_s"] = [round(args.steps / t, 3) for t in per_rank_dt]
             out["ranks_consistent"] = ranks_consistent
@@ -649,6 +695,9 @@ def _run(args):
         sched = measured_schedule(args.workload)
         if sched is not None:
             out["scene_schedule"].update(sched)
+        # (not under a profiler: its preloaded library would ride into the child processes)
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+        live_sched_wanted = world == 1 and args.schedule_epochs > 0 and args.workload in ("c3", "c2") and not profiled
         if world == 1 and args.f32_steps > 0 and ops.CONV_MODE != "f32" and args.mfma is None:
             out["f32_mode"] = f32_leg(args, wl, cfg, schedule, dev, barrier)
         if world == 1 and args.many_views_steps > 0:
@@ -661,6 +710,11 @@ def _run(args):
             out["cpu_baseline"] = cpu_baseline(wl, views_cpu[(total_steps - 1) // wl["index_repeat"] % len(views)], args.cpu_steps)
         else:
             out["cpu_baseline"] = None
+        if live_sched_wanted:
+            # (last: the engine's legs are done; the child gets the GPU to itself apart from this process's idle buffers)
+            del eng
+            torch.cuda.empty_cache()
+            out["scene_schedule"].update(live_schedule_leg(args, wl))
         line = json.dumps(out)
     if world > 1:
         if comm is not None and hasattr(comm, "destroy"):

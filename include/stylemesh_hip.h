@@ -9,8 +9,8 @@
  * Conventions
  *  - extern "C", plain pointers and sizes, no torch types. All pointers are DEVICE pointers unless a
  *    parameter is documented as host. Every tensor, sum, loss and optimizer state is fp32 (the reference computes
- *    in fp32). The matrix-core kernels come in three arithmetic flavours with fp32 accumulation: exact fp32 MFMA
- *    (sm_conv3x3*, sm_gram_masked, sm_gram_backward), bf16x3-split operands (*_split: 6 partial products) and
+ *    in fp32). The matrix-core kernels come in two arithmetic flavours with fp32 accumulation: exact fp32 MFMA
+ *    (sm_conv3x3*, sm_gram_masked, sm_gram_backward) and
  *    fp16x2-split operands scaled by recorded power-of-two bounds (*_split2: 3 partial products; the default of the
  *    Python host: |err| <= 2^-21 sum|x||w| + 2^-38 (max|x| sum|w| + max|w| sum|x|) elementwise).
  *  - Every call is asynchronous on the caller's hipStream_t (passed as void*), allocates nothing and
@@ -46,7 +46,13 @@ extern "C" {
 #define SM_LIST_QUADS 32   /* (ABI 10; not an epilogue) sm_conv3x3_grouped_split2 with Cout = 64, Cin % 64 == 0 and a tile list
                             * whose every four entries are a QUAD - the same 32 columns of four consecutive rows: q, q + Wp,
                             * q + 2 Wp, q + 3 Wp (sm_cover_problem::quad) - takes the resident-input kernel: the block stages
-                            * its (4 + 2) x 34 input positions of 64 channels once. Same results, bit for bit. */
+                            * its (4 + 2) x 34 input positions of 64 channels once. Same results, bit for bit.
+                            * PRECONDITIONS (not checked - a list that breaks them gives wrong outputs, not an error;
+                            * sm_cover_segments with sm_cover_problem::quad = 1 produces conforming lists): every four
+                            * entries really are q, q + Wp, q + 2 Wp, q + 3 Wp of ONE problem (or padding behind a live
+                            * first entry); the quad's first row is image row 4 Y; with unpool_code the first column is
+                            * even. The kernel reads window rows of 36 floats with 16-byte loads: behind the last channel's
+                            * plane it relies on the SM_FMAP_GUARD floats every feature-map buffer must have. */
 
 /* ---- layout helpers (host, pure functions) -------------------------------------------------------- */
 int sm_fmap_row_stride(int W);        /* Wp */
@@ -134,7 +140,7 @@ int sm_tex_scatter_planned(const uint32_t* keys, const uint64_t* vals, size_t n_
  * grad_scale multiplies the data-term gradient first (1/R after an all-reduce over R ranks).
  * bias_corr1 = 1-beta1^t and bias_corr2 = 1-beta2^t are computed by the caller in double; the betas are
  * doubles because torch derives the fp32 constants 1-beta from Python doubles.
- * dev_hyper (optional, device, 3 floats - ABI 9): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2), valid}
+ * dev_hyper (optional, device, 2 floats): when given, the kernel reads {lr / bias_corr1, 1 / sqrt(bias_corr2)}
  * from it instead of the scalar arguments, so a captured launch (hipGraph) can be replayed across steps
  * (sm_adam_hyper_step maintains it on the device).
  * touched (optional, device, one int32 per 2^touched_chunk_log2 floats of the arena, log2 in [2, 24]): chunks whose
@@ -152,12 +158,11 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
 
 /* Device-side step counter of the fused update for hipGraph replay (torch.optim.Adam's state['step'] and the
  * bias corrections of model/model.py:387-395's optimizer): state = {lr, step} (device, 2 doubles). Adds 1 to the
- * step and writes dev_hyper = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step), 1} (3 floats, computed in double as
+ * step and writes dev_hyper = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} (2 floats, computed in double as
  * torch does). Captured together with sm_adam_fused(dev_hyper=...), every replay advances one step with no
- * step-dependent value crossing from the host. guard (ABI 9, optional, device int32 - sm_pair_check's status): when
- * *guard == 0 the step count stays and dev_hyper[2] = 0: sm_adam_fused(dev_hyper) then leaves p, m, v as they are
- * (sum(p^2) is still taken, the gradient still zeroed) - the step is repeated by the caller. */
-int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, const int32_t* guard, void* stream);
+ * step-dependent value crossing from the host. (ABI 11: the `guard` argument and the `valid` word of ABI 9 left with
+ * the pair images.) */
+int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream);
 
 /* Head of a training step in ONE launch: *reg_out = sum_l coef[l] * sumsq[l] (the regulariser loss `tex_reg` of the
  * current texture from the per-layer sums of squares the previous sm_adam_fused left; model/model.py:387-395), and a
@@ -227,9 +232,6 @@ typedef struct {
     const float* gram_mask1;
     const float* gram_amax_feat;
     const float* gram_amax_d;
-    /* ABI 9, sm_conv3x3_grouped_pair with SM_EPI_ADD (NULL elsewhere): the addend is read from these fp32 planes
-     * [Cout][plane(H, W)] instead of from `out` - required when the output is stored as pairs. */
-    const float* addend;
 } sm_conv_problem;
 /* "amax" bounds. An amax argument is a DEVICE array of sm_amax_floats() floats (64 slots, 256 bytes apart), zeroed by
  * the caller before the first launch that records into it; its VALUE is the maximum over the slots. Writers atomically
@@ -241,26 +243,11 @@ int sm_amax_floats(void);
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
                        int Cin_pad, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
                        size_t ws_floats, float* amax_out, void* stream);
-/* The same grouped convolution on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split into three
- * bf16 parts (x = h + m + l, 24 significand bits) and each product is evaluated as its six partial products of
- * weight >= 2^-16 with fp32 accumulation (stylemesh_amd/csrc/conv_split_kernel.h). Activations / outputs are
- * the same fp32 planes; wt3 = the weights pre-split by the host: [9 taps][Cin/16][3 parts][2][Cout][8] bf16 (as
- * uint16 bit patterns; runtime/ops.py:pack_conv_split builds it from the fp32 tap-major pack). Cin % 16 == 0,
- * Cout % 64 == 0; tiles cover sm_conv_split_tile_positions() = 128 positions. Same flags / ws semantics as sm_conv3x3_grouped.
- * tile_list (both split entry points, ABI 6): a list of 32-position SEGMENTS, not of whole tiles - entry =
- * (problem << 24) | q, q = index of the segment's first position in the padded plane (a multiple of 4, >= Wp; segments
- * of one launch must not overlap), consumed tile positions / 32 entries per tile: ANY live segments of ONE problem form
- * a tile (the dead 32-position ranges inside 128-position tiles were 8-17 % of all matrix instructions of a step);
- * every problem's run is padded to a whole number of tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and
- * must be a multiple of tile positions / 32. sm_cover_segments builds such lists from need maps.
- * Replaces the same reference operators (F.conv2d forward / backward of content_and_style_losses.py:11-32). */
-int sm_conv_split_tile_positions(void);
-int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3,
-                             const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
-                             float* ws, size_t ws_floats, float* amax_out, void* stream);
-/* The same convolution with TWO fp16 parts per fp32 operand and THREE partial products (hh' + hl' + lh', each exact in
+/* The same grouped convolution on the fp16 matrix cores (stylemesh_amd/csrc/conv_split_kernel.h), Cin % 16 == 0,
+ * Cout % 64 == 0: TWO fp16 parts per fp32 operand and THREE partial products (hh' + hl' + lh', each exact in
  * fp32, fp32 accumulate; v_mfma_f32_32x32x16_f16): x s = h + l carries 22 significand bits, the dropped ll' is below
- * 2^-22 of a product. fp16 has 5 exponent bits, so both operands are scaled by powers of two:
+ * 2^-22 of a product. Activations / outputs are the same fp32 planes. fp16 has 5 exponent bits, so both operands are
+ * scaled by powers of two:
  *   wt2 = the weights times a power of two s_w that puts max |w| into [2^14, 2^15), split by the host into
  *         [9 taps][Cin/16][2 parts][2][Cout][8] fp16 (runtime/ops.py:pack_conv_split2); w_scale_inv = 1 / s_w;
  *   amax_in (amax array, required) = an upper bound of max |x| over the input planes of all problems, recorded by
@@ -268,39 +255,23 @@ int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, co
  *         kernel scales x by the power of two that maps amax_in into [2^14, 2^15) while it stages the operand;
  *   the epilogue multiplies the accumulators by the (exact) inverse scales before bias / add / gate.
  * Elements more than 2^18 below amax_in lose low bits of l: an absolute error <= 2^-40 amax_in per element.
- * Same flags / tile_list / ws / amax_out semantics as above; a tile covers sm_conv_split2_tile_positions(Cout)
+ * tile_list (ABI 6): a list of 32-position SEGMENTS, not of whole tiles - entry = (problem << 24) | q, q = index of the
+ * segment's first position in the padded plane (a multiple of 4, >= Wp; segments of one launch must not overlap),
+ * consumed tile positions / 32 entries per tile: ANY live segments of ONE problem form a tile (the dead 32-position
+ * ranges inside 128-position tiles were 8-17 % of all matrix instructions of a step); every problem's run is padded to a
+ * whole number of tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and must be a multiple of tile positions
+ * / 32. sm_cover_segments builds such lists from need maps.
+ * ws (ABI 11): as sm_conv3x3_grouped, but the K-split tail is reduced INSIDE the launch (csrc/conv_tail.h: the unit that
+ * arrives last at its tile sums the tile's partial slabs and runs the epilogue - no second launch): the LAST 1024 words of
+ * ws[0 .. ws_floats) are the tail tiles' arrival counters. They must be ZERO when a workspace is first passed; every
+ * launch leaves them zero. One workspace per stream (concurrent launches must not share slabs or counters).
+ * Same flags / amax_out semantics as sm_conv3x3_grouped; a tile covers sm_conv_split2_tile_positions(Cout)
  * positions (128; 256 for the 64-channel layers, whose 64 x 256 tiles keep four 64 x 64 wave tiles busy). Error against
  * an fp64 convolution: same class as the fp32-MFMA kernel (tests/test_kernels_gpu.py). */
 int sm_conv_split2_tile_positions(int Cout);
 int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
                               const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
                               float* ws, size_t ws_floats, const float* amax_in, float* amax_out, void* stream);
-/* PAIR IMAGES (ABI 9; stylemesh_amd/csrc/conv_split_kernel.h). A feature map may be stored as packed fp16 pairs - one
- * 32-bit word per element, h | l << 16 with h = fp16(x s), l = fp16(x s - h): the two operand parts the fp16x2 kernels
- * otherwise build from the fp32 value every time they stage it (that conversion was 13.5 % of a four-level step). Same
- * [C][plane] addressing and size, zero word = zero. The power-of-two scale s must be fixed BEFORE the producer runs:
- *   sm_pair_roll   table[i] = {s, 1 / s} for every entry i of an amax book (n_entries arrays of sm_amax_floats() floats,
- *                  back to back) from the bound the book holds - what the PREVIOUS step recorded - times `headroom`
- *                  (>= 1; the engine uses 4): s maps headroom x bound into [2^14, 2^15); no bound yet: {1, 1};
- *   sm_conv3x3_grouped_pair  = sm_conv3x3_grouped_split2 with pair_in / pair_out / pair_gate: device pointers to the
- *                  {s, 1 / s} of the input / output / gate tensor, NULL = that tensor is fp32 planes (pair_in NULL:
- *                  amax_in gives the operand scale as before). Outputs saturate at +-65000 / s. amax_out records the
- *                  fp32 bound as always. SM_EPI_ADD with pair_out needs sm_conv_problem::addend;
- *   sm_pair_check  after the step's last producer: status[0] = 1 if for every listed entry bound x s is in [2^9, 65000]
- *                  (nothing saturated, at most 2^5 of precision head-room given away; an all-zero tensor always passes)
- *                  else 0, status[1] += 1 per failed check, status[2] += 1 per check, status[3] = first failing entry
- *                  or -1. sm_adam_hyper_step(guard = status) then marks the update invalid and sm_adam_fused leaves
- *                  p, m, v untouched (gradient zeroed): the caller repeats the step - with scales from the bounds the
- *                  failed attempt recorded.
- * Results equal the fp32-plane path's bit for bit whenever the table's scales equal the scales that path derives from
- * the exact bounds (same pairs, same product order); with head-room the pairs of elements more than 2^16 below the
- * tensor's maximum lose low bits of l earlier (absolute error <= 2^-36 of the maximum instead of 2^-40). */
-int sm_pair_roll(const float* amax_book, int n_entries, float headroom, float* table, void* stream);
-int sm_pair_check(const float* amax_book, const float* table, const int32_t* entries, int n, int32_t* status, void* stream);
-int sm_conv3x3_grouped_pair(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
-                            const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
-                            float* ws, size_t ws_floats, const float* amax_in, float* amax_out, const float* pair_in,
-                            const float* pair_out, const float* pair_gate, void* stream);
 /* max |x| over a feature map [C][plane(H,W)], max-ed into the amax array like the convolutions' amax_out: the operand
  * bound of sm_conv3x3_grouped_split2 for tensors no convolution produced (the deepest loss layer's gradient). */
 int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void* stream);
@@ -371,14 +342,13 @@ int sm_gram_workspace_slabs(int C, int H, int W);
 int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                    int H, int W, void* stream);
 
-/* K5a on the bf16 matrix cores at fp32 accuracy (bf16x3 split, 6 partial products, fp32 accumulate - see
- * sm_conv3x3_grouped_split). Same arguments and results class as sm_gram_masked, but the position ranges add into
+/* K5a on the fp16 matrix cores at fp32 accuracy (fp16x2 split, 3 partial products, fp32 accumulate - see
+ * sm_conv3x3_grouped_split2). Same arguments and results class as sm_gram_masked, but the position ranges add into
  * ONE slab with fp32 atomics (no reduction pass): afterwards S_k = the first sm_gram_split_num_slabs() = 1 slab
  * (upper-triangular 64x64 tiles valid; S0 / S1 need room for one [C][C] slab only). Stages whose 16 mask values
  * are all zero are skipped before their data is loaded.
- * amax_feat (optional, amax array): bound of max |feat| recorded by the producing conv - given, the operand is
- * split into two fp16 parts scaled by a power of two and three partial products are taken (sm_conv3x3_grouped_split2);
- * NULL = three bf16 parts, six products. */
+ * amax_feat (REQUIRED since ABI 11, amax array): bound of max |feat| recorded by the producing conv - the operand is
+ * split into two fp16 parts scaled by a power of two from it (sm_conv3x3_grouped_split2). */
 int sm_gram_split_num_slabs(void);
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
                          int H, int W, const float* amax_feat, void* stream);
@@ -399,8 +369,6 @@ typedef struct {
     float* S1;
     const float* amax_feat; /* amax array: bound of max |feat| */
     int C, H, W;
-    const float* pair_feat; /* ABI 9, optional: feat holds packed fp16 PAIRS (sm_conv3x3_grouped_pair: pair_out) under the
-                             * device {scale, 1 / scale} given here; amax_feat is then not read */
 } sm_gram_problem;
 int sm_gram_masked_split2_grouped(const sm_gram_problem* problems, int n_problems, void* stream);
 
@@ -427,11 +395,10 @@ int sm_style_loss(const float* S0, const float* S1, const float* counts, const f
 int sm_gram_backward(const float* feat, const float* mask0, const float* mask1, const float* D0,
                      const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* stream);
 
-/* K5c on the bf16 matrix cores (same split). ws: DEVICE scratch of sm_gram_backward_split_ws_bytes(C) bytes that
+/* K5c on the fp16 matrix cores (same split). ws: DEVICE scratch of sm_gram_backward_split_ws_bytes(C) bytes that
  * receives the split image of D0 / D1 (a small pack kernel runs first on the same stream).
- * amax_feat / amax_d (both or neither; amax arrays): bounds of max |feat| and max(|D0|, |D1|) - given, the
- * operands are split into two fp16 parts scaled by powers of two and three partial products are taken (as
- * sm_conv3x3_grouped_split2); NULL = three bf16 parts, six products. */
+ * amax_feat / amax_d (REQUIRED since ABI 11; amax arrays): bounds of max |feat| and max(|D0|, |D1|) - the operands are
+ * split into two fp16 parts scaled by powers of two from them (as sm_conv3x3_grouped_split2). */
 size_t sm_gram_backward_split_ws_bytes(int C);
 int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0,
                            const float* D1, float* dfeat, int C, int H, int W, int relu_gate, void* ws,
@@ -473,7 +440,6 @@ typedef struct {
     const float* amax_d;
     float* amax_out;        /* optional amax array: records max |dfeat| (see sm_conv3x3_grouped: amax_out) */
     int C, H, W, relu_gate;
-    const float* pair_feat; /* ABI 9, optional: as sm_gram_problem::pair_feat (dfeat stays fp32) */
 } sm_gram_bwd_problem;
 int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream);
 

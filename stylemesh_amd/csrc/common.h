@@ -13,29 +13,6 @@ namespace sm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// bf16x3 split of an fp32 number: x -> (h, m, l) bf16 with h + m + l == x to 24 significand bits; round-to-nearest
-// conversions (v_cvt_pk_bf16_f32). Six partial products of two such triples reproduce the fp32 product to 2^-23.
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-// eight fp32 values -> three MFMA operand vectors
-__device__ __forceinline__ void split3x8(const float (&x)[8], f32x4& vh, f32x4& vm, f32x4& vl) {
-    bf16x8 h, m, l;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        __bf16 a, b, d;
-        split3(x[c], a, b, d);
-        h[c] = a; m[c] = b; l[c] = d;
-    }
-    vh = __builtin_bit_cast(f32x4, h);
-    vm = __builtin_bit_cast(f32x4, m);
-    vl = __builtin_bit_cast(f32x4, l);
-}
 
 // ---- "amax" bounds: max |x| of what a launch writes = the operand bound of the fp16x2 kernels that read it ----------
 // A bound is SM_AMAX_SLOTS words spaced SM_AMAX_STRIDE floats (256 bytes) apart; its value is the maximum over the

@@ -16,8 +16,10 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "conv_tail.h"
 #include "conv_split_kernel.h"
 
+#define SM_TAIL_COUNTERS 1024   // >= the tail tiles of a launch (< 3 x 256 block slots)
 #ifndef SM_SPLIT2_BN256
 #define SM_SPLIT2_BN256 1   // fp16x2, Cout % 128 != 0: 64 x 256 tiles instead of 64 x 128
 #endif
@@ -219,151 +221,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     record_amax(a.amax_out, vmax, amax_seen);
 }
 
-// Tail second pass: one block per tail tile; out = epilogue(sum over its K-splits), 4 positions per thread.
-template <int BM, int BN, int FLAGS>
-__global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
-    const int tile = a.n_whole + blockIdx.x;
-    const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
-    const int e_ = blockIdx.y * 256 + threadIdx.x;
-    const int row = e_ / (BN / 4), c4 = (e_ - row * (BN / 4)) * 4;   // this thread's float4 of the BM x BN slab
-    ConvProblem P = a.p[0];
-    int n_tile = n_glob;
-    int q = 0;
-    bool alive = true;
-    if (a.tile_list && a.list_segments) {
-        // the split kernels' lists: BN / 32 entries per tile, (problem << 24) | first position of a segment, 0xFFFFFF = padding
-        const int* e = a.tile_list + (size_t)n_glob * (BN / 32);
-        const int gsel = e[0] >> 24;
-#pragma unroll
-        for (int g = 1; g < SM_MAX_GROUP; ++g)
-            if (g == gsel) P = a.p[g];
-        const int sg = e[c4 >> 5] & 0xFFFFFF;
-        alive = sg != 0xFFFFFF;
-        q = sg + (c4 & 31);
-    } else {
-        if (a.tile_list) {
-            const int e = a.tile_list[n_glob];
-            const int gsel = e >> 24;
-            n_tile = e & 0xFFFFFF;
-#pragma unroll
-            for (int g = 1; g < SM_MAX_GROUP; ++g)
-                if (g == gsel) P = a.p[g];
-        } else {
-#pragma unroll
-            for (int g = 1; g < SM_MAX_GROUP; ++g)
-                if (g < a.n_problems && n_glob >= a.tile_begin[g]) {
-                    P = a.p[g];
-                    n_tile = n_glob - a.tile_begin[g];
-                }
-        }
-        q = P.Wp + n_tile * BN + c4;
-    }
-    const int m0 = m_tile * BM, q_end = (P.H + 1) * P.Wp;
-    const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN);
-    const float amax_seen = amax_peek(a.amax_out);   // beside the slab loads, not behind the stores
-    {   // one float4 per thread; blockIdx.y walks the tile's BM*BN/1024 slices (many small blocks: latency-bound)
-        float m = 0.f;            // max |output| of this thread (all lanes stay active for the wave reduction below)
-        if (alive && q < q_end) { // q_end and q are multiples of 4
-            f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
-            for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
-            const int co = m0 + row;
-            const size_t o = (size_t)co * P.plane + q;
-            f32x4 prev;
-            bool open[4] = {true, true, true, true};
-            if (FLAGS & SM_EPI_ADD) prev = *reinterpret_cast<const f32x4*>((P.addend ? P.addend : P.out) + o);
-            if (FLAGS & SM_EPI_RELU_MASK) {
-                // gate planes as pair images (conv_split_kernel.h): x > 0 <=> word != 0
-                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                const u32x4_ gw = *reinterpret_cast<const u32x4_*>(P.gate + o);
-                // (the element goes through a scalar first: __builtin_bit_cast applied to a vector ELEMENT reads element 0
-                // for every index on this compiler)
-                const bool gate_pair = a.pair_gate != nullptr;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned w = gw[j];
-                    const float f = __builtin_bit_cast(float, w);
-                    open[j] = gate_pair ? w != 0u : f > 0.f;
-                }
-            }
-            const float b = (FLAGS & SM_EPI_BIAS_RELU) ? a.bias[co] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = v[j];
-                if (FLAGS & SM_EPI_BIAS_RELU) x = fmaxf(x + b, 0.f);
-                if (FLAGS & SM_EPI_ADD) x += prev[j];
-                if (FLAGS & SM_EPI_RELU_MASK) x = open[j] ? x : 0.f;
-                v[j] = interior(q + j, P.H, P.W, P.Wp) ? x : 0.f;
-                m = fmaxf(m, fabsf(v[j]));
-            }
-            if (a.pair_out != nullptr) {
-                const float ps = a.pair_out[0];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = v[j];
-                    const unsigned w = pair_encode(x, ps);
-                    v[j] = __builtin_bit_cast(float, w);
-                }
-            }
-            *reinterpret_cast<f32x4*>(P.out + o) = v;
-        }
-        record_amax(a.amax_out, m, amax_seen);
-    }
-}
-
-// Tail second pass of a forward conv with SM_EPI_POOL (split kernels; the tile's segments are vertical pairs, see
-// conv_split_kernel.h): block = (tail tile, 8-channel group, two segment pairs); thread = (channel of the group, one of
-// the 32 pooling windows): sums the K-splits of its four elements, bias + ReLU, 2x2 maximum + argmax code; the eight
-// channels' nibbles meet through three lane exchanges. Writes the pooled map and the code image only.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
-    const int tile = a.n_whole + blockIdx.x;
-    const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
-    const int c = threadIdx.x & 7, w = threadIdx.x >> 3;         // channel of the group, window 0..31 of the block
-    const int pair = blockIdx.z * 2 + (w >> 4), X = w & 15;      // segment pair of the tile, window of the pair
-    const int* e = a.tile_list + (size_t)n_glob * (BN / 32);
-    const int gsel = e[0] >> 24;
-    ConvProblem P = a.p[0];
-#pragma unroll
-    for (int g = 1; g < SM_MAX_GROUP; ++g)
-        if (g == gsel) P = a.p[g];
-    const int sg = e[2 * pair] & 0xFFFFFF;
-    const float amax_seen = amax_peek(a.amax_out);
-    float m = 0.f;
-    unsigned code = 4u;
-    bool ok = false;
-    int qo = 0;
-    const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
-    const int row = blockIdx.y * 8 + c;
-    if (sg != 0xFFFFFF) {
-        const int q = sg + 2 * X;
-        const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
-        ok = ((yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
-        qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
-        const float* wt = a.ws + (size_t)blockIdx.x * a.splits * (BM * BN) + (size_t)row * BN + pair * 64 + 2 * X;
-        f32x2 t = *reinterpret_cast<const f32x2*>(wt), b = *reinterpret_cast<const f32x2*>(wt + 32);
-        for (int s = 1; s < a.splits; ++s) {
-            t += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN));
-            b += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN) + 32);
-        }
-        const float bv = a.bias[m_tile * BM + row];
-        const float v00 = fmaxf(t[0] + bv, 0.f), v01 = fmaxf(t[1] + bv, 0.f), v10 = fmaxf(b[0] + bv, 0.f), v11 = fmaxf(b[1] + bv, 0.f);
-        m = v00;
-        code = 0u;
-        if (v01 > m) { m = v01; code = 1u; }
-        if (v10 > m) { m = v10; code = 2u; }
-        if (v11 > m) { m = v11; code = 3u; }
-        if (!(m > 0.f)) code = 4u;
-        if (ok) P.pool_out[(size_t)(m_tile * BM + row) * plane_o + qo] =
-            a.pair_out != nullptr ? __builtin_bit_cast(float, pair_encode(m, a.pair_out[0])) : m;
-    }
-    unsigned word = code << (4 * c);
-    word |= (unsigned)__shfl_xor((int)word, 1, 64);
-    word |= (unsigned)__shfl_xor((int)word, 2, 64);
-    word |= (unsigned)__shfl_xor((int)word, 4, 64);
-    if (ok && c == 0) P.pool_code[(size_t)((m_tile * BM) / 8 + blockIdx.y) * plane_o + qo] = word;
-    record_amax(a.amax_out, ok ? m : 0.f, amax_seen);
-}
-
 // max |x| over the interior rows of C planes (producers without an amax epilogue: the deepest loss layer's gradient)
 __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict__ in, int plane, int q_begin, int q_end,
                                                         float* amax_out) {
@@ -377,55 +234,8 @@ __global__ __launch_bounds__(256) void fmap_amax_kernel(const float* __restrict_
     record_amax(amax_out, m, seen);
 }
 
-// ---- pair images (conv_split_kernel.h): the scale table of a step and its verification
-// table[i] = {s, 1 / s}: the power of two that maps headroom x (the bound entry i of the amax book holds - what the
-// PREVIOUS step recorded) into [2^14, 2^15); an entry without a bound yet gets {1, 1}. One wave per entry.
-__global__ __launch_bounds__(64) void pair_roll_kernel(const float* __restrict__ book, float headroom, float* __restrict__ table) {
-    const float v = amax_read(book + (size_t)blockIdx.x * (SM_AMAX_SLOTS * SM_AMAX_STRIDE));
-    float inv;
-    const float s = pow2_scale_for(v * headroom, inv);
-    if (threadIdx.x == 0) {
-        table[2 * blockIdx.x] = s;
-        table[2 * blockIdx.x + 1] = inv;
-    }
-}
-// The step stored entry list[k] as pairs under table[.]: valid if nothing saturated (bound x s <= 65000) and the
-// operands kept their precision (bound x s >= 2^9: at most 2^5 below the ideal window - an absolute error floor of
-// 2^-34 of the tensor's maximum instead of 2^-39; an all-zero tensor is fine under any scale). status[0] = 1 / 0 (this
-// step), status[1] += 1 per invalid step, status[2] += 1 per check, status[3] = first failing entry of this step or -1.
-__global__ __launch_bounds__(64) void pair_check_kernel(const float* __restrict__ book, const float* __restrict__ table,
-                                                        const int* __restrict__ list, int n, int* __restrict__ status) {
-    int bad = -1;
-    for (int k = 0; k < n; ++k) {
-        const int i = list[k];
-        const float am = amax_read(book + (size_t)i * (SM_AMAX_SLOTS * SM_AMAX_STRIDE));
-        const float v = am * table[2 * i];
-        const int ex = (int)((__builtin_bit_cast(unsigned, am) >> 23) & 0xff);
-        const bool unscalable = ex < 16 || ex > 250;   // pow2_scale_for gives up on such a bound: scale 1 is all there is
-        if (!(v <= SM_F16_CLAMP) || (v != 0.f && v < 512.f && !(unscalable && table[2 * i] == 1.f))) bad = bad < 0 ? i : bad;
-    }
-    if (threadIdx.x == 0) {
-        status[0] = bad < 0 ? 1 : 0;
-        status[1] += bad < 0 ? 0 : 1;
-        status[2] += 1;
-        status[3] = bad;
-    }
-}
-
-// SPLIT = false: exact fp32 MFMA kernel; true: bf16x3-split kernel of conv_split_kernel.h (KC must be 16).
-// KG = 2 (fp16x2 kernel, launches of at most one tile per CU): blocks of two wave groups that split the block's K range
-// between them (conv_split_kernel.h) - chosen below, never by the caller.
-#ifndef SM_CONV_KG2_DEFAULT
-#define SM_CONV_KG2_DEFAULT 0   // measured (profiles/r05/kg2_c2_layers.txt): -8 % on the one-level layers - the groups run in lock-step
-#endif
-#ifndef SM_CONV_SMALL_BM64_DEFAULT
-#define SM_CONV_SMALL_BM64_DEFAULT 0   // (tiles of 128 x 128 up to which a launch takes 64 x 128 tiles; 0 = never)
-#endif
-#ifndef SM_CONV_KG2_BUILD
-#define SM_CONV_KG2_BUILD 0   // 1: compile the two-wave-group variants (selected with SM_CONV_KG=2)
-#endif
-template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, int NP = 3, bool UNPOOL = false, int KG = 1,
-          bool PIN = false, bool RES = false>
+// SPLIT = false: exact fp32 MFMA kernel; true: fp16x2-split kernel of conv_split_kernel.h (KC must be 16).
+template <int BM, int BN, int KC, int WGM, int WGN, int FLAGS, bool SPLIT = false, bool UNPOOL = false, bool RES = false>
 static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStream_t s) {
     ConvArgs a = a0;
     a.m_tiles = a.Cout / BM;
@@ -438,16 +248,10 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     a.n_tiles = a.tile_list ? (SPLIT ? n_list / (BN / 32) : n_list) : a.tile_begin[a.n_problems];
     if (a.n_tiles == 0) return 0;
     constexpr size_t lds = RES ? conv_resident_lds_bytes()
-                         : SPLIT ? KG * conv_split_lds_bytes(BM, BN, NP)
+                         : SPLIT ? conv_split_lds_bytes(BM, BN)
                                  : (size_t)(9 * KC * BM + 3 * KC * (BN + 8)) * sizeof(float);
     if (RES && (a.tile_list == nullptr || a.Cin_pad % 64 != 0)) return (int)hipErrorInvalidValue;   // quads of a list; 64-channel phases
     const int tiles = a.m_tiles * a.n_tiles, chunks = a.Cin_pad / KC;
-    if constexpr (SM_CONV_KG2_BUILD && SPLIT && NP == 2 && KG == 1 && !PIN && (FLAGS & SM_EPI_GRAM) == 0) {
-        // small grids (<= one tile per CU): 512-thread blocks of two wave groups; SM_CONV_KG=1 keeps the 4-wave blocks (A/B)
-        static const bool kg2 = getenv("SM_CONV_KG") ? atoi(getenv("SM_CONV_KG")) == 2 : SM_CONV_KG2_DEFAULT != 0;
-        if (kg2 && tiles <= SM_NUM_CU && chunks % 2 == 0)
-            return launch_conv<BM, BN, KC, WGM, WGN, FLAGS, SPLIT, NP, UNPOOL, 2>(a0, n_list, ws_floats, s);
-    }
     // Full rounds of one tile per resident block slot run whole; the tail of `rem` tiles is split along K so that
     // it becomes about one more (short) round of rem * splits small units. Pick the split count that minimises the
     // tail's duration ceil(rem * S / slots) / S, each split keeping >= 2 K-chunks. (The split kernel keeps two
@@ -463,30 +267,11 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 #endif
     // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
     // (64 x 128 tiles - the small-grid choice of round 5, dispatch_conv_split2 - are sized for three blocks per CU)
-    constexpr int SLOTS = SM_NUM_CU * ((SPLIT && NP == 2) ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
+    constexpr int SLOTS = SM_NUM_CU * (SPLIT ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
     a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;
     int rem = tiles - a.n_whole;
-    if constexpr (KG == 2) {
-        // tiles <= CUs: all of them whole (S = 1) or all of them split S ways. A unit of cps chunks takes its groups
-        // cps / 2 chunk times + ~1 of prologue / exchange / epilogue; a split launch pays the second pass on top
-        // (SM_CONV_SPLIT_PENALTY, in the same unit). Every unit's chunk count stays even (cps even, chunks even).
-        static const float penalty = getenv("SM_CONV_SPLIT_PENALTY") ? (float)atof(getenv("SM_CONV_SPLIT_PENALTY")) : SM_CONV_SPLIT_PENALTY_DEFAULT;
-        a.n_whole = tiles;
-        rem = 0;
-        float best = chunks * 0.5f + 1.f;
-        if (a.ws != nullptr && chunks >= 4) {
-            const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)tiles * BM * BN)});
-            for (int S = 2; S <= max_s; ++S) {
-                const int cps = ((chunks + S - 1) / S + 1) & ~1, S_eff = (chunks + cps - 1) / cps;
-                if (S_eff < 2) continue;
-                const float cost = (float)((tiles * S_eff + SM_NUM_CU - 1) / SM_NUM_CU) * (cps * 0.5f + 1.f) + penalty;
-                if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
-            }
-        }
-        if (a.splits > 1) { a.n_whole = 0; rem = tiles; }
-    } else
     if (a.ws != nullptr && rem > 0 && chunks >= 4) {
         const int max_s = (int)std::min<size_t>({(size_t)chunks / 2, (size_t)16, ws_floats / ((size_t)rem * BM * BN)});
         // cost of the tail in units of one whole tile; every unit pays ~1 chunk of fixed prologue / epilogue time
@@ -506,32 +291,39 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
         if (force_s > 0 && a.ws != nullptr && tiles - tiles / SLOTS * SLOTS > 0) {
             a.n_whole = tiles / SLOTS * SLOTS;
             rem = tiles - a.n_whole;
-            const int S = std::max(1, std::min({force_s, chunks / KG, (int)(ws_floats / ((size_t)rem * BM * BN))}));
-            a.chunks_per_split = ((chunks + S - 1) / S + KG - 1) / KG * KG;
+            const int S = std::max(1, std::min({force_s, chunks, (int)(ws_floats / ((size_t)rem * BM * BN))}));
+            a.chunks_per_split = (chunks + S - 1) / S;
             a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
         }
     }
     if (RES) a.splits = 1;                       // resident input: whole tiles only (K <= 1152: nothing to split)
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
+    // fp16x2 kernel: the tail is reduced INSIDE the launch (conv_tail.h) - the counters are the last SM_TAIL_COUNTERS words
+    // of the workspace, zero between launches (sm_conv3x3_grouped_split2: ws). SM_CONV_TAIL_PASS=1: the second-pass launch.
+    a.tail_count = nullptr;
     if constexpr (SPLIT) {
-        static_assert(KC == 16, "one bf16 MFMA K-step per tap");
+        static const bool tail_pass = getenv("SM_CONV_TAIL_PASS") != nullptr && atoi(getenv("SM_CONV_TAIL_PASS")) != 0;
+        if (rem > 0 && !tail_pass) a.tail_count = reinterpret_cast<int*>(a.ws + ws_floats);   // (ws_floats: see the caller)
+    }
+    if constexpr (SPLIT) {
+        static_assert(KC == 16, "one fp16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
         static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && !UNPOOL && !PIN && !RES) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !PIN && !RES, NP, UNPOOL, KG, PIN, RES>
-                                                    : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, NP, UNPOOL, KG, PIN, RES>;
+        auto k = (stamp && !UNPOOL && !RES) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !RES, UNPOOL, RES>
+                                            : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, UNPOOL, RES>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
             attr_done = true;
         }
-        hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256 * KG), lds, s, a);
+        hipLaunchKernelGGL(k, dim3(a.n_whole + rem * a.splits), dim3(256), lds, s, a);
     } else {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<BM, BN, KC, WGM, WGN, FLAGS>), dim3(a.n_whole + rem * a.splits),
                            dim3(256), lds, s, a);
     }
     SM_LAUNCH_CHECK();
-    if (rem > 0) {
+    if (rem > 0 && a.tail_count == nullptr) {
         if constexpr ((FLAGS & SM_EPI_POOL) != 0)
             hipLaunchKernelGGL((conv_tail_pool_kernel<BM, BN>), dim3(rem, BM / 8, BN / 128), dim3(256), 0, s, a);
         else
@@ -541,13 +333,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     return 0;
 }
 
-template <int FLAGS>
-static int dispatch_conv_split(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
-    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true>(a, n_list, ws_floats, s);
-    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true>(a, n_list, ws_floats, s);
-}
-
-template <int FLAGS, bool UNPOOL = false, bool PIN = false>
+template <int FLAGS, bool UNPOOL = false>
 static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
 #if SM_SPLIT2_BN256
     // 64 output channels: 64 x 256 tiles (the same 12 MFMAs per stage and wave as the 128-row tile), waves 2 x 2 with
@@ -557,29 +343,11 @@ static int dispatch_conv_split2(const ConvArgs& a, int n_list, size_t ws_floats,
 #define SM_SPLIT2_W64GM 2
 #endif
     if (a.Cout % 128 != 0)
-        return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
+        return launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, FLAGS, true, UNPOOL>(a, n_list, ws_floats, s);
 #else
-    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
+    if (a.Cout % 128 != 0) return launch_conv<64, 128, 16, 2, 2, FLAGS, true, UNPOOL>(a, n_list, ws_floats, s);
 #endif
-#if SM_SPLIT2_BM256
-    // one wave per SIMD with a 64 x 128 wave tile (128 accumulator registers): 24 MFMAs per stage and wave
-    if (a.Cout % 256 == 0) return launch_conv<256, 128, 16, 4, 1, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
-#endif
-    // Small grids (round 5; a one-level view: 12 - 172 tiles of 128 x 128 on 256 CUs): a lone 128 x 128 block per CU is
-    // bound by the LATENCY of its own pipeline, not by its MFMAs (without any MFMA the c2 layers still take 78 % of their
-    // time: profiles/r05/c2_layer_ablation.txt). 64 x 128 tiles double the blocks, three of them share a CU (34.8 KB of LDS,
-    // 129 VGPRs) and cover each other's stalls; the K-split count is chosen for 3 x 256 slots.
-    {
-        static const int small = getenv("SM_CONV_SMALL_BM64") ? atoi(getenv("SM_CONV_SMALL_BM64")) : SM_CONV_SMALL_BM64_DEFAULT;
-        if (small && (FLAGS & SM_EPI_GRAM) == 0) {
-            long long ntile = 0;
-            if (a.tile_list) ntile = n_list / 4;
-            else for (int g = 0; g < a.n_problems; ++g) ntile += (a.p[g].H * a.p[g].Wp + 127) / 128;
-            if (ntile * (a.Cout / 128) <= small)
-                return launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
-        }
-    }
-    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, 2, UNPOOL, 1, PIN>(a, n_list, ws_floats, s);
+    return launch_conv<128, 128, 16, SM_SPLIT_WGM, 4 / SM_SPLIT_WGM, FLAGS, true, UNPOOL>(a, n_list, ws_floats, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -924,18 +692,7 @@ extern "C" {
 
 int sm_fmap_row_stride(int W) { return sm::row_stride(W); }
 int sm_fmap_plane(int H, int W) { return sm::plane_size(H, W); }
-int sm_abi_version(void) { return 10; }
-
-static int conv_dispatch_flags_split(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
-    switch (flags) {
-        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split<SM_EPI_BIAS_RELU>(a, n_list, ws_floats, s);
-        case 0: return sm::dispatch_conv_split<0>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split<SM_EPI_RELU_MASK>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_RELU_MASK | SM_EPI_ADD>(a, n_list, ws_floats, s);
-        case SM_EPI_ADD: return sm::dispatch_conv_split<SM_EPI_ADD>(a, n_list, ws_floats, s);
-        default: return (int)hipErrorInvalidValue;
-    }
-}
+int sm_abi_version(void) { return 11; }
 
 }  // extern "C"
 // SM_LIST_QUADS: the list holds vertical quads of segments and the launch has 64 output channels - the resident-input
@@ -945,11 +702,10 @@ static int launch_conv_resident(sm::ConvArgs& a, int n_list, hipStream_t s) {
 #ifndef SM_RES_TRACE
     a.ws = nullptr;
 #endif
-    return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, 2, UNPOOL, 1, false, true>(a, n_list, 0, s);
+    return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, UNPOOL, true>(a, n_list, 0, s);
 }
 static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool unpool, hipStream_t s) {
-    if (a.Cout != 64 || a.Cin_pad % 64 != 0 || a.tile_list == nullptr || a.pair_in || a.pair_out || a.pair_gate)
-        return (int)hipErrorInvalidValue;
+    if (a.Cout != 64 || a.Cin_pad % 64 != 0 || a.tile_list == nullptr) return (int)hipErrorInvalidValue;
     if (unpool) {
         switch (flags) {
             case SM_EPI_RELU_MASK | SM_EPI_GRAM: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_GRAM, true>(a, n_list, s);
@@ -967,40 +723,36 @@ static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool u
         default: return (int)hipErrorInvalidValue;
     }
 }
-template <bool PIN>
 static int conv_dispatch_flags_split2_t(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (unpool) {   // the data gradients below a max-pool: gated by the pool input's own producer conv
         if (flags == (SM_EPI_RELU_MASK | SM_EPI_GRAM)) {   // + the Gram backward of the 64-channel output layer; whole tiles only
             a.ws = nullptr;
             if (a.Cout == 64)
-                return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true, 1, PIN>(a, n_list, 0, s);
+                return sm::launch_conv<64, 256, 16, SM_SPLIT2_W64GM, 4 / SM_SPLIT2_W64GM, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, true>(a, n_list, 0, s);
             if (a.Cout == 128)   // (four waves of 32 rows: the 128-row tile holds all channels of its positions)
-                return sm::launch_conv<128, 128, 16, 4, 1, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, 2, true, 1, PIN>(a, n_list, 0, s);
+                return sm::launch_conv<128, 128, 16, 4, 1, SM_EPI_RELU_MASK | SM_EPI_GRAM, true, true>(a, n_list, 0, s);
             return (int)hipErrorInvalidValue;
         }
         switch (flags) {
-            case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true, PIN>(a, n_list, ws_floats, s);
-            case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true, PIN>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, ws_floats, s);
             default: return (int)hipErrorInvalidValue;
         }
     }
     switch (flags) {
-        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU, false, PIN>(a, n_list, ws_floats, s);
-        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU | SM_EPI_POOL, false, PIN>(a, n_list, ws_floats, s);
-        case 0: return sm::dispatch_conv_split2<0, false, PIN>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, false, PIN>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, false, PIN>(a, n_list, ws_floats, s);
-        case SM_EPI_ADD:
-            if constexpr (!PIN) return sm::dispatch_conv_split2<SM_EPI_ADD>(a, n_list, ws_floats, s);
-            return (int)hipErrorInvalidValue;
+        case SM_EPI_BIAS_RELU: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU, false>(a, n_list, ws_floats, s);
+        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return sm::dispatch_conv_split2<SM_EPI_BIAS_RELU | SM_EPI_POOL, false>(a, n_list, ws_floats, s);
+        case 0: return sm::dispatch_conv_split2<0, false>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK, false>(a, n_list, ws_floats, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_RELU_MASK | SM_EPI_ADD, false>(a, n_list, ws_floats, s);
+        case SM_EPI_ADD: return sm::dispatch_conv_split2<SM_EPI_ADD>(a, n_list, ws_floats, s);
         default: return (int)hipErrorInvalidValue;
     }
 }
 extern "C" {
 static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
     if (flags & SM_LIST_QUADS) return conv_dispatch_resident(a, n_list, flags & ~SM_LIST_QUADS, unpool, s);
-    return a.pair_in != nullptr ? conv_dispatch_flags_split2_t<true>(a, n_list, flags, ws_floats, unpool, s)
-                                : conv_dispatch_flags_split2_t<false>(a, n_list, flags, ws_floats, unpool, s);
+    return conv_dispatch_flags_split2_t(a, n_list, flags, ws_floats, unpool, s);
 }
 
 static int conv_dispatch_flags(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, hipStream_t s) {
@@ -1025,23 +777,7 @@ int sm_fmap_amax(const float* planes, int C, int H, int W, float* amax_out, void
     return 0;
 }
 
-int sm_pair_roll(const float* amax_book, int n_entries, float headroom, float* table, void* stream) {
-    if (n_entries < 1 || !(headroom >= 1.f)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sm::pair_roll_kernel, dim3(n_entries), dim3(64), 0, (hipStream_t)stream, amax_book, headroom, table);
-    SM_LAUNCH_CHECK();
-    return 0;
-}
-
-int sm_pair_check(const float* amax_book, const float* table, const int32_t* entries, int n, int32_t* status, void* stream) {
-    if (n < 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sm::pair_check_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_book, table,
-                       reinterpret_cast<const int*>(entries), n, reinterpret_cast<int*>(status));
-    SM_LAUNCH_CHECK();
-    return 0;
-}
-
 int sm_conv_tile_positions(int Cin_pad, int Cout) { return Cin_pad == 4 ? 1024 : (Cout % 128 != 0 ? 256 : 128); }
-int sm_conv_split_tile_positions(void) { return 128; }
 int sm_conv_split2_tile_positions(int Cout) { return (SM_SPLIT2_BN256 && Cout % 128 != 0) ? 256 : 128; }
 
 int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const float* wt, const float* bias,
@@ -1105,77 +841,9 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
     a.amax_out = amax_out;
     a.w_scale_inv = w_scale_inv;
     if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
+    // the last SM_TAIL_COUNTERS words of the workspace are the tail tiles' arrival counters (conv_tail.h)
+    ws_floats = (ws != nullptr && ws_floats >= 2 * SM_TAIL_COUNTERS) ? ws_floats - SM_TAIL_COUNTERS : 0;
     return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
-}
-
-int sm_conv3x3_grouped_pair(const sm_conv_problem* problems, int n_problems, const uint16_t* wt2, float w_scale_inv,
-                            const float* bias, int Cin, int Cout, int flags, const int32_t* tile_list, int n_list,
-                            float* ws, size_t ws_floats, const float* amax_in, float* amax_out, const float* pair_in,
-                            const float* pair_out, const float* pair_gate, void* stream) {
-    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
-    if (Cout % 64 != 0 || Cin % 16 != 0 || !(w_scale_inv > 0.f)) return (int)hipErrorInvalidValue;
-    if (amax_in == nullptr && pair_in == nullptr) return (int)hipErrorInvalidValue;   // one of them carries the input's scale
-    sm::ConvArgs a{};
-    int unpool = 0;
-    for (int g = 0; g < n_problems; ++g) {
-        unpool += problems[g].unpool_code != nullptr;
-        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, problems[g].unpool_code,
-                                 problems[g].H, problems[g].W, sm::row_stride(problems[g].W),
-                                 sm::plane_size(problems[g].H, problems[g].W), problems[g].pool_out, problems[g].pool_code,
-                                 reinterpret_cast<const sm::f32x4*>(problems[g].gram_ws), problems[g].gram_mask0,
-                                 problems[g].gram_mask1, problems[g].gram_amax_feat, problems[g].gram_amax_d,
-                                 problems[g].addend};
-        if ((flags & SM_EPI_GRAM) != 0 && (problems[g].gram_ws == nullptr || problems[g].gram_mask0 == nullptr ||
-                                          problems[g].gram_amax_feat == nullptr || problems[g].gram_amax_d == nullptr ||
-                                          problems[g].gate == nullptr || problems[g].unpool_code == nullptr))
-            return (int)hipErrorInvalidValue;
-        if ((flags & SM_EPI_POOL) != 0 && (problems[g].pool_out == nullptr || problems[g].pool_code == nullptr ||
-                                          problems[g].H < 2 || problems[g].W < 2))
-            return (int)hipErrorInvalidValue;
-        // a pair output cannot be its own fp32 addend
-        if ((flags & SM_EPI_ADD) != 0 && pair_out != nullptr && problems[g].addend == nullptr) return (int)hipErrorInvalidValue;
-    }
-    if ((flags & SM_EPI_POOL) != 0 && (tile_list == nullptr || bias == nullptr || unpool != 0)) return (int)hipErrorInvalidValue;
-    a.n_problems = n_problems;
-    a.wt = reinterpret_cast<const float*>(wt2);
-    a.bias = bias;
-    a.Cin_pad = Cin;
-    a.Cout = Cout;
-    a.ws = ws;
-    a.splits = 1;
-    a.tile_list = tile_list;
-    a.amax_in = amax_in;
-    a.amax_out = amax_out;
-    a.w_scale_inv = w_scale_inv;
-    a.pair_in = pair_in;
-    a.pair_out = pair_out;
-    a.pair_gate = pair_gate;
-    if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
-    return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
-}
-
-int sm_conv3x3_grouped_split(const sm_conv_problem* problems, int n_problems, const uint16_t* wt3, const float* bias,
-                             int Cin, int Cout, int flags, const int32_t* tile_list, int n_list, float* ws,
-                             size_t ws_floats, float* amax_out, void* stream) {
-    if (n_problems < 1 || n_problems > sm::SM_MAX_GROUP) return (int)hipErrorInvalidValue;
-    if (Cout % 64 != 0 || Cin % 16 != 0) return (int)hipErrorInvalidValue;
-    sm::ConvArgs a{};
-    for (int g = 0; g < n_problems; ++g)
-    {
-        if (problems[g].unpool_code != nullptr) return (int)hipErrorInvalidValue;   // fp16x2 kernel only
-        a.p[g] = sm::ConvProblem{problems[g].in, problems[g].out, problems[g].gate, nullptr, problems[g].H, problems[g].W,
-                                 sm::row_stride(problems[g].W), sm::plane_size(problems[g].H, problems[g].W)};
-    }
-    a.n_problems = n_problems;
-    a.wt = reinterpret_cast<const float*>(wt3);
-    a.bias = bias;
-    a.Cin_pad = Cin;
-    a.Cout = Cout;
-    a.ws = ws;
-    a.splits = 1;
-    a.tile_list = tile_list;
-    a.amax_out = amax_out;
-    return conv_dispatch_flags_split(a, n_list, flags, ws_floats, (hipStream_t)stream);
 }
 
 int sm_conv3x3(const float* in, const float* wt, const float* bias, float* out, const float* gate, int Cin_pad,

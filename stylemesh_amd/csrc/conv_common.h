@@ -1,4 +1,4 @@
-// Launch arguments shared by the conv kernels (conv.hip: exact fp32 MFMA; conv_split.hip: bf16x3-split MFMA).
+// Launch arguments shared by the conv kernels (conv.hip: exact fp32 MFMA; conv_split_kernel.h: fp16x2-split MFMA).
 #pragma once
 #include "common.h"
 
@@ -31,9 +31,6 @@ struct ConvProblem {
     const float* gram_mask1;
     const float* gram_amax_feat;
     const float* gram_amax_d;
-    // SM_EPI_ADD, optional: the addend is read from these fp32 planes instead of from `out` (pair images: `out` holds
-    // packed pairs, the loss kernels keep writing their gradients as fp32)
-    const float* addend;
 };
 
 struct ConvArgs {
@@ -52,24 +49,21 @@ struct ConvArgs {
     // Work decomposition. The first n_whole tiles (a multiple of the CU count) are computed whole; the remaining
     // "tail" tiles - whose last, partially filled round would otherwise leave most CUs idle - are split along K
     // into `splits` units each, so the tail is made of many small units that spread over all CUs. Split units
-    // store raw partial tiles to ws[(tail_tile * splits + split)][BM][BN]; conv_tail_epilogue_kernel reduces them.
+    // store raw partial tiles to ws[(tail_tile * splits + split)][BM][BN]; conv_tail.h reduces them.
     float* ws;
     int n_whole;
     int splits;
     int chunks_per_split;
-    // Operand scaling of the fp16x2 split kernel (conv_split_kernel.h, NP = 2). amax_in (device, optional): max |x| of
+    // fp16x2 kernel, in-kernel tail reduction (conv_tail.h): one int per tail tile, ZERO on entry and on exit - the unit
+    // that arrives last at its tile's counter reduces the tile's slabs; nullptr = the second-pass launch reduces them.
+    int* tail_count;
+    // Operand scaling of the fp16x2 split kernel (conv_split_kernel.h). amax_in (device, optional): max |x| of
     // the input tensor(s), recorded by their producer; w_scale_inv: 1 / (power-of-two scale the host applied to the
     // weights). amax_out (device, optional, any kernel): this launch's max |output| is atomically max-ed into it (as
     // the bit pattern of a non-negative float) for the conv that consumes the output.
     const float* amax_in;
     float* amax_out;
     float w_scale_inv;
-    // Pair images (fp16x2 kernel; conv_split_kernel.h): device {scale, 1 / scale} of the tensor, NULL = fp32 planes.
-    // pair_in: the input planes hold packed fp16 pairs (amax_in is not read); pair_out: outputs (out / pool_out) are
-    // stored as pairs; pair_gate: the gate planes are pairs.
-    const float* pair_in;
-    const float* pair_out;
-    const float* pair_gate;
 };
 
 constexpr int SM_NUM_CU = 256;

@@ -1,59 +1,41 @@
-// K3s/K4s: the 3x3 convolutions on the bf16 matrix cores at fp32 accuracy ("bf16x3 split, 6 products").
+// K3s/K4s: the 3x3 convolutions on the fp16 matrix cores at fp32 accuracy ("fp16x2 split, 3 products").
 //
-// Every fp32 operand x is written as h + m + l, three bf16 numbers (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
-// 3 x 8 = 24 significand bits, i.e. the split is exact up to the last rounding of l), and a product x*y is evaluated
-// as the six partial products of weight >= 2^-16:  hh' + (hm' + mh') + (mm' + hl' + lh').  The dropped terms
-// (ml', lm', ll') are below 2^-23 |xy|, each partial product of two bf16 numbers is exact in fp32, and all sums are
-// taken in the MFMA's fp32 accumulators. The result is as close to the exact dot product as the fp32 MFMA chain of
-// conv.hip (tests/test_kernels_gpu.py measures both against an fp64 convolution) - but
-// v_mfma_f32_32x32x16_bf16 retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32, so six of them per fp32 MAC
-// still leave a 2.67x higher ceiling (2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent, against 157 TFLOP/s).
+// Every fp32 operand x is scaled by a power of two s (from the bound its producer recorded) and written as h + l, two
+// fp16 numbers: h = fp16(x s), l = fp16(x s - h) - 2 x 11 = 22 significand bits. A product x y is evaluated as the three
+// partial products hh' + hl' + lh' (each exact in fp32; the dropped ll' is < 2^-22 of the product), summed in the MFMA's
+// fp32 accumulators; the epilogue multiplies by the exact inverse scales. v_mfma_f32_32x32x16_f16 retires 16x the MACs
+// per cycle of v_mfma_f32_32x32x2_f32, so three of them per fp32 MAC leave a 5.3x higher ceiling (2.5 PFLOP/s / 3 =
+// 833 TFLOP/s fp32-equivalent, against 157 TFLOP/s). Measured against an fp64 convolution: tests/test_kernels_gpu.py.
+// (Round 1's bf16x3 form - three parts, six products - shared this source as NP = 3 until round 6; profiles/r02 keeps
+// its measurements.)
 //
 // Same GEMM view, tile scheduling, grouped launch, active-tile list, tail split-K and epilogues as conv.hip.
-// Differences: weights arrive pre-split from the host ([9][Cin/16][3 parts][2 k-groups][Cout][8 ci] bf16, the exact
+// Differences: weights arrive pre-split from the host ([9][Cin/16][2 parts][2 k-groups][Cout][8 ci] fp16, the exact
 // image of an LDS weight stage); activations stay fp32 in HBM and are split when they are staged into LDS, as
-// [ky slice][3 parts][2 k-groups][BN+2 positions][8 ci] bf16 - a tap shift is again a pure offset (16 bytes per
-// position). One K-stage = one tap of a 16-channel chunk = ONE bf16 MFMA K-step (24 MFMAs per wave):
+// [ky slice][2 parts][2 k-groups][BN+2 positions][8 ci] fp16 - a tap shift is again a pure offset (16 bytes per
+// position). One K-stage = one tap of a 16-channel chunk = ONE fp16 MFMA K-step (12 MFMAs per wave):
 //   * weights: the global stage image is the MFMA A-fragment layout, so each wave loads its fragments straight into
 //     a register ring three stages ahead - no LDS copy, no per-stage barrier;
 //   * activations: the three ky slices of a chunk live in a ring of FOUR LDS slots; the next chunk's slice k is
 //     loaded at tap 3k and written at the end of tap 3k+2 into the slot that the current chunk stopped reading
 //     three taps earlier (one barrier per three stages); the next stage's fragments are read under the current
 //     stage's MFMAs.
-// LDS: 4 x 12.2 KB = 48.8 KB; two blocks per CU (register-limited): the two waves that share a SIMD's matrix pipe
-// belong to different blocks and cover each other's store / barrier phases.
+// Two blocks per CU (register-limited): the two waves that share a SIMD's matrix pipe belong to different blocks and
+// cover each other's store / barrier phases.
 #pragma once
 #include "conv_common.h"
+#include "conv_tail.h"
 
-// tuning knobs (A/B builds: build.sh -DSM_SPLIT_AD=1 ..., compared with tools/ab_libs.sh). Measured on c3 / the layer
-// micro-benchmark, relative to the defaults (187-190 TFLOP/s): AD=1 -22 %; no fragment prefetch -5 %; 3 waves per
-// SIMD (AD=1, no prefetch, 168 VGPRs) -14 %; PIN_READS=1 (fragment reads pinned a full stage ahead: the densest
-// MFMA stream, 245 VGPRs) -8 %; any s_setprio (MFMA cluster or the load/convert tail) -9 %: each of them fences the
-// compiler's own interleaving of the tail instructions with the MFMAs. 3 waves per SIMD with AD=3 and no fragment
-// prefetch needs 168 VGPRs: the 128-row variant spills ~25 dwords and loses 14 %. What the loop is sensitive to is the
-// NUMBER of vector-memory instructions (ablation: no weight loads +15 %, no activation loads +8 %, no conversion
-// arithmetic / no LDS fragment reads / no epilogue stores +-1 %): hence the 32 x 128 wave tiles (SM_SPLIT_WGM = 4 in
-// conv.hip) and the buffer loads.
-#ifndef SM_SPLIT_AD
-#define SM_SPLIT_AD 3          // weight prefetch distance in stages (must divide 9)
-#endif
+// tuning knobs (A/B builds: build.sh -DSM_SPLIT2_AD=1 ..., compared with tools/ab_libs.sh). What the loop is sensitive to
+// is the NUMBER of vector-memory instructions (round-2 ablation: no weight loads +15 %, no activation loads +8 %, no
+// conversion arithmetic / no LDS fragment reads / no epilogue stores +-1 %): hence the 32 x 128 wave tiles (SM_SPLIT_WGM =
+// 4 in conv.hip) and the buffer loads. Any s_setprio, pinned fragment reads or a third wave per SIMD lose 8-14 %
+// (profiles/r02 - r05 keep the records; the switches left with round 6).
 #ifndef SM_SPLIT_PREFETCH_B
 #define SM_SPLIT_PREFETCH_B 1  // read the next stage's activation fragments under this stage's MFMAs
 #endif
-#ifndef SM_SPLIT_PIN_READS
-#define SM_SPLIT_PIN_READS 0
-#endif
-#ifndef SM_SPLIT_TAIL_PRIO
-#define SM_SPLIT_TAIL_PRIO 0
-#endif
-#ifndef SM_SPLIT_MFMA_PRIO
-#define SM_SPLIT_MFMA_PRIO 0
-#endif
 #ifndef SM_SPLIT_WAVES64
 #define SM_SPLIT_WAVES64 3
-#endif
-#ifndef SM_SPLIT_WAVES
-#define SM_SPLIT_WAVES 2       // resident waves per SIMD the register budget is set for
 #endif
 
 namespace sm {
@@ -91,35 +73,13 @@ __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2]
 #undef SM_H
 }
 
-// NP = number of parts an fp32 operand is split into:
-//   NP = 3  bf16 x 3 (above): 6 partial products per fp32 product, no scaling needed (bf16 has the fp32 exponent range);
-//   NP = 2  fp16 x 2: x s = h + l with h = fp16(x s), l = fp16(x s - h): 2 x 11 = 22 significand bits, products
-//           hh' + hl' + lh' (each exact in fp32; the dropped ll' is < 2^-22 of the product) - THREE MFMAs
-//           (v_mfma_f32_32x32x16_f16, same rate as bf16) per fp32 product instead of six. fp16 has 5 exponent bits, so
-//           every operand tensor is scaled by a power of two s that puts its largest magnitude into [2^14, 2^15): the
-//           producer of an activation / gradient tensor records max |x| (ConvArgs::amax_out, one atomic max per wave),
-//           the consumer derives s from it (amax_in) and the epilogue multiplies the accumulators by 1 / (s s_w) (exact).
-//           Elements more than 2^18 below the tensor's maximum lose low bits of l (absolute error <= 2^-40 max|x|).
-//           Measured against an fp64 convolution: tests/test_kernels_gpu.py, tools/bench_conv_split.py.
-#ifndef SM_ABL_NOCVT
-#define SM_ABL_NOCVT 0          // 1 (ablation build, timing only): activations staged without the fp32 -> fp16-pair conversion
-#endif
-#ifndef SM_ABL_NOSEL
-#define SM_ABL_NOSEL 0          // 1 (ablation build, timing only): the un-pooling input without its argmax selection
-#endif
 #ifndef SM_SPLIT2_PAIR_ROWS
 #define SM_SPLIT2_PAIR_ROWS 1  // forward convs with the pooling epilogue: the lower segment of a pair re-uses the upper one's rows
 #endif
-#ifndef SM_SPLIT2_ILV
-#define SM_SPLIT2_ILV 0        // experiment: 1 = no scheduling fence below a stage's MFMAs; 2 = tail instructions dealt between the MFMAs
-#endif
-#ifndef SM_SPLIT2_RING6
-#define SM_SPLIT2_RING6 0      // fp16x2: six LDS slots (two whole chunks), ONE barrier per chunk instead of three
-#endif
-// (128-row tiles only: six slots of the 64 x 256 tile would be 99 KB per block - one block per CU)
-constexpr int conv_split_slots(int NP, int BM = 128) { return (NP == 2 && BM == 128 && SM_SPLIT2_RING6) ? 6 : 4; }
-constexpr size_t conv_split_lds_bytes(int BM, int BN, int NP = 3) {
-    return (size_t)(conv_split_slots(NP, BM) * 2 * NP * (BN / 32 * 34)) * 16;   // 34 staged positions per 32-position segment
+constexpr int SM_SPLIT_NP = 2;      // parts per operand
+constexpr int SM_SPLIT_SLOTS = 4;   // ky-slice ring of a block
+constexpr size_t conv_split_lds_bytes(int BM, int BN) {
+    return (size_t)(SM_SPLIT_SLOTS * 2 * SM_SPLIT_NP * (BN / 32 * 34)) * 16;   // 34 staged positions per 32-position segment
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -139,35 +99,8 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
     return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);    // 2^(141 - ex)
 }
 
-// ---- pair images (round 5). A feature map may be stored as PACKED fp16 PAIRS instead of fp32: word = h | l << 16 with
-// h = fp16(x s), l = fp16(x s - h) - exactly the two operand parts the fp16x2 kernels build from an fp32 value while
-// they stage it, so a consumer only un-packs (two byte permutes per channel pair instead of mul / clamp / cvt / cvt /
-// sub / cvt per element: that conversion was 13.5 % of a four-level step, profiles/r05/staging_ablation_c2_c3.txt).
-// Same 4 bytes per element, same [C][plane] addressing, zero word = zero. The power-of-two scale s must be known BEFORE
-// the producer runs: it is derived from the bound the PREVIOUS step recorded for the tensor, with head-room
-// (sm_pair_scales); sm_pair_check compares the bound this step recorded with it and invalidates the step on overflow
-// (values beyond the fp16 range saturate at +-65000 s^-1; the engine skips the update and repeats the step).
-__device__ __forceinline__ unsigned pair_encode(float v, float s) {
-    const float xs = __builtin_amdgcn_fmed3f(v * s, -SM_F16_CLAMP, SM_F16_CLAMP);
-    const _Float16 h = (_Float16)xs;
-    const _Float16 l = (_Float16)(xs - (float)h);
-    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
-// eight pair words (channels c .. c + 7 of one position) -> the h unit and the l unit (8 fp16 each)
-__device__ __forceinline__ void pair_units(const float (&w)[8], f32x4& vh, f32x4& vl) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned a = __builtin_bit_cast(unsigned, w[2 * k + 1]), b = __builtin_bit_cast(unsigned, w[2 * k]);
-        vh[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x05040100u));
-        vl[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x07060302u));
-    }
-}
-
 // STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 // the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
-#ifndef SM_SPLIT_BSETS
-#define SM_SPLIT_BSETS 1
-#endif
 #ifndef SM_SPLIT2_AD
 #define SM_SPLIT2_AD 3
 #endif
@@ -175,17 +108,9 @@ __device__ __forceinline__ void pair_units(const float (&w)[8], f32x4& vh, f32x4
 #define SM_SPLIT2_WAVES 2      // resident waves per SIMD of the 128-row fp16x2 variant
 #endif
 // resident waves per SIMD the register budget of a variant is set for
-constexpr int conv_split_waves(int BM, int BN, int NP) {
-    return BM == 256 ? 1 : (BM == 64 && BN == 128) ? SM_SPLIT_WAVES64 : NP == 2 ? SM_SPLIT2_WAVES : SM_SPLIT_WAVES;
+constexpr int conv_split_waves(int BM, int BN) {
+    return BM == 256 ? 1 : (BM == 64 && BN == 128) ? SM_SPLIT_WAVES64 : SM_SPLIT2_WAVES;
 }
-// KG (round 5) = wave GROUPS per block. KG = 2: a block is 512 threads = two groups of four waves; both compute the SAME
-// output tile, group g over half g of the block's K-chunks, each with a slice ring and weight registers of its own (the
-// groups only meet at the stages' barriers), and exchange accumulator halves through LDS before the epilogue, which each
-// group runs for half of the wave's column tiles. For launches of <= one block per CU (every layer of a one-level view:
-// 12 - 172 tiles): a lone 4-wave block is latency-bound - one wave per SIMD cannot cover its own load / convert / store
-// stage tail with MFMAs (a stage takes ~800 cycles against ~475 per block when two blocks share a CU) - and getting the
-// second wave per SIMD from MORE global K-splits doubles the partial slabs instead.
-// PIN (round 5): the input planes hold packed fp16 pairs (above): staging un-packs instead of converting.
 // RES (round 5): RESIDENT INPUT, for the 64-output-channel launches (conv1_2 forward / data gradient, conv2_1's data
 // gradient: K = 576 / 1152). The 64 x 256 tile stages every chunk's three ky slices for each of its eight free segments -
 // 3 x 34 / 32 = 3.2 staged positions per output position and 16 channels - and spends twice the staging per MFMA of the
@@ -197,22 +122,13 @@ constexpr int conv_split_waves(int BM, int BN, int NP) {
 // loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
 constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
 constexpr size_t conv_resident_lds_bytes() { return (size_t)(4 * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, int NP = 3, bool UNPOOL = false, int KG = 1,
-          bool PIN = false, bool RES = false>
-__global__ __launch_bounds__(256 * KG)
-__attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN, NP), conv_split_waves(BM, BN, NP))))
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, bool UNPOOL = false, bool RES = false>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN), conv_split_waves(BM, BN))))
 void conv3x3_split_kernel(ConvArgs a) {
-    static_assert(NP == 2 || NP == 3, "bf16 x 3 or fp16 x 2");
-    static_assert(!RES || (NP == 2 && BM == 64 && BN == 128 && WGM == 2 && WGN == 2 && KG == 1 && !PIN && !STAMP),
-                  "resident input: the fp16x2 kernel on 64 x 128 tiles (a quad of segments), waves 2 x 2");
-    static_assert(!PIN || NP == 2, "pair images are the fp16x2 kernel's operand format");
-    static_assert(KG == 1 || (KG == 2 && NP == 2 && conv_split_waves(BM, BN, NP) == 2 && !(FLAGS & SM_EPI_GRAM)),
-                  "two wave groups: the fp16x2 kernel at two waves per SIMD, without the Gram epilogue");
-    static_assert(KG == 1 || !SM_SPLIT2_RING6, "two wave groups: the four-slot ring (a barrier at the end of every chunk)");
-    static_assert(!UNPOOL || NP == 2, "the unpool input exists for the fp16x2 kernel");
-    // activation register sets: 1 = a slice is loaded two stages before it is converted; 3 = one set per ky slice, loaded a
-    // whole chunk (nine stages) ahead. (the un-pooling input and the pair rows keep one set)
-    constexpr int BSETS = (UNPOOL || ((FLAGS & SM_EPI_POOL) != 0 && NP == 2 && SM_SPLIT2_PAIR_ROWS)) ? 1 : SM_SPLIT_BSETS;
+    constexpr int NP = SM_SPLIT_NP;
+    static_assert(!RES || (BM == 64 && BN == 128 && WGM == 2 && WGN == 2 && !STAMP),
+                  "resident input: 64 x 128 tiles (a quad of segments), waves 2 x 2");
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
     static_assert((MI == 1 || MI == 2) && BM == WGM * MI * 32 && (NJ == 2 || NJ == 4) && BN == WGN * NJ * 32 &&
@@ -229,10 +145,9 @@ void conv3x3_split_kernel(ConvArgs a) {
     constexpr int BNP = SEG * SEGP;       // staged positions per slice
     constexpr int SLICE = 2 * NP * BNP;   // 16-byte units of one ky slice of a chunk: [part][kgroup][position]
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
-    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);        // wave group (wave-uniform)
-    f32x4* Bs = smem4 + grp * (conv_split_slots(NP, BM) * SLICE);   // [4 slots][SLICE] of this group
+    f32x4* Bs = smem4;   // [4 slots][SLICE]
 
-    const int tid = KG == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);   // thread / wave index INSIDE the group
+    const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l31 = lane & 31;
@@ -241,7 +156,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int wn = (wave % WGN) * (32 * NJ);
 #define SM_TS(slot_)                                                                                     \
     if (STAMP && lane == 0) {                                                                            \
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)(blockIdx.x * KG + grp) * 4 + wave) * 64 + (slot_)] = \
+        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)blockIdx.x * 4 + wave) * 64 + (slot_)] = \
             __builtin_readcyclecounter();                                                                \
     }
 
@@ -280,13 +195,8 @@ void conv3x3_split_kernel(ConvArgs a) {
         }
     }
     const int n_chunks = a.Cin_pad / KC;
-    int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
-    int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
-    if constexpr (KG == 2) {   // (the host keeps every unit's chunk count even: both groups run the same number of stages)
-        const int half = (ch_end - ch_begin) >> 1;
-        ch_begin += grp * half;
-        ch_end = ch_begin + half;
-    }
+    const int ch_begin = split < 0 ? 0 : split * a.chunks_per_split;
+    const int ch_end = split < 0 ? n_chunks : min(n_chunks, ch_begin + a.chunks_per_split);
     const int m0 = m_tile * BM;
 
     const float amax_seen = split < 0 ? amax_peek(a.amax_out) : 0.f;   // whole tiles record their output's bound
@@ -299,7 +209,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- staging plan
-    // weights: the global image of a stage, [part][kgroup][Cout] units of 8 bf16, IS the MFMA A-fragment layout
+    // weights: the global image of a stage, [part][kgroup][Cout] units of 8 fp16, IS the MFMA A-fragment layout
     // (row = lane & 31, k-group = lane >> 5), so every wave loads its own 3 MI fragments (MI row tiles x 3 parts) of a
     // stage straight into registers, three stages ahead: no LDS copy of the weights and no per-stage barrier.
     // (buffer loads: scalar base in an SGPR resource + one 32-bit lane offset + a scalar stage offset - no 64-bit
@@ -309,19 +219,10 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int a_voff = (lhi * a.Cout + m0 + wm + l31) * 16;   // bytes
     const int a_part = 2 * a.Cout * 16;            // bytes between the parts of a stage
     const int a_stage_bytes = 2 * NP * a.Cout * 16;   // bytes per (tap, chunk) stage
-    // NP = 2: operand scale from the producer's recorded max |x| (one vector load of the bound's slots per wave)
-    float in_scale = 1.f, out_scale = 1.f;
-    if constexpr (PIN) {
-        out_scale = a.pair_in[1] * a.w_scale_inv;          // {scale, 1 / scale} of the stored pairs
-    } else if (NP == 2) {
-        float inv;
-        in_scale = pow2_scale_for(a.amax_in ? amax_read(a.amax_in) : 1.f, inv);
-        out_scale = inv * a.w_scale_inv;
-    }
-    // outputs as pairs (fp16x2 kernel; wave-uniform), the ReLU gate planes as pairs (x > 0 <=> word != 0)
-    const bool pout = NP == 2 && a.pair_out != nullptr;
-    const float po_scale = pout ? a.pair_out[0] : 1.f;
-    const bool gate_pair = NP == 2 && a.pair_gate != nullptr;
+    // operand scale from the producer's recorded max |x| (one vector load of the bound's slots per wave)
+    float inv_in;
+    const float in_scale = pow2_scale_for(a.amax_in ? amax_read(a.amax_in) : 1.f, inv_in);
+    const float out_scale = inv_in * a.w_scale_inv;
     // activations, per ky slice: thread -> unit (kgroup = tid / 128, position px = tid % 128), the 8 channels of the
     // k-group at stride `plane`; the 2 remaining halo positions x 2 k-groups x 8 channels = 32 single elements are
     // fetched one per lane (every half-wave does the same 32: identical values to identical addresses)
@@ -378,7 +279,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         off_ = ok_ ? (((y_) >> 1) + 1) * up_Wp + ((x_) >> 1) + 1 : 0;                                    \
         par_ = ok_ ? ((((y_) & 1) << 1) | ((x_) & 1)) : -1;                                              \
     }
-    const int h_dst = (h_kg * BNP + h_seg * SEGP + 32 + h_which) * 8 + h_c;   // in bf16 elements (+ part * 2 * BNP * 8)
+    const int h_dst = (h_kg * BNP + h_seg * SEGP + 32 + h_which) * 8 + h_c;   // in fp16 elements (+ part * 2 * BNP * 8)
     // PAIRS (round 4): a forward conv with the pooling epilogue takes its segments in vertical pairs - entries 2k, 2k + 1 =
     // the same 32 columns of image rows 2Y and 2Y + 1 - so slice ky of the LOWER segment holds the input row that slice
     // ky + 1 of the UPPER one holds. The lower segment's slices 0 and 1 are therefore not staged at all: its fragments for
@@ -388,8 +289,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     // per MFMA of the 128-row tile, and staging is what bounds it. Bit-identical: the same input
     // values go through the same conversion. Slices 0 / 1 are staged with a mapping of their own over the UPPER segments:
     // one unit per thread for BN = 256 (instead of two); for BN = 128 half the threads convert and store.
-    constexpr bool PAIRS = NP == 2 && !UNPOOL && (FLAGS & SM_EPI_POOL) != 0 && BSETS == 1 && !SM_SPLIT2_RING6 &&
-                           SM_SPLIT2_PAIR_ROWS;
+    constexpr bool PAIRS = !UNPOOL && (FLAGS & SM_EPI_POOL) != 0 && SM_SPLIT2_PAIR_ROWS;
     const int a_kg = BN == 256 ? (tid >> 7) : ((tid >> 6) & 1);
     const int a_px = BN == 256 ? (tid & 127) : (tid & 63);
     const bool a_active = BN == 256 || tid < 128;
@@ -407,16 +307,11 @@ void conv3x3_split_kernel(ConvArgs a) {
 #ifndef SM_RES_AD
 #define SM_RES_AD SM_SPLIT2_AD
 #endif
-#ifndef SM_RES_ABL
-#define SM_RES_ABL 0           // ablation builds (timing only): 1 = no MFMA loop, 2 = no staging, 3 = no weight loads in the loop
-#endif
-    constexpr int AD = RES ? SM_RES_AD : NP == 2 ? SM_SPLIT2_AD : SM_SPLIT_AD;
+    constexpr int AD = RES ? SM_RES_AD : SM_SPLIT2_AD;
     static_assert(9 % AD == 0, "ring slot of a stage is the same in every chunk");
     f32x4 ra[AD][MI][NP];
-    // in-flight activation loads: SM_SPLIT_BSETS = 1: one register set, a slice is loaded two stages before it is
-    // converted and stored; 3: one set per ky slice, re-loaded right after its store - a slice's loads then have a
-    // whole chunk (nine stages) to arrive
-    // (register sets 1 and 2 of the one-set variant only carry the prologue's three slices)
+    // in-flight activation loads: one register set - a slice is loaded two stages before it is converted and stored
+    // (register sets 1 and 2 only carry the prologue's three slices)
     constexpr int NSET = 3;
     float rbs[NSET][NU][8], rhs[NSET];
     unsigned rcs[UNPOOL ? NSET : 1][NU], rhc[UNPOOL ? NSET : 1];   // UNPOOL: argmax codes of the loaded gradients (one
@@ -460,55 +355,14 @@ void conv3x3_split_kernel(ConvArgs a) {
         rhs[set_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, h_src, so_, 0)); \
     }
 #define SM_STORE_B(set_, slot_, ky_)                                                                     \
-    if constexpr (NP == 3) {                                                                             \
+    {                                                                                                    \
         f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
-        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                 \
-            bf16x8 vh, vm, vl;                                                                           \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
-                __bf16 h, m, l;                                                                          \
-                split3(rbs[set_][u][c], h, m, l);                                                        \
-                vh[c] = h; vm[c] = m; vl[c] = l;                                                         \
-            }                                                                                            \
-            d_[b_dst[u]] = __builtin_bit_cast(f32x4, vh);                                                \
-            d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vm);                                      \
-            d_[b_dst[u] + 4 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
-        }                                                                                                \
-        __bf16 h, m, l;                                                                                  \
-        split3(rhs[set_], h, m, l);                                                                      \
-        __bf16* e_ = reinterpret_cast<__bf16*>(d_);                                                      \
-        e_[h_dst] = h;                                                                                   \
-        e_[h_dst + 2 * BNP * 8] = m;                                                                     \
-        e_[h_dst + 4 * BNP * 8] = l;                                                                     \
-    } else {                                                                                             \
-        f32x4* d_ = Bs + (slot_) * SLICE;                                                                \
-        if constexpr (UNPOOL && !SM_ABL_NOSEL) {   /* gradient only at the window element that held the maximum */ \
+        if constexpr (UNPOOL) {   /* gradient only at the window element that held the maximum */       \
             _Pragma("unroll") for (int u = 0; u < NU; ++u)                                               \
                 _Pragma("unroll") for (int c = 0; c < 8; ++c)                                            \
                     rbs[set_][u][c] = ((int)((rcs[set_][u] >> (4 * c)) & 15u) == rps[set_][u]) ? rbs[set_][u][c] : 0.f; \
             rhs[set_] = ((int)((rhc[set_] >> (4 * h_c)) & 15u) == rhp[set_]) ? rhs[set_] : 0.f;          \
         }                                                                                                \
-        if constexpr (PIN) {   /* stored pairs: un-pack (a stale word of an unlisted tile is still a finite pair) */ \
-            if (PAIRS && (ky_) < 2) {                                                                    \
-                f32x4 vh, vl;                                                                            \
-                pair_units(rbs[set_][0], vh, vl);                                                        \
-                if (a_active) { d_[a_dst] = vh; d_[a_dst + 2 * BNP] = vl; }                              \
-            } else {                                                                                     \
-                _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                         \
-                    f32x4 vh, vl;                                                                        \
-                    pair_units(rbs[set_][u], vh, vl);                                                    \
-                    d_[b_dst[u]] = vh;                                                                   \
-                    d_[b_dst[u] + 2 * BNP] = vl;                                                         \
-                }                                                                                        \
-            }                                                                                            \
-        } else                                                                                           \
-        if constexpr (SM_ABL_NOCVT) {   /* (ablation, timing only: raw bits instead of the scaled fp16 pairs) */ \
-            _Pragma("unroll") for (int u = 0; u < ((PAIRS && (ky_) < 2) ? 1 : NU); ++u) {               \
-                f32x4 vh = {rbs[set_][u][0], rbs[set_][u][1], rbs[set_][u][2], rbs[set_][u][3]};         \
-                f32x4 vl = {rbs[set_][u][4], rbs[set_][u][5], rbs[set_][u][6], rbs[set_][u][7]};         \
-                if (PAIRS && (ky_) < 2) { if (a_active) { d_[a_dst] = vh; d_[a_dst + 2 * BNP] = vl; } }  \
-                else { d_[b_dst[u]] = vh; d_[b_dst[u] + 2 * BNP] = vl; }                                 \
-            }                                                                                            \
-        } else                                                                                           \
         if (PAIRS && (ky_) < 2) {                                                                        \
             f16x8 vh, vl;                                                                                \
             _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                              \
@@ -532,18 +386,11 @@ void conv3x3_split_kernel(ConvArgs a) {
             d_[b_dst[u] + 2 * BNP] = __builtin_bit_cast(f32x4, vl);                                      \
         }                                                                                                \
         }                                                                                                \
-        if constexpr (PIN) {                                                                             \
-            const unsigned w_ = __builtin_bit_cast(unsigned, rhs[set_]);                                 \
-            unsigned short* e_ = reinterpret_cast<unsigned short*>(d_);                                  \
-            e_[h_dst] = (unsigned short)(w_ & 0xffffu);                                                  \
-            e_[h_dst + 2 * BNP * 8] = (unsigned short)(w_ >> 16);                                        \
-        } else {                                                                                         \
         const float xs_ = __builtin_amdgcn_fmed3f(rhs[set_] * in_scale, -SM_F16_CLAMP, SM_F16_CLAMP);    \
         const _Float16 h_ = (_Float16)xs_;                                                               \
         _Float16* e_ = reinterpret_cast<_Float16*>(d_);                                                  \
         e_[h_dst] = h_;                                                                                  \
         e_[h_dst + 2 * BNP * 8] = (_Float16)(xs_ - (float)h_);                                           \
-        }                                                                                                \
     }
 #define SM_READ_B(dst_, slot_, kx_)                                                                      \
     {                                                                                                    \
@@ -636,7 +483,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         const int n_phases = a.Cin_pad / 64;
         for (int ph = 0; ph < n_phases; ++ph) {
             if (ph > 0) __syncthreads();                 // the previous phase's last fragment reads
-            if (SM_RES_ABL != 2) {
+            {
                 if constexpr (UNPOOL) {
                     typedef float f32x2_ __attribute__((ext_vector_type(2)));
                     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -720,7 +567,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int s = 0; s < NP; ++s)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) fb[i][s] = b_frag[s * 2 * RP + i * SEGP];
-            for (int cc = 0; cc < (SM_RES_ABL == 1 ? 0 : 4); ++cc) {
+            for (int cc = 0; cc < 4; ++cc) {
                 const int ch = ph * 4 + cc;
                 const int ch_next = ch + 1 < n_chunks ? ch + 1 : ch;   // (loads stay unconditional: see the ring loop)
                 const f32x4* bc = b_frag + cc * 4 * RP;
@@ -745,12 +592,10 @@ void conv3x3_split_kernel(ConvArgs a) {
                     SM_RES_PRODUCT(0, 0)
 #undef SM_RES_PRODUCT
                     __builtin_amdgcn_sched_barrier(0);
-                    if (SM_RES_ABL != 3) {
                     if (tap + AD < 9) {
                         SM_LOAD_A(tap + AD, ch);
                     } else {
                         SM_LOAD_A(tap + AD - 9, ch_next);
-                    }
                     }
 #pragma unroll
                     for (int s = 0; s < NP; ++s)
@@ -771,40 +616,18 @@ void conv3x3_split_kernel(ConvArgs a) {
     }
     {
         const int ch1 = ch_begin + 1 < ch_end ? ch_begin + 1 : ch_begin;
-        if constexpr (BSETS == 1) {
-            SM_LOAD_B(0, 0, ch1);      // stored at the end of tap 1 of the first chunk
-        } else {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) SM_LOAD_B(ky, ky, ch1);   // stored at the end of taps 1, 4, 7 of the first chunk
-        }
+        SM_LOAD_B(0, 0, ch1);      // stored at the end of tap 1 of the first chunk
     }
     __syncthreads();
     SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
-    constexpr bool RING6 = conv_split_slots(NP, BM) == 6;
     // slot of slice ky of the current / of the next chunk
-#define SM_CUR_SLOT(ky_) (RING6 ? base + (ky_) : (base + (ky_)) & 3)
-#define SM_NEXT_SLOT(ky_) (RING6 ? (3 - base) + (ky_) : (base + 3 + (ky_)) & 3)
+#define SM_CUR_SLOT(ky_) ((base + (ky_)) & 3)
+#define SM_NEXT_SLOT(ky_) ((base + 3 + (ky_)) & 3)
     const f32x4* b_frag = Bs + lhi * BNP + (wn / 32) * SEGP + l31;   // n-tile i of the wave = segment wn / 32 + i
-    f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 bf16 / fp16)
+    f32x4 fb[NJ][NP], fb_next[NJ][NP];   // operand fragments as raw 16-byte units (8 fp16)
 #if SM_SPLIT_PREFETCH_B
     SM_READ_B_KY(fb, 0, 1, 0, 0)
-#endif
-    // SM_SPLIT2_ILV = 2 (experiment): a stage's instruction stream is dictated - the next stage's fragment reads first, then
-    // its MFMAs with the tail's instructions dealt between them (a lone wave per SIMD cannot hide a tail that FOLLOWS
-    // its MFMAs): per MFMA `valu_` VALU instructions (the convert-and-store stage) or one vector-memory load
-#if SM_SPLIT2_ILV == 2
-#define SM_ILV_PIPE(valu_)                                                                               \
-    if constexpr (NP == 2) {                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x100, NJ * NP, 0);                                         \
-        _Pragma("unroll") for (int g_ = 0; g_ < MI * NJ * 3; ++g_) {                                     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
-            if ((valu_) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (valu_), 0);                    \
-            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                      \
-        }                                                                                                \
-    }
-#else
-#define SM_ILV_PIPE(valu_)
 #endif
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         // Every load below is issued UNCONDITIONALLY (the last chunk re-reads its own data instead of the next
@@ -817,12 +640,7 @@ void conv3x3_split_kernel(ConvArgs a) {
             const int ky = tap / 3, kx = tap % 3;
             // the next stage's activation fragments are read under this stage's MFMAs (its slice is complete: slices
             // are written a full barrier before their first use)
-#if SM_SPLIT2_ILV == 2
-            __builtin_amdgcn_sched_barrier(0);   // a scheduling region = one stage
-#endif
-#if defined(SM_ABL_NOREAD)
-            if (ch == ch_begin && tap == 0) { SM_READ_B(fb_next, 0, 1) }
-#elif SM_SPLIT_PREFETCH_B
+#if SM_SPLIT_PREFETCH_B
             if (tap < 8) {
                 SM_READ_B_KY(fb_next, SM_CUR_SLOT((tap + 1) / 3), SM_CUR_SLOT((tap + 1) / 3 + 1), (tap + 1) / 3, (tap + 1) % 3)
             } else {
@@ -830,11 +648,6 @@ void conv3x3_split_kernel(ConvArgs a) {
             }
 #else
             SM_READ_B_KY(fb, SM_CUR_SLOT(ky), SM_CUR_SLOT(ky + 1), ky, kx)
-#endif
-#if SM_SPLIT_PIN_READS
-            // keep the fragment reads HERE, a full stage ahead of their use: left alone, the scheduler sinks them to the
-            // end of the stage (shorter live ranges) and the next stage's first MFMAs wait out the LDS round trip
-            __builtin_amdgcn_sched_barrier(0);
 #endif
             f32x4 fa[MI][NP];
 #pragma unroll
@@ -844,91 +657,37 @@ void conv3x3_split_kernel(ConvArgs a) {
             // the partial products per output tile, smallest first; consecutive MFMAs target different accumulators
 #define SM_PRODUCT(pa_, pb_)                                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                 \
-            if constexpr (NP == 3)                                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][pa_]), \
-                                                                    __builtin_bit_cast(bf16x8, fb[j][pb_]), acc[i][j], 0, 0, 0); \
-            else                                                                                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][pa_]), \
-                                                                   __builtin_bit_cast(f16x8, fb[j][pb_]), acc[i][j], 0, 0, 0); \
-        }
-#if SM_SPLIT_MFMA_PRIO
-            __builtin_amdgcn_s_setprio(SM_SPLIT_MFMA_PRIO);
-#endif
-#ifdef SM_ABL_NOMFMA
-            _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {
-                _Pragma("unroll") for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i][s_]));
-                _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(fb[j][s_]));
-            }
-            if constexpr (false)
-#endif
-            if constexpr (NP == 3) {
-                SM_PRODUCT(2, 0)
-                SM_PRODUCT(0, 2)
-                SM_PRODUCT(1, 1)
-                SM_PRODUCT(1, 0)
-                SM_PRODUCT(0, 1)
-                SM_PRODUCT(0, 0)
-            } else {
-                SM_PRODUCT(1, 0)
-                SM_PRODUCT(0, 1)
-                SM_PRODUCT(0, 0)
-            }
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                   \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][pa_]),    \
+                                                               __builtin_bit_cast(f16x8, fb[j][pb_]), acc[i][j], 0, 0, 0);
+            SM_PRODUCT(1, 0)
+            SM_PRODUCT(0, 1)
+            SM_PRODUCT(0, 0)
 #undef SM_PRODUCT
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
-#if SM_SPLIT2_ILV == 0
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if (STAMP && ch - ch_begin == 1) SM_TS(32 + tap)      // this stage's MFMAs are issued
-#if SM_SPLIT_TAIL_PRIO
-            __builtin_amdgcn_s_setprio(SM_SPLIT_TAIL_PRIO);   // the load / convert / store tail outranks the partner's MFMAs
-#elif SM_SPLIT_MFMA_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#ifndef SM_ABL_NOA   // (ablation builds, timing only: -DSM_ABL_NOA / _NOB / _NOREAD / _NOMFMA drop one ingredient of the loop)
             if (tap + AD < 9) {
                 SM_LOAD_A(tap + AD, ch);
             } else {
                 SM_LOAD_A(tap + AD - 9, ch_next);
             }
-#endif
             // next chunk's slice ky -> slot (base + 3 + ky) & 3: for ky = 0 the spare slot (the previous chunk's
             // ky = 2), for ky = 1, 2 the slot of this chunk's slice ky - 1, whose last readers passed the barrier of
             // tap 3 ky - 1. The slice is loaded at the end of tap 3 ky - 1 (for ky = 0: tap 8 of the previous chunk),
             // converted and written at the end of tap 3 ky + 1 - a stage WITHOUT a barrier, so that the conversion does
             // not sit on a barrier's critical path - and published by the barrier at the end of tap 3 ky + 2.
-            if constexpr (BSETS == 1) {
-#ifndef SM_ABL_NOB
-                if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky), ky); SM_ILV_PIPE(6 * NU) }
-                if (kx == 0) { SM_ILV_PIPE(0) }
-#endif
-                // six slots: the next chunk is written into the other half of the ring, which nobody reads after the
-                // barrier at the end of tap 7 of the previous chunk (tap 8 already prefetches from the new half): that
-                // one barrier per chunk both publishes the three new slices and releases the old half
-                if (RING6 && tap == 7) __syncthreads();
-                if (kx == 2) {
-#ifndef SM_ABL_NOB
-                    if (ky < 2) {
-                        SM_LOAD_B(0, ky + 1, ch_next);
-                    } else {
-                        SM_LOAD_B(0, 0, ch_next2);
-                    }
-#endif
-                    SM_ILV_PIPE(0)
-                    if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
-                    if (!RING6) __syncthreads();
+            if (kx == 1) { SM_STORE_B(0, SM_NEXT_SLOT(ky), ky); }
+            if (kx == 2) {
+                if (ky < 2) {
+                    SM_LOAD_B(0, ky + 1, ch_next);
+                } else {
+                    SM_LOAD_B(0, 0, ch_next2);
                 }
-            } else {
-                if (kx == 1) {   // slice ky of the next chunk out of its register set, the chunk after that into it
-                    SM_STORE_B(ky, SM_NEXT_SLOT(ky), ky);
-                    SM_LOAD_B(ky, ky, ch_next2);
-                }
-                if (RING6 ? tap == 7 : kx == 2) __syncthreads();
+                if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
+                __syncthreads();
             }
-#if SM_SPLIT_TAIL_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
 #if SM_SPLIT_PREFETCH_B
 #pragma unroll
             for (int s = 0; s < NP; ++s)
@@ -937,7 +696,7 @@ void conv3x3_split_kernel(ConvArgs a) {
 #endif
             if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
         }
-        base = RING6 ? 3 - base : (base + 3) & 3;
+        base = (base + 3) & 3;
     }
     }   // (ring kernel)
     SM_TS(30)
@@ -950,67 +709,22 @@ void conv3x3_split_kernel(ConvArgs a) {
 #undef SM_STORE_B
 #undef SM_READ_B
 #undef SM_READ_B_KY
-#undef SM_ILV_PIPE
-
-    // ---- KG = 2: the two groups' partial sums meet. Wave w of group g keeps column tiles [g NJ/2, (g + 1) NJ/2) of its
-    // 32 MI x 32 NJ tile and hands the other half to wave w of the other group through the (now idle) slice rings; both
-    // form group 0's sum + group 1's sum - one fixed order, deterministic - and each runs the epilogue for the tiles it
-    // kept, in acc[.][0 .. NJ/2). (The loop's last barrier is behind every fragment read of the rings.)
-    constexpr int NJE = NJ / KG;          // column tiles per wave in the epilogue
-    const int nj0 = grp * NJE;            // first of them
-    if constexpr (KG == 2) {
-        static_assert(NJ % 2 == 0 && NJE % 2 == 0, "whole segment pairs per group");
-        static_assert((size_t)8 * MI * NJE * 16 * 64 * 4 <= 2 * conv_split_lds_bytes(BM, BN, NP), "exchange fits the two rings");
-        float* X = reinterpret_cast<float*>(smem4);
-        float* mine = X + (size_t)((grp * 4 + wave) * (MI * NJE * 16)) * 64 + lane;
-        const float* theirs = X + (size_t)(((1 - grp) * 4 + wave) * (MI * NJE * 16)) * 64 + lane;
-        if (grp == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int j = 0; j < NJE; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((mi * NJE + j) * 16 + r) * 64] = acc[mi][NJE + j][r];
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int j = 0; j < NJE; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((mi * NJE + j) * 16 + r) * 64] = acc[mi][j][r];
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int j = 0; j < NJE; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][j][r] = acc[mi][j][r] + theirs[((mi * NJE + j) * 16 + r) * 64];
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int j = 0; j < NJE; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][j][r] = theirs[((mi * NJE + j) * 16 + r) * 64] + acc[mi][NJE + j][r];
-        }
-        SM_TS(50)
-    }
 
     // ---- epilogue (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31,
-    //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); column tile nj0 + j of the wave is in acc[.][j]
+    //      row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); column tile j of the wave is in acc[.][j]
     if (split >= 0) {
         float* wt = a.ws + ((size_t)(tile - a.n_whole) * a.splits + split) * (BM * BN);
 #pragma unroll
-        for (int j = 0; j < NJE; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + (nj0 + j) * 32 + l31] =
-                        NP == 2 ? acc[mi][j][r] * out_scale : acc[mi][j][r];   // power of two: exact
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + j * 32 + l31] =
+                        acc[mi][j][r] * out_scale;   // power of two: exact
         SM_TS(51)
+        // round 6: the last unit of the tile to get here reduces the slabs and runs the epilogue (conv_tail.h)
+        if (a.tail_count != nullptr) conv_tail_fused<BM, BN, FLAGS>(a, P, tile, tid, reinterpret_cast<int*>(smem4));
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
@@ -1034,12 +748,12 @@ void conv3x3_split_kernel(ConvArgs a) {
         static_assert(FLAGS == (SM_EPI_BIAS_RELU | SM_EPI_POOL) && NJ % 2 == 0, "forward epilogue, segment pairs per wave");
         const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
 #pragma unroll
-        for (int pj = 0; pj < NJE; pj += 2) {
+        for (int pj = 0; pj < NJ; pj += 2) {
             int q_seg = qs[0];
             bool alive = live[0];
 #pragma unroll
             for (int k = 1; k < SEG; ++k)
-                if (wn / 32 + nj0 + pj == k) { q_seg = qs[k]; alive = live[k]; }
+                if (wn / 32 + pj == k) { q_seg = qs[k]; alive = live[k]; }
             if (!alive) continue;                                  // (wave-uniform: a padding pair)
             const int q = q_seg + l31;                             // this lane's position in the upper row
             const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
@@ -1053,7 +767,8 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float t = acc[mi][pj][r], b = acc[mi][pj + 1][r];
-                    if (NP == 2) { t *= out_scale; b *= out_scale; }
+                    t *= out_scale;
+                    b *= out_scale;
                     const float bv = bias4[mi][r >> 2][r & 3];
                     t = fmaxf(t + bv, 0.f);
                     b = fmaxf(b + bv, 0.f);
@@ -1068,8 +783,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                     if (bp > m) { m = bp; c = 3u; }
                     if (!(m > 0.f)) c = 4u;
                     vmax = ok ? fmaxf(vmax, m) : vmax;         // (bound of the POOLED map: what the next conv reads)
-                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] =
-                        pout ? __builtin_bit_cast(float, pair_encode(m, po_scale)) : m;
+                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] = m;
                     codes[r >> 2] |= c << (4 * ((r & 3) + 4 * lhi));
                 }
 #pragma unroll
@@ -1087,18 +801,13 @@ void conv3x3_split_kernel(ConvArgs a) {
     // epilogue adds its masked Gram backward, sum_k m_k(q) (D_k F)(q), F = the gate operand - C / 16 sixteen-channel steps
     // per mask on the matrix cores for each of the wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
     // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
-#ifdef SM_ABL_NOGRAM   // (ablation build, timing only)
-    constexpr bool GRAM = false;
-#else
     constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
-#endif
     float g_fscale = 1.f, g_oscale = 1.f;
     if constexpr (GRAM) {
-        static_assert(NP == 2 && MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
+        static_assert(MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
                       "the Gram term replaces the addend of a data gradient whose row tile holds all C = BM channels");
         float inv_f, inv_d;
         g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
-        if (gate_pair) inv_f = a.pair_gate[1];   // F = the gate planes, stored as pairs under their own scale
         conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
         g_oscale = inv_f * inv_d;
     }
@@ -1112,7 +821,7 @@ void conv3x3_split_kernel(ConvArgs a) {
     if constexpr (GRAM) {
         constexpr int PH = BM / 64;             // phases of 64 channels (the ring holds 2 parts x 8 k-groups x BN units)
         constexpr int GU = 8 * BN / 256;        // staging units (k-group, position) per thread and phase
-        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= (RES ? conv_resident_lds_bytes() : (size_t)conv_split_slots(NP, BM) * SLICE * 16),
+        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= (RES ? conv_resident_lds_bytes() : (size_t)SM_SPLIT_SLOTS * SLICE * 16),
                       "a phase of the Gram operand + the gate bits of all channels fit the slice ring");
         f32x4* Gs = smem4;
         // F is also the ReLU gate of this launch's output: the staging threads - which hold the raw values - leave one bit
@@ -1166,14 +875,13 @@ void conv3x3_split_kernel(ConvArgs a) {
                 for (int u = 0; u < GU; ++u) {
                     const int kg = tid / BN + u * (256 / BN);
                     f32x4 vh, vl;
-                    if (gate_pair) pair_units(rb[u], vh, vl);
-                    else conv_gram_split(rb[u], g_fscale, vh, vl);
+                    conv_gram_split(rb[u], g_fscale, vh, vl);
                     Gs[kg * BN + g_pos] = vh;
                     Gs[(8 + kg) * BN + g_pos] = vl;
                     unsigned bits = 0u;
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        bits |= ((gate_pair ? __builtin_bit_cast(unsigned, rb[u][c]) != 0u : rb[u][c] > 0.f) ? 1u : 0u) << c;
+                        bits |= (rb[u][c] > 0.f ? 1u : 0u) << c;
                     Gb[(ph * 8 + kg) * BN + g_pos] = (unsigned char)bits;
                 }
             }
@@ -1205,12 +913,12 @@ void conv3x3_split_kernel(ConvArgs a) {
         SM_RT(9)
     }
 #pragma unroll
-    for (int nj = 0; nj < NJE; ++nj) {   // (KG = 2: column tile nj0 + nj of the wave, held in acc[.][nj])
+    for (int nj = 0; nj < NJ; ++nj) {
         int q_seg = qs[0];
         bool alive = live[0];
 #pragma unroll
         for (int k = 1; k < SEG; ++k)
-            if (wn / 32 + nj0 + nj == k) { q_seg = qs[k]; alive = live[k]; }
+            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
         const int q = q_seg + l31;
         if (!alive || q >= q_end) continue;
         // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
@@ -1226,11 +934,8 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                if (FLAGS & SM_EPI_ADD) prev[r] = P.addend ? P.addend[o] : P.out[o];
-                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) {
-                    const float gv = P.gate[o];
-                    gate[r] = gate_pair ? (__builtin_bit_cast(unsigned, gv) != 0u ? 1.f : 0.f) : gv;
-                }
+                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
+                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
             }
             if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
 #pragma unroll
@@ -1244,13 +949,13 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
                 float v = acc[mi][nj][r];
-                if (NP == 2) v *= out_scale;
+                v *= out_scale;
                 if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
                 if (FLAGS & SM_EPI_ADD) v += prev[r];
                 if constexpr (GRAM) v += accg[nj][r] * g_oscale;
                 if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
                 v = inside ? v : 0.f;
-                P.out[o] = pout ? __builtin_bit_cast(float, pair_encode(v, po_scale)) : v;
+                P.out[o] = v;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         }

@@ -434,7 +434,7 @@ static int gram_group_qb(int MI, long long total_block_positions) {
     return (int)std::max<long long>(8 * sp, std::min<long long>(qb, MI == 1 ? 4096 : 2048));
 }
 
-template <int MI, int NP, bool PAIR = false>
+template <int MI>
 static int launch_gram_group(const sm_gram_problem* problems, const int* idx, int n, hipStream_t s) {
     if (n == 0) return 0;
     constexpr int TS = 64 * MI;
@@ -454,13 +454,13 @@ static int launch_gram_group(const sm_gram_problem* problems, const int* idx, in
             const int Wp = sm::row_stride(q.W), T = q.C / TS;
             sm::GramProb& P = G.p[i];
             P = sm::GramProb{q.feat, q.mask0, q.mask1, q.S0, q.S1, q.amax_feat, q.C, sm::plane_size(q.H, q.W), Wp,
-                             (q.H + 1) * Wp, qb, (q.H * Wp + qb - 1) / qb, q.pair_feat};
+                             (q.H + 1) * Wp, qb, (q.H * Wp + qb - 1) / qb};
             G.first_block[i + 1] = G.first_block[i] + P.n_ranges * (T * (T + 1) / 2) * (q.mask1 ? 2 : 1);
         }
         bool diag_only = true;
         for (int i = 0; i < G.n; ++i) diag_only &= G.p[i].C == TS;
-        const size_t lds = sm::gram_group_lds_bytes(MI, NP, diag_only), lds_max = sm::gram_group_lds_bytes(MI, NP);
-        auto k = sm::gram_group_kernel<MI, NP, PAIR>;
+        const size_t lds = sm::gram_group_lds_bytes(MI, diag_only), lds_max = sm::gram_group_lds_bytes(MI);
+        auto k = sm::gram_group_kernel<MI>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -475,25 +475,19 @@ static int launch_gram_group(const sm_gram_problem* problems, const int* idx, in
 
 // All problems in at most two launches (64-channel tiles for C % 128 != 0, 128-channel tiles otherwise). S0 / S1 must
 // be zero on entry.
-static int gram_masked_grouped_impl(const sm_gram_problem* problems, int n, bool np2, hipStream_t s) {
+static int gram_masked_grouped_impl(const sm_gram_problem* problems, int n, hipStream_t s) {
     if (n < 1 || n > 256) return (int)hipErrorInvalidValue;
-    int idx1[256], idx2[256], idp1[256], idp2[256], n1 = 0, n2 = 0, p1 = 0, p2 = 0;
+    int idx1[256], idx2[256], n1 = 0, n2 = 0;
     for (int i = 0; i < n; ++i) {
         const sm_gram_problem& q = problems[i];
         if (q.C % 64 != 0 || q.feat == nullptr || q.mask0 == nullptr || q.S0 == nullptr || (q.mask1 && !q.S1) ||
-            (np2 && q.amax_feat == nullptr && q.pair_feat == nullptr) || (!np2 && q.pair_feat != nullptr))
+            q.amax_feat == nullptr)
             return (int)hipErrorInvalidValue;
-        // feature maps stored as fp16 pairs (pair_feat) take the un-packing kernels: one launch per (tile class, format)
-        if (q.pair_feat != nullptr) { if (q.C % 128 == 0) idp2[p2++] = i; else idp1[p1++] = i; }
-        else if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
+        if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
     }
-    int rc = np2 ? launch_gram_group<2, 2>(problems, idx2, n2, s) : launch_gram_group<2, 3>(problems, idx2, n2, s);
+    const int rc = launch_gram_group<2>(problems, idx2, n2, s);
     if (rc) return rc;
-    rc = launch_gram_group<2, 2, true>(problems, idp2, p2, s);
-    if (rc) return rc;
-    rc = launch_gram_group<1, 2, true>(problems, idp1, p1, s);
-    if (rc) return rc;
-    return np2 ? launch_gram_group<1, 2>(problems, idx1, n1, s) : launch_gram_group<1, 3>(problems, idx1, n1, s);
+    return launch_gram_group<1>(problems, idx1, n1, s);
 }
 
 
@@ -511,7 +505,7 @@ static int fill_style_terms(sm::StyleTerms& t, const float* const* targets, cons
     return 0;
 }
 
-template <int MI, bool PAIR = false>
+template <int MI>
 static int launch_gram_bwd_group(const sm_gram_bwd_problem* problems, const int* idx, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += sm::GRAM_MAX_GROUP) {
         sm::GramBwdGroup G{};
@@ -524,10 +518,10 @@ static int launch_gram_bwd_group(const sm_gram_bwd_problem* problems, const int*
             sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(q.ws);
             G.p[i] = sm::GramBwdProb{q.feat, q.mask0, two ? q.mask1 : nullptr, P0, P0 + (size_t)6 * q.C * q.C / 16, q.dfeat,
                                      q.amax_feat, q.amax_d, q.amax_out, q.C, sm::plane_size(q.H, q.W), Wp, (q.H + 1) * Wp,
-                                     q.relu_gate, np, q.pair_feat};
+                                     q.relu_gate, np};
             G.first_block[i + 1] = G.first_block[i] + np * (q.C / (64 * MI));
         }
-        hipLaunchKernelGGL((sm::gram_backward_group_kernel<MI, 2, PAIR>), dim3(G.first_block[G.n]), dim3(256), 0, s, G);
+        hipLaunchKernelGGL((sm::gram_backward_group_kernel<MI>), dim3(G.first_block[G.n]), dim3(256), 0, s, G);
         SM_LAUNCH_CHECK();
     }
     return 0;
@@ -574,7 +568,7 @@ int sm_gram_masked(const float* feat, const float* mask0, const float* mask1, fl
 int sm_gram_split_num_slabs(void) { return 1; }
 
 int sm_gram_masked_split2_grouped(const sm_gram_problem* problems, int n_problems, void* stream) {
-    return gram_masked_grouped_impl(problems, n_problems, true, (hipStream_t)stream);
+    return gram_masked_grouped_impl(problems, n_problems, (hipStream_t)stream);
 }
 
 static int gram_masked_split_impl(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C,
@@ -587,8 +581,8 @@ static int gram_masked_split_impl(const float* feat, const float* mask0, const f
         if (e == hipSuccess && mask1) e = hipMemsetAsync(S1, 0, cc * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    const sm_gram_problem q{feat, mask0, mask1, S0, S1, amax_feat, C, H, W, nullptr};
-    return gram_masked_grouped_impl(&q, 1, amax_feat != nullptr, s);
+    const sm_gram_problem q{feat, mask0, mask1, S0, S1, amax_feat, C, H, W};
+    return gram_masked_grouped_impl(&q, 1, s);
 }
 
 int sm_gram_masked_split(const float* feat, const float* mask0, const float* mask1, float* S0, float* S1, int C, int H,
@@ -606,26 +600,20 @@ size_t sm_gram_backward_split_ws_bytes(int C) { return (size_t)2 * 6 * C * C; }
 int sm_gram_backward_split(const float* feat, const float* mask0, const float* mask1, const float* D0, const float* D1,
                            float* dfeat, int C, int H, int W, int relu_gate, void* ws, const float* amax_feat,
                            const float* amax_d, void* stream) {
-    if (C % 64 != 0 || ws == nullptr || (amax_feat == nullptr) != (amax_d == nullptr)) return (int)hipErrorInvalidValue;
-    const bool np2 = amax_feat != nullptr;
+    if (C % 64 != 0 || ws == nullptr || amax_feat == nullptr || amax_d == nullptr) return (int)hipErrorInvalidValue;
     const int Wp = sm::row_stride(W), plane = sm::plane_size(H, W);
     const int q_begin = Wp, q_end = (H + 1) * Wp;
     hipStream_t s = (hipStream_t)stream;
     const bool two = mask1 && D1;
     sm::f32x4* P0 = reinterpret_cast<sm::f32x4*>(ws);
     sm::f32x4* P1 = P0 + (size_t)6 * C * C / 16;
-    if (np2)
-        hipLaunchKernelGGL(sm::gram_d_pack_kernel<2>, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1,
-                           P0, P1, C, amax_d);
-    else
-        hipLaunchKernelGGL(sm::gram_d_pack_kernel<3>, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1,
-                           P0, P1, C, amax_d);
+    hipLaunchKernelGGL(sm::gram_d_pack_kernel, dim3((C * (C / 8) + 255) / 256, two ? 2 : 1), dim3(256), 0, s, D0, D1,
+                       P0, P1, C, amax_d);
     SM_LAUNCH_CHECK();
     const float* m1 = two ? mask1 : nullptr;
-#define SM_GBS_(MI_, RG, NP_)                                                                                         \
-    hipLaunchKernelGGL((sm::gram_backward_split_kernel<MI_, RG, NP_>), dim3((q_end - q_begin + 127) / 128, C / (64 * MI_)), \
+#define SM_GBS(MI_, RG)                                                                                               \
+    hipLaunchKernelGGL((sm::gram_backward_split_kernel<MI_, RG>), dim3((q_end - q_begin + 127) / 128, C / (64 * MI_)), \
                        dim3(256), 0, s, feat, mask0, m1, P0, P1, dfeat, C, plane, q_begin, q_end, amax_feat, amax_d)
-#define SM_GBS(MI_, RG) do { if (np2) SM_GBS_(MI_, RG, 2); else SM_GBS_(MI_, RG, 3); } while (0)
     // 128-row tiles only when they still fill the chip: deep layers of small levels have a handful of position tiles,
     // and a block's K loop (C x live masks) is serial
     if (C % 128 == 0 && (long long)((q_end - q_begin + 127) / 128) * (C / 128) >= 256) {
@@ -634,7 +622,6 @@ int sm_gram_backward_split(const float* feat, const float* mask0, const float* m
         if (relu_gate) SM_GBS(1, true); else SM_GBS(1, false);
     }
 #undef SM_GBS
-#undef SM_GBS_
     SM_LAUNCH_CHECK();
     return 0;
 }
@@ -711,14 +698,13 @@ int sm_style_loss_grouped(const sm_style_problem* problems, int n_problems, floa
 int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_problems, void* stream) {
     if (n_problems < 1 || n_problems > 256) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    int idx1[256], idx2[256], idp1[256], idp2[256], n1 = 0, n2 = 0, p1 = 0, p2 = 0;
+    int idx1[256], idx2[256], n1 = 0, n2 = 0;
     for (int i = 0; i < n_problems; ++i) {
         const sm_gram_bwd_problem& q = problems[i];
         if (q.C % 64 != 0 || q.ws == nullptr || q.amax_feat == nullptr || q.amax_d == nullptr || q.D0 == nullptr)
             return (int)hipErrorInvalidValue;
         if (q.dfeat == nullptr) continue;   // pack only: the caller's conv epilogue consumes the operand images (SM_EPI_GRAM)
-        if (q.pair_feat != nullptr) { if (q.C % 128 == 0) idp2[p2++] = i; else idp1[p1++] = i; }
-        else if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
+        if (q.C % 128 == 0) idx2[n2++] = i; else idx1[n1++] = i;
     }
     // operand images of all derivative matrices in one launch
     for (int i0 = 0; i0 < n_problems; i0 += sm::GRAM_MAX_GROUP) {
@@ -733,14 +719,10 @@ int sm_gram_backward_split2_grouped(const sm_gram_bwd_problem* problems, int n_p
             G.p[i] = sm::GramPackProb{q.D0, two ? q.D1 : nullptr, P0, P0 + (size_t)6 * q.C * q.C / 16, q.amax_d, q.C, blocks};
             G.first_block[i + 1] = G.first_block[i] + blocks * (two ? 2 : 1);
         }
-        hipLaunchKernelGGL(sm::gram_d_pack_group_kernel<2>, dim3(G.first_block[G.n]), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(sm::gram_d_pack_group_kernel, dim3(G.first_block[G.n]), dim3(256), 0, s, G);
         SM_LAUNCH_CHECK();
     }
-    int rc = launch_gram_bwd_group<2>(problems, idx2, n2, s);
-    if (rc) return rc;
-    rc = launch_gram_bwd_group<2, true>(problems, idp2, p2, s);
-    if (rc) return rc;
-    rc = launch_gram_bwd_group<1, true>(problems, idp1, p1, s);
+    const int rc = launch_gram_bwd_group<2>(problems, idx2, n2, s);
     if (rc) return rc;
     return launch_gram_bwd_group<1>(problems, idx1, n1, s);
 }

@@ -1,6 +1,6 @@
-// K5a-s / K5c-s: the Gram contraction S = (mF)(mF)^T and its backward GEMM dF = m0 (D0 F) + m1 (D1 F) on the bf16
-// matrix cores at fp32 accuracy - the same bf16x3 split as conv_split_kernel.h (x = h + m + l, six partial products
-// per fp32 product, fp32 accumulate). Replace the same reference operators as gram_masked_kernel /
+// K5a-s / K5c-s: the Gram contraction S = (mF)(mF)^T and its backward GEMM dF = m0 (D0 F) + m1 (D1 F) on the fp16
+// matrix cores at fp32 accuracy - the same fp16x2 split as conv_split_kernel.h (x s = h + l, three partial products
+// per fp32 product, fp32 accumulate; round 1's bf16x3 form left in round 6). Replace the same reference operators as gram_masked_kernel /
 // gram_backward_kernel (bool-mask gather + torch.bmm and its backward, content_and_style_losses.py:74-80,136-143).
 //
 // Both kernels run the same pipeline per K stage: global loads into one of two register sets - re-issued straight
@@ -30,8 +30,9 @@ namespace sm {
 
 constexpr int GRAM_MAX_GROUP = 24;   // problems per grouped launch (kernel-argument tables)
 
-// NP = 3: bf16 x 3 operands, six partial products; NP = 2: fp16 x 2 operands scaled by a power of two from the
-// tensor's recorded max |x| (conv_split_kernel.h), three partial products. Fragments travel as raw 16-byte units.
+// fp16 x 2 operands scaled by a power of two from the tensor's recorded max |x| (conv_split_kernel.h), three partial
+// products. Fragments travel as raw 16-byte units.
+constexpr int GNP = 2;   // parts per operand
 typedef _Float16 g_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float gram_pow2_scale(float amax, float& inv) {
     const unsigned bits = __builtin_bit_cast(unsigned, amax);
@@ -53,24 +54,12 @@ __device__ __forceinline__ void split2x8(const float (&x)[8], f32x4& vh, f32x4& 
     vh = __builtin_bit_cast(f32x4, h);
     vl = __builtin_bit_cast(f32x4, l);
 }
-template <int NP>
-__device__ __forceinline__ void mfma_parts(f32x16& acc, const f32x4 (&fa)[NP], const f32x4 (&fb)[NP]) {
-    if constexpr (NP == 3) {
-#define SM_B(x_) __builtin_bit_cast(bf16x8, x_)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[2]), SM_B(fb[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[2]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[1]), SM_B(fb[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[1]), SM_B(fb[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SM_B(fa[0]), SM_B(fb[0]), acc, 0, 0, 0);
-#undef SM_B
-    } else {
+__device__ __forceinline__ void mfma_parts(f32x16& acc, const f32x4 (&fa)[GNP], const f32x4 (&fb)[GNP]) {
 #define SM_H(x_) __builtin_bit_cast(g_f16x8, x_)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[1]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[0]), SM_H(fb[0]), acc, 0, 0, 0);
 #undef SM_H
-    }
 }
 // eight fp32 values times eight per-position factors (the operand scale where the 0/1 mask is set, 0 elsewhere) -> h, l
 // fp16x8 units. No clamp: every position with a non-zero factor is live data below the recorded bound, and a masked-out
@@ -87,62 +76,25 @@ __device__ __forceinline__ void split2x8_scaled(const float (&x)[8], const float
     vh = __builtin_bit_cast(f32x4, h);
     vl = __builtin_bit_cast(f32x4, l);
 }
-// eight fp32 values -> NP operand units (NP = 2: scaled by `scale` first)
-template <int NP>
-__device__ __forceinline__ void split_parts(const float (&x)[8], float scale, f32x4 (&v)[NP]) {
-    if constexpr (NP == 3) {
-        split3x8(x, v[0], v[1], v[2]);
-    } else {
-        float y[8];
+// eight fp32 values, scaled by `scale` first -> the two operand units
+__device__ __forceinline__ void split_parts(const float (&x)[8], float scale, f32x4 (&v)[GNP]) {
+    float y[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) y[c] = x[c] * scale;
-        split2x8(y, v[0], v[1]);
-    }
+    for (int c = 0; c < 8; ++c) y[c] = x[c] * scale;
+    split2x8(y, v[0], v[1]);
 }
-
-// eight fp32 values x eight per-position factors (NP = 2: operand scale or 0; NP = 3: 1 or 0) -> NP operand units
-template <int NP>
-__device__ __forceinline__ void masked_parts(const float (&x)[8], const float (&sm)[8], f32x4 (&v)[NP]) {
-    if constexpr (NP == 3) {
-        float y[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) y[c] = (sm[c] != 0.f) ? x[c] : 0.f;
-        split3x8(y, v[0], v[1], v[2]);
-    } else {
-        split2x8_scaled(x, sm, v[0], v[1]);
-    }
-}
-
-// PAIR (round 5; conv_split_kernel.h "pair images"): eight stored fp16 pairs (word = h | l << 16) x eight per-position
-// factors (non-zero: keep, 0: masked out) -> the h unit and the l unit - two byte permutes per pair of words instead of
-// the conversion above. The pairs ARE what split2x8_scaled would build from the fp32 values under the same scale.
-__device__ __forceinline__ void masked_pair_units(const float (&w)[8], const float (&sm)[8], f32x4& vh, f32x4& vl) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned a = sm[2 * k + 1] != 0.f ? __builtin_bit_cast(unsigned, w[2 * k + 1]) : 0u;
-        const unsigned b = sm[2 * k] != 0.f ? __builtin_bit_cast(unsigned, w[2 * k]) : 0u;
-        vh[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x05040100u));
-        vl[k] = __builtin_bit_cast(float, __builtin_amdgcn_perm(a, b, 0x07060302u));
-    }
-}
-template <int NP, bool PAIR>
-__device__ __forceinline__ void masked_operand(const float (&x)[8], const float (&sm)[8], f32x4 (&v)[NP]) {
-    if constexpr (PAIR) {
-        static_assert(NP == 2, "stored pairs are fp16x2 operands");
-        masked_pair_units(x, sm, v[0], v[1]);
-    } else {
-        masked_parts<NP>(x, sm, v);
-    }
+// eight fp32 values x eight per-position factors (operand scale or 0) -> the two operand units
+__device__ __forceinline__ void masked_parts(const float (&x)[8], const float (&sm)[8], f32x4 (&v)[GNP]) {
+    split2x8_scaled(x, sm, v[0], v[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// D [C][C] fp32 (symmetric) -> MFMA A-fragment image [C/16 chunks][3 parts][2 k-groups][C rows][8] bf16
+// D [C][C] fp32 (symmetric) -> MFMA A-fragment image [C/16 chunks][2 parts][2 k-groups][C rows][8] fp16
 // ---------------------------------------------------------------------------------------------------
-template <int NP>
 __device__ __forceinline__ void gram_d_pack_body(const float* __restrict__ D, f32x4* __restrict__ P, int C,
                                                  const float* __restrict__ amax_d, int block_x) {
     float scale = 1.f;
-    if (NP == 2) {   // both matrices share one bound (max |D0|, |D1| of the style-loss kernel)
+    if (GNP == 2) {   // both matrices share one bound (max |D0|, |D1| of the style-loss kernel)
         float inv;
         scale = gram_pow2_scale(amax_read(amax_d), inv);
     }
@@ -155,18 +107,17 @@ __device__ __forceinline__ void gram_d_pack_body(const float* __restrict__ D, f3
     const f32x4 b = *reinterpret_cast<const f32x4*>(D + (size_t)row * C + g * 8 + 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { x[c] = a[c]; x[4 + c] = b[c]; }
-    f32x4 v[NP];
-    split_parts<NP>(x, scale, v);
+    f32x4 v[GNP];
+    split_parts(x, scale, v);
     const int chunk = g >> 1, kg = g & 1;
-    f32x4* d = P + (size_t)(chunk * 2 * NP + kg) * C + row;
+    f32x4* d = P + (size_t)(chunk * 2 * GNP + kg) * C + row;
 #pragma unroll
-    for (int part = 0; part < NP; ++part) d[2 * part * (size_t)C] = v[part];
+    for (int part = 0; part < GNP; ++part) d[2 * part * (size_t)C] = v[part];
 }
-template <int NP>
 __global__ __launch_bounds__(256) void gram_d_pack_kernel(const float* __restrict__ D0, const float* __restrict__ D1,
                                                           f32x4* __restrict__ P0, f32x4* __restrict__ P1, int C,
                                                           const float* __restrict__ amax_d) {
-    gram_d_pack_body<NP>(blockIdx.y ? D1 : D0, blockIdx.y ? P1 : P0, C, amax_d, blockIdx.x);
+    gram_d_pack_body(blockIdx.y ? D1 : D0, blockIdx.y ? P1 : P0, C, amax_d, blockIdx.x);
 }
 // GROUPED: the derivative matrices of many (level, layer) problems in one launch
 struct GramPackProb {
@@ -182,7 +133,6 @@ struct GramPackGroup {
     int first_block[GRAM_MAX_GROUP + 1];
     int n;
 };
-template <int NP>
 __global__ __launch_bounds__(256) void gram_d_pack_group_kernel(GramPackGroup G) {
     int g = 0;
     for (int i = 1; i < G.n; ++i)
@@ -190,7 +140,7 @@ __global__ __launch_bounds__(256) void gram_d_pack_group_kernel(GramPackGroup G)
     const GramPackProb P = G.p[g];
     const int local = blockIdx.x - G.first_block[g];
     const int which = local / P.blocks;
-    gram_d_pack_body<NP>(which ? P.D1 : P.D0, which ? P.P1 : P.P0, P.C, P.amax_d, local - which * P.blocks);
+    gram_d_pack_body(which ? P.D1 : P.D0, which ? P.P1 : P.P0, P.C, P.amax_d, local - which * P.blocks);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -209,11 +159,10 @@ struct GramBwdProb {
     const f32x4* P0;          // operand images of D0 / D1 (gram_d_pack_kernel)
     const f32x4* P1;
     float* dfeat;
-    const float* amax_feat;   // NP = 2 only
+    const float* amax_feat;
     const float* amax_d;
     float* amax_out;          // optional: records max |dF| (the operand bound of the conv that consumes dfeat)
     int C, plane, q_begin, q_end, relu_gate, n_ptiles;
-    const float* pair_feat;   // PAIR kernels: {scale, 1 / scale} of the stored pairs of feat
 };
 struct GramBwdGroup {
     GramBwdProb p[GRAM_MAX_GROUP];
@@ -221,7 +170,7 @@ struct GramBwdGroup {
     int n;
 };
 
-template <int MI, int NP, bool PAIR = false>
+template <int MI>
 __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const int block_x, const int block_y) {
     const float* __restrict__ feat = G.feat;
     const float* __restrict__ mask0 = G.mask0;
@@ -236,12 +185,11 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
     const float amax_seen = amax_peek(G.amax_out);
     constexpr int BN = 128;
     constexpr int KS = 2;                 // MFMA K-steps (16 channels each) per stage
-    constexpr int SLICE = KS * 2 * NP * BN;    // [kstep][part][kgroup][position] units of 8 channels
+    constexpr int SLICE = KS * 2 * GNP * BN;    // [kstep][part][kgroup][position] units of 8 channels
     float f_scale = 1.f, out_scale = 1.f;
-    if (NP == 2) {
+    if (GNP == 2) {
         float inv_f, inv_d;
         f_scale = gram_pow2_scale(amax_read(amax_feat), inv_f);
-        if constexpr (PAIR) inv_f = G.pair_feat[1];
         gram_pow2_scale(amax_read(amax_d), inv_d);
         out_scale = inv_f * inv_d;
     }
@@ -272,7 +220,7 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         const int kfix = live0 ? 0 : 1;
         const float* bsrc = feat + (size_t)b_kg * 8 * plane + q0 + b_px;
         const int a_off = lhi * C + m0 + wm + l31;
-        f32x4 ra[2][KS][1][NP];
+        f32x4 ra[2][KS][1][GNP];
         float rb[2][KS][8];
         // stage s -> (chunk, mask); beyond the last stage the last one is re-read (unconditional loads keep the
         // compiler's vmcnt bookkeeping exact, see conv_split_kernel.h)
@@ -283,10 +231,10 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
 #define SM_LOAD_A(set_, s_)                                                                 \
     {                                                                                       \
         SM_STAGE_OF(s_, chunk_, k_)                                                         \
-        const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 2 * NP * C + a_off;        \
+        const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 2 * GNP * C + a_off;        \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part)                         \
-                ra[set_][ks][0][part] = p_[(ks * 2 * NP + part * 2) * C];                   \
+            _Pragma("unroll") for (int part = 0; part < GNP; ++part)                         \
+                ra[set_][ks][0][part] = p_[(ks * 2 * GNP + part * 2) * C];                   \
     }
 #define SM_LOAD_B(set_, s_)                                                                 \
     {                                                                                       \
@@ -304,10 +252,10 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         float sm_[8];   /* the operand scale where this position's mask is set, 0 elsewhere */ \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) sm_[c] = (mv_ != 0.f) ? f_scale : 0.f; \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
-            f32x4 v_[NP];                                                                   \
-            masked_operand<NP, PAIR>(rb[set_][ks], sm_, v_);                                \
-            f32x4* d_ = &Bs[buf_][ks * 2 * NP * BN + b_kg * BN + b_px];                     \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[2 * part * BN] = v_[part]; \
+            f32x4 v_[GNP];                                                                   \
+            masked_parts(rb[set_][ks], sm_, v_);                                \
+            f32x4* d_ = &Bs[buf_][ks * 2 * GNP * BN + b_kg * BN + b_px];                     \
+            _Pragma("unroll") for (int part = 0; part < GNP; ++part) d_[2 * part * BN] = v_[part]; \
         }                                                                                   \
     }
 #define SM_STAGE(s_, par_)                                                                  \
@@ -316,13 +264,13 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         SM_LOAD_B(1 - (par_), (s_) + 3)   /* back into the set just stored: two stages of lead */ \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
-            f32x4 fa[1][NP], fb[NJ][NP];                                                    \
-            const f32x4* bf_ = &Bs[par_][ks * 2 * NP * BN + lhi * BN + wn + l31];           \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part) {                       \
+            f32x4 fa[1][GNP], fb[NJ][GNP];                                                    \
+            const f32x4* bf_ = &Bs[par_][ks * 2 * GNP * BN + lhi * BN + wn + l31];           \
+            _Pragma("unroll") for (int part = 0; part < GNP; ++part) {                       \
                 fa[0][part] = ra[par_][ks][0][part];                                        \
                 _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb[j][part] = bf_[part * 2 * BN + j * 32]; \
             }                                                                               \
-            _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma_parts<NP>(acc[0][j], fa[0], fb[j]); \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma_parts(acc[0][j], fa[0], fb[j]); \
         }                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         SM_LOAD_A(par_, (s_) + 2)                                                           \
@@ -360,8 +308,8 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[0][nj][r];
-            if (NP == 2) v *= out_scale;
-            if (RELU_GATE) v = (PAIR ? __builtin_bit_cast(unsigned, gate[r]) != 0u : gate[r] > 0.f) ? v : 0.f;
+            if (GNP == 2) v *= out_scale;
+            if (RELU_GATE) v = gate[r] > 0.f ? v : 0.f;
             side_store(v, dfeat + o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane);
             vmax = fmaxf(vmax, fabsf(v));
         }
@@ -369,24 +317,24 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
     record_amax(G.amax_out, vmax, amax_seen);
 }
 
-template <int MI, bool RELU_GATE_, int NP>
+template <int MI, bool RELU_GATE_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2, MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2))) void gram_backward_split_kernel(
     const float* __restrict__ feat, const float* __restrict__ mask0, const float* __restrict__ mask1,
     const f32x4* __restrict__ P0, const f32x4* __restrict__ P1, float* __restrict__ dfeat, int C, int plane, int q_begin,
     int q_end, const float* __restrict__ amax_feat, const float* __restrict__ amax_d) {
-    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, nullptr, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0, nullptr};
-    gram_backward_body<MI, NP>(G, blockIdx.x, blockIdx.y);
+    const GramBwdProb G{feat, mask0, mask1, P0, P1, dfeat, amax_feat, amax_d, nullptr, C, plane, q_begin, q_end, RELU_GATE_ ? 1 : 0, 0};
+    gram_backward_body<MI>(G, blockIdx.x, blockIdx.y);
 }
 
 // GROUPED: one launch over the (level, layer) problems of one row-tile class; block -> (problem, position tile, row tile)
-template <int MI, int NP, bool PAIR = false>
+template <int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2, MI == 1 ? SM_GRAM_BWD_W1 : SM_GRAM_BWD_W2))) void gram_backward_group_kernel(GramBwdGroup G) {
     int g = 0;
     for (int i = 1; i < G.n; ++i)
         if ((int)blockIdx.x >= G.first_block[i]) g = i;
     const GramBwdProb P = G.p[g];
     const int local = blockIdx.x - G.first_block[g];
-    gram_backward_body<MI, NP, PAIR>(P, local % P.n_ptiles, local / P.n_ptiles);
+    gram_backward_body<MI>(P, local % P.n_ptiles, local / P.n_ptiles);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -408,9 +356,8 @@ struct GramProb {
     const float* mask1;       // nullptr: one mask
     float* S0;
     float* S1;
-    const float* amax_feat;   // NP = 2 only
+    const float* amax_feat;
     int C, plane, q_begin, q_end, qb, n_ranges;
-    const float* pair_feat;   // PAIR kernels: {scale, 1 / scale} of the stored pairs of feat
 };
 struct GramGroup {
     GramProb p[GRAM_MAX_GROUP];
@@ -419,18 +366,18 @@ struct GramGroup {
 };
 constexpr int gram_ks(int MI) { return MI == 1 ? 4 : 2; }
 constexpr int gram_kg_stride(int MI) { return MI == 1 ? 64 + 1 : 128 + 2; }
-constexpr int gram_ks_stride(int MI, int NP) {
-    int v = 2 * NP * gram_kg_stride(MI);
+constexpr int gram_ks_stride(int MI) {
+    int v = 2 * GNP * gram_kg_stride(MI);
     while (v % 8 != (MI == 1 ? 2 : 4)) ++v;
     return v;
 }
-constexpr size_t gram_group_lds_bytes(int MI, int NP, bool diag_only = false) {
-    return (size_t)(diag_only ? 2 : 4) * gram_ks(MI) * gram_ks_stride(MI, NP) * 16;
+constexpr size_t gram_group_lds_bytes(int MI, bool diag_only = false) {
+    return (size_t)(diag_only ? 2 : 4) * gram_ks(MI) * gram_ks_stride(MI) * 16;
 }
 
 // MI = 1 (126 VGPRs): four blocks per CU when every problem of the launch is a single diagonal tile (C = 64: the Bt
 // half of the LDS image is not allocated then) - a block keeps ~one 16 KB stage in flight, a CU needs ~50 KB
-template <int MI, int NP, bool PAIR = false>
+template <int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? SM_GRAM_FWD_W1 : 2, MI == 1 ? SM_GRAM_FWD_W1 : 2))) void gram_group_kernel(GramGroup G) {
     constexpr int TS = 64 * MI;                 // tile size (channels)
     constexpr int KS = gram_ks(MI);             // MFMA K-steps per stage
@@ -439,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     constexpr int CP = 256 / NG;                // channels per staging pass
     constexpr int R = TS / CP;                  // staging passes
     static_assert(R == 2, "two staging units per thread and operand");
-    constexpr int KG = gram_kg_stride(MI), PART = 2 * KG, KSS = gram_ks_stride(MI, NP), BUF = KS * KSS;
+    constexpr int KG = gram_kg_stride(MI), PART = 2 * KG, KSS = gram_ks_stride(MI), BUF = KS * KSS;
     extern __shared__ __attribute__((aligned(16))) f32x4 gsm[];
     f32x4* As = gsm;                            // [2][BUF]
     f32x4* Bt = gsm + 2 * BUF;                  // [2][BUF]
@@ -465,14 +412,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     const int C = P.C, plane = P.plane;
 
     float f_scale = 1.f, out_scale = 1.f;
-    if (NP == 2) {
+    if (GNP == 2) {
         float inv;
-        if constexpr (PAIR) {
-            f_scale = 1.f;   // (only its being non-zero matters: the masks select stored pairs)
-            inv = P.pair_feat[1];
-        } else {
-            f_scale = gram_pow2_scale(amax_read(P.amax_feat), inv);
-        }
+        f_scale = gram_pow2_scale(amax_read(P.amax_feat), inv);
         out_scale = inv * inv;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -524,7 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
 #ifdef SM_ABL_GRAM_NOMFMA
 #define SM_GRAM_MFMA(acc_, fa_, fb_) asm volatile("" :: "v"(fa_[0]), "v"(fb_[0]), "v"(fa_[1]), "v"(fb_[1]))
 #else
-#define SM_GRAM_MFMA(acc_, fa_, fb_) mfma_parts<NP>(acc_, fa_, fb_)
+#define SM_GRAM_MFMA(acc_, fa_, fb_) mfma_parts(acc_, fa_, fb_)
 #endif
 #ifdef SM_ABL_GRAM_NOLOAD
 #define SM_ABL_LOAD_COND(i_) if ((i_) < 2)
@@ -561,14 +503,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     SM_ABL_STORE_COND                                                                                   \
     {                                                                                                   \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
-            f32x4 v_[NP];                                                                               \
-            masked_operand<NP, PAIR>(rA[set_][r], rM[set_], v_);                                        \
+            f32x4 v_[GNP];                                                                               \
+            masked_parts(rA[set_][r], rM[set_], v_);                                        \
             f32x4* d_ = As + (buf_) * BUF + u_dst + r * CP;                                             \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part) d_[part * PART] = v_[part];         \
+            _Pragma("unroll") for (int part = 0; part < GNP; ++part) d_[part * PART] = v_[part];         \
             if constexpr (!DIAG) {                                                                                \
-                masked_operand<NP, PAIR>(rB[set_][r], rM[set_], v_);                                    \
+                masked_parts(rB[set_][r], rM[set_], v_);                                    \
                 f32x4* e_ = Bt + (buf_) * BUF + u_dst + r * CP;                                         \
-                _Pragma("unroll") for (int part = 0; part < NP; ++part) e_[part * PART] = v_[part];     \
+                _Pragma("unroll") for (int part = 0; part < GNP; ++part) e_[part * PART] = v_[part];     \
             }                                                                                           \
         }                                                                                               \
     }
@@ -580,8 +522,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
         const f32x4* af_ = As + (par_) * BUF + lhi * KG + wm + l31;                                     \
         const f32x4* bf_ = (DIAG ? As : Bt) + (par_) * BUF + lhi * KG + wn + l31;                       \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                             \
-            f32x4 fa[MI][NP], fb[MI][NP];                                                               \
-            _Pragma("unroll") for (int part = 0; part < NP; ++part)                                     \
+            f32x4 fa[MI][GNP], fb[MI][GNP];                                                               \
+            _Pragma("unroll") for (int part = 0; part < GNP; ++part)                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                        \
                     fa[i][part] = af_[ks * KSS + part * PART + i * 32];                                 \
                     fb[i][part] = bf_[ks * KSS + part * PART + i * 32];                                 \
@@ -626,7 +568,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
 #ifdef SM_ABL_GRAM_NOATOMIC   // (ablation build, timing only)
                 if (acc[mi][nj][r] == 12345.f) S[(size_t)row * C + col] = 1.f;
 #else
-                atomicAdd(&S[(size_t)row * C + col], NP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r]);
+                atomicAdd(&S[(size_t)row * C + col], GNP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r]);
 #endif
             }
 }

@@ -62,7 +62,7 @@ const Entry ENTRIES[] = {
     SM_ENTRY(sm_tex_sample_fwd), SM_ENTRY(sm_tex_sample_fwd_grouped), SM_ENTRY(sm_tex_sample_bwd),
     SM_ENTRY(sm_tex_touch_flags), SM_ENTRY(sm_tex_scatter_planned), SM_ENTRY(sm_adam_fused),
     SM_ENTRY(sm_adam_hyper_step), SM_ENTRY(sm_step_begin), SM_ENTRY(sm_flags_or), SM_ENTRY(sm_clamp_sumsq),
-    SM_ENTRY(sm_conv3x3), SM_ENTRY(sm_conv3x3_grouped), SM_ENTRY(sm_conv3x3_grouped_split),
+    SM_ENTRY(sm_conv3x3), SM_ENTRY(sm_conv3x3_grouped),
     SM_ENTRY(sm_conv3x3_grouped_split2), SM_ENTRY(sm_fmap_amax), SM_ENTRY(sm_conv3x3_dgrad_c3),
     SM_ENTRY(sm_maxpool2x2_fwd), SM_ENTRY(sm_maxpool2x2_bwd_relu), SM_ENTRY(sm_conv3x3_dgrad_c3_grouped),
     SM_ENTRY(sm_maxpool2x2_fwd_grouped), SM_ENTRY(sm_maxpool2x2_bwd_relu_grouped), SM_ENTRY(sm_conv3x3_dgrad_c3_tiles),
@@ -70,8 +70,7 @@ const Entry ENTRIES[] = {
     SM_ENTRY(sm_gram_masked), SM_ENTRY(sm_gram_masked_split), SM_ENTRY(sm_gram_masked_split_acc),
     SM_ENTRY(sm_gram_masked_split2_grouped), SM_ENTRY(sm_style_loss), SM_ENTRY(sm_gram_backward),
     SM_ENTRY(sm_gram_backward_split), SM_ENTRY(sm_style_loss_grouped), SM_ENTRY(sm_gram_backward_split2_grouped),
-    SM_ENTRY(sm_mse_masked), SM_ENTRY(sm_copy_floats), SM_ENTRY(sm_zero_floats), SM_ENTRY(sm_conv3x3_grouped_pair),
-    SM_ENTRY(sm_pair_roll), SM_ENTRY(sm_pair_check),
+    SM_ENTRY(sm_mse_masked), SM_ENTRY(sm_copy_floats), SM_ENTRY(sm_zero_floats),
 };
 constexpr int N_ENTRIES = (int)(sizeof(ENTRIES) / sizeof(ENTRIES[0]));
 

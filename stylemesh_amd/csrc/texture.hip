@@ -358,14 +358,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ sumsq, const float* __restrict__ dev_hyper,
                                                    int tiles_per_block, const int32_t* __restrict__ touched,
                                                    int touched_log2) {
-    // dev_hyper[2] == 0 (round 5): the step was INVALIDATED on the device (pair images: a stored operand overflowed its
-    // predicted scale, sm_pair_check) - p, m, v stay as they are, sum(p^2) is still taken and the gradient still zeroed,
-    // so that the repeated step starts from the same state.
-    bool skip = false;
     if (ADAM && dev_hyper) {   // step-dependent scalars from device memory: the launch can be replayed from a hipGraph
         lr_over_bc1 = dev_hyper[0];
         inv_sqrt_bc2 = dev_hyper[1];
-        skip = dev_hyper[2] == 0.f;
     }
     // A block walks tiles_per_block consecutive tiles of 1024 elements and keeps sum(p^2) of the segment it is in in
     // registers: one atomic per block and segment instead of one per tile - tens of thousands of atomics on the same
@@ -446,7 +441,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             for (int j = 0; j < 4; ++j) {
                 const int k = seg_of(segs, i0 + j);
                 float x = pv[u][j];
-                if (ADAM && !skip) {
+                if (ADAM) {
                     const float gr = fmaf(gv[u][j], grad_scale, segs.reg[k] * x);  // data term (+ mean over ranks) + reg
                     mv[u][j] = mv[u][j] + (gr - mv[u][j]) * one_minus_beta1;       // exp_avg.lerp_(grad, 1 - beta1)
                     vv[u][j] = vv[u][j] * beta2 + (gr * gr) * one_minus_beta2;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
@@ -461,12 +456,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 }
             }
             if (full) {
-                if (!skip) adam_store4(p + i0, pv[u]);
+                adam_store4(p + i0, pv[u]);
                 if (ADAM) {
-                    if (!skip) {
-                        adam_store4(m + i0, mv[u]);
-                        adam_store4(v + i0, vv[u]);
-                    }
+                    adam_store4(m + i0, mv[u]);
+                    adam_store4(v + i0, vv[u]);
                     if (zero_grad && g) {
                         const float z[4] = {0.f, 0.f, 0.f, 0.f};
                         adam_store4(g + i0, z);
@@ -474,12 +467,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 }
             } else {
                 for (int j = 0; j < 4 && i0 + j < n; ++j) {
-                    if (!skip) p[i0 + j] = pv[u][j];
+                    p[i0 + j] = pv[u][j];
                     if (ADAM) {
-                        if (!skip) {
-                            m[i0 + j] = mv[u][j];
-                            v[i0 + j] = vv[u][j];
-                        }
+                        m[i0 + j] = mv[u][j];
+                        v[i0 + j] = vv[u][j];
                         if (zero_grad && g) g[i0 + j] = 0.f;
                     }
                 }
@@ -496,18 +487,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 // Step-dependent Adam scalars kept ON THE DEVICE (hipGraph replay: the host may run many steps ahead of the GPU, so
 // nothing step-dependent may travel through a host buffer that a later step overwrites): state = {lr, step} in double;
 // one thread advances the step and writes {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} - the doubles torch computes.
-// out3[2] = 1: the update is valid. guard (optional, sm_pair_check's status): *guard == 0 leaves the step count where
-// it is and writes 0 - sm_adam_fused then changes nothing but the gradient (zeroed) and sum(p^2).
-__global__ void adam_hyper_step_kernel(double* state, double beta1, double beta2, float* out3, const int* guard) {
-    if (guard != nullptr && *guard == 0) {
-        out3[2] = 0.f;
-        return;
-    }
+__global__ void adam_hyper_step_kernel(double* state, double beta1, double beta2, float* out2) {
     const double t = state[1] + 1.0;
     state[1] = t;
-    out3[0] = (float)(state[0] / (1.0 - pow(beta1, t)));
-    out3[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
-    out3[2] = 1.f;
+    out2[0] = (float)(state[0] / (1.0 - pow(beta1, t)));
+    out2[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
 }
 
 __global__ __launch_bounds__(256) void flags_or_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, size_t n) {
@@ -639,9 +623,8 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
     return 0;
 }
 
-int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, const int32_t* guard, void* stream) {
-    hipLaunchKernelGGL(sm::adam_hyper_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2, dev_hyper,
-                       reinterpret_cast<const int*>(guard));
+int sm_adam_hyper_step(double* state, double beta1, double beta2, float* dev_hyper, void* stream) {
+    hipLaunchKernelGGL(sm::adam_hyper_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2, dev_hyper);
     SM_LAUNCH_CHECK();
     return 0;
 }

@@ -30,17 +30,11 @@ SWITCHES = {
                                 "first visit and is copied back at the next one instead of being recomputed (one rank, grouped view "
                                 "path). +7.5 % when the view changes every step and views recur (bench.py's `resident_views` leg), "
                                 "neutral on the reference's index_repeat-20 schedules (profiles/r05/resident_views.txt): opt-in"),
-    "STYLEMESH_PAIR_IMAGES": ("0", "experiment", "round 5: VGG tensors stored as packed fp16 pairs by their producers under predicted "
-                              "scales (verify-and-repeat protocol). Kernel time -3.7 %, step -3.6 % on c3: opt-in "
-                              "(profiles/r05/pair_images_ab.txt)"),
-    "STYLEMESH_PAIR_HEADROOM": ("4", "experiment", "head-room factor of the predicted pair-image scales (power of two)"),
     "SM_CONV_SPLIT_PENALTY": ("3", "tuning", "(C library) cost of a K-split tail's second pass in tile-chunks, in the split-count "
                               "model (c2 +0.6 % at 2-4, -5 % at 8: profiles/r04/split_penalty_ab.txt)"),
+    "SM_CONV_TAIL_PASS": ("0", "diagnostic", "(C library) 1 = the fp16x2 conv kernel's K-split tail reduced by a second launch (rounds 2-5) "
+                          "instead of inside the launch (csrc/conv_tail.h; same bits: tests/test_round6_gpu.py)"),
     "SM_CONV_FORCE_SPLITS": ("(unset)", "experiment", "(C library) force the tail's K-split count (tools/bench_c2_layers.py sweeps)"),
-    "SM_CONV_KG": ("1", "experiment", "(C library, needs -DSM_CONV_KG2_BUILD=1) 2 = 512-thread blocks of two wave groups for small "
-                   "grids: -8 % on the one-level layers (profiles/r05/kg2_c2_layers.txt)"),
-    "SM_CONV_SMALL_BM64": ("0", "experiment", "(C library) launches of up to N 128 x 128 tiles take 64 x 128 tiles, three blocks per CU: "
-                           "no effect on the one-level layers (profiles/r05/c2_layer_ablation.txt)"),
     "SM_CONV_STAMP": ("(unset)", "diagnostic", "(C library) the conv build that writes s_memtime stage stamps (tools/ts_split.py, ts_small.py)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),
     # ---- step structure
@@ -65,8 +59,8 @@ SWITCHES = {
     # ---- multi-GPU
     "STYLEMESH_DIST_BACKEND": ("nccl", "mode", "process-group backend of bench.py / the launcher (gloo: functional runs with all ranks on one GPU)"),
     "STYLEMESH_COMM": ("(rccl over nccl groups)", "mode", "rccl = the product's own communicator (fails loudly), torch = torch.distributed"),
-    "STYLEMESH_PIPELINE_EXCHANGE": ("auto", "mode", "gradient exchange in pieces overlapped with the update: auto = from "
-                                    "STYLEMESH_PIPELINE_MIN_MB of flagged chunks on; 1 / 0 = always / never"),
+    "STYLEMESH_PIPELINE_EXCHANGE": ("0", "mode", "gradient exchange in pieces overlapped with the update: 1 / 0 = always / never; "
+                                    "auto = from STYLEMESH_PIPELINE_MIN_MB of flagged chunks on (opt-in until timed over RCCL)"),
     "STYLEMESH_PIPELINE_MIN_MB": ("32", "tuning", "threshold of the auto policy above"),
     "STYLEMESH_LAUNCHED_BY": ("(set by the launcher)", "diagnostic", "who started the ranks, echoed in the bench line"),
     # ---- host

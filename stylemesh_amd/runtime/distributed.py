@@ -737,8 +737,10 @@ class SparseGradReducer:
         and ``update_range(lo, hi)`` - the fused optimizer over arena elements [lo, hi) - is issued for a piece as
         soon as its sums have arrived, while the later pieces are still on the links. The ranges tile [0, n) in
         order; same arithmetic as ``__call__`` followed by one update over the whole arena. OPT-IN
-        (``StepEngine.pipeline_exchange``, ``bench.py --pipeline-exchange``): verified functionally (2 ranks over gloo,
-        CPU and one shared GPU), not yet timed on RCCL hardware - the 1-GPU boxes cannot."""
+        (``StepEngine.pipeline_exchange`` / STYLEMESH_PIPELINE_EXCHANGE=1|auto, ``bench.py --pipeline-exchange``): verified
+        functionally and bit for bit (2 and 8 ranks over gloo, CPU and one shared GPU), never timed over RCCL on separate
+        GPUs - the 1-GPU boxes cannot - so the plain exchange-then-update, which keeps the measured early half of the split
+        update, stays the default."""
         n = flat_grad.numel()
         dist = self.dist
         sparse = self._sparse(n)

@@ -148,8 +148,6 @@ class StepEngine:
     N_SLOTS = 2         # buffer sets of per-view constants: the current view + the views prepared ahead. (3 = TWO views in
                         # preparation, measured on the dip schedule in round 4: 663 views/s either way - that schedule is
                         # bound by the ~210 kernel dispatches of a step + a preparation, not by a wait for the read-back)
-    _pair_pending = ()  # pair-image bookkeeping (set per instance in __init__): nothing outstanding on an engine whose
-    _pair_failed = 0    # kernels are stubbed (tests/test_distributed_cpu.py builds one without __init__)
 
     def __init__(self, cfg: EngineConfig, vgg_state: dict, device="cuda", random_init=False):
         cfg.validate()
@@ -247,13 +245,14 @@ class StepEngine:
         self._scatter_levels = None
         self._grad_dirty = False   # does the gradient arena hold anything since the last fused update?
         self._lv_streams = []
-        # N > 1, opt-in: all-reduce the gradient in pieces and update each arena range as soon as its sums arrive
-        # (functionally verified over gloo; not yet timed under RCCL, so the plain exchange-then-update is the default)
-        # ... round 5: by DEFAULT whenever the ranks' views flag at least STYLEMESH_PIPELINE_MIN_MB (32) megabytes of the
-        # arena - where the exchange is long enough for the update of the early pieces to hide behind the later ones;
-        # STYLEMESH_PIPELINE_EXCHANGE=1 / 0 forces / forbids it. Same arithmetic either way (update by ranges:
-        # test_adam_fused_by_ranges_equals_one_launch; 2-rank bit-identity: tests/test_round5_gpu.py)
-        self.pipeline_exchange = {"1": True, "0": False}.get(os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "auto"), "auto")
+        # N > 1, OPT-IN (STYLEMESH_PIPELINE_EXCHANGE=1, or =auto: whenever the ranks' views flag at least
+        # STYLEMESH_PIPELINE_MIN_MB megabytes of the arena): all-reduce the gradient in pieces and update each arena range as
+        # soon as its sums arrive. Same arithmetic as exchange-then-update (update by ranges:
+        # test_adam_fused_by_ranges_equals_one_launch; 2-rank bit-identity: tests/test_round5_gpu.py), but only ever timed
+        # over gloo with every rank on ONE GPU - and a pipelined step gives up the early half of the split update, whose gain
+        # IS measured. So the default stays the plain exchange until an RCCL run on separate GPUs has timed both.
+        self.pipeline_exchange = {"1": True, "0": False, "auto": "auto"}.get(
+            os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0"), False)
         self.pipeline_min_bytes = int(float(os.environ.get("STYLEMESH_PIPELINE_MIN_MB", "32")) * (1 << 20))
         self.view_tiles = None
         # Resident views (round 5; viewplan.ResidentView), OPT-IN (STYLEMESH_VIEW_CACHE_GB=<budget>): the per-view state of
@@ -290,25 +289,6 @@ class StepEngine:
         self._adam_early_done = None   # event: the update of the other chunks (issued at the head of the step) is done
         self.split_update = os.environ.get("STYLEMESH_SPLIT_UPDATE", "1") != "0"
         self._gram_fused = {}
-        # Pair images (round 5; include/stylemesh_hip.h "PAIR IMAGES", runtime/vgg.py:PairCtx): in the multi-level steps
-        # (grouped loss phase on side streams, one rank) the VGG activations / gradients are stored as packed fp16 pairs by
-        # their producers, under scales predicted from the bounds the PREVIOUS step recorded (x head-room); a step whose
-        # tensors outgrew their scales is invalidated on the device (no update) and repeated - see ``_pair_*`` below.
-        # OPT-IN (STYLEMESH_PAIR_IMAGES=1): measured on c3 (profiles/r05/pair_images_ab.txt) the conv kernels gain 1-5 %, the
-        # Gram forward 11 %, the whole step's kernel time 3.7 % - and the step LOSES 3.6 % end to end (the early half of the
-        # split update can no longer hide beside the convs, five more small launches per step), 22 % in the first steps
-        # from a zero texture, where every other step is invalidated. The 13.5 % the conversion-free ablation build had
-        # promised was the clock the chip gains on garbage operands, not the conversion's cost.
-        self.pair_images = os.environ.get("STYLEMESH_PAIR_IMAGES", "0") == "1"
-        self.pair_headroom = float(os.environ.get("STYLEMESH_PAIR_HEADROOM", "4"))
-        self._pair_step = False        # is the step in flight a pair-image step?
-        self._pair_ctx = None
-        self._pair_table = None        # {scale, 1 / scale} per AmaxBook entry
-        self._pair_status = None       # device int32 [4]: sm_pair_check
-        self._pair_pending = []        # [(event, pinned int32[4])]: status copies of steps the host has not looked at yet
-        self._pair_failed = 0          # invalidated steps of the current view that still have to be repeated
-        self._pair_dev_step = False    # the device-side Adam step counter is current (consecutive pair steps)
-        self.pair_stats = {"steps": 0, "invalid": 0, "repeated": 0}
         self.overlap_min_pixels = int(os.environ.get("STYLEMESH_OVERLAP_MIN_PIXELS", "400000"))
         self.sparse_update = True   # bench.py --dense-adam / tests switch it off
 
@@ -340,22 +320,18 @@ class StepEngine:
         return self.cfg.learning_rate * self.cfg.decay_gamma ** (self.epoch // self.cfg.decay_step_size)
 
     # ------------------------------------------------------------------ buffers
-    def _level_bufs(self, H, W, pair=False) -> LevelBuffers:
-        """``pair``: the buffer set of the pair-image steps - planes that are only ever written in their pair form (a
-        stale fp32 value read as a pair could be an fp16 infinity)."""
-        key = (H, W, "pair") if pair else (H, W)
+    def _level_bufs(self, H, W) -> LevelBuffers:
+        key = (H, W)
         if key not in self._bufs:
             self._bufs[key] = LevelBuffers(H, W, self.deepest, True, self.device)
         return self._bufs[key]
 
     def _grad_planes(self, H, W, skip):
-        """Gradient planes (of every buffer set that exists) of one level size: re-zeroed when a new view arrives."""
+        """Gradient planes of one level size: re-zeroed when a new view arrives."""
         out = []
-        for key in ((H, W), (H, W, "pair")):
-            b = self._bufs.get(key)
-            if b is not None:
-                out += [g.buf for name, g in b.grad.items() if name not in skip]
-                out += [g.buf for g in b.gradp.values()]
+        b = self._bufs.get((H, W))
+        if b is not None:
+            out += [g.buf for name, g in b.grad.items() if name not in skip]
         return out
 
     def _gram_scratch(self, key, n_slabs=1):
@@ -934,7 +910,7 @@ class StepEngine:
             from .viewplan import TileLists, resident_lists
             self.view_tiles = TileLists()
             dsts, srcs = [], []
-            lists = build_tile_lists(needs, self.deepest, msums, resident=resident_lists() and not self.pair_images)
+            lists = build_tile_lists(needs, self.deepest, msums, resident=resident_lists())
             if msums is not None:
                 lists, sums_host = lists
             self.view_tiles.quads = lists.quads
@@ -974,23 +950,18 @@ class StepEngine:
         ``accumulate_grad=False`` (validation): everything but the final texture scatter - the arena is untouched."""
         if self.view is None or self.targets is None:
             raise RuntimeError("set_style_image() and set_view() must be called first")
-        self._join_early()
         cfg = self.cfg
         from .vgg import OUT_NAMES as vgg_names
         w_style = float(cfg.loss_weights.get("style", 0.0))
         w_content = float(cfg.loss_weights.get("content", 0.0))
         active = [lv for lv in self.view if lv.active]
         if not active or self.deepest is None:
-            self._pair_step = False
             if self._adam_early_pending:
                 self._adam_early()
             self._zero_step_accumulators()
             return
         # layer-major over the active UV levels: every conv layer is ONE grouped launch over all levels
-        pair = self._pair_wanted(active, accumulate_grad)
-        if self._pair_step and not pair:
-            self._pair_step = False        # (decided in step_compute, before the view's shape was looked at)
-        bufs = [self._level_bufs(lv.H, lv.W, pair=pair) for lv in active]
+        bufs = [self._level_bufs(lv.H, lv.W) for lv in active]
         self._reserve_gram_scratch(active, bufs)
         self._zero_step_accumulators()
         if len({(lv.H, lv.W) for lv in active}) != len(active):
@@ -1110,23 +1081,15 @@ class StepEngine:
             upd_at = self.early_update_at if (self.early_update_at in vgg_names
                                               and depth_of(self.early_update_at) <= depth_of(self.deepest)) else None
 
-            pctx = None
-            if pair:
-                # the early half of the split update waits for the step's verdict (``_pair_close``): it must not touch
-                # the texture of a step that is going to be repeated
-                upd_at = None
-                from .vgg import PairCtx
-                pctx = self._pair_ctx = PairCtx(self._pair_table, self.amax, cfg.content_layers, self.deepest)
-
             def on_layer(layer):
-                if self._adam_early_pending and layer == upd_at and not pair:
+                if self._adam_early_pending and layer == upd_at:
                     self._adam_early()
                 if side:
                     fork(layer)
-            if self._adam_early_pending and upd_at is None and not pair:
+            if self._adam_early_pending and upd_at is None:
                 self._adam_early()
             self.vgg.forward_group(bufs, self.view_tiles, on_layer=on_layer if (side or self._adam_early_pending) else None,
-                                   amax=self.amax, pair=pctx)
+                                   amax=self.amax)
             injected = set()
             concurrent = (self.level_streams and len(active) > 1 and cfg.gram_mode != "average"
                           and not torch.cuda.is_current_stream_capturing())
@@ -1171,11 +1134,9 @@ class StepEngine:
                     injected = self._inject_losses(lv, b, w_style, w_content)
             self.vgg.backward_group(bufs, injected - {self.deepest}, self.deepest, self.view_tiles, amax=self.amax,
                                     start_bound_recorded=start_bound, before_layer=join if side else None,
-                                    gram_terms=self._gram_fused, pair=pctx)
+                                    gram_terms=self._gram_fused)
             for done in side_done.values():
                 torch.cuda.current_stream().wait_event(done)
-            if pair:
-                self._pair_close()
         if not accumulate_grad:
             return
         if self.planned_scatter and self._scatter_plan is not None and self._scatter_levels == [lv.index for lv in active]:
@@ -1199,10 +1160,9 @@ class StepEngine:
         if not layers:
             return
         l0 = cfg.style_layers[0]
-        pctx = self._pair_ctx if self._pair_step else None
         sig = (tuple((lv.index, b.act[l0].ptr, b.grad[l0].ptr, lv.masks[l0].ptr, lv.counts[l0].data_ptr())
                      for lv, b in zip(active, bufs)),
-               w_style, ops.CONV_MODE, tuple(cfg.style_weights), pctx is not None,
+               w_style, ops.CONV_MODE, tuple(cfg.style_weights),
                tuple(t.data_ptr() for tl in self.targets for t in tl.values()),
                None if self._gram_arena is None else self._gram_arena.data_ptr(), cfg.style_pyramid_mode)
         if self._loss_tables is None:
@@ -1244,8 +1204,7 @@ class StepEngine:
                     if ws is None:
                         ws = self._gram_bwd_ws[key] = torch.empty(ops.gram_backward_ws_bytes(f.C), dtype=torch.uint8,
                                                                   device=self.device)
-                    pf = None if pctx is None else pctx.act(layer)     # the layer's planes hold fp16 pairs under this scale
-                    fwd.append(ops.gram_problem(f, m0, m1, S0, S1, af, pair_feat=pf))
+                    fwd.append(ops.gram_problem(f, m0, m1, S0, S1, af))
                     sp = ops.style_problem(S0, S1, counts, lv.factor[layer], targets, term_mask, skip, weight, f.C, D0, D1, ad)
                     if cfg.gram_mode == "average":     # the layer's ring of 9 detached previous Grams (position set per step)
                         if layer not in self._hist:
@@ -1259,7 +1218,7 @@ class StepEngine:
                     # this layer's gradient adds the Gram backward in its epilogue (vgg.backward_group, EPI_GRAM)
                     bwd.append(ops.gram_bwd_problem(f, m0, m1, D0, D1, None if layer in fused else b.grad[layer], ws, af, ad,
                                                     relu_gate=(layer == self.deepest),
-                                                    amax_out=self.amax["g:" + layer] if rec else None, pair_feat=pf))
+                                                    amax_out=self.amax["g:" + layer] if rec else None))
                     if layer in fused:
                         fused[layer].append((ws, m0, m1 if D1 is not None else None, af, ad))
                     keys.append(key)
@@ -1422,102 +1381,6 @@ class StepEngine:
             out.append(ops.fmap_to_image(b.grad["img"], 3)[None])
         return out
 
-    # ------------------------------------------------------------------ pair images (round 5)
-    def _pair_wanted(self, active, accumulate_grad=True) -> bool:
-        """Does this step store its VGG tensors as fp16 pairs? Only where the conversion it removes matters and where the
-        verify-and-repeat protocol is cheap: training steps of the grouped side-stream path (several UV levels), fp16x2
-        arithmetic with the pooling epilogues and the fused pool backward, one rank, no graphs."""
-        from . import vgg as _vgg
-        cfg = self.cfg
-        return bool(self._pair_step and accumulate_grad and self.pair_images and not self.overlap_style
-                    and float(cfg.loss_weights.get("style", 0.0)) != 0.0
-                    and self.group_losses and ops.CONV_MODE == "split2" and ops.GRAM_MODE == "split2"
-                    and cfg.gram_mode != "average" and self.side_streams and self._overlap_pays(active)
-                    and not torch.cuda.is_current_stream_capturing() and not self._can_graph()
-                    and self.view_tiles is not None and _vgg.fuse_pool_fwd()
-                    and not getattr(self.view_tiles, "quads", ())   # (quad lists feed the resident-input kernel: fp32 planes)
-                    and all(("conv%s_%s" % (k[1], k[2]), "fp") in self.view_tiles for k in _vgg.PRE_POOL
-                            if depth_of(k) < depth_of(self.deepest)))
-
-    def _join_early(self):
-        """The early half of a pair-image step's update runs beside its closing half: whatever reads the texture or the
-        sums of squares next waits for it here."""
-        join, self._adam_early_join = getattr(self, "_adam_early_join", None), None
-        if join is not None:
-            torch.cuda.current_stream().wait_event(join)
-
-    def _pair_begin(self):
-        """Head of a pair-image step (before ``_step_begin`` zeroes the bounds): the scales of this step's stored tensors
-        from the bounds the previous step recorded."""
-        if self._pair_table is None:
-            self._pair_table = torch.zeros(2 * AmaxBook.N, device=self.device)
-            self._pair_status = torch.zeros(4, dtype=torch.int32, device=self.device)
-            self._pair_entries = {}
-            self._hyper3 = torch.zeros(3, device=self.device)
-            self._hyper_state3 = torch.zeros(2, dtype=torch.float64, device=self.device)
-        ops.pair_roll(self.amax.buf, AmaxBook.N, self.pair_headroom, self._pair_table)
-
-    def _pair_close(self):
-        """After the last producer of a pair-image step: verify the scales against the bounds the step recorded, advance
-        the device-side Adam step (or mark the update invalid), hand the verdict to the host without a sync, and only now
-        issue the early half of the split update."""
-        ctx = self._pair_ctx
-        key = tuple(sorted(ctx.used))
-        ent = self._pair_entries.get(key)
-        if ent is None:
-            ent = self._pair_entries[key] = torch.tensor(list(key), dtype=torch.int32, device=self.device)
-        ops.pair_check(self.amax.buf, self._pair_table, ent, self._pair_status)
-        # the device owns the step counter while pair steps follow each other: an invalidated step must not advance it,
-        # and the host only learns about it a step or two later
-        if not self._pair_dev_step:
-            self._hyper_state3[1:2].fill_(float(self.step_count))
-            self._pair_dev_step = True
-        self._hyper_state3[0:1].fill_(self.lr)
-        ops.adam_hyper_step(self._hyper_state3, self._hyper3, guard=self._pair_status)
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-        host.copy_(self._pair_status, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self._pair_pending.append((ev, host))
-        self.pair_stats["steps"] += 1
-        if self._adam_early_pending:
-            # (beside the scatter and the closing update - both walk other chunks; joined at the head of the next step)
-            ops.zero_floats(self.sumsq)
-            self._adam_early(dev_hyper=self._hyper3, zero_sumsq=False)
-
-    def _pair_poll(self, block=False):
-        """Look at the verdicts that have arrived (``block``: all of them): every invalidated step took no update and is
-        owed to the current view."""
-        while self._pair_pending and (block or self._pair_pending[0][0].query()):
-            ev, host = self._pair_pending.pop(0)
-            ev.synchronize()
-            if int(host[0]) == 0:
-                self._pair_failed += 1
-                self.step_count -= 1           # the host counted an update that did not happen
-                self.pair_stats["invalid"] += 1
-
-    def _pair_settle(self):
-        """Before the view changes (or the caller reads state): wait for the outstanding verdicts and repeat, on the
-        CURRENT view, every step that was invalidated - a repeat runs under the scales of the bounds the failed attempt
-        recorded, and may itself have to be repeated (the first steps from a zero texture, where bounds grow by orders of
-        magnitude per step)."""
-        guard = 0
-        while True:
-            self._pair_poll(block=True)
-            if self._pair_failed == 0:
-                return
-            guard += 1
-            if guard > 64:
-                raise RuntimeError("pair images: a step keeps overflowing its predicted operand scales "
-                                   "(STYLEMESH_PAIR_IMAGES=0 stores fp32 planes)")
-            n, self._pair_failed = self._pair_failed, 0
-            for _ in range(n):
-                self.pair_stats["repeated"] += 1
-                out = torch.empty(3, device=self.device)
-                self._pair_step = True
-                self._step_compute_eager(out, None, False)
-                self.optimizer_step(1)
-
     def optimizer_step(self, world_size: int = 1):
         """Fused regulariser-gradient + Adam + clamp + zero-grad over the whole arena (one launch)."""
         self.step_count += 1
@@ -1545,12 +1408,6 @@ class StepEngine:
             self._prog_end_recording(discard=(world_size != 1))
 
     def _optimizer_step_eager(self, world_size):
-        if self._pair_step:
-            # the device-side step counter and the validity flag were written by ``_pair_close``
-            self._optimizer_launch(world_size, self._hyper3, hyper_done=True)
-            self._pair_step = False
-            return
-        self._pair_dev_step = False     # a host-counted update: the device counter is re-seeded by the next pair step
         if self._can_graph():
             # The step-dependent scalars live ON THE DEVICE: a captured one-thread kernel advances {lr, step} and
             # writes {lr / bc1, 1 / sqrt(bc2)} for the update that follows it in the same graph. (Sending them through
@@ -1637,20 +1494,17 @@ class StepEngine:
             self._adam_early_done = torch.cuda.Event()
             self._adam_early_done.record(st)
 
-    def _optimizer_launch(self, world_size, dev_hyper, hyper_done=False):
+    def _optimizer_launch(self, world_size, dev_hyper):
         self._grad_dirty = False   # the fused update zeroes the gradient arena
         if self._adam_early_done is not None:   # second half of the split update: the view's own chunks
-            if hyper_done:      # pair-image step: the early half was only issued after the step's verdict - it runs BESIDE
-                self._adam_early_join = self._adam_early_done      # this update and is joined by the next step's head
-            else:
-                torch.cuda.current_stream().wait_event(self._adam_early_done)
+            torch.cuda.current_stream().wait_event(self._adam_early_done)
             self._adam_early_done = None
             ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
                            self.lr, self.step_count, grad_scale=1.0 / world_size, sumsq_out=self.sumsq,
                            dev_hyper=dev_hyper, touched=self._view_flags, touched_log2=self.touched_log2)
             return
         ops.zero_floats(self.sumsq)
-        if dev_hyper is not None and not hyper_done:
+        if dev_hyper is not None:
             ops.adam_hyper_step(self._hyper_state, dev_hyper)
         touched, tl2 = self._touched_arg()
         ops.adam_fused(self.arena.p, self.arena.g, self.arena.m, self.arena.v, self.arena.seg_end, self.reg_coef,
@@ -1709,14 +1563,7 @@ class StepEngine:
             self._graphs[sig] = g
         g.replay()
 
-    def finish_pending(self):
-        """Repeat the pair-image steps the device invalidated and the host has not made up for yet (waits for their
-        verdicts): call before reading the texture or timing a run; a view change and ``end_epoch`` do it themselves."""
-        if self._pair_pending or self._pair_failed:
-            self._pair_settle()
-
     def end_epoch(self):
-        self.finish_pending()
         self.epoch += 1
 
     def request_prepare(self, batch, ready_event=None):
@@ -1739,12 +1586,7 @@ class StepEngine:
             raise RuntimeError("step_compute() was called again before optimizer_step() closed the previous step: the "
                                "split update needs exactly one optimizer_step per step (STYLEMESH_SPLIT_UPDATE=0 "
                                "disables the split)")
-        self._join_early()
         self.begin_step(batch, reducer, new_view)
-        self._pair_poll()
-        # (whether the step really stores pairs is decided once its levels are known: ``forward_backward``)
-        self._pair_step = (self.pair_images and reducer is None and ops.CONV_MODE == "split2" and not self.use_graphs
-                           and not self.overlap_style)
         reqs, self._prepare_request = self._prepare_request, []
         self._steps_on_view = getattr(self, "_steps_on_view", 0) + 1
         if reducer is None:
@@ -1756,7 +1598,6 @@ class StepEngine:
         self._prog_run = None
         key = self._program_key(reducer)
         if key is not None:
-            self._pair_step = False                 # (a small step served by a replayed program: fp32 planes)
             prog = self._programs.get(key)
             if prog is not None and self.step_programs != "verify":
                 return self._program_compute(prog, key, out)
@@ -1784,13 +1625,10 @@ class StepEngine:
                 ops.lib = _hip.lib
 
     def _step_compute_eager(self, out, reducer, exchange):
-        self._join_early()
-        if self._pair_step:
-            self._pair_begin()
         losses = self._step_begin(out[2:3])    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
         pipelined = self.use_pipelined_exchange(reducer)
         if not pipelined:
-            if (self._can_graph() or self.early_update_at == "head") and not self._pair_step:
+            if self._can_graph() or self.early_update_at == "head":
                 self._adam_early()
             else:
                 self._adam_early_pending = True   # forked inside the forward pass (``early_update_at``)
@@ -1998,8 +1836,6 @@ class StepEngine:
         else:
             key = self.view_key
         changed = self.view is None or key != self.view_key
-        if changed and (self._pair_pending or self._pair_failed):
-            self._pair_settle()      # invalidated pair-image steps are repeated on the view they belong to
         if new_view is None:
             new_view = getattr(batch, "new_view", None)
         # is the per-view collective due at this schedule position?

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libstylemesh_hip.so")
 
-ABI_VERSION = 10         # sm_abi_version() of the library this binding was written against
+ABI_VERSION = 11         # sm_abi_version() of the library this binding was written against
 SM_MAX_TEX_LAYERS = 8
 SM_FMAP_GUARD = 4096
 EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ADD, EPI_POOL, EPI_GRAM = 1, 2, 4, 8, 16
@@ -39,21 +39,16 @@ SIGNATURES = {
     "sm_tex_scatter_plan": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp],
     "sm_tex_scatter_planned": [_vp, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp],
     "sm_adam_fused": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _f, _d, _d, _f, _d, _d, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp],
-    "sm_adam_hyper_step": [_vp, _d, _d, _vp, _vp, _vp],
+    "sm_adam_hyper_step": [_vp, _d, _d, _vp, _vp],
     "sm_step_begin": [_vp, _vp, _i, _vp, _vp, _sz, _vp, _sz, _vp],
     "sm_flags_or": [_vp, _vp, _sz, _vp],
     "sm_clamp_sumsq": [_vp, _sz, _vp, _i, _f, _f, _vp, _vp],
     "sm_conv3x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     "sm_conv3x3_grouped": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp],
-    "sm_conv3x3_grouped_split": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp],
     "sm_conv3x3_grouped_split2": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp],
-    "sm_conv3x3_grouped_pair": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sm_pair_roll": [_vp, _i, _f, _vp, _vp],
-    "sm_pair_check": [_vp, _vp, _vp, _i, _vp, _vp],
     "sm_amax_floats": [],
     "sm_fmap_amax": [_vp, _i, _i, _i, _vp, _vp],
     "sm_conv_tile_positions": [_i, _i],
-    "sm_conv_split_tile_positions": [],
     "sm_conv_split2_tile_positions": [_i],
     "sm_conv3x3_dgrad_c3": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "sm_conv3x3_dgrad_c3_grouped": [_vp, _i, _vp, _i, _vp],
@@ -123,7 +118,7 @@ SIGNATURES = {
 
 # entry points that are pure host functions (sizes, layout constants, ids): no stream, nothing to replay
 PURE_HOST = {"sm_fmap_row_stride", "sm_fmap_plane", "sm_abi_version", "sm_sizeof_problem", "sm_tex_scatter_plan_temp_bytes",
-             "sm_tex_scatter_plan_cross_bytes", "sm_amax_floats", "sm_conv_tile_positions", "sm_conv_split_tile_positions",
+             "sm_tex_scatter_plan_cross_bytes", "sm_amax_floats", "sm_conv_tile_positions",
              "sm_conv_split2_tile_positions", "sm_plane_tile_positions", "sm_gram_num_slabs", "sm_gram_workspace_slabs",
              "sm_gram_split_num_slabs", "sm_gram_backward_split_ws_bytes", "sm_reproject_blocks", "sm_flags_compact_ws_ints",
              "sm_comm_unique_id_bytes", "sm_cover_segments_ws_bytes", "sm_view_lists_ws_bytes", "sm_call_id",
@@ -135,14 +130,13 @@ class ConvProblem(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("gate", C.c_void_p), ("H", C.c_int), ("W", C.c_int),
                 ("unpool_code", C.c_void_p), ("pool_out", C.c_void_p), ("pool_code", C.c_void_p),
                 ("gram_ws", C.c_void_p), ("gram_mask0", C.c_void_p), ("gram_mask1", C.c_void_p),
-                ("gram_amax_feat", C.c_void_p), ("gram_amax_d", C.c_void_p), ("addend", C.c_void_p)]
+                ("gram_amax_feat", C.c_void_p), ("gram_amax_d", C.c_void_p)]
 
 
 class GramProblem(C.Structure):
     """sm_gram_problem of include/stylemesh_hip.h"""
     _fields_ = [("feat", C.c_void_p), ("mask0", C.c_void_p), ("mask1", C.c_void_p), ("S0", C.c_void_p),
-                ("S1", C.c_void_p), ("amax_feat", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("pair_feat", C.c_void_p)]
+                ("S1", C.c_void_p), ("amax_feat", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
 
 class StyleProblem(C.Structure):
@@ -159,7 +153,7 @@ class GramBwdProblem(C.Structure):
     _fields_ = [("feat", C.c_void_p), ("mask0", C.c_void_p), ("mask1", C.c_void_p), ("D0", C.c_void_p),
                 ("D1", C.c_void_p), ("dfeat", C.c_void_p), ("ws", C.c_void_p), ("amax_feat", C.c_void_p),
                 ("amax_d", C.c_void_p), ("amax_out", C.c_void_p), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("relu_gate", C.c_int), ("pair_feat", C.c_void_p)]
+                ("relu_gate", C.c_int)]
 
 
 class CoverProblem(C.Structure):

@@ -78,22 +78,8 @@ def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
 
 
 def split_eligible(cin_pad: int, cout: int) -> bool:
-    """Shapes the bf16x3-split conv kernel takes (sm_conv3x3_grouped_split)."""
+    """Shapes the fp16x2-split conv kernel takes (sm_conv3x3_grouped_split2)."""
     return cin_pad % 16 == 0 and cout % 64 == 0
-
-
-def pack_conv_split(wt: torch.Tensor) -> torch.Tensor:
-    """fp32 tap-major pack [9][Cin][Cout] (``pack_conv_fwd`` / ``pack_conv_dgrad``) -> the pre-split weights of
-    sm_conv3x3_grouped_split: [9][Cin/16][3 parts][2 k-groups][Cout][8 ci] bf16 bit patterns (int16), where
-    w = part0 + part1 + part2 to 24 significand bits (round-to-nearest at every step)."""
-    taps, cin, cout = wt.shape
-    assert taps == 9 and split_eligible(cin, cout)
-    w = wt.view(9, cin // 16, 2, 8, cout).permute(0, 1, 2, 4, 3)            # [9][chunk][kgroup][cout][8]
-    h = w.bfloat16()
-    r1 = w - h.float()
-    m = r1.bfloat16()
-    l = (r1 - m.float()).bfloat16()
-    return torch.stack([h, m, l], dim=2).contiguous().view(torch.int16)      # [9][chunk][3][2][cout][8]
 
 
 def pack_conv_split2(wt: torch.Tensor):
@@ -111,10 +97,12 @@ def pack_conv_split2(wt: torch.Tensor):
     return torch.stack([h, l], dim=2).contiguous().view(torch.int16), 2.0 ** -k    # [9][chunk][2][2][cout][8]
 
 
-# 'f32' = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains); 'split' = bf16x3-split MFMA (6 partial
-# products, fp32 accumulate, same accuracy class) wherever a layer's shape allows and its split pack is given;
-# 'split2' = fp16x2-split MFMA (3 partial products, operands scaled by powers of two from recorded maxima).
+# 'f32' = v_mfma_f32_32x32x2_f32 everywhere (bit-exact fmaf chains); 'split2' = fp16x2-split MFMA (3 partial products,
+# fp32 accumulate, operands scaled by powers of two from recorded maxima) wherever a layer's shape allows.
+# (round 1's bf16x3 arithmetic - 'split', 6 partial products - was removed in round 6: profiles/r02 keeps its measurements)
 CONV_MODE = os.environ.get("STYLEMESH_CONV_MODE", "split2")
+if CONV_MODE not in ("split2", "f32"):
+    raise ValueError(f"STYLEMESH_CONV_MODE={CONV_MODE!r}: 'split2' (default) or 'f32'")
 
 
 # ---- texture -------------------------------------------------------------------------------------------------
@@ -277,28 +265,11 @@ def adam_fused(p, g, m, v, seg_end, reg_coef, lr, step, grad_scale=1.0, beta1=0.
                           ptr(sumsq_out), ptr(dev_hyper), ptr(touched), touched_log2, hip.stream()), "sm_adam_fused"))
 
 
-def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999, guard=None):
+def adam_hyper_step(state, dev_hyper, beta1=0.9, beta2=0.999):
     """``state``: device float64 [lr, step]; advances the step and writes the step-dependent scalars of the fused update
-    into ``dev_hyper`` (device float32 [3]: lr / bc1, 1 / sqrt(bc2), valid = 1) - on the device, so the launch can live
-    in a hipGraph. ``guard`` (device int32, ``pair_check``'s status): 0 there leaves the step where it is and marks the
-    update invalid (``adam_fused(dev_hyper=...)`` then changes nothing but the gradient, which it zeroes)."""
-    assert state.dtype == torch.float64 and state.numel() == 2 and dev_hyper.dtype == torch.float32 and dev_hyper.numel() >= 3
-    assert guard is None or guard.dtype == torch.int32
-    hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), ptr(guard), hip.stream()), "sm_adam_hyper_step")
-
-
-def pair_roll(book, n_entries: int, headroom: float, table):
-    """``table[i] = {s, 1 / s}`` of every entry of an amax book from the bounds it holds (the previous step's) times
-    ``headroom``: the scales this step's pair images are stored under (include/stylemesh_hip.h, PAIR IMAGES)."""
-    assert book.numel() >= n_entries * AMAX_FLOATS and table.numel() >= 2 * n_entries and table.dtype == torch.float32
-    hip.check(lib.sm_pair_roll(ptr(book), n_entries, float(headroom), ptr(table), hip.stream()), "sm_pair_roll")
-
-
-def pair_check(book, table, entries, status):
-    """``status[0] = 1`` if every listed entry's bound (recorded by this step) fits the scale it was stored under, else 0
-    (``status``: device int32 [4], see sm_pair_check)."""
-    assert entries.dtype == torch.int32 and status.dtype == torch.int32 and status.numel() >= 4
-    hip.check(lib.sm_pair_check(ptr(book), ptr(table), ptr(entries), entries.numel(), ptr(status), hip.stream()), "sm_pair_check")
+    into ``dev_hyper`` (device float32 [2]: lr / bc1, 1 / sqrt(bc2)) - on the device, so the launch can live in a hipGraph."""
+    assert state.dtype == torch.float64 and state.numel() == 2 and dev_hyper.dtype == torch.float32 and dev_hyper.numel() >= 2
+    hip.check(lib.sm_adam_hyper_step(ptr(state), beta1, beta2, ptr(dev_hyper), hip.stream()), "sm_adam_hyper_step")
 
 
 def step_begin(sumsq, coef, reg_out, zero_a, zero_b=None):
@@ -365,16 +336,17 @@ def splitk_workspace(device) -> torch.Tensor:
     # ahead on a side stream) must not share their split-K partial slabs
     key = (str(device), hip.stream())
     if key not in _SPLITK_WS:
-        _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+        # (zeros: the workspace's last 1024 words are the fp16x2 kernel's tail counters, zero between launches - the header)
+        _SPLITK_WS[key] = torch.zeros(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]
 
 
-def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None, wt3=None, wt2=None,
+def conv3x3(inp: FMap, wt: torch.Tensor, bias, out: FMap, flags: int, gate: FMap | None = None, wt2=None,
             amax_in=None, amax_out=None):
     cin_pad, cout = wt.shape[1], wt.shape[2]
     assert inp.C >= cin_pad and out.C == cout and (inp.H, inp.W) == (out.H, out.W)
-    if (wt3 is not None and CONV_MODE == "split") or (wt2 is not None and CONV_MODE == "split2") or amax_out is not None:
-        return conv3x3_grouped([(inp, out, gate)], wt, bias, flags, None, 1.0, wt3, wt2, amax_in, amax_out)
+    if (wt2 is not None and CONV_MODE == "split2") or amax_out is not None:
+        return conv3x3_grouped([(inp, out, gate)], wt, bias, flags, None, 1.0, wt2, amax_in, amax_out)
 
     def run():
         ws = splitk_workspace(wt.device)
@@ -406,8 +378,8 @@ def fmap_amax(f: FMap, amax_out: torch.Tensor):
 
 def conv_tile_positions(cin_pad: int, cout: int) -> int:
     """Positions per tile of the kernel that ``conv3x3_grouped`` will pick for this layer shape (``CONV_MODE``)."""
-    if CONV_MODE in ("split", "split2") and split_eligible(cin_pad, cout):
-        return lib.sm_conv_split2_tile_positions(cout) if CONV_MODE == "split2" else lib.sm_conv_split_tile_positions()
+    if CONV_MODE == "split2" and split_eligible(cin_pad, cout):
+        return lib.sm_conv_split2_tile_positions(cout)
     return lib.sm_conv_tile_positions(cin_pad, cout)
 
 
@@ -416,14 +388,13 @@ def conv_list_format(cin_pad: int, cout: int):
     take 32-position SEGMENTS, tile positions / 32 of them per tile (any live segments of one level, padded per level with
     (level << 24) | 0xFFFFFF: ``sparsity.build_tile_lists``); the fp32 kernel whole tiles (entries per tile 0)."""
     bn = conv_tile_positions(cin_pad, cout)
-    if CONV_MODE in ("split", "split2") and split_eligible(cin_pad, cout):
+    if CONV_MODE == "split2" and split_eligible(cin_pad, cout):
         return 32, bn // 32
     return bn, 0
 
 
-def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0, wt3=None,
-                    wt2=None, amax_in=None, amax_out=None, pair_in=None, pair_out=None, pair_gate=None, addends=None,
-                    quads=False):
+def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None, active_fraction=1.0,
+                    wt2=None, amax_in=None, amax_out=None, quads=False):
     """One launch over several feature maps: ``problems`` = [(inp, out, gate-or-None[, code[, pooled, pool_code]]), ...]
     (FMaps; with a ``code`` tensor - 'split2' mode only - ``inp`` is the gradient of the 2x2-pooled map and the kernel
     takes the pool's backward on the fly, see ``maxpool_fwd_grouped``; with ``flags & EPI_POOL`` - 'split2' mode, a
@@ -432,13 +403,9 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
     amax_d) - the operand images ``gram_backward_grouped`` left in ``ws`` for a problem without ``dfeat`` and the style
     layer's masks / bounds - makes the epilogue add the layer's masked Gram backward).
     ``tile_list``: optional int32 device tensor of active tiles ((problem << 24) | tile).
-    ``wt3``: the layer's ``pack_conv_split`` weights; used when ``CONV_MODE == 'split'``.
     ``wt2``: ``pack_conv_split2`` result (pack, w_scale_inv); used when ``CONV_MODE == 'split2'`` together with
     ``amax_in`` (device float: upper bound of max |input|). ``amax_out`` (device float, caller-zeroed, any mode):
     receives max |output| of the launch.
-    Pair images ('split2' mode; include/stylemesh_hip.h): ``pair_in`` / ``pair_out`` / ``pair_gate`` = device {scale,
-    1 / scale} of the input / output / gate tensor when its planes hold packed fp16 pairs (None: fp32 planes);
-    ``addends``: per problem the fp32 FMap ``EPI_ADD`` reads instead of ``out`` (required with ``pair_out``).
     ``quads``: ``tile_list`` holds vertical QUADS of segments (``cover_segments`` quad modes; 'split2' mode, 64 output
     channels, fp32 planes): the launch takes the resident-input kernel (``SM_LIST_QUADS``)."""
     cin_pad, cout = wt.shape[1], wt.shape[2]
@@ -465,8 +432,7 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         gws, gm0, gm1, gaf, gad = gram if gram is not None else (None,) * 5
         arr[i] = hip.ConvProblem(inp.ptr, out.ptr, ptr(gate), out.H, out.W, ptr(code),
                                  None if pooled is None else pooled.ptr, ptr(pool_code),
-                                 ptr(gws), ptr(gm0), ptr(gm1), ptr(gaf), ptr(gad),
-                                 None if addends is None else addends[i].ptr)
+                                 ptr(gws), ptr(gm0), ptr(gm1), ptr(gaf), ptr(gad))
         cin_true = 3 if cin_pad == 4 else cin_pad
         flops += 2.0 * 9 * cin_true * cout * out.H * out.W
         # algorithmic HBM bytes: input read once, output written once (pooled: a quarter + 1/2 byte of codes per element),
@@ -476,35 +442,25 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
             streams = cout * (0.25 + 0.125 / 4)
         nbytes += 4.0 * streams * out.H * out.W + (4.0 if code is None else 4.5) * cin_true * inp.H * inp.W
 
-    pair = pair_in is not None or pair_out is not None or pair_gate is not None or addends is not None
-    use_split2 = wt2 is not None and (amax_in is not None or pair_in is not None) and CONV_MODE == "split2"
-    use_split = wt3 is not None and CONV_MODE == "split"
-    assert not pair or use_split2, "pair images are the fp16x2 kernel's format"
-    assert not quads or (use_split2 and not pair and tile_list is not None and cout == 64), "quad lists: fp16x2 kernel, 64 output channels"
+    use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
+    assert not quads or (use_split2 and tile_list is not None and cout == 64), "quad lists: fp16x2 kernel, 64 output channels"
 
     def run():
         ws = splitk_workspace(wt.device)
         n_list = 0 if tile_list is None else tile_list.numel()
-        if pair:
-            hip.check(lib.sm_conv3x3_grouped_pair(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
-                                                  flags, ptr(tile_list), n_list, ptr(ws), ws.numel(), ptr(amax_in),
-                                                  ptr(amax_out), ptr(pair_in), ptr(pair_out), ptr(pair_gate),
-                                                  hip.stream()), "sm_conv3x3_grouped_pair")
-            return
         if use_split2:
             hip.check(lib.sm_conv3x3_grouped_split2(arr, len(problems), ptr(wt2[0]), wt2[1], ptr(bias), cin_pad, cout,
                                                     flags | (hip.LIST_QUADS if quads else 0), ptr(tile_list), n_list,
                                                     ptr(ws), ws.numel(), ptr(amax_in),
                                                     ptr(amax_out), hip.stream()), "sm_conv3x3_grouped_split2")
             return
-        fn, w = (lib.sm_conv3x3_grouped_split, wt3) if use_split else (lib.sm_conv3x3_grouped, wt)
-        hip.check(fn(arr, len(problems), ptr(w), ptr(bias), cin_pad, cout, flags, ptr(tile_list), n_list, ptr(ws),
-                     ws.numel(), ptr(amax_out), hip.stream()), "sm_conv3x3_grouped")
+        hip.check(lib.sm_conv3x3_grouped(arr, len(problems), ptr(wt), ptr(bias), cin_pad, cout, flags, ptr(tile_list), n_list,
+                                         ptr(ws), ws.numel(), ptr(amax_out), hip.stream()), "sm_conv3x3_grouped")
     if CONV_TIMER is None:
         run()
     else:   # algorithmic FLOPs of the tiles actually required
-        tag = "split2" if use_split2 else ("split" if use_split else "f32")
-        wbytes = wt2[0].numel() * 2 if use_split2 else (wt3.numel() * 2 if use_split else wt.numel() * 4)
+        tag = "split2" if use_split2 else "f32"
+        wbytes = wt2[0].numel() * 2 if use_split2 else wt.numel() * 4
         CONV_TIMER.launch(run, flops * active_fraction, tag, nbytes * active_fraction + wbytes,
                           f"{cin_pad:3d}->{cout:3d} flags {flags} levels {len(problems)} active {active_fraction:.2f}")
 
@@ -583,22 +539,24 @@ def maxpool_bwd_relu_grouped(problems, tile_list=None):
 # ---- losses --------------------------------------------------------------------------------------------------
 def gram_num_slabs(C: int, H: int, W: int) -> int:
     """How many leading slabs of the Gram workspace sum to S (mode dependent: the split kernel accumulates into one)."""
-    if GRAM_MODE in ("split", "split2"):
+    if GRAM_MODE == "split2":
         return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_num_slabs(C, H, W)
 
 
 def gram_workspace_slabs(C: int, H: int, W: int) -> int:
     """Slabs the workspace must hold in the current mode (split: the one slab every position range adds into)."""
-    if GRAM_MODE in ("split", "split2"):
+    if GRAM_MODE == "split2":
         return lib.sm_gram_split_num_slabs()
     return lib.sm_gram_workspace_slabs(C, H, W)
 
 
 # 'split2' = the Gram contraction and its backward GEMM on the fp16 matrix cores with fp16x2-split operands scaled by
-# powers of two from recorded maxima (3 partial products; see CONV_MODE 'split2'); 'split' = bf16x3-split operands
-# (6 partial products); 'f32' = v_mfma_f32_32x32x2_f32 kernels. Default: follows the conv mode.
-GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", {"split2": "split2", "split": "split"}.get(CONV_MODE, "f32"))
+# powers of two from recorded maxima (3 partial products; see CONV_MODE 'split2'); 'f32' = v_mfma_f32_32x32x2_f32
+# kernels. Default: follows the conv mode.
+GRAM_MODE = os.environ.get("STYLEMESH_GRAM_MODE", CONV_MODE)
+if GRAM_MODE not in ("split2", "f32"):
+    raise ValueError(f"STYLEMESH_GRAM_MODE={GRAM_MODE!r}: 'split2' or 'f32'")
 
 
 def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False, amax_feat=None):
@@ -608,22 +566,20 @@ def gram_masked(feat: FMap, mask0, mask1, S0, S1, prezeroed=False, amax_feat=Non
     n = gram_num_slabs(feat.C, feat.H, feat.W)
     na = gram_workspace_slabs(feat.C, feat.H, feat.W)
     assert S0.numel() >= na * feat.C * feat.C and (S1 is None or S1.numel() >= na * feat.C * feat.C)
-    if GRAM_MODE in ("split", "split2"):
-        assert GRAM_MODE == "split" or amax_feat is not None, "GRAM_MODE 'split2' needs the feature map's bound"
+    if GRAM_MODE == "split2":
+        assert amax_feat is not None, "GRAM_MODE 'split2' needs the feature map's bound"
         fn = lib.sm_gram_masked_split_acc if prezeroed else lib.sm_gram_masked_split
         hip.check(fn(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
-                     ptr(amax_feat) if GRAM_MODE == "split2" else None, hip.stream()), "sm_gram_masked_split")
+                     ptr(amax_feat), hip.stream()), "sm_gram_masked_split")
         return n
     hip.check(lib.sm_gram_masked(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), feat.C, feat.H, feat.W,
                                  hip.stream()), "sm_gram_masked")
     return n
 
 
-def gram_problem(feat: FMap, mask0, mask1, S0, S1, amax_feat, pair_feat=None) -> "hip.GramProblem":
-    """One entry of ``gram_masked_grouped`` (pointers only: valid while the tensors live). ``pair_feat``: device {scale,
-    1 / scale} when ``feat`` holds packed fp16 pairs."""
-    return hip.GramProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), ptr(amax_feat), feat.C, feat.H, feat.W,
-                           ptr(pair_feat))
+def gram_problem(feat: FMap, mask0, mask1, S0, S1, amax_feat) -> "hip.GramProblem":
+    """One entry of ``gram_masked_grouped`` (pointers only: valid while the tensors live)."""
+    return hip.GramProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(S0), ptr(S1), ptr(amax_feat), feat.C, feat.H, feat.W)
 
 
 def gram_problem_array(problems):
@@ -655,14 +611,14 @@ def style_problem(S0, S1, counts, factor, targets, term_mask, skip_if_empty, wei
 
 
 def gram_bwd_problem(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, ws, amax_feat, amax_d, relu_gate,
-                     amax_out=None, pair_feat=None) -> "hip.GramBwdProblem":
+                     amax_out=None) -> "hip.GramBwdProblem":
     """One entry of ``gram_backward_grouped``; ``ws``: uint8 scratch of ``gram_backward_ws_bytes(C)`` bytes of its own;
     ``amax_out`` (optional amax bound): max |dfeat| is max-ed into it. ``dfeat`` None: only the operand images of D0 / D1
     are written into ``ws`` (a conv launch with ``EPI_GRAM`` consumes them)."""
     assert ws.numel() >= lib.sm_gram_backward_split_ws_bytes(feat.C)
     return hip.GramBwdProblem(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), None if dfeat is None else dfeat.ptr,
                               ptr(ws), ptr(amax_feat),
-                              ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate), ptr(pair_feat))
+                              ptr(amax_d), ptr(amax_out), feat.C, feat.H, feat.W, int(relu_gate))
 
 
 def gram_backward_ws_bytes(C: int) -> int:
@@ -694,14 +650,13 @@ def style_loss(S0, S1, counts, factor, targets, term_mask, skip_if_empty, weight
                                 ptr(amax_d_out), hip.stream()), "sm_style_loss")
 
 
-_GRAM_BWD_WS = {}   # device -> scratch for the bf16x3 image of D0 / D1 (largest C = 512: 3 MB)
+_GRAM_BWD_WS = {}   # device -> scratch for the fp16x2 operand image of D0 / D1 (largest C = 512)
 
 
 def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool, amax_feat=None, amax_d=None):
     """``amax_feat`` / ``amax_d`` (device floats; 'split2' mode): bounds of max |feat| and max(|D0|, |D1|)."""
-    if GRAM_MODE in ("split", "split2"):
-        two = GRAM_MODE == "split2"
-        assert not two or (amax_feat is not None and amax_d is not None), "GRAM_MODE 'split2' needs the operand bounds"
+    if GRAM_MODE == "split2":
+        assert amax_feat is not None and amax_d is not None, "GRAM_MODE 'split2' needs the operand bounds"
         key = (str(D0.device), hip.stream())   # one scratch per launch stream
         need = lib.sm_gram_backward_split_ws_bytes(feat.C)
         if key not in _GRAM_BWD_WS or _GRAM_BWD_WS[key].numel() < need:
@@ -709,7 +664,7 @@ def gram_backward(feat: FMap, mask0, mask1, D0, D1, dfeat: FMap, relu_gate: bool
                                             device=D0.device)
         hip.check(lib.sm_gram_backward_split(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C,
                                              feat.H, feat.W, int(relu_gate), ptr(_GRAM_BWD_WS[key]),
-                                             ptr(amax_feat) if two else None, ptr(amax_d) if two else None,
+                                             ptr(amax_feat), ptr(amax_d),
                                              hip.stream()), "sm_gram_backward_split")
         return
     hip.check(lib.sm_gram_backward(feat.ptr, ptr(mask0), ptr(mask1), ptr(D0), ptr(D1), dfeat.ptr, feat.C, feat.H,

@@ -95,41 +95,6 @@ class AmaxBook:
         self.buf.zero_()
 
 
-class PairCtx:
-    """Pair images of a grouped pass (include/stylemesh_hip.h, PAIR IMAGES): which VGG tensors are stored as packed fp16
-    pairs by their producer, and under which scales. ``table``: {scale, 1 / scale} per entry of ``book`` (``ops.pair_roll``
-    of the previous step's bounds). Kept as fp32 planes: the image, relu1_1 (written / read by the first layer's VALU
-    kernels), the content layers (the masked MSE reads them), the gradient of relu1_1 (read by conv1_1's data gradient)
-    and the gradient the loss kernels write for the deepest layer; the gradients the loss kernels write for the other
-    injected layers stay fp32 ADDEND planes (``grad[layer]``) - the data-gradient conv stores its pair output beside them
-    (``gradp[layer]``)."""
-
-    def __init__(self, table: torch.Tensor, book: AmaxBook, fp32_acts, start_layer: str):
-        self.table, self.book = table, book
-        self.fp32_acts = set(fp32_acts) | {"img", "r11"}
-        self.start = start_layer
-        self.used = set()          # book indices of the tensors stored as pairs by this pass (ops.pair_check's list)
-
-    def _entry(self, name, producer=False):
-        i = self.book.idx[name]
-        if producer:
-            self.used.add(i)
-        return self.table[2 * i:2 * i + 2]
-
-    def act(self, layer, producer=False):
-        """scale entry of activation tensor ``layer`` (a conv or a pool output), None: fp32 planes"""
-        base = POOL_INPUT.get(layer, layer)
-        if layer in self.fp32_acts or base in self.fp32_acts:
-            return None
-        return self._entry("a:" + base, producer)
-
-    def grad(self, layer, producer=False):
-        """scale entry of the gradient planes of ``layer`` (as ``AmaxBook.grad_bound``), None: fp32 planes"""
-        if layer in ("r11", "img", self.start):
-            return None
-        return self._entry("g:" + POOL_OUTPUT.get(layer, layer), producer)
-
-
 def _amax_on():
     return ops.CONV_MODE == "split2" or ops.GRAM_MODE == "split2"
 
@@ -155,13 +120,6 @@ class LevelBuffers:
                 if kind == "pool":   # argmax codes of the pool (fused pool backward of the fp16x2 data-gradient convs)
                     self.code[out] = torch.zeros(cout // 8 * self.act[out].plane, dtype=torch.int32, device=device)
         self.amax = AmaxBook(device)   # bounds of this buffer set's tensors (single-level passes)
-        self.gradp = {}                # pair images: the data-gradient convs' outputs of layers whose grad[.] is an fp32 addend
-
-    def pair_grad(self, layer) -> FMap:
-        if layer not in self.gradp:
-            g = self.grad[layer]
-            self.gradp[layer] = FMap(g.C, g.H, g.W, g.buf.device)
-        return self.gradp[layer]
 
     def nbytes(self):
         return sum(f.buf.numel() * 4 for f in list(self.act.values()) + list(self.grad.values()))
@@ -171,19 +129,16 @@ class VGGNet:
     def __init__(self, state_dict: dict, device="cuda"):
         self.device = device
         self.wf, self.wd, self.bias = {}, {}, {}
-        self.wf3, self.wd3 = {}, {}     # bf16x3-split packs of the layers whose shape the split kernel takes
-        self.wf2, self.wd2 = {}, {}     # fp16x2-split packs (pack, 1 / weight scale) of the same layers
+        self.wf2, self.wd2 = {}, {}     # fp16x2-split packs (pack, 1 / weight scale) of the layers the split kernel takes
         for kind, _, _, _, _ in NODES:
             if kind == "pool":
                 continue
             w = state_dict[kind + ".weight"].detach().to(device=device, dtype=torch.float32)
             self.wf[kind] = ops.pack_conv_fwd(w)
             self.wd[kind] = ops.pack_conv_dgrad(w)
-            for packs, splits, splits2 in ((self.wf, self.wf3, self.wf2), (self.wd, self.wd3, self.wd2)):
+            for packs, splits2 in ((self.wf, self.wf2), (self.wd, self.wd2)):
                 p = packs[kind]
-                ok = ops.split_eligible(p.shape[1], p.shape[2])
-                splits[kind] = ops.pack_conv_split(p) if ok else None
-                splits2[kind] = ops.pack_conv_split2(p) if ok else None
+                splits2[kind] = ops.pack_conv_split2(p) if ops.split_eligible(p.shape[1], p.shape[2]) else None
             self.bias[kind] = state_dict[kind + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
 
     def forward(self, b: LevelBuffers):
@@ -195,12 +150,11 @@ class VGGNet:
             if kind == "pool":
                 ops.maxpool_fwd(b.act[src], b.act[out])
             else:
-                ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU,
-                            wt3=self.wf3[kind], wt2=self.wf2[kind],
+                ops.conv3x3(b.act[src], self.wf[kind], self.bias[kind], b.act[out], hip.EPI_BIAS_RELU, wt2=self.wf2[kind],
                             amax_in=None if am is None or src == "img" else am.act_bound(src),
                             amax_out=None if am is None else am["a:" + out])
 
-    def forward_group(self, bufs, tiles=None, on_layer=None, amax: AmaxBook | None = None, pair: PairCtx | None = None):
+    def forward_group(self, bufs, tiles=None, on_layer=None, amax: AmaxBook | None = None):
         """``forward`` for several levels at once: one grouped conv launch per layer (all levels share the
         weights), which fills the chip where a single small level cannot. ``tiles``: optional active-tile
         lists from ``sparsity.build_tile_lists`` (only tiles that can influence the loss are computed).
@@ -212,16 +166,9 @@ class VGGNet:
         pooled_by_conv = set()   # pools whose output the conv below them has already written (EPI_POOL)
         quads = getattr(tiles, "quads", ())   # lists of vertical segment quads: the resident-input kernel (viewplan.TileLists)
         for kind, src, out, _, _ in NODES[:last + 1]:
-            pkw = {}
-            if pair is not None and kind != "pool" and src != "img":
-                # pair images: input / output stored as fp16 pairs where the context says so (the pooled map a conv with
-                # the pooling epilogue writes carries the bound - and the scale - of the pre-pool layer ``out``)
-                pkw = dict(pair_in=pair.act(src), pair_out=pair.act(out, producer=True))
             if kind == "pool":
                 if out in pooled_by_conv:
                     continue
-                if pair is not None:
-                    raise RuntimeError("pair images need the pooling epilogues (STYLEMESH_FUSE_POOL_FWD, active lists)")
                 fused = FUSE_POOL_BWD and ops.CONV_MODE == "split2" and all(out in b.code for b in bufs)
                 ops.maxpool_fwd_grouped([(b.act[src], b.act[out]) for b in bufs],
                                         tiles[("pool", out)][0] if tiles else None,
@@ -231,9 +178,9 @@ class VGGNet:
                 tl, frac = tiles[(kind, "fp")]
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None, None, b.act[po], b.code[po]) for b in bufs],
                                     self.wf[kind], self.bias[kind], hip.EPI_BIAS_RELU | hip.EPI_POOL, tl, frac,
-                                    self.wf3[kind], self.wf2[kind],
+                                    self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out], quads=(kind, "fp") in quads, **pkw)
+                                    None if am is None else am["a:" + out], quads=(kind, "fp") in quads)
                 pooled_by_conv.add(po)
                 if on_layer is not None:
                     on_layer(out)
@@ -243,15 +190,14 @@ class VGGNet:
                                        "but this pass cannot use it (no code buffers / mode changed since set_view)")
                 tl, frac = tiles[(kind, "f")] if tiles else (None, 1.0)
                 ops.conv3x3_grouped([(b.act[src], b.act[out], None) for b in bufs], self.wf[kind], self.bias[kind],
-                                    hip.EPI_BIAS_RELU, tl, frac, self.wf3[kind], self.wf2[kind],
+                                    hip.EPI_BIAS_RELU, tl, frac, self.wf2[kind],
                                     None if am is None or src == "img" else am.act_bound(src),
-                                    None if am is None else am["a:" + out], quads=(kind, "f") in quads, **pkw)
+                                    None if am is None else am["a:" + out], quads=(kind, "f") in quads)
                 if on_layer is not None:
                     on_layer(out)      # the layer's activation is enqueued: side work may branch off here
 
     def backward_group(self, bufs, injected: set, start_layer: str, tiles=None, before_layer=None,
-                       amax: AmaxBook | None = None, start_bound_recorded=False, gram_terms=None,
-                       pair: PairCtx | None = None):
+                       amax: AmaxBook | None = None, start_bound_recorded=False, gram_terms=None):
         """``backward`` for several levels at once (same injected layers on every level). ``amax``: as in
         ``forward_group``; the bound of the start layer's gradient (written by the loss kernels) is taken here unless
         the loss kernels recorded it themselves (``start_bound_recorded``)."""
@@ -264,12 +210,6 @@ class VGGNet:
         quads = getattr(tiles, "quads", ())   # (as in forward_group)
         unpool = None   # fused pool backward: name of the pooled map whose gradient the next conv un-pools on the fly
 
-        def gin(b, layer):
-            # the planes that hold the gradient of ``layer``: with pair images an injected layer's final gradient is the
-            # conv's pair output beside the fp32 addend the loss kernels wrote
-            return b.gradp[layer] if (pair is not None and layer in b.gradp and layer != start_layer) else b.grad[layer]
-        if pair is not None and not fuse:
-            raise RuntimeError("pair images need the fused pool backward (argmax codes)")
         for kind, src, out, _, _ in reversed(NODES[:depth_of(start_layer) + 1]):
             if before_layer is not None and kind != "pool":
                 before_layer(src)      # the injected gradient of ``src`` is about to be consumed
@@ -286,10 +226,9 @@ class VGGNet:
                                              tiles[("img", "d")][0] if tiles else None)
             elif src.startswith("p"):
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
-                pkw = {} if pair is None else dict(pair_in=pair.grad(out), pair_out=pair.grad(src, producer=True))
-                ops.conv3x3_grouped([(gin(b, out), b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
-                                    self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads, **pkw)
+                ops.conv3x3_grouped([(b.grad[out], b.grad[src], None) for b in bufs], self.wd[kind], None, 0, tl, frac,
+                                    self.wd2[kind], None if am is None else am.grad_bound(out),
+                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads)
             else:
                 tl, frac = tiles[(kind, "b")] if tiles else (None, 1.0)
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
@@ -300,23 +239,16 @@ class VGGNet:
                     if unpool is None or len(gt) != len(bufs) or ops.CONV_MODE != "split2":
                         raise RuntimeError(f"{kind}: a fused Gram backward needs the un-pooling fp16x2 data gradient")
                     flags = hip.EPI_RELU_MASK | hip.EPI_GRAM
-                pkw, dst = {}, [b.grad[src] for b in bufs]
-                if pair is not None:
-                    pkw = dict(pair_in=pair.grad(out), pair_out=pair.grad(src, producer=True), pair_gate=pair.act(src))
-                    if (flags & hip.EPI_ADD) and pkw["pair_out"] is not None:
-                        # the loss kernels' fp32 gradient stays in grad[src] as the addend, the sum is stored as pairs
-                        pkw["addends"] = dst
-                        dst = [b.pair_grad(src) for b in bufs]
                 if unpool is not None:
-                    probs = [(b.grad[unpool], d, b.act[src], b.code[unpool]) for b, d in zip(bufs, dst)]
+                    probs = [(b.grad[unpool], b.grad[src], b.act[src], b.code[unpool]) for b in bufs]
                     if gt is not None:
                         probs = [p + (None, None, g) for p, g in zip(probs, gt)]
                     unpool = None
                 else:
-                    probs = [(gin(b, out), d, b.act[src]) for b, d in zip(bufs, dst)]
+                    probs = [(b.grad[out], b.grad[src], b.act[src]) for b in bufs]
                 ops.conv3x3_grouped(probs, self.wd[kind], None, flags,
-                                    tl, frac, self.wd3[kind], self.wd2[kind], None if am is None else am.grad_bound(out),
-                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads, **pkw)
+                                    tl, frac, self.wd2[kind], None if am is None else am.grad_bound(out),
+                                    None if am is None else am["g:" + src], quads=(kind, "b") in quads)
             assert unpool is None or kind == "pool", "a fused pool backward must be consumed by the conv below it"
 
     def backward(self, b: LevelBuffers, injected: set, start_layer: str):
@@ -338,11 +270,10 @@ class VGGNet:
             elif src == "img":
                 ops.conv3x3_dgrad_c3(b.grad[out], self.wd[kind], b.grad["img"])
             elif src.startswith("p"):
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0, wt3=self.wd3[kind], wt2=self.wd2[kind],
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], 0, wt2=self.wd2[kind],
                             amax_in=None if am is None else am.grad_bound(out),
                             amax_out=None if am is None else am["g:" + src])
             else:
                 flags = hip.EPI_RELU_MASK | (hip.EPI_ADD if src in injected else 0)
-                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src], wt3=self.wd3[kind],
-                            wt2=self.wd2[kind], amax_in=None if am is None else am.grad_bound(out),
+                ops.conv3x3(b.grad[out], self.wd[kind], None, b.grad[src], flags, gate=b.act[src],                             wt2=self.wd2[kind], amax_in=None if am is None else am.grad_bound(out),
                             amax_out=None if am is None else am["g:" + src])

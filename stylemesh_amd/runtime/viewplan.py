@@ -157,7 +157,7 @@ class ViewPlan:
         self.level_hw, self.maps_levels, self.active = list(level_hw), list(maps_levels), list(active_levels)
         # what a resident view's state is valid for: this plan's shape, whatever the slot
         self.cache_key = (h, w, tuple(level_hw), tuple(active_levels), ops.CONV_MODE, tuple(eng.injected),
-                          fuse_pool_fwd(), resident_lists() and not eng.pair_images, bool(cfg.use_depth_scaling),
+                          fuse_pool_fwd(), resident_lists(), bool(cfg.use_depth_scaling),
                           bool(cfg.use_angle_weight), float(cfg.angle_threshold), tuple(cfg.content_layers or ()))
         n_levels = len(level_hw)
         depth = bool(cfg.use_depth_scaling)
@@ -175,7 +175,7 @@ class ViewPlan:
         n_ll = len(eng.loss_layers)
         self.consts = eng._persist(("consts", n_levels, n_ll), lambda: torch.zeros(n_levels, n_ll, 4, device=dev))
         # ---- lists: jobs -> unique list specs ----------------------------------------------------------------
-        self.jobs = list_jobs(eng.deepest, fuse_pool_fwd(), resident_lists() and not eng.pair_images)
+        self.jobs = list_jobs(eng.deepest, fuse_pool_fwd(), resident_lists())
         layer_names = ["img"] + [n[2] for n in NODES[:depth_of(eng.deepest) + 1]]
         self.layer_index = {n: i for i, n in enumerate(layer_names)}
         n_specs = len({(j[1], j[2], j[3], j[4], j[5]) for j in self.jobs})

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_layout_helpers_are_pure_host_functions():
     from stylemesh_amd.runtime import hip
-    assert hip.lib.sm_abi_version() == hip.ABI_VERSION == 10
+    assert hip.lib.sm_abi_version() == hip.ABI_VERSION == 11
     for W in (1, 3, 4, 21, 341, 1045):
         wp = hip.row_stride(W)
         assert wp % 4 == 0 and wp >= W + 1 and wp < W + 5

@@ -246,15 +246,13 @@ def test_graph_replay_equals_eager():
     eager = make_engine(FLAGSETS["with_angle_and_depth"], init)
     graph = make_engine(FLAGSETS["with_angle_and_depth"], init)
     graph.use_graphs = True
+    from stepcmp import assert_same_step, lock
     for step in range(8):
-        for name in ("p", "m", "v"):
-            getattr(graph.arena, name).copy_(getattr(eager.arena, name))
-        graph.sumsq.copy_(eager.sumsq)
+        m0, v0 = lock(graph, eager)
         le = eager.losses(eager.training_step(views[step // 4]))
         lg = graph.losses(graph.training_step(views[step // 4]))
         np.testing.assert_allclose(lg["total"], le["total"], rtol=1e-5)
-        err = (graph.arena.p - eager.arena.p).abs()
-        assert float((err > 1e-4).float().mean()) < 5e-3, (step, float((err > 1e-4).float().mean()))
+        assert_same_step(graph, eager, m0, v0, what=f"step {step}")       # (tests/stepcmp.py: through Adam's moments)
     assert len(graph._graphs) >= 1 and graph._opt_graph is not None
 
 

@@ -165,7 +165,7 @@ def test_resident_forward_with_pooling_epilogue(hws, monkeypatch):
         codes = [torch.zeros(8 * p.plane, dtype=torch.int32, device="cuda") for p in pooled]
         am = ops.new_amax("cuda")
         ops.conv3x3_grouped([(i, o, None, None, p, c) for i, o, p, c in zip(ins, outs, pooled, codes)], w, b,
-                            hip.EPI_BIAS_RELU | hip.EPI_POOL, lst, 1.0, None, w2, amax_in, am, quads=quads)
+                            hip.EPI_BIAS_RELU | hip.EPI_POOL, lst, 1.0, w2, amax_in, am, quads=quads)
         return outs, pooled, codes, am
     _, p_ref, c_ref, _ = run(_dense_rows(hip, hws, 2, 8), False)
     needs = _needs(hws, True, 5)
@@ -250,7 +250,7 @@ def test_resident_kernel_matches_ring_kernel(variant, hws, monkeypatch):
                 o.from_dense(ad)
         am = ops.new_amax("cuda")
         probs = [(i, o, g) + ((c,) if unpool else ()) for i, o, g, c in zip(ins, outs, gates, codes if unpool else [None] * len(hws))]
-        ops.conv3x3_grouped(probs, w, bias, flags, lst, 1.0, None, w2, amax_in, am, quads=quads)
+        ops.conv3x3_grouped(probs, w, bias, flags, lst, 1.0, w2, amax_in, am, quads=quads)
         return outs, am
     ref, _ = run(None, False)                    # the ring kernel over the whole planes
     needs = _needs(hws, False, 9)
@@ -321,7 +321,7 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
     with monkeypatch.context() as mp:
         mp.setattr(ops, "splitk_workspace", lambda device: tiny)
         ops.conv3x3_grouped([(d, r, f, c) for d, r, f, c in zip(dps, ref, feats, codes)], wd, None,
-                            hip.EPI_RELU_MASK | hip.EPI_ADD, None, 1.0, None, wd2, amax_in, ops.new_amax("cuda"))
+                            hip.EPI_RELU_MASK | hip.EPI_ADD, None, 1.0, wd2, amax_in, ops.new_amax("cuda"))
     needs = _needs(hws, False, 13)
     lst = torch.cat([_quad_cover(ops, hip, nd, g) for g, nd in enumerate(needs)])
     out = [FMap(C, H, W) for (H, W) in hws]
@@ -332,7 +332,7 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
     amax_out = ops.new_amax("cuda")
     ops.conv3x3_grouped([(d, o, f, c, None, None, (w_, mptr(m, 0), mptr(m, 1) if two_masks else None, af, ad))
                          for d, o, f, c, w_, m in zip(dps, out, feats, codes, ws2, masks)], wd, None,
-                        hip.EPI_RELU_MASK | hip.EPI_GRAM, lst, 1.0, None, wd2, amax_in, amax_out, quads=True)
+                        hip.EPI_RELU_MASK | hip.EPI_GRAM, lst, 1.0, wd2, amax_in, amax_out, quads=True)
     for g, ((H, W), o, r) in enumerate(zip(hws, out, ref)):
         cov = _covered_mask(hip, lst, g, H, W, o.plane)
         assert torch.equal(o.planes[:, cov], r.planes[:, cov]) and int((o.planes != 0).sum()) > 0
@@ -344,11 +344,12 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
 @pytest.mark.parametrize("env", [{}, {"STYLEMESH_FUSE_POOL_FWD": "0"}, {"STYLEMESH_FUSE_POOL_BWD": "0"},
                                  {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"}])
 def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
-    """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses up
-    to the operand scales - the quads list a few more dead positions, whose values may raise a tensor's recorded bound -
-    and textures that agree in bulk after two steps (Adam at lr 1 turns last-bit gradient differences into +-lr steps)."""
+    """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses and
+    the same GRADIENT after one forward + backward from the same random texture (tests/stepcmp.py) - up to the operand
+    scales: the quads list a few more dead positions, whose values may raise a tensor's recorded bound."""
     require_gpu()
     from golden_cases import MULTIVIEW_SEEDS
+    from stepcmp import assert_same_pass, one_pass
     from test_round3_gpu import _engine, _small_view
     res = {}
     for on in ("1", "0"):
@@ -362,16 +363,10 @@ def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
         torch.manual_seed(11)
         torch.cuda.manual_seed(11)
         eng = _engine(random_init=True)
-        view = _small_view(MULTIVIEW_SEEDS[0])
-        losses = [eng.losses(eng.training_step(view)) for _ in range(2)]
-        torch.cuda.synchronize()
+        res[on] = one_pass(eng, _small_view(MULTIVIEW_SEEDS[0]))
         quads = getattr(eng.view_tiles, "quads", frozenset())
         assert (len(quads) == 3) == (on == "1"), quads          # conv1_2 forward / data gradient, conv2_1's data gradient
         if on == "1":
             assert (("conv1_2", "fp") in quads) == (env.get("STYLEMESH_FUSE_POOL_FWD") != "0" and env.get("STYLEMESH_FUSE_POOL_BWD") != "0")
-        res[on] = (losses, eng.arena.p.clone())
-    for k in res["1"][0][0]:
-        a, b = res["1"][0][0][k], res["0"][0][0][k]
-        assert abs(a - b) <= 1e-6 * abs(b) + 1e-6, (k, a, b)
-    d = (res["1"][1] - res["0"][1]).abs()
-    assert float((d > 1e-3).float().mean()) < 0.02
+    d = assert_same_pass(res["1"], res["0"], what=f"quad lists vs ring lists {env}")
+    print(f"\n[quads {env}] max|dg| / max|g| = {d:.2e}")

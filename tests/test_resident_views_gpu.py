@@ -90,30 +90,28 @@ def test_restored_view_state_equals_the_computed_one(cfg_kw, monkeypatch):
 
 def test_resident_views_under_a_view_change_every_step(monkeypatch):
     """The dip schedule (index_repeat 1, the next view prepared beside the current step): three epochs over five views
-    with and without resident views - the same losses step by step up to the Gram sums' atomic order, the same texels moved."""
+    with and without resident views, in LOCK-STEP (tests/stepcmp.py: the engine without resident views hands its state -
+    Gram history included - to the other before every step): every step has the same losses and the same gradient up to
+    the Gram sums' atomic order, and the same texels moved."""
     require_gpu()
+    from stepcmp import assert_same_step, lock
     views = _views_multi((2, 6, 9, 0, 7))
     kw = dict(hierarchical=False, n_layers=1, gram_mode="average", style_pyramid_mode="single", use_angle_weight=False,
               use_depth_scaling=False, angle_threshold=3000.0)
-    res = {}
-    for gb in (4, 0):
-        torch.manual_seed(3)
-        eng = _engine(monkeypatch, gb, **kw)
-        sched = [views[i % len(views)] for i in range(3 * len(views))]
-        losses = []
-        for i, v in enumerate(sched):
-            nxt = sched[i + 1] if i + 1 < len(sched) else None
-            losses.append(eng.losses(eng.training_step(v, new_view=True, next_batch=nxt)))
-        eng.finish_pending()
-        torch.cuda.synchronize()
-        res[gb] = (losses, eng.arena.p.clone(), eng.view_cache_hits)
-    assert res[4][2] == 2 * len(views) and res[0][2] == 0
-    for la, lb in zip(res[4][0], res[0][0]):
+    torch.manual_seed(3)
+    a, b = _engine(monkeypatch, 4, **kw), _engine(monkeypatch, 0, **kw)
+    sched = [views[i % len(views)] for i in range(3 * len(views))]
+    for i, v in enumerate(sched):
+        nxt = sched[i + 1] if i + 1 < len(sched) else None
+        m0, v0 = lock(a, b)
+        la = a.losses(a.training_step(v, new_view=True, next_batch=nxt))
+        lb = b.losses(b.training_step(v, new_view=True, next_batch=nxt))
         for k in la:
-            assert abs(la[k] - lb[k]) <= 2e-4 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
-    pa, pb = res[4][1], res[0][1]
-    assert torch.equal(pa != 0, pb != 0)
-    assert float(((pa - pb).abs() > 1e-3).float().mean()) < 0.02
+            assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-6, (i, k, la[k], lb[k])
+        assert_same_step(a, b, m0, v0, what=f"step {i}")
+    torch.cuda.synchronize()
+    assert a.view_cache_hits == 2 * len(views) and b.view_cache_hits == 0
+    assert torch.equal(a.arena.p != 0, b.arena.p != 0)
 
 
 def test_budget_and_configuration_changes(monkeypatch):

@@ -95,28 +95,37 @@ def main():
     elif mode == "dense_vs_sparse":
         # a ZERO-initialised texture (sparse ever-touched update) with the plain dense reducer. Each
         # rank optimises its own views; the other rank's gradients arrive in chunks this rank's views never flagged.
+        # LOCK-STEP (tests/stepcmp.py): before every step the sparse-reducer engine receives the dense-reducer engine's
+        # state, both take the step, and the step is compared through Adam's moments - free-running engines at lr 1 drift
+        # apart chaotically, which says nothing about either reducer.
+        from stepcmp import lock, step_deviation
         from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
-        out = {}
+        engs, reds = {}, {}
         for kind in ("dense", "sparse"):
             cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                                angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
                                use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
                                learning_rate=1, decay_gamma=0.1, decay_step_size=1)
-            eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
+            eng = engs[kind] = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
             eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
             assert eng.touched is not None
-            red = D.make_grad_reducer(comm, world) if kind == "dense" else D.make_sparse_grad_reducer(comm, world)
-            get = lambda i: S.make_view(MULTIVIEW_SEEDS[i], view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW,
-                                        level_heights=[40, 64], min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
-            for batch in D.scheduled_batches(get, range(len(MULTIVIEW_SEEDS)), rank, world, index_repeat=3):
-                eng.training_step(batch, world_size=world, reducer=red)
-            torch.cuda.synchronize()
-            out[kind] = {"p": eng.arena.p.cpu().clone(), "g": eng.arena.g.cpu().clone(), "m": eng.arena.m.cpu().clone(),
-                         "dense_update": eng.touched is None}
+            reds[kind] = D.make_grad_reducer(comm, world) if kind == "dense" else D.make_sparse_grad_reducer(comm, world)
+        get = lambda i: S.make_view(MULTIVIEW_SEEDS[i], view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW,
+                                    level_heights=[40, 64], min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+        devs = []
+        for batch in D.scheduled_batches(get, range(len(MULTIVIEW_SEEDS)), rank, world, index_repeat=3):
+            m0, v0 = lock(engs["sparse"], engs["dense"])
+            for kind in ("dense", "sparse"):
+                engs[kind].training_step(batch, world_size=world, reducer=reds[kind])
+            devs.append(step_deviation(engs["sparse"], engs["dense"], m0, v0))
+        torch.cuda.synchronize()
+        out = {kind: {"p": eng.arena.p.cpu().clone(), "g": eng.arena.g.cpu().clone(), "m": eng.arena.m.cpu().clone(),
+                      "dense_update": eng.touched is None} for kind, eng in engs.items()}
+        out["lockstep"] = torch.stack(devs).cpu()
+        out["lr"] = engs["dense"].lr
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
     elif mode == "pipelined":
-        # the pipelined exchange + update (the default from STYLEMESH_PIPELINE_MIN_MB of flagged chunks
-        # on) against exchange-then-update, from the SAME state and the SAME local gradients: bit-identical p, m, v.
+        # the pipelined exchange + update (opt-in: STYLEMESH_PIPELINE_EXCHANGE=1 / auto) against exchange-then-update, from the SAME state and the SAME local gradients: bit-identical p, m, v.
         from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
         cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                            angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
