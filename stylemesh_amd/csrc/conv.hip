@@ -267,7 +267,11 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 #endif
     // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
     // (64 x 128 tiles - the small-grid choice of round 5, dispatch_conv_split2 - are sized for three blocks per CU)
-    constexpr int SLOTS = SM_NUM_CU * (SPLIT ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
+    constexpr int SLOTS_DEFAULT = SM_NUM_CU * (SPLIT ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
+    // (experiment: SM_CONV_SLOTS=<blocks per CU a round is sized for> - with the tail reduced in-kernel a second block per
+    // CU costs slab traffic only, no second pass)
+    static const int slots_env = getenv("SM_CONV_SLOTS") ? atoi(getenv("SM_CONV_SLOTS")) : 0;
+    const int SLOTS = (SPLIT && slots_env > 0 && !(BM == 64 && BN == 128)) ? SM_NUM_CU * slots_env : SLOTS_DEFAULT;
     a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;

@@ -9,17 +9,47 @@
 //     view is tail all over - every layer has fewer tiles than the chip has CUs - and its 22 second passes of 6 - 9 us
 //     were 165 us of a 1.06 ms step (profiles/r05/c2_step_timeline.txt), most of it launch latency: the reduction of a
 //     128 x 128 tile is 64 KB x splits of reads that come out of the L2 / MALL the slabs were just written through.
-//     Visibility across the XCDs (their L2s are not coherent with each other): every unit RELEASES its slab with an
-//     agent-scope fence (L2 write-back) before it bumps the counter, the last one ACQUIRES (L2 invalidate) after it has
-//     seen splits - 1 there. No unit waits for another: nothing can dead-lock, whatever the order the blocks run in.
+//     Visibility across the XCDs (their L2s are not coherent with each other): NO cache-wide operation - the first version
+//     released every slab with an agent-scope fence (buffer_wbl2: the XCD's whole L2 written back) and acquired with an
+//     L2 invalidate, and a launch took 75 us instead of 35 + 8 (profiles/r06/tail_fused_ab.txt): hundreds of units each
+//     flushing the L2 under the blocks still in their main loops. Instead the slabs themselves travel at DEVICE SCOPE:
+//     the units store them with sc1 (write-through, slab_store) and wait for the stores (vmcnt) before the block's
+//     thread 0 bumps the counter with a device-scope atomic; the last unit reads them with sc1 loads (slab_load4: served
+//     from the coherence point, never from a stale line of this XCD's L2). No unit waits for another: nothing can
+//     dead-lock, whatever the order the blocks run in.
 #pragma once
 #include "conv_common.h"
 
 namespace sm {
 
-// slice y (of BM * BN / 1024) of tail tile `tail`: one float4 of the BM x BN slab per thread
+// device-scope (sc1) accesses of the split-K slabs; COH = false: plain accesses (the second-pass kernels, which run behind
+// a kernel boundary)
+__device__ __forceinline__ void slab_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ f32x4 slab_load4(const float* ws, size_t idx) {
+    if constexpr (COH) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7ffffff0, 0x00020000);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 16 /* sc1 */));
+    } else {
+        return *reinterpret_cast<const f32x4*>(ws + idx);
+    }
+}
+template <bool COH>
+__device__ __forceinline__ f32x2 slab_load2(const float* ws, size_t idx) {
+    if constexpr (COH) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7ffffff0, 0x00020000);
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(idx * 4), 0, 16 /* sc1 */));
+    } else {
+        return *reinterpret_cast<const f32x2*>(ws + idx);
+    }
+}
+
+// slice y (of BM * BN / 1024) of tail tile `tail`: one float4 of the BM x BN slab per thread - element e = y * 256 + tid of
+// the slab's float4s (row e / (BN / 4), columns 4 (e % (BN / 4)) ...: float index 4 e). `v`: the sum of the tile's slabs there.
 template <int BM, int BN, int FLAGS>
-__device__ __forceinline__ float conv_tail_epilogue_body(const ConvArgs& a, int tail, int y, int tid) {
+__device__ __forceinline__ float conv_tail_epilogue_apply(const ConvArgs& a, int tail, int y, int tid, f32x4 v) {
     const int tile = a.n_whole + tail;
     const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
     const int e_ = y * 256 + tid;
@@ -57,11 +87,8 @@ __device__ __forceinline__ float conv_tail_epilogue_body(const ConvArgs& a, int 
         q = P.Wp + n_tile * BN + c4;
     }
     const int m0 = m_tile * BM, q_end = (P.H + 1) * P.Wp;
-    const float* wt = a.ws + (size_t)tail * a.splits * (BM * BN);
     float m = 0.f;            // max |output| of this thread (all lanes stay active for the wave reduction of the caller)
     if (alive && q < q_end) { // q_end and q are multiples of 4
-        f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * BN + c4);
-        for (int s = 1; s < a.splits; ++s) v += *reinterpret_cast<const f32x4*>(wt + (size_t)s * (BM * BN) + row * BN + c4);
         const int co = m0 + row;
         const size_t o = (size_t)co * P.plane + q;
         f32x4 prev;
@@ -92,7 +119,10 @@ __device__ __forceinline__ float conv_tail_epilogue_body(const ConvArgs& a, int 
 template <int BM, int BN, int FLAGS>
 __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     const float amax_seen = amax_peek(a.amax_out);   // beside the slab loads, not behind the stores
-    const float m = conv_tail_epilogue_body<BM, BN, FLAGS>(a, blockIdx.x, blockIdx.y, threadIdx.x);
+    const size_t wt = (size_t)blockIdx.x * a.splits * (BM * BN) + (size_t)(blockIdx.y * 256 + threadIdx.x) * 4;
+    f32x4 v = slab_load4<false>(a.ws, wt);
+    for (int s = 1; s < a.splits; ++s) v += slab_load4<false>(a.ws, wt + (size_t)s * (BM * BN));
+    const float m = conv_tail_epilogue_apply<BM, BN, FLAGS>(a, blockIdx.x, blockIdx.y, threadIdx.x, v);
     record_amax(a.amax_out, m, amax_seen);
 }
 
@@ -112,8 +142,16 @@ __device__ __forceinline__ ConvProblem conv_tail_problem(const ConvArgs& a, int 
         if (g == gsel) P = a.p[g];
     return P;
 }
+// index into ws of the upper-row pair of window (y, z, tid) in split 0's slab (the lower row: + 32)
 template <int BM, int BN>
-__device__ __forceinline__ float conv_tail_pool_body(const ConvArgs& a, const ConvProblem& P, int tail, int y, int z, int tid) {
+__device__ __forceinline__ size_t conv_tail_pool_index(const ConvArgs& a, int tail, int y, int z, int tid) {
+    const int c = tid & 7, w = tid >> 3;
+    return (size_t)tail * a.splits * (BM * BN) + (size_t)(y * 8 + c) * BN + (z * 2 + (w >> 4)) * 64 + 2 * (w & 15);
+}
+// t / b: the sums of the tile's slabs at the window's upper / lower row pair
+template <int BM, int BN>
+__device__ __forceinline__ float conv_tail_pool_apply(const ConvArgs& a, const ConvProblem& P, int tail, int y, int z, int tid,
+                                                      f32x2 t, f32x2 b) {
     const int tile = a.n_whole + tail;
     const int m_tile = tile / a.n_tiles, n_glob = tile - m_tile * a.n_tiles;
     const int c = tid & 7, w = tid >> 3;                         // channel of the group, window 0..31 of the block
@@ -131,12 +169,6 @@ __device__ __forceinline__ float conv_tail_pool_body(const ConvArgs& a, const Co
         const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
         ok = ((yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
         qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
-        const float* wt = a.ws + (size_t)tail * a.splits * (BM * BN) + (size_t)row * BN + pair * 64 + 2 * X;
-        f32x2 t = *reinterpret_cast<const f32x2*>(wt), b = *reinterpret_cast<const f32x2*>(wt + 32);
-        for (int s = 1; s < a.splits; ++s) {
-            t += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN));
-            b += *reinterpret_cast<const f32x2*>(wt + (size_t)s * (BM * BN) + 32);
-        }
         const float bv = a.bias[m_tile * BM + row];
         const float v00 = fmaxf(t[0] + bv, 0.f), v01 = fmaxf(t[1] + bv, 0.f), v10 = fmaxf(b[0] + bv, 0.f), v11 = fmaxf(b[1] + bv, 0.f);
         m = v00;
@@ -159,7 +191,13 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
     const float amax_seen = amax_peek(a.amax_out);
     const ConvProblem P = conv_tail_problem<BN>(a, blockIdx.x);
-    const float m = conv_tail_pool_body<BM, BN>(a, P, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+    const size_t wt = conv_tail_pool_index<BM, BN>(a, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+    f32x2 t = slab_load2<false>(a.ws, wt), b = slab_load2<false>(a.ws, wt + 32);
+    for (int s = 1; s < a.splits; ++s) {
+        t += slab_load2<false>(a.ws, wt + (size_t)s * (BM * BN));
+        b += slab_load2<false>(a.ws, wt + (size_t)s * (BM * BN) + 32);
+    }
+    const float m = conv_tail_pool_apply<BM, BN>(a, P, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, t, b);
     record_amax(a.amax_out, m, amax_seen);
 }
 
@@ -167,25 +205,60 @@ __global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
 // `flag` = one LDS word nobody else uses any more). Returns after the tile is reduced (last unit) or at once (the others).
 template <int BM, int BN, int FLAGS>
 __device__ __forceinline__ void conv_tail_fused(const ConvArgs& a, const ConvProblem& P, int tile, int tid, int* flag) {
-    __threadfence();                          // release: this unit's slab is visible to every XCD before the counter moves
+    // (the slab was stored with slab_store: write-through at device scope) every wave's stores have completed ...
+    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) expcnt(0) lgkmcnt(0)
     __syncthreads();
     const int tail = tile - a.n_whole;
-    if (tid == 0) {
-        const int last = atomicAdd(a.tail_count + tail, 1) == a.splits - 1;
-        if (last) a.tail_count[tail] = 0;     // every unit of the tile has arrived: zero again for the next launch
+    if (tid == 0) {                           // ... before the counter moves
+        const int last = __hip_atomic_fetch_add(a.tail_count + tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.splits - 1;
+        // every unit of the tile has arrived: zero again for the next launch
+        if (last) __hip_atomic_store(a.tail_count + tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = last;
     }
     __syncthreads();
     if (*flag == 0) return;
-    __threadfence();                          // acquire: the other units' slabs, not this XCD's stale lines of an earlier launch
     const float amax_seen = amax_peek(a.amax_out);
     float m = 0.f;
+    // One block reduces the whole tile: ALL of its slab loads of a split are issued before the first is used (the
+    // second-pass launch had 16 blocks per tile to hide the coherence point's latency; a dependent load-add chain per
+    // slice cost 18 us per launch). Every element is still summed in split order: the second pass's bits.
     if constexpr ((FLAGS & SM_EPI_POOL) != 0) {
-        for (int y = 0; y < BM / 8; ++y)
+        constexpr int NY = BM / 8, NZ = BN / 128, NW = NY * NZ;
+        f32x2 t[NW], b[NW];
+        size_t wt[NW];
 #pragma unroll
-            for (int z = 0; z < BN / 128; ++z) m = fmaxf(m, conv_tail_pool_body<BM, BN>(a, P, tail, y, z, tid));
+        for (int k = 0; k < NW; ++k) {
+            wt[k] = conv_tail_pool_index<BM, BN>(a, tail, k / NZ, k % NZ, tid);
+            t[k] = slab_load2<true>(a.ws, wt[k]);
+            b[k] = slab_load2<true>(a.ws, wt[k] + 32);
+        }
+        for (int s = 1; s < a.splits; ++s) {
+            f32x2 t1[NW], b1[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                t1[k] = slab_load2<true>(a.ws, wt[k] + (size_t)s * (BM * BN));
+                b1[k] = slab_load2<true>(a.ws, wt[k] + (size_t)s * (BM * BN) + 32);
+            }
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { t[k] += t1[k]; b[k] += b1[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) m = fmaxf(m, conv_tail_pool_apply<BM, BN>(a, P, tail, k / NZ, k % NZ, tid, t[k], b[k]));
     } else {
-        for (int y = 0; y < BM * BN / 1024; ++y) m = fmaxf(m, conv_tail_epilogue_body<BM, BN, FLAGS>(a, tail, y, tid));
+        constexpr int NY = BM * BN / 1024;
+        const size_t wt = (size_t)tail * a.splits * (BM * BN) + (size_t)tid * 4;
+        f32x4 v[NY];
+#pragma unroll
+        for (int y = 0; y < NY; ++y) v[y] = slab_load4<true>(a.ws, wt + (size_t)y * 1024);
+        for (int s = 1; s < a.splits; ++s) {
+            f32x4 v1[NY];
+#pragma unroll
+            for (int y = 0; y < NY; ++y) v1[y] = slab_load4<true>(a.ws, wt + (size_t)s * (BM * BN) + (size_t)y * 1024);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) v[y] += v1[y];
+        }
+#pragma unroll
+        for (int y = 0; y < NY; ++y) m = fmaxf(m, conv_tail_epilogue_apply<BM, BN, FLAGS>(a, tail, y, tid, v[y]));
     }
     record_amax(a.amax_out, m, amax_seen);
 }
