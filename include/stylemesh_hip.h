@@ -261,11 +261,7 @@ int sm_conv3x3_grouped(const sm_conv_problem* problems, int n_problems, const fl
  * ranges inside 128-position tiles were 8-17 % of all matrix instructions of a step); every problem's run is padded to a
  * whole number of tiles with (problem << 24) | 0xFFFFFF, n_list counts entries and must be a multiple of tile positions
  * / 32. sm_cover_segments builds such lists from need maps.
- * ws (ABI 11): as sm_conv3x3_grouped, but the K-split tail is reduced INSIDE the launch (csrc/conv_tail.h: the unit that
- * arrives last at its tile sums the tile's partial slabs and runs the epilogue - no second launch): the LAST 1024 words of
- * ws[0 .. ws_floats) are the tail tiles' arrival counters. They must be ZERO when a workspace is first passed; every
- * launch leaves them zero. One workspace per stream (concurrent launches must not share slabs or counters).
- * Same flags / amax_out semantics as sm_conv3x3_grouped; a tile covers sm_conv_split2_tile_positions(Cout)
+ * Same flags / ws / amax_out semantics as sm_conv3x3_grouped; a tile covers sm_conv_split2_tile_positions(Cout)
  * positions (128; 256 for the 64-channel layers, whose 64 x 256 tiles keep four 64 x 64 wave tiles busy). Error against
  * an fp64 convolution: same class as the fp32-MFMA kernel (tests/test_kernels_gpu.py). */
 int sm_conv_split2_tile_positions(int Cout);

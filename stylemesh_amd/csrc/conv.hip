@@ -19,7 +19,6 @@
 #include "conv_tail.h"
 #include "conv_split_kernel.h"
 
-#define SM_TAIL_COUNTERS 1024   // >= the tail tiles of a launch (< 3 x 256 block slots)
 #ifndef SM_SPLIT2_BN256
 #define SM_SPLIT2_BN256 1   // fp16x2, Cout % 128 != 0: 64 x 256 tiles instead of 64 x 128
 #endif
@@ -267,11 +266,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
 #endif
     // (the fp16x2 variant is not matrix-pipe-bound with one block per CU: its rounds take SM_SPLIT2_SLOTS blocks per CU)
     // (64 x 128 tiles - the small-grid choice of round 5, dispatch_conv_split2 - are sized for three blocks per CU)
-    constexpr int SLOTS_DEFAULT = SM_NUM_CU * (SPLIT ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
-    // (experiment: SM_CONV_SLOTS=<blocks per CU a round is sized for> - with the tail reduced in-kernel a second block per
-    // CU costs slab traffic only, no second pass)
-    static const int slots_env = getenv("SM_CONV_SLOTS") ? atoi(getenv("SM_CONV_SLOTS")) : 0;
-    const int SLOTS = (SPLIT && slots_env > 0 && !(BM == 64 && BN == 128)) ? SM_NUM_CU * slots_env : SLOTS_DEFAULT;
+    constexpr int SLOTS = SM_NUM_CU * (SPLIT ? ((BM == 64 && BN == 128) ? SM_SMALL_SLOTS : SM_SPLIT2_SLOTS) : 1);
     a.n_whole = tiles / SLOTS * SLOTS;
     a.splits = 1;
     a.chunks_per_split = chunks;
@@ -302,13 +297,6 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
     }
     if (RES) a.splits = 1;                       // resident input: whole tiles only (K <= 1152: nothing to split)
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
-    // fp16x2 kernel: the tail is reduced INSIDE the launch (conv_tail.h) - the counters are the last SM_TAIL_COUNTERS words
-    // of the workspace, zero between launches (sm_conv3x3_grouped_split2: ws). SM_CONV_TAIL_PASS=1: the second-pass launch.
-    a.tail_count = nullptr;
-    if constexpr (SPLIT) {
-        static const bool tail_pass = getenv("SM_CONV_TAIL_PASS") != nullptr && atoi(getenv("SM_CONV_TAIL_PASS")) != 0;
-        if (rem > 0 && !tail_pass) a.tail_count = reinterpret_cast<int*>(a.ws + ws_floats);   // (ws_floats: see the caller)
-    }
     if constexpr (SPLIT) {
         static_assert(KC == 16, "one fp16 MFMA K-step per tap");
         // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
@@ -327,7 +315,7 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
                            dim3(256), lds, s, a);
     }
     SM_LAUNCH_CHECK();
-    if (rem > 0 && a.tail_count == nullptr) {
+    if (rem > 0) {
         if constexpr ((FLAGS & SM_EPI_POOL) != 0)
             hipLaunchKernelGGL((conv_tail_pool_kernel<BM, BN>), dim3(rem, BM / 8, BN / 128), dim3(256), 0, s, a);
         else
@@ -845,8 +833,6 @@ int sm_conv3x3_grouped_split2(const sm_conv_problem* problems, int n_problems, c
     a.amax_out = amax_out;
     a.w_scale_inv = w_scale_inv;
     if (unpool != 0 && unpool != n_problems) return (int)hipErrorInvalidValue;
-    // the last SM_TAIL_COUNTERS words of the workspace are the tail tiles' arrival counters (conv_tail.h)
-    ws_floats = (ws != nullptr && ws_floats >= 2 * SM_TAIL_COUNTERS) ? ws_floats - SM_TAIL_COUNTERS : 0;
     return conv_dispatch_flags_split2(a, n_list, flags, ws_floats, unpool != 0, (hipStream_t)stream);
 }
 

@@ -54,9 +54,6 @@ struct ConvArgs {
     int n_whole;
     int splits;
     int chunks_per_split;
-    // fp16x2 kernel, in-kernel tail reduction (conv_tail.h): one int per tail tile, ZERO on entry and on exit - the unit
-    // that arrives last at its tile's counter reduces the tile's slabs; nullptr = the second-pass launch reduces them.
-    int* tail_count;
     // Operand scaling of the fp16x2 split kernel (conv_split_kernel.h). amax_in (device, optional): max |x| of
     // the input tensor(s), recorded by their producer; w_scale_inv: 1 / (power-of-two scale the host applied to the
     // weights). amax_out (device, optional, any kernel): this launch's max |output| is atomically max-ed into it (as

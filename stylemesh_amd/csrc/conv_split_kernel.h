@@ -24,7 +24,6 @@
 // cover each other's store / barrier phases.
 #pragma once
 #include "conv_common.h"
-#include "conv_tail.h"
 
 // tuning knobs (A/B builds: build.sh -DSM_SPLIT2_AD=1 ..., compared with tools/ab_libs.sh). What the loop is sensitive to
 // is the NUMBER of vector-memory instructions (round-2 ablation: no weight loads +15 %, no activation loads +8 %, no
@@ -720,12 +719,9 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    // (device scope, write-through: the unit that reduces the tile may sit on another XCD - conv_tail.h)
-                    slab_store(&wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + j * 32 + l31],
-                               acc[mi][j][r] * out_scale);   // power of two: exact
+                    wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + j * 32 + l31] =
+                        acc[mi][j][r] * out_scale;   // power of two: exact
         SM_TS(51)
-        // round 6: the last unit of the tile to get here reduces the slabs and runs the epilogue (conv_tail.h)
-        if (a.tail_count != nullptr) conv_tail_fused<BM, BN, FLAGS>(a, P, tile, tid, reinterpret_cast<int*>(smem4));
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;

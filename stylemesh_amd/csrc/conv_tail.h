@@ -1,50 +1,21 @@
 // The K-split TAIL of a conv launch: tiles of the last, partially filled round are split along K into `splits` units that
 // store raw partial tiles ("slabs") to ConvArgs::ws; the tile's output = epilogue(sum of its slabs in split order).
 //
-// Two forms of that reduction, the same arithmetic and the same bits:
-//   * SECOND PASS (conv_tail_epilogue_kernel / conv_tail_pool_kernel): a launch of its own behind the conv launch - what
-//     the exact-fp32 kernel (conv3x3_mfma_kernel) uses, and the fp16x2 kernel under SM_CONV_TAIL_PASS=1;
-//   * IN-KERNEL (round 6, conv_tail_fused; the fp16x2 kernel's default): the unit that ARRIVES LAST at its tile's counter
-//     (ConvArgs::tail_count, one int per tail tile, zero between launches) reduces the tile before it exits. A one-level
-//     view is tail all over - every layer has fewer tiles than the chip has CUs - and its 22 second passes of 6 - 9 us
-//     were 165 us of a 1.06 ms step (profiles/r05/c2_step_timeline.txt), most of it launch latency: the reduction of a
-//     128 x 128 tile is 64 KB x splits of reads that come out of the L2 / MALL the slabs were just written through.
-//     Visibility across the XCDs (their L2s are not coherent with each other): NO cache-wide operation - the first version
-//     released every slab with an agent-scope fence (buffer_wbl2: the XCD's whole L2 written back) and acquired with an
-//     L2 invalidate, and a launch took 75 us instead of 35 + 8 (profiles/r06/tail_fused_ab.txt): hundreds of units each
-//     flushing the L2 under the blocks still in their main loops. Instead the slabs themselves travel at DEVICE SCOPE:
-//     the units store them with sc1 (write-through, slab_store) and wait for the stores (vmcnt) before the block's
-//     thread 0 bumps the counter with a device-scope atomic; the last unit reads them with sc1 loads (slab_load4: served
-//     from the coherence point, never from a stale line of this XCD's L2). No unit waits for another: nothing can
-//     dead-lock, whatever the order the blocks run in.
+// The reduction is a SECOND PASS (conv_tail_epilogue_kernel / conv_tail_pool_kernel): a launch of its own behind the conv
+// launch, 16 blocks per tile, 7.5 us per layer launch included. Round 6 built the alternative the r5 verdict asked for - the
+// K-split unit that ARRIVES LAST at its tile (an atomic counter per tile) reduces the tile before it exits, no second launch -
+// in three versions (agent-scope fences; device-scope sc1 slab stores / loads; all loads of a split in flight), bit-identical
+// to this pass, and measured it in situ: 75 / 53 / 45 us per one-level conv layer against 35 (profiles/r06/tail_fused_ab.txt;
+// git 8b07e84 has the code). One block owning a tile's whole latency chain behind its main loop - write-through stores,
+// counter, loads that by construction miss this XCD's L2, gate loads, stores - is slower than a kernel boundary plus a 16x
+// wider pass: the XCDs' L2s are only coherent through write-back / invalidate or bypass. The second pass stays.
 #pragma once
 #include "conv_common.h"
 
 namespace sm {
 
-// device-scope (sc1) accesses of the split-K slabs; COH = false: plain accesses (the second-pass kernels, which run behind
-// a kernel boundary)
-__device__ __forceinline__ void slab_store(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ f32x4 slab_load4(const float* ws, size_t idx) {
-    if constexpr (COH) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7ffffff0, 0x00020000);
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(idx * 4), 0, 16 /* sc1 */));
-    } else {
-        return *reinterpret_cast<const f32x4*>(ws + idx);
-    }
-}
-template <bool COH>
-__device__ __forceinline__ f32x2 slab_load2(const float* ws, size_t idx) {
-    if constexpr (COH) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7ffffff0, 0x00020000);
-        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(idx * 4), 0, 16 /* sc1 */));
-    } else {
-        return *reinterpret_cast<const f32x2*>(ws + idx);
-    }
-}
+__device__ __forceinline__ f32x4 slab_ld4(const float* ws, size_t idx) { return *reinterpret_cast<const f32x4*>(ws + idx); }
+__device__ __forceinline__ f32x2 slab_ld2(const float* ws, size_t idx) { return *reinterpret_cast<const f32x2*>(ws + idx); }
 
 // slice y (of BM * BN / 1024) of tail tile `tail`: one float4 of the BM x BN slab per thread - element e = y * 256 + tid of
 // the slab's float4s (row e / (BN / 4), columns 4 (e % (BN / 4)) ...: float index 4 e). `v`: the sum of the tile's slabs there.
@@ -120,8 +91,8 @@ template <int BM, int BN, int FLAGS>
 __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvArgs a) {
     const float amax_seen = amax_peek(a.amax_out);   // beside the slab loads, not behind the stores
     const size_t wt = (size_t)blockIdx.x * a.splits * (BM * BN) + (size_t)(blockIdx.y * 256 + threadIdx.x) * 4;
-    f32x4 v = slab_load4<false>(a.ws, wt);
-    for (int s = 1; s < a.splits; ++s) v += slab_load4<false>(a.ws, wt + (size_t)s * (BM * BN));
+    f32x4 v = slab_ld4(a.ws, wt);
+    for (int s = 1; s < a.splits; ++s) v += slab_ld4(a.ws, wt + (size_t)s * (BM * BN));
     const float m = conv_tail_epilogue_apply<BM, BN, FLAGS>(a, blockIdx.x, blockIdx.y, threadIdx.x, v);
     record_amax(a.amax_out, m, amax_seen);
 }
@@ -192,74 +163,12 @@ __global__ __launch_bounds__(256) void conv_tail_pool_kernel(ConvArgs a) {
     const float amax_seen = amax_peek(a.amax_out);
     const ConvProblem P = conv_tail_problem<BN>(a, blockIdx.x);
     const size_t wt = conv_tail_pool_index<BM, BN>(a, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
-    f32x2 t = slab_load2<false>(a.ws, wt), b = slab_load2<false>(a.ws, wt + 32);
+    f32x2 t = slab_ld2(a.ws, wt), b = slab_ld2(a.ws, wt + 32);
     for (int s = 1; s < a.splits; ++s) {
-        t += slab_load2<false>(a.ws, wt + (size_t)s * (BM * BN));
-        b += slab_load2<false>(a.ws, wt + (size_t)s * (BM * BN) + 32);
+        t += slab_ld2(a.ws, wt + (size_t)s * (BM * BN));
+        b += slab_ld2(a.ws, wt + (size_t)s * (BM * BN) + 32);
     }
     const float m = conv_tail_pool_apply<BM, BN>(a, P, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x, t, b);
-    record_amax(a.amax_out, m, amax_seen);
-}
-
-// IN-KERNEL form: called by every K-split unit of the fp16x2 kernel right after its slab is stored (all 256 threads;
-// `flag` = one LDS word nobody else uses any more). Returns after the tile is reduced (last unit) or at once (the others).
-template <int BM, int BN, int FLAGS>
-__device__ __forceinline__ void conv_tail_fused(const ConvArgs& a, const ConvProblem& P, int tile, int tid, int* flag) {
-    // (the slab was stored with slab_store: write-through at device scope) every wave's stores have completed ...
-    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) expcnt(0) lgkmcnt(0)
-    __syncthreads();
-    const int tail = tile - a.n_whole;
-    if (tid == 0) {                           // ... before the counter moves
-        const int last = __hip_atomic_fetch_add(a.tail_count + tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.splits - 1;
-        // every unit of the tile has arrived: zero again for the next launch
-        if (last) __hip_atomic_store(a.tail_count + tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-    const float amax_seen = amax_peek(a.amax_out);
-    float m = 0.f;
-    // One block reduces the whole tile: ALL of its slab loads of a split are issued before the first is used (the
-    // second-pass launch had 16 blocks per tile to hide the coherence point's latency; a dependent load-add chain per
-    // slice cost 18 us per launch). Every element is still summed in split order: the second pass's bits.
-    if constexpr ((FLAGS & SM_EPI_POOL) != 0) {
-        constexpr int NY = BM / 8, NZ = BN / 128, NW = NY * NZ;
-        f32x2 t[NW], b[NW];
-        size_t wt[NW];
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            wt[k] = conv_tail_pool_index<BM, BN>(a, tail, k / NZ, k % NZ, tid);
-            t[k] = slab_load2<true>(a.ws, wt[k]);
-            b[k] = slab_load2<true>(a.ws, wt[k] + 32);
-        }
-        for (int s = 1; s < a.splits; ++s) {
-            f32x2 t1[NW], b1[NW];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                t1[k] = slab_load2<true>(a.ws, wt[k] + (size_t)s * (BM * BN));
-                b1[k] = slab_load2<true>(a.ws, wt[k] + (size_t)s * (BM * BN) + 32);
-            }
-#pragma unroll
-            for (int k = 0; k < NW; ++k) { t[k] += t1[k]; b[k] += b1[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < NW; ++k) m = fmaxf(m, conv_tail_pool_apply<BM, BN>(a, P, tail, k / NZ, k % NZ, tid, t[k], b[k]));
-    } else {
-        constexpr int NY = BM * BN / 1024;
-        const size_t wt = (size_t)tail * a.splits * (BM * BN) + (size_t)tid * 4;
-        f32x4 v[NY];
-#pragma unroll
-        for (int y = 0; y < NY; ++y) v[y] = slab_load4<true>(a.ws, wt + (size_t)y * 1024);
-        for (int s = 1; s < a.splits; ++s) {
-            f32x4 v1[NY];
-#pragma unroll
-            for (int y = 0; y < NY; ++y) v1[y] = slab_load4<true>(a.ws, wt + (size_t)s * (BM * BN) + (size_t)y * 1024);
-#pragma unroll
-            for (int y = 0; y < NY; ++y) v[y] += v1[y];
-        }
-#pragma unroll
-        for (int y = 0; y < NY; ++y) m = fmaxf(m, conv_tail_epilogue_apply<BM, BN, FLAGS>(a, tail, y, tid, v[y]));
-    }
     record_amax(a.amax_out, m, amax_seen);
 }
 

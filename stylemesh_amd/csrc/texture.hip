@@ -484,6 +484,145 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K7s (round 6): the same update over FLAGGED 256-byte chunks, for views whose footprint is a small, fragmented share of
+// the arena (closing half of the split update: 14 % of the chunks at c3; the early half: 25 %). adam_kernel walks every
+// 1024-element tile of the arena and asks the flag of each thread's chunk first: a dependent flag -> data round trip per
+// tile, sixteen tiles in a row per block - 157 us for 268 MB (1.7 TB/s), most of it waiting on flags of chunks that are not
+// flagged. Here a block owns a SPAN of 1024 chunks of ONE segment (layer): it reads the span's 1024 flags with one
+// 16-byte load per thread, compacts the flagged chunk numbers into LDS (ballot + prefix counts), and then streams the
+// listed chunks, 32 per iteration (sixteen lanes x float4 per chunk, two chunks per lane group: eight loads in flight per
+// thread): no work and no latency for an unflagged chunk. Same arithmetic per element as adam_kernel (the same bits of
+// p, m, v, g); sum(p^2) of the block's segment in registers, one atomic per block. Requires chunks of 64 floats and
+// chunk-aligned segment boundaries (else sm_adam_fused takes adam_kernel).
+// ---------------------------------------------------------------------------------------------------
+constexpr int ADAM_SPAN = 1024;          // chunks per block
+struct SpanTable {
+    int first_block[SM_MAX_TEX_LAYERS + 1];   // blocks of segment k: [first_block[k], first_block[k + 1])
+    size_t begin[SM_MAX_TEX_LAYERS];          // first element of segment k
+};
+
+__global__ __launch_bounds__(256) void adam_sparse_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, size_t n, Segs segs, SpanTable spans,
+                                                          float lr_over_bc1, float one_minus_beta1, float beta2,
+                                                          float one_minus_beta2, float eps, float inv_sqrt_bc2,
+                                                          float grad_scale, float lo, float hi, int zero_grad,
+                                                          float* __restrict__ sumsq, const float* __restrict__ dev_hyper,
+                                                          const int32_t* __restrict__ touched) {
+    if (dev_hyper) {
+        lr_over_bc1 = dev_hyper[0];
+        inv_sqrt_bc2 = dev_hyper[1];
+    }
+    __shared__ unsigned short list[ADAM_SPAN];
+    __shared__ int wave_count[4];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < SM_MAX_TEX_LAYERS; ++i)
+        if (i < segs.n && (int)blockIdx.x >= spans.first_block[i]) k = i;
+    const size_t seg_begin = spans.begin[k], seg_end = segs.end[k];
+    const size_t chunk0 = (seg_begin >> 6) + (size_t)((int)blockIdx.x - spans.first_block[k]) * ADAM_SPAN;   // first chunk of the span
+    const size_t seg_chunks_end = (seg_end + 63) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- the span's flags -> ascending list of its flagged chunks
+    int4 f = make_int4(0, 0, 0, 0);
+    const size_t c = chunk0 + 4 * (size_t)tid;
+    if (c + 4 <= seg_chunks_end && (reinterpret_cast<size_t>(touched + c) & 15) == 0) {
+        f = *reinterpret_cast<const int4*>(touched + c);
+    } else {
+        if (c + 3 < seg_chunks_end) f.w = touched[c + 3];
+        if (c < seg_chunks_end) f.x = touched[c];
+        if (c + 1 < seg_chunks_end) f.y = touched[c + 1];
+        if (c + 2 < seg_chunks_end) f.z = touched[c + 2];
+    }
+    const int mine = (f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0);
+    int incl = mine;                       // inclusive prefix over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_count[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) base += wave_count[w];
+        total += wave_count[w];
+    }
+    int at = base + incl - mine;
+    if (f.x != 0) list[at++] = (unsigned short)(4 * tid);
+    if (f.y != 0) list[at++] = (unsigned short)(4 * tid + 1);
+    if (f.z != 0) list[at++] = (unsigned short)(4 * tid + 2);
+    if (f.w != 0) list[at++] = (unsigned short)(4 * tid + 3);
+    __syncthreads();
+    // ---- the listed chunks: lane group tid / 16 takes entries it, it + 16 of every 32; lane tid % 16 one float4 of the chunk
+    const float reg = segs.reg[k];
+    float sq = 0.f;
+    for (int it = 0; it < total; it += 32) {
+        size_t i0[2];
+        bool on[2];
+        float pv[2][4], gv[2][4], mv[2][4], vv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = it + 16 * u + (tid >> 4);
+            on[u] = e < total;
+            i0[u] = ((chunk0 + list[on[u] ? e : 0]) << 6) + (size_t)(tid & 15) * 4;
+            on[u] = on[u] && i0[u] < seg_end;                          // (the segment's last chunk may be a partial one)
+            if (on[u] && i0[u] + 4 <= seg_end) {
+                *reinterpret_cast<float4*>(pv[u]) = *reinterpret_cast<const float4*>(p + i0[u]);
+                *reinterpret_cast<float4*>(gv[u]) = g ? *reinterpret_cast<const float4*>(g + i0[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(mv[u]) = *reinterpret_cast<const float4*>(m + i0[u]);
+                *reinterpret_cast<float4*>(vv[u]) = *reinterpret_cast<const float4*>(v + i0[u]);
+            } else if (on[u]) {
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = i0[u] + j < seg_end;
+                    pv[u][j] = ok ? p[i0[u] + j] : 0.f;
+                    gv[u][j] = (ok && g) ? g[i0[u] + j] : 0.f;
+                    mv[u][j] = ok ? m[i0[u] + j] : 0.f;
+                    vv[u][j] = ok ? v[i0[u] + j] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!on[u]) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = pv[u][j];
+                const float gr = fmaf(gv[u][j], grad_scale, reg * x);          // data term (+ mean over ranks) + reg
+                mv[u][j] = mv[u][j] + (gr - mv[u][j]) * one_minus_beta1;       // exp_avg.lerp_(grad, 1 - beta1)
+                vv[u][j] = vv[u][j] * beta2 + (gr * gr) * one_minus_beta2;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+                const float denom = sqrtf(vv[u][j]) * inv_sqrt_bc2 + eps;
+                x = x - lr_over_bc1 * (mv[u][j] / denom);
+                x = fminf(hi, fmaxf(x, lo));
+                pv[u][j] = x;
+                if (i0[u] + j < seg_end) sq += x * x;
+            }
+            if (i0[u] + 4 <= seg_end) {
+                adam_store4(p + i0[u], pv[u]);
+                adam_store4(m + i0[u], mv[u]);
+                adam_store4(v + i0[u], vv[u]);
+                if (zero_grad && g) {
+                    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    adam_store4(g + i0[u], z);
+                }
+            } else {
+                for (int j = 0; j < 4 && i0[u] + j < seg_end; ++j) {
+                    p[i0[u] + j] = pv[u][j];
+                    m[i0[u] + j] = mv[u][j];
+                    v[i0[u] + j] = vv[u][j];
+                    if (zero_grad && g) g[i0[u] + j] = 0.f;
+                }
+            }
+        }
+    }
+    if (sumsq) {
+        __syncthreads();
+        const float s_ = block_sum(sq);
+        if (threadIdx.x == 0 && s_ != 0.f) atomicAdd(sumsq + k, s_);
+    }
+}
+
 // Step-dependent Adam scalars kept ON THE DEVICE (hipGraph replay: the host may run many steps ahead of the GPU, so
 // nothing step-dependent may travel through a host buffer that a later step overwrites): state = {lr, step} in double;
 // one thread advances the step and writes {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} - the doubles torch computes.
@@ -611,11 +750,34 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
     if (touched != nullptr && (touched_chunk_log2 < 2 || touched_chunk_log2 > 24)) return (int)hipErrorInvalidValue;
     sm::Segs s;
     if (int e = make_segs(s, n, seg_end, reg_coef, n_seg)) return e;
-    const int tpb = sm::adam_tiles_per_block(n);
-    const size_t blocks = ((n + 1023) / 1024 + tpb - 1) / tpb;
     // step_size = lr / bias_correction1 and 1 / sqrt(bias_correction2) in double, as torch computes them
     const float lr_over_bc1 = (float)((double)lr / bias_corr1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_corr2));
+    if (touched != nullptr && touched_chunk_log2 == 6) {
+        // flagged chunks of 64 floats and every segment starting on a chunk boundary: the span kernel (adam_sparse_kernel)
+        bool aligned = true;
+        for (int k = 0; k + 1 < n_seg; ++k) aligned = aligned && seg_end[k] % 64 == 0;
+        static const bool dense_walk = getenv("SM_ADAM_DENSE_WALK") != nullptr && atoi(getenv("SM_ADAM_DENSE_WALK")) != 0;
+        if (aligned && !dense_walk) {
+            sm::SpanTable t{};
+            size_t begin = 0;
+            t.first_block[0] = 0;
+            for (int k = 0; k < n_seg; ++k) {
+                t.begin[k] = begin;
+                const size_t chunks = (seg_end[k] - begin + 63) / 64;
+                t.first_block[k + 1] = t.first_block[k] + (int)((chunks + sm::ADAM_SPAN - 1) / sm::ADAM_SPAN);
+                begin = seg_end[k];
+            }
+            if (t.first_block[n_seg] > 0)
+                hipLaunchKernelGGL(sm::adam_sparse_kernel, dim3((unsigned)t.first_block[n_seg]), dim3(256), 0, (hipStream_t)stream,
+                                   p, g, m, v, n, s, t, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps,
+                                   inv_sqrt_bc2, grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper, touched);
+            SM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    const int tpb = sm::adam_tiles_per_block(n);
+    const size_t blocks = ((n + 1023) / 1024 + tpb - 1) / tpb;
     hipLaunchKernelGGL(sm::adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        s, lr_over_bc1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, inv_sqrt_bc2,
                        grad_scale, clamp_lo, clamp_hi, zero_grad, sumsq_out, dev_hyper, tpb, touched, touched_chunk_log2);

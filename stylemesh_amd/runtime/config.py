@@ -32,9 +32,8 @@ SWITCHES = {
                                 "neutral on the reference's index_repeat-20 schedules (profiles/r05/resident_views.txt): opt-in"),
     "SM_CONV_SPLIT_PENALTY": ("3", "tuning", "(C library) cost of a K-split tail's second pass in tile-chunks, in the split-count "
                               "model (c2 +0.6 % at 2-4, -5 % at 8: profiles/r04/split_penalty_ab.txt)"),
-    "SM_CONV_TAIL_PASS": ("0", "diagnostic", "(C library) 1 = the fp16x2 conv kernel's K-split tail reduced by a second launch (rounds 2-5) "
-                          "instead of inside the launch (csrc/conv_tail.h; same bits: tests/test_round6_gpu.py)"),
-    "SM_CONV_SLOTS": ("(1)", "experiment", "(C library) blocks per CU the fp16x2 kernel's rounds / K-split tails are sized for"),
+    "SM_ADAM_DENSE_WALK": ("0", "diagnostic", "(C library) 1 = the flagged update walks every tile of the arena and asks each chunk's flag "
+                           "(rounds 2-5) instead of compacting a span's flags first (adam_sparse_kernel, round 6; same bits of p, m, v)"),
     "SM_CONV_FORCE_SPLITS": ("(unset)", "experiment", "(C library) force the tail's K-split count (tools/bench_c2_layers.py sweeps)"),
     "SM_CONV_STAMP": ("(unset)", "diagnostic", "(C library) the conv build that writes s_memtime stage stamps (tools/ts_split.py, ts_small.py)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),

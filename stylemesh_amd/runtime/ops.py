@@ -336,8 +336,7 @@ def splitk_workspace(device) -> torch.Tensor:
     # ahead on a side stream) must not share their split-K partial slabs
     key = (str(device), hip.stream())
     if key not in _SPLITK_WS:
-        # (zeros: the workspace's last 1024 words are the fp16x2 kernel's tail counters, zero between launches - the header)
-        _SPLITK_WS[key] = torch.zeros(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+        _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]
 
 

@@ -309,7 +309,7 @@ def test_one_step_matches_oracle_at_full_size(name, seed_index, monkeypatch):
     _one_step_case(name, c, seed, _view(c, seed), _tex0(c), monkeypatch, f"{name}_seed{seed}")
 
 
-def _one_step_case(name, c, seed, view, tex0, monkeypatch, record_key, flip_frac_max=None, max_err=None):
+def _one_step_case(name, c, seed, view, tex0, monkeypatch, record_key, flip_frac_max=None, max_err=None, outside_tol=1e-5):
     """ONE step's losses and texture gradient from the texture ``tex0``: engine (both arithmetic modes) against the oracle,
     the out-of-bound texels identified (module docstring). Returns the recorded entry."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -382,7 +382,7 @@ def _one_step_case(name, c, seed, view, tex0, monkeypatch, record_key, flip_frac
         # gate that differs); (b) outside the footprints the gradient is the oracle's to 1e-5 of its maximum - twenty times
         # tighter than the tight bound (measured over the thirty cases of round 5: <= 1.4e-6, profiles/r05/fullsize_parity.json)
         assert e["out_of_bound_texels_outside_footprints"] == 0, (name, mode, e)
-        assert e["max_err_outside_footprints_over_max_ref"] <= 1e-5, (name, mode, e)
+        assert e["max_err_outside_footprints_over_max_ref"] <= outside_tol, (name, mode, e)
         assert e["out_of_bound_texels"] == 0 or e["flipped_pool_windows"] + e["relu_gate_differences"] > 0, (name, mode, e)
         assert e["fraction_of_touched_texels_beyond_tight_bound"] <= flip_frac_max, \
             f"{name} {mode}: {fracs[mode]:.5f} of the touched texels beyond 1e-3|ref| + 2e-4 max|ref|"
@@ -446,8 +446,12 @@ def test_one_step_matches_oracle_on_a_late_texture(monkeypatch):
     assert max(float(t.abs().max()) for t in tex_late) > 1.0          # a trained texture, not the zero it started from
     seed = LATE_VIEWS[2]
     view = _view(c, seed)
+    # (outside the identified footprints: measured 7.7e-6 of max|ref| in fp16x2 against 1.3e-6 in fp32-MFMA on this state -
+    # late in training 3 - 7 % of the non-zero elements of the style-loss derivative matrices lie more than 2^18 below their
+    # tensor's bound, profiles/r06/split2_dynamic_range.json; the early-training cases show <= 1.4e-6 in both modes. Bound:
+    # 5e-5 = a quarter of the tight bound's absolute term)
     entry = _one_step_case("c3", c, seed, view, tex_late, monkeypatch, f"late_c3_seed{seed}", flip_frac_max=0.05,
-                           max_err={"split2": 0.25, "f32": 0.25})
+                           max_err={"split2": 0.25, "f32": 0.25}, outside_tol=5e-5)
     key = "fraction_of_touched_texels_beyond_tight_bound"
     assert entry["split2"][key] <= 1.5 * entry["f32"][key] + 2e-4, (entry["split2"][key], entry["f32"][key])
     # the operand census of this very step (dense tiles: every stored position is this step's)

@@ -922,3 +922,49 @@ def test_gram_split2_dynamic_range_stress(rt, C, H, W, kind, monkeypatch):
     assert float(gotb[~live].abs().max()) == 0.0
     print(f"\n[gram stress {kind} C={C}] max err / bound: forward {worst_f:.3f}, backward {worst_b:.3f}")
     assert worst_f <= 1.0 and worst_b <= 1.0, (worst_f, worst_b)
+
+
+@pytest.mark.parametrize("density", [0.0, 0.02, 0.15, 0.6, 1.0])
+@pytest.mark.parametrize("sizes,with_g", [([3 * 256 * 256, 3 * 128 * 128, 3 * 64 * 64, 3 * 32 * 32], True),
+                                           ([3 * 64 * 64, 3 * 32 * 32, 3 * 16 * 16, 3 * 8 * 8], True),     # segments start on chunk 3 mod 4
+                                           ([3 * 512 * 512 + 64 * 7 + 20], False),                          # one layer, partial last chunk
+                                           ([3 * 16 * 16, 3 * 4 * 4, 3 * 2 * 2], True)])                    # unaligned segments: the tile walk
+def test_adam_flagged_span_kernel_equals_the_elementwise_update(rt, sizes, with_g, density):
+    """sm_adam_fused over FLAGGED 256-byte chunks (round 6: a block compacts the flags of a span of 1024 chunks of one
+    layer and streams the listed chunks) against the same update computed element by element in torch on the flagged chunks:
+    p, m, v within fp32 rounding of the reference formula (model/model.py:387-395 + the regulariser gradient,
+    texture.py:102-108, + the clamp, texture.py:41-44), unflagged chunks untouched bit for bit, the gradient zeroed on the
+    flagged chunks only, sum(p^2) per layer over the WHOLE flagged set."""
+    torch.manual_seed(len(sizes) * 7 + int(density * 100))
+    seg_end = np.cumsum(sizes).tolist()
+    n = seg_end[-1]
+    reg = [0.41, 0.2, 0.05, 0.0][:len(sizes)]
+    p0 = (torch.randn(n) * 60).clamp(O.CLAMP_LO, O.CLAMP_HI)
+    m0, v0, g0 = torch.randn(n) * 0.1, torch.rand(n) * 0.01, torch.randn(n)
+    n_chunks = -(-n // 64)
+    flags = (torch.rand(n_chunks) < density).int()
+    if density >= 1.0:
+        flags[:] = 1
+    P, M, V = dev(p0), dev(m0), dev(v0)
+    G = dev(g0) if with_g else None
+    sumsq = torch.zeros(len(sizes)).cuda()
+    lr, step, gs = 0.5, 3, 0.5
+    rt.ops.adam_fused(P, G, M, V, seg_end, reg, lr, step, grad_scale=gs, sumsq_out=sumsq, touched=flags.cuda(), touched_log2=6)
+    on = flags.bool().repeat_interleave(64)[:n]
+    seg = torch.bucketize(torch.arange(n), torch.tensor(seg_end), right=True)
+    gr = (g0 if with_g else torch.zeros(n)) * gs + torch.tensor(reg)[seg] * p0
+    m1 = m0 + (gr - m0) * 0.1
+    v1 = v0 * 0.999 + gr * gr * (1 - 0.999)
+    bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+    p1 = (p0 - (lr / bc1) * (m1 / (v1.sqrt() / bc2 ** 0.5 + 1e-8))).clamp(O.CLAMP_LO, O.CLAMP_HI)
+    Pc, Mc, Vc = P.cpu(), M.cpu(), V.cpu()
+    assert torch.equal(Pc[~on], p0[~on]) and torch.equal(Mc[~on], m0[~on]) and torch.equal(Vc[~on], v0[~on])
+    if bool(on.any()):
+        assert_close(Mc[on], m1[on], 1e-6, 1e-7)
+        assert_close(Vc[on], v1[on], 1e-6, 1e-9)
+        assert_close(Pc[on], p1[on], 1e-5, 1e-4)
+    if with_g:
+        Gc = G.cpu()
+        assert float(Gc[on].abs().max() if bool(on.any()) else 0.0) == 0.0 and torch.equal(Gc[~on], g0[~on])
+    want = torch.zeros(len(sizes)).index_add_(0, seg[on], (Pc[on].double() ** 2).float())
+    assert_close(sumsq, want, 1e-5, 1e-3)
