@@ -489,14 +489,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 // the arena (closing half of the split update: 14 % of the chunks at c3; the early half: 25 %). adam_kernel walks every
 // 1024-element tile of the arena and asks the flag of each thread's chunk first: a dependent flag -> data round trip per
 // tile, sixteen tiles in a row per block - 157 us for 268 MB (1.7 TB/s), most of it waiting on flags of chunks that are not
-// flagged. Here a block owns a SPAN of 1024 chunks of ONE segment (layer): it reads the span's 1024 flags with one
-// 16-byte load per thread, compacts the flagged chunk numbers into LDS (ballot + prefix counts), and then streams the
+// flagged. Here a block owns a SPAN of 256 chunks of ONE segment (layer): it reads the span's flags, one per thread,
+// compacts the flagged chunk numbers into LDS (ballot + prefix counts), and then streams the
 // listed chunks, 32 per iteration (sixteen lanes x float4 per chunk, two chunks per lane group: eight loads in flight per
 // thread): no work and no latency for an unflagged chunk. Same arithmetic per element as adam_kernel (the same bits of
 // p, m, v, g); sum(p^2) of the block's segment in registers, one atomic per block. Requires chunks of 64 floats and
 // chunk-aligned segment boundaries (else sm_adam_fused takes adam_kernel).
 // ---------------------------------------------------------------------------------------------------
-constexpr int ADAM_SPAN = 1024;          // chunks per block
+constexpr int ADAM_SPAN = 256;           // chunks per block: one flag per thread = 16 K elements, the tile walk's block size
+                                         // (measured at c3 / c2, closing half: 64 -> 185 / 79 us, 128 -> 112 / 76, 256 -> 91 / 82,
+                                         // 1024 with 16-byte flag loads -> 127 / 109: a view's footprint is a few blobs, long
+                                         // spans leave most blocks idle; the tile walk: 151 / 89 - profiles/r06/adam_span_ab.txt)
 struct SpanTable {
     int first_block[SM_MAX_TEX_LAYERS + 1];   // blocks of segment k: [first_block[k], first_block[k + 1])
     size_t begin[SM_MAX_TEX_LAYERS];          // first element of segment k
@@ -524,24 +527,10 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(float* __restrict__ p,
     const size_t seg_chunks_end = (seg_end + 63) >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- the span's flags -> ascending list of its flagged chunks
-    int4 f = make_int4(0, 0, 0, 0);
-    const size_t c = chunk0 + 4 * (size_t)tid;
-    if (c + 4 <= seg_chunks_end && (reinterpret_cast<size_t>(touched + c) & 15) == 0) {
-        f = *reinterpret_cast<const int4*>(touched + c);
-    } else {
-        if (c + 3 < seg_chunks_end) f.w = touched[c + 3];
-        if (c < seg_chunks_end) f.x = touched[c];
-        if (c + 1 < seg_chunks_end) f.y = touched[c + 1];
-        if (c + 2 < seg_chunks_end) f.z = touched[c + 2];
-    }
-    const int mine = (f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0);
-    int incl = mine;                       // inclusive prefix over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wave_count[wave] = incl;
+    const size_t c = chunk0 + (size_t)tid;
+    const bool flagged = c < seg_chunks_end && touched[c] != 0;
+    const unsigned long long ball = __ballot(flagged);
+    if (lane == 0) wave_count[wave] = __popcll(ball);
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
@@ -549,11 +538,7 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(float* __restrict__ p,
         if (w < wave) base += wave_count[w];
         total += wave_count[w];
     }
-    int at = base + incl - mine;
-    if (f.x != 0) list[at++] = (unsigned short)(4 * tid);
-    if (f.y != 0) list[at++] = (unsigned short)(4 * tid + 1);
-    if (f.z != 0) list[at++] = (unsigned short)(4 * tid + 2);
-    if (f.w != 0) list[at++] = (unsigned short)(4 * tid + 3);
+    if (flagged) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = (unsigned short)tid;
     __syncthreads();
     // ---- the listed chunks: lane group tid / 16 takes entries it, it + 16 of every 32; lane tid % 16 one float4 of the chunk
     const float reg = segs.reg[k];
@@ -759,13 +744,14 @@ int sm_adam_fused(float* p, float* g, float* m, float* v, size_t n, const size_t
         for (int k = 0; k + 1 < n_seg; ++k) aligned = aligned && seg_end[k] % 64 == 0;
         static const bool dense_walk = getenv("SM_ADAM_DENSE_WALK") != nullptr && atoi(getenv("SM_ADAM_DENSE_WALK")) != 0;
         if (aligned && !dense_walk) {
+            constexpr int span = sm::ADAM_SPAN;
             sm::SpanTable t{};
             size_t begin = 0;
             t.first_block[0] = 0;
             for (int k = 0; k < n_seg; ++k) {
                 t.begin[k] = begin;
                 const size_t chunks = (seg_end[k] - begin + 63) / 64;
-                t.first_block[k + 1] = t.first_block[k] + (int)((chunks + sm::ADAM_SPAN - 1) / sm::ADAM_SPAN);
+                t.first_block[k + 1] = t.first_block[k] + (int)((chunks + span - 1) / span);
                 begin = seg_end[k];
             }
             if (t.first_block[n_seg] > 0)
