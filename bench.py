@@ -128,6 +128,11 @@ def cpu_baseline(wl, view_cpu, steps):
         tried.append({"threads": threads, "views_per_s": round(rate, 4)})
         if best is None or rate > best["value"]:
             best = {"value": rate, "unit": "views/s", "cores": threads, "kind": "port", "sample": sample}
+    #  `cores` is the contract's field: the THREADS of torch's intra-op pool that gave the best rate -
+    # under a CPU quota (cgroup cpu.max) of `cpu_quota` of the host's `hardware_threads_visible`: not physical cores
+    best["cores_are"] = "threads of the CPU pool (not physical cores)"
+    best["cpu_quota"] = float(quota)
+    best["hardware_threads_visible"] = int(avail)
     best["thread_counts_tried"] = tried
     best["host_cpu"] = f"{cpu_model_string()} ({avail} hardware threads visible, CPU quota of the container {quota:g})"
     return best
@@ -161,6 +166,8 @@ def timed_leg(eng, schedule, args, wl, world, reducer, barrier, timer):
         if timer is not None:
             timer.enabled = (i - args.warmup) % args.timer_every == 0
         step(i)
+    # (the last step's deferred sums, if the exchange defers any: applied INSIDE the timed region)
+    eng.finish_exchange(world if reducer is not None else 1, reducer)
     barrier()
     dt = time.perf_counter() - t0
     ops.CONV_TIMER = None
@@ -204,6 +211,12 @@ def exchange_report(eng, comm, reducer, args):
         rep["rccl"] = comm.info()          # ranks RCCL saw, its version, link type of this rank's device to the others
     else:
         rep["process_group"] = {"backend": str(comm.get_backend()), "nranks": comm.get_world_size()}
+    if getattr(reducer, "owner_aware", False):
+        # critical = all-reduced before the update; deferred = in the background of the next step
+        rep["deferred_exchange"] = {"enabled": bool(eng.use_deferred_exchange(reducer)),
+                                    "critical_bytes_per_step": reducer.last_critical_bytes,
+                                    "deferred_bytes_per_step": reducer.last_deferred_bytes,
+                                    "shared_chunks": reducer.n_shared, "single_owner_chunks": reducer.n_single}
     rep["pipelined"] = bool(eng.use_pipelined_exchange(reducer))
     rep["pipelined_policy"] = {True: "forced on", False: "forced off"}.get(
         eng.pipeline_exchange, f"auto: from {eng.pipeline_min_bytes >> 20} MB of flagged chunks on")
@@ -218,6 +231,11 @@ def exchange_report(eng, comm, reducer, args):
                         "predicted_exchange_ms": {"eta_0.6": round(model(0.6), 3), "eta_0.7": round(model(0.7), 3),
                                                   "eta_0.8": round(model(0.8), 3)},
                         "note": "xGMI figures: only meaningful for the own-RCCL communicator on separate GPUs"}
+        if "deferred_exchange" in rep:
+            cb, db = rep["deferred_exchange"]["critical_bytes_per_step"], rep["deferred_exchange"]["deferred_bytes_per_step"]
+            mb = lambda b, eta: round(1e3 * (2.0 * (N - 1) / N * b / ((N - 1) * 76.8e9 * eta) + 2.0 * b / 4e12), 3)
+            rep["model"]["predicted_critical_ms"] = {f"eta_{e}": mb(cb, e) for e in (0.6, 0.7, 0.8)}
+            rep["model"]["predicted_deferred_ms_in_the_background"] = {f"eta_{e}": mb(db, e) for e in (0.6, 0.7, 0.8)}
     t = getattr(eng, "phase_timer", None)
     if t is not None:
         for tag, key in (("exchange", "exchange_ms"), ("update", "update_ms"), ("exchange+update", "exchange_update_ms")):
@@ -404,6 +422,10 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline-exchange", action="store_true", help="N > 1: all-reduce the (sparse) gradient in pieces "
                     "with the update of each arena range issued as its sums arrive (default: exchange, then update; "
                     "STYLEMESH_PIPELINE_EXCHANGE=1 selects it for the trainer)")
+    ap.add_argument("--deferred-exchange", action="store_true", help="N > 1: only the chunks two or more ranks' views touch are "
+                    "all-reduced before the update; single-owner chunks are updated by their owner at once and reach the "
+                    "other ranks in a background all-reduce (runtime/distributed.py:OwnerAwareGradReducer; "
+                    "STYLEMESH_DEFERRED_EXCHANGE=1 selects it for the trainer)")
     ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate) "
                     "or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
@@ -547,7 +569,15 @@ def _run(args):
     comm = make_comm(dist, rank, world, dev) if sharded else None
     reducer = None
     if sharded:
-        reducer = make_grad_reducer(comm, world) if args.dense_allreduce else make_sparse_grad_reducer(comm, world)
+        if args.dense_allreduce:
+            reducer = make_grad_reducer(comm, world)
+        elif args.deferred_exchange:
+            # (a second communicator for the background exchange: collectives of one communicator are serialised)
+            comm2 = make_comm(dist, rank, world, dev)
+            reducer = make_sparse_grad_reducer(comm, world, rank=rank, deferred_dist=comm2)
+            eng.deferred_exchange = True
+        else:
+            reducer = make_sparse_grad_reducer(comm, world)
 
     def barrier():
         if world > 1:

@@ -63,7 +63,12 @@ class FusedTextureAdam:
         eng.cfg.learning_rate = self.param_groups[0]["lr"]
         eng.cfg.decay_gamma, eng.epoch = 1.0, 0    # the scheduler owns the learning rate
         reducer = getattr(self.module, "grad_reducer", None)
-        if eng.use_pipelined_exchange(reducer):
+        if eng.use_deferred_exchange(reducer):
+            # STYLEMESH_DEFERRED_EXCHANGE=1 with an owner-aware reducer: critical exchange of the shared chunks, the
+            # single-owner ones in the background (``StepEngine.exchange_and_update_deferred``)
+            eng._world_size = self.world_size
+            eng.exchange_and_update_deferred(self.world_size, reducer)
+        elif eng.use_pipelined_exchange(reducer):
             # STYLEMESH_PIPELINE_EXCHANGE=1: ``step_compute`` left the gradient un-exchanged - all-reduce it in pieces,
             # the update of each arena range issued as its sums arrive (``StepEngine.exchange_and_update``)
             eng.exchange_and_update(self.world_size, reducer)

@@ -130,7 +130,11 @@ def main(args):
         save_texture=args.save_texture and rank == 0, texture_dir=log_dir)
     from ..runtime.distributed import make_comm, make_sparse_grad_reducer
     comm = make_comm(dist, rank, world, device) if world > 1 else None   # the product's own RCCL communicator
-    model.grad_reducer = make_sparse_grad_reducer(comm, world)
+    if os.environ.get("STYLEMESH_DEFERRED_EXCHANGE", "0") == "1" and world > 1:
+        # owner-aware reducer + a second communicator for its background exchange (runtime/distributed.py)
+        model.grad_reducer = make_sparse_grad_reducer(comm, world, rank=rank, deferred_dist=make_comm(dist, rank, world, device))
+    else:
+        model.grad_reducer = make_sparse_grad_reducer(comm, world)
 
     trainer = MiniTrainer(max_epochs=args.max_epochs, logger=logger, device=device, rank=rank, world_size=world)
     _mark("model built")

@@ -61,6 +61,9 @@ SWITCHES = {
     "STYLEMESH_COMM": ("(rccl over nccl groups)", "mode", "rccl = the product's own communicator (fails loudly), torch = torch.distributed"),
     "STYLEMESH_PIPELINE_EXCHANGE": ("0", "mode", "gradient exchange in pieces overlapped with the update: 1 / 0 = always / never; "
                                     "auto = from STYLEMESH_PIPELINE_MIN_MB of flagged chunks on (opt-in until timed over RCCL)"),
+    "STYLEMESH_DEFERRED_EXCHANGE": ("0", "mode", "N > 1 with an owner-aware reducer: only chunks two or more ranks' views touch are exchanged "
+                                    "before the update; single-owner chunks are updated by their owner at once and travel in the "
+                                    "background (round 6; bit-identical over gloo, not timed over RCCL: opt-in)"),
     "STYLEMESH_PIPELINE_MIN_MB": ("32", "tuning", "threshold of the auto policy above"),
     "STYLEMESH_LAUNCHED_BY": ("(set by the launcher)", "diagnostic", "who started the ranks, echoed in the bench line"),
     # ---- host

@@ -771,5 +771,178 @@ class SparseGradReducer:
         self.last_bytes = 4 * buf.numel()
 
 
-def make_sparse_grad_reducer(dist_module, world_size: int, **kw):
-    return None if world_size <= 1 else SparseGradReducer(dist_module, world_size, **kw)
+class OwnerAwareGradReducer(SparseGradReducer):
+    """``SparseGradReducer`` that takes the chunks only ONE rank's view touches off the step's critical path (round 6,
+    VERDICT r5 item 8).
+
+    At N = 8 the union of the ranks' footprints is 75 % of the arena (profiles/r05/final_bench_n8_gloo.json) and every
+    chunk of it crossed the links before the update - although a chunk only one rank's view reaches needs NO reduction: its
+    sum over the ranks is that rank's own gradient (the others hold zeros there: x + 0 = x, bit for bit), and no other rank
+    samples it before its own view changes. Per VIEW the collective therefore also finds, for every chunk of the union,
+    whether exactly one rank touches it (one MAX all-reduce of two int32 words per chunk: the highest and - mirrored - the
+    lowest rank that flags it; equal = a single owner). Three compact lists come out of it, identical on every rank:
+
+    * ``idx`` (base class): the union - what the plain exchange and ``pipelined`` use;
+    * ``idx_shared``: chunks two or more ranks touch - the CRITICAL exchange of a step, all-reduced before the update;
+    * ``idx_single``: chunks with one owner - the DEFERRED exchange.
+
+    Per STEP (``step``; the engine's ``exchange_and_update_deferred``), in this order on the caller's stream:
+
+    1. the deferred sums of the PREVIOUS step, if any, have arrived on the side stream: scatter the other ranks' single
+       chunks into the gradient arena and update them with THAT step's learning rate and step count (``update``);
+    2. stage this step's deferred buffer (the gradients of all single chunks: this rank's own, zeros elsewhere), then update
+       this rank's OWN single chunks at once from its own gradient;
+    3. all-reduce the shared chunks (gather / all-reduce / scatter as the base class) and update them;
+    4. start the deferred all-reduce asynchronously: it overlaps the next step's forward and backward passes.
+
+    ``drain`` (step 1 alone) runs before every per-view collective and at the end of training. After a drain the textures
+    and Adam moments are those of exchange-then-update: every chunk received the same sums and the same sequence of
+    updates - the single ones one step later on the ranks that do not own them (tests/test_distributed_cpu.py: bit for
+    bit on two ranks; on more ranks the SHARED sums may differ in the last bit where the collective's summation order
+    depends on a chunk's offset in the buffer). The regulariser loss VALUE a non-owner reports lags one step on those
+    chunks (their p^2 enters ``sumsq`` when their update is applied)."""
+
+    owner_aware = True
+
+    def __init__(self, dist_module, world_size: int, rank: int, deferred_dist=None, **kw):
+        """``deferred_dist``: the collective provider of the deferred exchange - a SECOND communicator (``make_comm`` again /
+        a second process group), so that a deferred all-reduce still on the links cannot hold up the next step's critical
+        one (collectives of one communicator are serialised in issue order); default: the same provider."""
+        super().__init__(dist_module, world_size, **kw)
+        self.rank = rank
+        self.deferred_dist = dist_module if deferred_dist is None else deferred_dist
+        self.idx_shared = self.idx_single = None
+        self.n_shared = self.n_single = None
+        self.f_shared = self.f_single_mine = self.f_single_others = None
+        self._counts_dev = None
+        self._pending = None          # (work, buffer, lr, step, flags of the others' single chunks, their (buffer row, chunk) lists)
+        self._bufs = [None, None]     # deferred send buffers, alternating
+        self._flip = 0
+        self._buf_shared = None
+        self.last_critical_bytes = self.last_deferred_bytes = 0
+
+    @property
+    def ready(self):
+        """lists of the current view known, and sparse enough for chunk lists to pay (else: the plain dense exchange)"""
+        return self.n_shared is not None and self.n_idx is not None and self.fraction <= self.dense_above
+
+    # ---- per view ------------------------------------------------------------------------------------------
+    def new_view_begin(self, flags):
+        import torch
+        assert self._pending is None, "drain() the deferred exchange before the next per-view collective"
+        n, R = flags.numel(), self.world
+        mine = flags != 0
+        enc = torch.zeros(2 * n, dtype=torch.int32, device=flags.device)
+        enc[:n] = mine.to(torch.int32) * (self.rank + 1)         # -> highest owner + 1
+        enc[n:] = mine.to(torch.int32) * (R - self.rank)         # -> R - lowest owner
+        self.dist.all_reduce(enc, op=self.dist.ReduceOp.MAX)
+        hi, lo_m = enc[:n], enc[n:]
+        union = hi > 0
+        single = union & (hi + lo_m == R + 1)                    # highest owner == lowest owner
+        self.f_shared = (union & ~single).to(torch.int32)
+        self.f_single_mine = (single & mine).to(torch.int32)
+        self.f_single_others = (single & ~mine).to(torch.int32)
+        f_single = single.to(torch.int32)
+        flags.copy_(union.to(torch.int32))                       # (contract of the base class: the union, in place)
+        # the union list exactly as the base class builds it (MAX of identical flags changes nothing)
+        n_flags = n
+        if flags.is_cuda:
+            from . import ops
+            if self.idx is None or self.idx.numel() < n or self.idx.device != flags.device:
+                self.idx = torch.empty(n, dtype=torch.int32, device=flags.device)
+                self._ws = torch.empty(ops.flags_compact_ws_ints(n), dtype=torch.int32, device=flags.device)
+                self.count_dev = torch.zeros(1, dtype=torch.int32, device=flags.device)
+            if self.idx_shared is None or self.idx_shared.numel() < n or self.idx_shared.device != flags.device:
+                self.idx_shared = torch.empty(n, dtype=torch.int32, device=flags.device)
+                self.idx_single = torch.empty(n, dtype=torch.int32, device=flags.device)
+                self._counts_dev = torch.zeros(2, dtype=torch.int32, device=flags.device)
+            ops.flags_compact(flags, self.idx, self.count_dev, self._ws)
+            ops.flags_compact(self.f_shared, self.idx_shared, self._counts_dev[0:1], self._ws)
+            ops.flags_compact(f_single, self.idx_single, self._counts_dev[1:2], self._ws)
+        else:
+            self.idx = flags.nonzero().flatten().to(torch.int32)
+            self.count_dev = torch.tensor([self.idx.numel()], dtype=torch.int32)
+            self.idx_shared = self.f_shared.nonzero().flatten().to(torch.int32)
+            self.idx_single = f_single.nonzero().flatten().to(torch.int32)
+            self._counts_dev = torch.tensor([self.idx_shared.numel(), self.idx_single.numel()], dtype=torch.int32)
+        self._n_flags = n_flags
+        self.n_idx = self.n_shared = self.n_single = None
+        return self.count_dev
+
+    def new_view_end(self, count: int):
+        super().new_view_end(count)
+        self.n_shared, self.n_single = (int(x) for x in self._counts_dev.tolist())      # (one small read-back per view)
+        import torch
+        # rows of the deferred buffer (= entries of idx_single) that belong to OTHER ranks, and their chunks
+        ids = self.idx_single[:self.n_single].long()
+        sel = (self.f_single_mine[ids] == 0).nonzero().flatten()
+        self._others_rows, self._others_idx = sel, self.idx_single[:self.n_single][sel].contiguous()
+
+    # ---- per step ------------------------------------------------------------------------------------------
+    def _move(self, flat_grad, idx, n, buf, gather):
+        if n == 0:
+            return
+        if flat_grad.is_cuda:
+            from . import ops
+            (ops.chunks_gather if gather else ops.chunks_scatter)(flat_grad, idx, n, self.chunk_log2, buf)
+        elif gather:
+            buf.copy_(flat_grad.view(-1, self.chunk).index_select(0, idx[:n].long()).reshape(-1))
+        else:
+            flat_grad.view(-1, self.chunk).index_copy_(0, idx[:n].long(), buf.view(-1, self.chunk))
+
+    def drain(self, flat_grad, update):
+        """Step 1: apply the deferred sums that are outstanding (no-op when there are none)."""
+        if self._pending is None:
+            return
+        work, buf, lr, step, f_others, rows, idx_others = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()                                           # (stream-ordered on the device path; blocking over gloo)
+        if rows.numel() > 0:
+            part = buf.view(-1, self.chunk).index_select(0, rows).reshape(-1)
+            self._move(flat_grad, idx_others, rows.numel(), part, gather=False)
+            update(f_others, lr, step)
+
+    def step(self, flat_grad, update, lr, step):
+        """Steps 1 - 4 of the class docstring. ``update(flags, lr, step)``: the fused optimizer over the chunks whose int32
+        flag is set, with the given learning rate and step count (it zeroes the gradient there)."""
+        import torch
+        assert self.ready
+        self.drain(flat_grad, update)
+        c = self.chunk
+        # 2. the deferred buffer, then the own single chunks
+        buf = None
+        if self.n_single > 0:
+            b = self._bufs[self._flip]
+            if b is None or b.numel() < self.n_single * c or b.device != flat_grad.device:
+                b = self._bufs[self._flip] = torch.empty(self.n_single * c, dtype=torch.float32, device=flat_grad.device)
+            buf = b[:self.n_single * c]
+            self._flip ^= 1
+            self._move(flat_grad, self.idx_single, self.n_single, buf, gather=True)
+            update(self.f_single_mine, lr, step)
+        # 3. the critical exchange
+        if self.n_shared > 0:
+            if self._buf_shared is None or self._buf_shared.numel() < self.n_shared * c or self._buf_shared.device != flat_grad.device:
+                self._buf_shared = torch.empty(self.n_shared * c, dtype=torch.float32, device=flat_grad.device)
+            sb = self._buf_shared[:self.n_shared * c]
+            self._move(flat_grad, self.idx_shared, self.n_shared, sb, gather=True)
+            self.dist.all_reduce(sb, op=self.dist.ReduceOp.SUM)
+            self._move(flat_grad, self.idx_shared, self.n_shared, sb, gather=False)
+            update(self.f_shared, lr, step)
+        # 4. the deferred exchange, in the background
+        if buf is not None:
+            work = self.deferred_dist.all_reduce(buf, op=self.deferred_dist.ReduceOp.SUM, async_op=True)
+            self._pending = (work, buf, lr, step, self.f_single_others, self._others_rows, self._others_idx)
+        self.last_critical_bytes = 4 * self.n_shared * c
+        self.last_deferred_bytes = 4 * self.n_single * c
+        self.last_bytes = self.last_critical_bytes + self.last_deferred_bytes
+
+
+def make_sparse_grad_reducer(dist_module, world_size: int, rank: int | None = None, **kw):
+    """``rank`` given: the owner-aware reducer (critical / deferred exchange, opt-in through the engine:
+    STYLEMESH_DEFERRED_EXCHANGE=1); else the plain union reducer."""
+    if world_size <= 1:
+        return None
+    if rank is not None:
+        return OwnerAwareGradReducer(dist_module, world_size, rank, **kw)
+    return SparseGradReducer(dist_module, world_size, **kw)

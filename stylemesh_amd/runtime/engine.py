@@ -254,6 +254,10 @@ class StepEngine:
         self.pipeline_exchange = {"1": True, "0": False, "auto": "auto"}.get(
             os.environ.get("STYLEMESH_PIPELINE_EXCHANGE", "0"), False)
         self.pipeline_min_bytes = int(float(os.environ.get("STYLEMESH_PIPELINE_MIN_MB", "32")) * (1 << 20))
+        # N > 1, OPT-IN with an ``OwnerAwareGradReducer``: only the chunks two or more ranks' views touch are exchanged before
+        # the update; single-owner chunks are updated by their owner at once and reach the others in the background
+        self.deferred_exchange = os.environ.get("STYLEMESH_DEFERRED_EXCHANGE", "0") == "1"
+        self._world_size = 1
         self.view_tiles = None
         # Resident views (round 5; viewplan.ResidentView), OPT-IN (STYLEMESH_VIEW_CACHE_GB=<budget>): the per-view state of
         # up to view_cache_gb gigabytes of views stays in HBM after a view's first visit; a revisit copies it back into the
@@ -1525,6 +1529,49 @@ class StepEngine:
         nbytes = 4 * self.arena.n if dense else 4 * n_idx * reducer.chunk
         return nbytes >= self.pipeline_min_bytes
 
+    def use_deferred_exchange(self, reducer) -> bool:
+        """Multi-GPU tail of the step with the single-owner chunks off the critical path (``OwnerAwareGradReducer``)?
+        OPT-IN (STYLEMESH_DEFERRED_EXCHANGE=1; identical on every rank: configuration and the all-reduced chunk lists only):
+        functional and bit-identical to exchange-then-update over gloo (tests/test_distributed_cpu.py), never timed over
+        RCCL on separate GPUs - the same status as the pipelined exchange."""
+        return (self.deferred_exchange and reducer is not None and getattr(reducer, "owner_aware", False)
+                and self.touched is not None and self.sparse_update and not self._can_graph() and reducer.ready)
+
+    def _chunk_update(self, world_size, with_sumsq=True):
+        a = self.arena
+
+        def update(flags, lr, step):
+            ops.adam_fused(a.p, a.g, a.m, a.v, a.seg_end, self.reg_coef, lr, step, grad_scale=1.0 / world_size,
+                           sumsq_out=self.sumsq if with_sumsq else None, touched=flags, touched_log2=self.touched_log2)
+        return update
+
+    def exchange_and_update_deferred(self, world_size: int, reducer):
+        """The step's tail under ``use_deferred_exchange``: ever-touched chunks outside the ranks' views (the early half of the
+        split update, or inline), then ``reducer.step``: the previous step's deferred sums, this rank's own single-owner
+        chunks, the critical exchange + update of the shared chunks, the deferred exchange in the background."""
+        assert reducer.chunk_log2 == self.touched_log2
+        self.step_count += 1
+        a = self.arena
+        if self._adam_early_done is not None:
+            torch.cuda.current_stream().wait_event(self._adam_early_done)
+            self._adam_early_done = None
+        else:
+            ops.zero_floats(self.sumsq)
+            if self._other_flags is None or self._other_flags[0] is not self.touched:
+                self._other_flags = (self.touched, ((self.touched != 0) & (self._view_flags == 0)).to(torch.int32))
+            ops.adam_fused(a.p, None, a.m, a.v, a.seg_end, self.reg_coef, self.lr, self.step_count, grad_scale=1.0,
+                           sumsq_out=self.sumsq, touched=self._other_flags[1], touched_log2=self.touched_log2)
+        reducer.step(a.g, self._chunk_update(world_size), self.lr, self.step_count)
+        self._grad_dirty = False
+
+    def finish_exchange(self, world_size: int, reducer):
+        """Apply the deferred sums still outstanding (end of training, before the texture is read or saved; the engine does
+        it itself before every per-view collective)."""
+        if reducer is not None and getattr(reducer, "owner_aware", False):
+            # (outside a step: sum(p^2) already holds these chunks once - their p^2 of one update ago; the regulariser loss
+            # VALUE of a non-owner lags by that one update on them, the gradient never does)
+            reducer.drain(self.arena.g, self._chunk_update(world_size, with_sumsq=False))
+
     def exchange_and_update(self, world_size: int, reducer):
         """Multi-GPU tail of the step: gradient exchange overlapped with the fused update (``reducer.pipelined``:
         the update of an arena range is issued as soon as its sums arrived, later pieces still on the links)."""
@@ -1626,7 +1673,8 @@ class StepEngine:
 
     def _step_compute_eager(self, out, reducer, exchange):
         losses = self._step_begin(out[2:3])    # tex_reg of the CURRENT (pre-update) texture, device tensors, no sync
-        pipelined = self.use_pipelined_exchange(reducer)
+        deferred = self.use_deferred_exchange(reducer)
+        pipelined = self.use_pipelined_exchange(reducer) and not deferred
         if not pipelined:
             if self._can_graph() or self.early_update_at == "head":
                 self._adam_early()
@@ -1639,7 +1687,7 @@ class StepEngine:
         # values (one 2-float copy), so that a caller may read them any number of steps later
         ops.copy_floats(out, self.loss_buf, 2)
         losses["content"], losses["style"] = out[0:1], out[1:2]
-        if exchange and reducer is not None and not pipelined:
+        if exchange and reducer is not None and not pipelined and not deferred:
             self._timed("exchange", lambda: reducer(self.arena.g))
         if self._prog_rec is not None:
             self._prog_rec[2] = len(self._prog_rec[0].calls)      # the optimizer's calls follow
@@ -1807,7 +1855,11 @@ class StepEngine:
             # one upcoming view, or a list of them in schedule order (index_repeat 1: the next two)
             for nb in (next_batch if isinstance(next_batch, list) else [next_batch]):
                 self.request_prepare(nb)
+        self._world_size = world_size
         losses = self.step_compute(batch, reducer, new_view)
+        if self.use_deferred_exchange(reducer):
+            self._timed("exchange+update", lambda: self.exchange_and_update_deferred(world_size, reducer))
+            return losses
         if self.use_pipelined_exchange(reducer):
             self._timed("exchange+update", lambda: self.exchange_and_update(world_size, reducer))
             return losses
@@ -1841,6 +1893,8 @@ class StepEngine:
         # is the per-view collective due at this schedule position?
         due = reducer is not None and hasattr(reducer, "new_view") and (changed if new_view is None else new_view)
         in_set_view = due and changed and hasattr(reducer, "new_view_begin")
+        if due:
+            self.finish_exchange(getattr(self, "_world_size", 1), reducer)   # (deferred sums of the last step: before the new view's collective)
         if changed:
             import time
             t0 = time.perf_counter()

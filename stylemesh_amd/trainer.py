@@ -223,6 +223,11 @@ class MiniTrainer:
                         tm["first_steps"] = tm.get("first_steps", 0) + 1
                         fs = tm.setdefault("_first", [0.0, 0.0, 0.0])
                         fs[0] += t_b - t_a; fs[1] += t_c - t_b; fs[2] += t_d - t_c
+            # N > 1 with the deferred exchange: the last step's background sums are applied before anything (validation,
+            # the epoch-end texture export, the next epoch's first collective) reads the texture
+            eng = getattr(model, "_engine", None)
+            if eng is not None and hasattr(eng, "finish_exchange"):
+                eng.finish_exchange(self.world_size, getattr(model, "grad_reducer", None))
             t_train = now()
             val_loader = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
             if val_loader is not None:

@@ -372,3 +372,84 @@ def test_sparse_grad_reducer_at_eight_ranks_crosses_the_dense_fallback(tmp_path)
             assert torch.equal(r[v][0], mine) and r[v][2] == frac and r[v][3] == nbytes and r[v][4] == sparse
         assert sparse == (frac <= 0.75)
         assert nbytes == (int(round(frac * 4096)) * 64 * 4 if sparse else 4096 * 64 * 4)
+
+
+def _adam_chunks(p, m, v, g, flags, lr, step, world, chunk):
+    """The fused update restricted to flagged chunks, in torch (elementwise: the same result whatever the launch order);
+    the data-term gradient is zeroed where it was applied (sm_adam_fused)."""
+    on = flags.bool().repeat_interleave(chunk)
+    gr = g[on] / world + 0.01 * p[on]
+    m[on] = m[on] + (gr - m[on]) * 0.1
+    v[on] = v[on] * 0.999 + gr * gr * 0.001
+    p[on] = p[on] - (lr / (1 - 0.9 ** step)) * (m[on] / (v[on].sqrt() / (1 - 0.999 ** step) ** 0.5 + 1e-8))
+    g[on] = 0
+
+
+def _owner_aware_worker(rank, world, port, out_dir):
+    """``OwnerAwareGradReducer`` (critical exchange of the shared chunks, deferred exchange of the single-owner ones) against
+    the plain union exchange followed by one update: the SAME local gradients, 3 views x 3 steps with a learning-rate change,
+    per-rank footprints that overlap partly. Compared after the drain."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_chunks, chunk = 192, 16
+    n = n_chunks * chunk
+    plain = D.make_sparse_grad_reducer(dist, world, chunk_log2=4)
+    aware = D.make_sparse_grad_reducer(dist, world, rank=rank, chunk_log2=4)
+    gen = torch.Generator().manual_seed(7)             # the SAME stream on every rank: footprints are derived per rank below
+    A = [torch.randn(n, generator=gen), torch.zeros(n), torch.zeros(n)]        # p, m, v of the plain path
+    B = [t.clone() for t in A]                                                  # ... of the owner-aware path
+    stats, step = [], 0
+    for view in range(3):
+        # rank r touches a window of chunks that overlaps its neighbours' windows by a third (+ one chunk everybody touches)
+        lo = (view * 17 + rank * 10) % n_chunks
+        mine = torch.zeros(n_chunks, dtype=torch.int32)
+        mine[torch.arange(lo, lo + 15) % n_chunks] = 1
+        mine[(view * 31) % n_chunks] = 1
+        fa, fb = mine.clone(), mine.clone()
+        plain.new_view(fa)
+        upd_b = lambda flags, lr_, st_: _adam_chunks(B[0], B[1], B[2], gB, flags, lr_, st_, world, chunk)
+        gB = torch.zeros(n)
+        aware.drain(gB, upd_b)                         # (the engine drains before the per-view collective)
+        aware.new_view(fb)
+        assert torch.equal(fa, fb)                     # both leave the union in place
+        assert aware.n_shared + aware.n_single == aware.n_idx == plain.n_idx
+        for k in range(3):
+            step += 1
+            lr = 1.0 if step < 5 else 0.1
+            g_local = torch.zeros(n_chunks, chunk)
+            g_local[mine.bool()] = torch.randn(int(mine.sum()), chunk, generator=torch.Generator().manual_seed(1000 * step + rank))
+            gA, gB = g_local.reshape(-1).clone(), g_local.reshape(-1).clone()
+            plain(gA)
+            _adam_chunks(A[0], A[1], A[2], gA, fa, lr, step, world, chunk)
+            aware.step(gB, upd_b, lr, step)
+            assert float(gA.abs().max()) == 0.0
+            stats.append((aware.last_critical_bytes, aware.last_deferred_bytes, plain.last_bytes))
+    gB = torch.zeros(n)
+    aware.drain(gB, upd_b)
+    assert aware._pending is None
+    torch.save({"A": A, "B": B, "stats": stats}, os.path.join(out_dir, f"aware{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_owner_aware_exchange_equals_exchange_then_update(tmp_path, world):
+    """chunks exactly one rank touches skip the critical exchange - their owner updates them at once,
+    the others one step later from a background all-reduce. After the drain p, m, v equal the plain path's BIT FOR BIT on
+    every rank (2 ranks; 8 ranks: the single-owner chunks bit for bit, the shared ones to the collective's summation
+    order), are identical across the ranks, and the critical bytes are what the shared chunks alone weigh."""
+    port = 35500 + (os.getpid() % 2000) + world
+    mp.spawn(_owner_aware_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"aware{r}.pt") for r in range(world)]
+    for r in res:
+        for a, b in zip(r["A"], r["B"]):
+            if world == 2:
+                assert torch.equal(a, b)
+            else:
+                assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+        for x, y in zip(r["B"], res[0]["B"]):
+            assert torch.equal(x, y)                                  # every rank holds the same texture and moments
+        assert all(c + d == p and d > 0 for c, d, p in r["stats"])    # critical + deferred = the union; something was deferred
+        assert r["stats"] == res[0]["stats"]
+    assert any(c > 0 for c, _, _ in res[0]["stats"])                  # and something was shared

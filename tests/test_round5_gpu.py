@@ -106,3 +106,32 @@ def test_own_radix_sort_is_the_stable_sort(n, key_bits):
     order = torch.sort(keys64, stable=True).indices
     assert torch.equal(ks.long() & 0xFFFFFFFF, keys64[order])
     assert torch.equal(vs, vin[order])
+
+
+def test_two_rank_deferred_exchange_equals_exchange_then_update_bit_for_bit():
+    """single-owner chunks off the step's critical path (``OwnerAwareGradReducer`` +
+    ``StepEngine.exchange_and_update_deferred``) against the union exchange followed by one update, with the real kernels on
+    two ranks (one device, gloo), two views x three steps and a learning-rate decay in between: after the drain p, m and v
+    are identical to the bit, on each rank and across the ranks; the gradient arena is zero; the critical exchange carried
+    less than the union."""
+    require_gpu()
+    import os
+    import tempfile
+    from conftest import REPO
+    from test_round2_gpu import _launch_ranks
+    with tempfile.TemporaryDirectory() as tmp:
+        r = _launch_ranks([os.path.join(REPO, "tests", "two_rank_worker.py"), "deferred", tmp], 2,
+                          {"STYLEMESH_TEST_BACKEND": "gloo"}, timeout=1200)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        r0, r1 = (torch.load(os.path.join(tmp, f"rank{k}.pt")) for k in (0, 1))
+    for res in (r0, r1):
+        assert res["steps"] == 6 and float(res["g"].abs().max()) == 0.0
+        for a, b in zip(res["A"][:3], res["B"][:3]):
+            assert torch.equal(a, b)
+        # (sum p^2 - the regulariser loss VALUE - of a non-owner holds the other rank's single-owner chunks one update late)
+        np.testing.assert_allclose(res["B"][3].numpy(), res["A"][3].numpy(), rtol=5e-2)
+        assert float(res["A"][0].abs().max()) > 0
+    for x, y in zip(r0["B"][:3], r1["B"][:3]):
+        assert torch.equal(x, y)
+    assert r0["stats"] == r1["stats"]
+    assert all(c + d == u for c, d, u in r0["stats"]) and any(d > 0 for _, d, _ in r0["stats"])

@@ -167,6 +167,81 @@ def main():
             large = eng.use_pipelined_exchange(red)
             out["auto_small"], out["auto_large"] = small, large
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    elif mode == "deferred":
+        # the owner-aware exchange (critical: shared chunks; deferred: single-owner chunks, one step late on
+        # the ranks that do not own them) against exchange-then-update - the real kernels, the SAME local gradients, two
+        # views x three steps with a learning-rate change in between; the two paths' states (p, m, v, sum p^2) live side by
+        # side and are swapped into the engine's arena for their tails. Compared after the drain.
+        from stylemesh_amd.runtime import ops
+        from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
+        cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
+                           angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
+                           use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
+                           learning_rate=1, decay_gamma=0.1, decay_step_size=1)
+        eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)      # zero texture: the ever-touched sparse update
+        eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
+        assert eng.touched is not None
+        plain = D.make_sparse_grad_reducer(comm, world)
+        aware = D.make_sparse_grad_reducer(comm, world, rank=rank)
+        a = eng.arena
+        fields = lambda: (a.p, a.m, a.v, eng.sumsq)
+        A = [t.clone() for t in fields()]
+        B = [t.clone() for t in fields()]
+
+        def load(state):
+            for dst, src in zip(fields(), state):
+                dst.copy_(src)
+
+        def save(state):
+            for dst, src in zip(state, fields()):
+                dst.copy_(src)
+        stats = []
+        seeds = D.shard_views(MULTIVIEW_SEEDS, rank, world)[:2]
+        for k, seed in enumerate(seeds):
+            batch = S.make_view(seed, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, level_heights=[40, 64],
+                                min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
+            load(B)                                        # (as the engine does before the per-view collective)
+            a.g.zero_()
+            eng.finish_exchange(world, aware)
+            save(B)
+            load(A)
+            eng.set_view(batch)
+            fa = eng.touch_flags(plain.chunk_log2)
+            fb = fa.clone()
+            plain.new_view(fa)
+            aware.new_view(fb)
+            assert torch.equal(fa, fb) and aware.n_shared + aware.n_single == plain.n_idx
+            ops.flags_or(eng.touched, fa)                  # what begin_step does with the union of the ranks' views
+            ops.flags_or(eng._view_flags, fa)
+            eng._other_flags = None
+            if k == 1:
+                eng.end_epoch()                            # StepLR: lr 1 -> 0.1
+            for rep in range(3):
+                load(A)
+                a.g.zero_()
+                eng.forward_backward()                     # this rank's local gradient of the step (from the texture both paths share on the view's own texels)
+                g_local = a.g.clone()
+                count = eng.step_count
+                red_bytes = None
+                # path A: union exchange, then one update over the ever-touched chunks
+                plain(a.g)
+                eng.optimizer_step(world)
+                save(A)
+                assert float(a.g.abs().max()) == 0.0
+                # path B: the deferred exchange
+                load(B)
+                a.g.copy_(g_local)
+                eng.step_count = count
+                eng.exchange_and_update_deferred(world, aware)
+                save(B)
+                stats.append((aware.last_critical_bytes, aware.last_deferred_bytes, plain.last_bytes))
+        load(B)
+        a.g.zero_()
+        eng.finish_exchange(world, aware)
+        save(B)
+        torch.cuda.synchronize()
+        torch.save({"A": [t.cpu() for t in A], "B": [t.cpu() for t in B], "g": a.g.cpu().clone(), "stats": stats,
+                    "steps": eng.step_count}, os.path.join(out_dir, f"rank{rank}.pt"))
     else:
         raise SystemExit(f"unknown mode {mode}")
     if hasattr(comm, "destroy"):
