@@ -285,24 +285,12 @@ static int launch_conv(const ConvArgs& a0, int n_list, size_t ws_floats, hipStre
             if (cost < best * 0.97f) { best = cost; a.splits = S_eff; a.chunks_per_split = cps; }
         }
     }
-    {   // experiments (tools/bench_c2_layers.py): SM_CONV_FORCE_SPLITS=<S> forces the tail's split count
-        static const int force_s = getenv("SM_CONV_FORCE_SPLITS") ? atoi(getenv("SM_CONV_FORCE_SPLITS")) : 0;
-        if (force_s > 0 && a.ws != nullptr && tiles - tiles / SLOTS * SLOTS > 0) {
-            a.n_whole = tiles / SLOTS * SLOTS;
-            rem = tiles - a.n_whole;
-            const int S = std::max(1, std::min({force_s, chunks, (int)(ws_floats / ((size_t)rem * BM * BN))}));
-            a.chunks_per_split = (chunks + S - 1) / S;
-            a.splits = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-        }
-    }
     if (RES) a.splits = 1;                       // resident input: whole tiles only (K <= 1152: nothing to split)
     if (a.splits == 1) { a.n_whole = tiles; rem = 0; }
     if constexpr (SPLIT) {
         static_assert(KC == 16, "one fp16 MFMA K-step per tap");
-        // > 64 KB of dynamic LDS needs the opt-in; SM_CONV_STAMP=1 selects the instrumented build (tools/ts_split.py)
-        static const bool stamp = getenv("SM_CONV_STAMP") != nullptr;
-        auto k = (stamp && !UNPOOL && !RES) ? conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, !UNPOOL && !RES, UNPOOL, RES>
-                                            : conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, false, UNPOOL, RES>;
+        // (> 64 KB of dynamic LDS needs the opt-in)
+        auto k = conv3x3_split_kernel<BM, BN, WGM, WGN, FLAGS, UNPOOL, RES>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -691,9 +679,7 @@ int sm_abi_version(void) { return 11; }
 // kernel (conv_split_kernel.h, RES). fp32 planes only.
 template <int FLAGS, bool UNPOOL>
 static int launch_conv_resident(sm::ConvArgs& a, int n_list, hipStream_t s) {
-#ifndef SM_RES_TRACE
     a.ws = nullptr;
-#endif
     return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, UNPOOL, true>(a, n_list, 0, s);
 }
 static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool unpool, hipStream_t s) {

@@ -98,7 +98,6 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
     return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);    // 2^(141 - ex)
 }
 
-// STAMP: debug build that records s_memtime stamps of every wave at the stage boundaries into the tail of ws.
 // the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
 #ifndef SM_SPLIT2_AD
 #define SM_SPLIT2_AD 3
@@ -121,12 +120,12 @@ constexpr int conv_split_waves(int BM, int BN) {
 // loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
 constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
 constexpr size_t conv_resident_lds_bytes() { return (size_t)(4 * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
-template <int BM, int BN, int WGM, int WGN, int FLAGS, bool STAMP = false, bool UNPOOL = false, bool RES = false>
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool UNPOOL = false, bool RES = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN), conv_split_waves(BM, BN))))
 void conv3x3_split_kernel(ConvArgs a) {
     constexpr int NP = SM_SPLIT_NP;
-    static_assert(!RES || (BM == 64 && BN == 128 && WGM == 2 && WGN == 2 && !STAMP),
+    static_assert(!RES || (BM == 64 && BN == 128 && WGM == 2 && WGN == 2),
                   "resident input: 64 x 128 tiles (a quad of segments), waves 2 x 2");
     constexpr int MI = BM / WGM / 32;     // 32-row MFMA tiles per wave: 2 (128-row blocks) or 1 (64-row blocks)
     constexpr int NJ = BN / WGN / 32;     // 32-position MFMA tiles per wave: 2 (waves 2 x 2) or 4 (waves 4 x 1)
@@ -153,11 +152,6 @@ void conv3x3_split_kernel(ConvArgs a) {
     const int lhi = lane >> 5;
     const int wm = (wave / WGN) * (32 * MI);
     const int wn = (wave % WGN) * (32 * NJ);
-#define SM_TS(slot_)                                                                                     \
-    if (STAMP && lane == 0) {                                                                            \
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[((size_t)blockIdx.x * 4 + wave) * 64 + (slot_)] = \
-            __builtin_readcyclecounter();                                                                \
-    }
 
     int tile, split;
     conv_unit(a, blockIdx.x, tile, split);   // XCD-aware order of whole tiles and of the tail's (tile, K-split) units
@@ -411,19 +405,6 @@ void conv3x3_split_kernel(ConvArgs a) {
         SM_READ_B(dst_, slot_, kx_)                                                                      \
     }
 
-    SM_TS(0)
-#ifdef SM_RES_TRACE   // (debug build: per block {start, staged, loop done, end, HW_ID, XCC_ID} into the tail of ws; tools/res_trace.py)
-#define SM_RT(slot_)                                                                                     \
-    if (RES && tid == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + (slot_)] = \
-        (long long)__builtin_amdgcn_s_memrealtime();
-    if (RES && tid == 0) {
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_getreg(63492);
-        reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_getreg(63508);
-    }
-#else
-#define SM_RT(slot_)
-#endif
-    SM_RT(0)
     if constexpr (RES) {
         constexpr int RP = SM_RES_RP;
         constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
@@ -431,7 +412,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         // phase, two per thread. A task loads its four positions of each channel with ONE 16-byte load (un-pooling input:
         // its two pooled elements with one 8-byte load + the codes of both) and builds the four positions' 8-channel units
         // in registers. (The single-position units of the first version issued 56 dword loads per thread: 3.0 us of a
-        // block's 7 us staging time passed before the last of them was issued, 2.4 us now - tools/res_trace.py; -3 % on
+        // block's 7 us staging time passed before the last of them was issued, 2.4 us now - profiles/r05/resident_kernel.txt; -3 % on
         // the launches.)
         // Window position (r, p) holds input position qs[0] - 1 + p + (r - 1) Wp.
         constexpr int RCB = 9, RT = RGRP * SM_RES_ROWS * RCB, RU = (RT + 255) / 256;
@@ -496,11 +477,6 @@ void conv3x3_split_kernel(ConvArgs a) {
                             rb[k][c] = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(gp_rsrc, r_src[k], sc_ + c * up_plane * 4, 0));
                         rc[k] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(code_rsrc, r_code[k], ph * 8 * up_plane * 4, 0));
                     }
-                    SM_RT(6)
-#ifdef SM_RES_TRACE
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    SM_RT(7)
-#endif
 #pragma unroll
                     for (int k = 0; k < RU; ++k)
 #pragma unroll
@@ -531,11 +507,6 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
                             rb[k][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, r_src[k], so_ + c * P.plane * 4, 0));
-                    SM_RT(6)
-#ifdef SM_RES_TRACE
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    SM_RT(7)
-#endif
 #pragma unroll
                     for (int k = 0; k < RU; ++k)
 #pragma unroll
@@ -555,12 +526,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         }
                 }
             }
-#ifdef SM_RES_TRACE   // every wave's "converted and stored" time (slots 10 .. 13) and "loads arrived" (wave 3: slot 14)
-            if (lane == 0) reinterpret_cast<long long*>(a.ws + 15 * 1024 * 1024)[(size_t)blockIdx.x * 16 + 10 + wave] =
-                (long long)__builtin_amdgcn_s_memrealtime();
-#endif
             __syncthreads();
-            SM_RT(1)
             f32x4 fb[NJ][NP], fb_next[NJ][NP];
 #pragma unroll
             for (int s = 0; s < NP; ++s)
@@ -618,7 +584,6 @@ void conv3x3_split_kernel(ConvArgs a) {
         SM_LOAD_B(0, 0, ch1);      // stored at the end of tap 1 of the first chunk
     }
     __syncthreads();
-    SM_TS(1)
     int base = 0;   // ring slot of the current chunk's ky = 0 slice
     // slot of slice ky of the current / of the next chunk
 #define SM_CUR_SLOT(ky_) ((base + (ky_)) & 3)
@@ -666,7 +631,6 @@ void conv3x3_split_kernel(ConvArgs a) {
             // the ring slot just consumed is refilled with the weights of stage + AD (pinned below the MFMAs: hoisting
             // the loads would need a fourth set of fragment registers)
             __builtin_amdgcn_sched_barrier(0);
-            if (STAMP && ch - ch_begin == 1) SM_TS(32 + tap)      // this stage's MFMAs are issued
             if (tap + AD < 9) {
                 SM_LOAD_A(tap + AD, ch);
             } else {
@@ -684,7 +648,6 @@ void conv3x3_split_kernel(ConvArgs a) {
                 } else {
                     SM_LOAD_B(0, 0, ch_next2);
                 }
-                if (STAMP && ch - ch_begin == 1) SM_TS(41 + tap)   // at the barrier
                 __syncthreads();
             }
 #if SM_SPLIT_PREFETCH_B
@@ -693,13 +656,10 @@ void conv3x3_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) fb[i][s] = fb_next[i][s];
 #endif
-            if (STAMP && ch - ch_begin < 2) SM_TS(2 + (ch - ch_begin) * 12 + tap)
         }
         base = (base + 3) & 3;
     }
     }   // (ring kernel)
-    SM_TS(30)
-    SM_RT(2)
 #undef SM_CUR_SLOT
 #undef SM_NEXT_SLOT
 #undef SM_UP_MAP
@@ -721,7 +681,6 @@ void conv3x3_split_kernel(ConvArgs a) {
                 for (int r = 0; r < 16; ++r)
                     wt[(wm + mi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2)) * BN + wn + j * 32 + l31] =
                         acc[mi][j][r] * out_scale;   // power of two: exact
-        SM_TS(51)
         return;
     }
     const int q_end = (P.H + 1) * P.Wp;
@@ -791,7 +750,6 @@ void conv3x3_split_kernel(ConvArgs a) {
             }
         }
         record_amax(a.amax_out, vmax, amax_seen);
-        SM_RT(3)
         return;
     }
     // SM_EPI_GRAM: the output layer is a style layer of C = BM channels (the block's row tile holds all of them) and this
@@ -883,7 +841,6 @@ void conv3x3_split_kernel(ConvArgs a) {
                 }
             }
             __syncthreads();
-            SM_RT(8)
 #pragma unroll
             for (int chunk = 0; chunk < 2; ++chunk)                    // 32 channels
 #pragma unroll
@@ -907,7 +864,6 @@ void conv3x3_split_kernel(ConvArgs a) {
                         }
                     }
         }
-        SM_RT(9)
     }
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
@@ -958,10 +914,6 @@ void conv3x3_split_kernel(ConvArgs a) {
         }
     }
     record_amax(a.amax_out, vmax, amax_seen);
-    SM_TS(31)
-    SM_RT(3)
-#undef SM_TS
-#undef SM_RT
 }
 
 }  // namespace sm

@@ -34,8 +34,6 @@ SWITCHES = {
                               "model (c2 +0.6 % at 2-4, -5 % at 8: profiles/r04/split_penalty_ab.txt)"),
     "SM_ADAM_DENSE_WALK": ("0", "diagnostic", "(C library) 1 = the flagged update walks every tile of the arena and asks each chunk's flag "
                            "(rounds 2-5) instead of compacting a span's flags first (adam_sparse_kernel, round 6; same bits of p, m, v)"),
-    "SM_CONV_FORCE_SPLITS": ("(unset)", "experiment", "(C library) force the tail's K-split count (tools/bench_c2_layers.py sweeps)"),
-    "SM_CONV_STAMP": ("(unset)", "diagnostic", "(C library) the conv build that writes s_memtime stage stamps (tools/ts_split.py, ts_small.py)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),
     # ---- step structure
     "STYLEMESH_SIDE_STREAMS": ("1", "tuning", "loss branches of the non-deepest layers + the early half of the update on side streams "

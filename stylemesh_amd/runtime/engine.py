@@ -1561,7 +1561,16 @@ class StepEngine:
                 self._other_flags = (self.touched, ((self.touched != 0) & (self._view_flags == 0)).to(torch.int32))
             ops.adam_fused(a.p, None, a.m, a.v, a.seg_end, self.reg_coef, self.lr, self.step_count, grad_scale=1.0,
                            sumsq_out=self.sumsq, touched=self._other_flags[1], touched_log2=self.touched_log2)
-        reducer.step(a.g, self._chunk_update(world_size), self.lr, self.step_count)
+        update = self._chunk_update(world_size)
+        # Chunks this rank SAMPLES without writing a gradient (pixels of weight zero: ``_view_flags`` is the sampled footprint,
+        # the reducer's lists the weighted ones of all ranks): outside the early half (which excludes the view's flags) and
+        # outside every exchange list - their regulariser / momentum update is this rank's own business, every step
+        ex = getattr(self, "_deferred_extra", None)
+        if ex is None or ex[0] is not reducer.f_shared:
+            union = (reducer.f_shared != 0) | (reducer.f_single_mine != 0) | (reducer.f_single_others != 0)
+            ex = self._deferred_extra = (reducer.f_shared, ((self._view_flags != 0) & ~union).to(torch.int32))
+        update(ex[1], self.lr, self.step_count)
+        reducer.step(a.g, update, self.lr, self.step_count)
         self._grad_dirty = False
 
     def finish_exchange(self, world_size: int, reducer):

@@ -181,8 +181,9 @@ def main():
         eng = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)      # zero texture: the ever-touched sparse update
         eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
         assert eng.touched is not None
-        plain = D.make_sparse_grad_reducer(comm, world)
-        aware = D.make_sparse_grad_reducer(comm, world, rank=rank)
+        # (dense_above 1: the tiny test texture's union footprint is most of the arena - keep the chunk lists anyway)
+        plain = D.make_sparse_grad_reducer(comm, world, dense_above=1.0)
+        aware = D.make_sparse_grad_reducer(comm, world, rank=rank, dense_above=1.0)
         a = eng.arena
         fields = lambda: (a.p, a.m, a.v, eng.sumsq)
         A = [t.clone() for t in fields()]
