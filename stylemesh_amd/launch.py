@@ -141,11 +141,29 @@ def kfd_gpu_count(topology="/sys/class/kfd/kfd/topology/nodes", env=None, dri="/
             return None
         if dri is None or minor < 0 or os.path.exists(os.path.join(dri, f"renderD{minor}")):
             n += 1
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = env.get(var)
-        if v is not None:
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
-    return n
+    # Visibility lists narrow the count in the runtime's own order: ROCR_VISIBLE_DEVICES first (the ROCr layer),
+    # then HIP_VISIBLE_DEVICES - of which CUDA_VISIBLE_DEVICES is an alias HIP only reads when the former is unset - over what
+    # ROCr left. Only integer indices BELOW the count before them are counted (an index the container does not have names
+    # no device); a list with anything else in it (UUIDs) cannot be judged from sysfs: None, the ranks decide.
+    def narrow(count, value):
+        if value is None:
+            return count
+        items = [x.strip() for x in value.split(",") if x.strip() != ""]
+        if any(not x.lstrip("-").isdigit() for x in items):
+            return None
+        seen = []
+        for x in items:
+            i = int(x)
+            if i < 0 or i >= count:
+                break            # (the runtime stops at the first invalid index)
+            if i not in seen:
+                seen.append(i)
+        return len(seen)
+    n = narrow(n, env.get("ROCR_VISIBLE_DEVICES"))
+    if n is None:
+        return None
+    hv = env.get("HIP_VISIBLE_DEVICES")
+    return narrow(n, hv if hv is not None else env.get("CUDA_VISIBLE_DEVICES"))
 
 
 def launch(n_gpus: int, argv, env=None, device_count=None, backend=None, timeout_s=None, out=None, err=None) -> int:

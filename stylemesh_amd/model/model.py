@@ -195,6 +195,7 @@ class TextureOptimizationStyleTransferPipeline(_Base):
                 p.grad = g
             style = self.style_image
             eng.set_style_image(style if style.dim() == 3 else style[0])
+            eng.set_scene(getattr(self, "scene_identity", None))
             self._engine = eng
         return self._engine
 

@@ -182,7 +182,15 @@ def _decode_main(get_view, tasks, results):
             return
         if isinstance(get_view, (bytes, bytearray)):
             import pickle
-            get_view = pickle.loads(get_view)
+            try:
+                get_view = pickle.loads(get_view)
+            except BaseException as e:   # noqa: BLE001 - a decoder that does not arrive whole: tell the consumer, do not hang it
+                err = f"the view decoder could not be un-pickled in the worker: {type(e).__name__}: {e}"
+                while True:              # every request gets the error (the consumer raises on the first)
+                    if tasks.get() is None:
+                        return
+                    results.put(("__error__", err))
+                    results.put(None)
     while True:
         order = tasks.get()
         if order is None:
@@ -223,11 +231,13 @@ class DecodeProcess:
             # pickled HERE, in the caller: a decoder that cannot be pickled raises now instead of leaving a traceback in
             # the queue's feeder thread and a child that waits for its first message forever; the bytes still
             # travel through the queue (see _decode_main: not through the start-up pipe)
+            # ... and ONCE PER WORKER: a ForkingPickler payload may hold single-use handles (a torch CPU tensor
+            # under the file_descriptor sharing strategy, a Connection) - the second worker to load the same bytes would die
             from multiprocessing.reduction import ForkingPickler
-            payload = bytes(ForkingPickler.dumps(get_view))
+            payloads = [bytes(ForkingPickler.dumps(get_view)) for _ in self.procs]
             for p in self.procs:
                 p.start()
-            for q in self.tasks:
+            for q, payload in zip(self.tasks, payloads):
                 q.put(payload)
         finally:
             for k, v in saved.items():

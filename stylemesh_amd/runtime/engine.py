@@ -267,6 +267,11 @@ class StepEngine:
         # first epoch pays for the copies) - hence off by default.
         self.view_cache_gb = float(os.environ.get("STYLEMESH_VIEW_CACHE_GB", "0"))
         self._resident, self._resident_bytes = {}, 0
+        # Resident views are keyed (scene_id, view index): the index alone says nothing about WHICH dataset it indexes
+        # (ADVICE r5). ``set_scene`` names the scene / datamodule the coming batches belong to (the trainer does; a caller
+        # that feeds one scene never needs to) - a new identity forgets every kept view; so do ``set_style_image`` and
+        # ``load_texture`` (masks and lists depend on neither, but an engine re-targeted that far starts clean).
+        self.scene_id = None
         self.view_cache_hits = self.view_cache_misses = 0
         self._gram = {}            # C -> scratch (S0, S1, D0, D1)
         self._gram_clean = set()   # keys of _gram whose S0 / S1 slabs currently hold zeros
@@ -309,8 +314,18 @@ class StepEngine:
         return torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ texture access
+    def set_scene(self, identity):
+        """The batches from now on belong to the scene / datamodule ``identity`` (anything hashable)."""
+        if identity != self.scene_id:
+            self.scene_id = identity
+            self.forget_resident_views()
+
+    def forget_resident_views(self):
+        self._resident, self._resident_bytes = {}, 0
+
     def load_texture(self, layer_tensors):
         """``from_tensor`` semantics (texture.py:34-39,83-94) + the clamp every forward starts with."""
+        self.forget_resident_views()
         for dst, src in zip(self.layers, layer_tensors):
             assert tuple(dst.shape) == tuple(src.shape), (dst.shape, src.shape)
             dst.copy_(src.to(self.device, torch.float32))
@@ -405,6 +420,7 @@ class StepEngine:
         """``ContentAndStyleLoss.set_style_image`` (content_and_style_losses.py:273-286): Gram matrices of the
         VGG features of the reversed style-image pyramid (``image_pyramid``, :83-133)."""
         from .pyramid import image_pyramid_sizes
+        self.forget_resident_views()
         img = style_image[0] if style_image.dim() == 4 else style_image
         img = img.to(self.device, torch.float32).contiguous()
         h, w = img.shape[1:]
@@ -613,7 +629,7 @@ class StepEngine:
         vkey = self._batch_key(batch)
         res = None     # the view's resident state (a revisit), when it was kept and still fits this engine's configuration
         if active_override is None and reducer is None and self.view_cache_gb > 0 and not self.use_graphs:
-            res = self._resident.get(vkey)
+            res = self._resident.get((self.scene_id, vkey))
         active = list(maps_levels) if active_override is None else list(active_override)
         if res is not None:
             active = list(res.active)
@@ -758,12 +774,16 @@ class StepEngine:
         if (not isinstance(pend, PendingView) or pend.reducer is not None or self.view_cache_gb <= 0 or self.use_graphs
                 or self._union_flags is not None):
             return
-        key = self._batch_key(batch)
-        if key in self._resident or self._resident_bytes >= self.view_cache_gb * (1 << 30):
+        key = (self.scene_id, self._batch_key(batch))
+        left = self.view_cache_gb * (1 << 30) - self._resident_bytes
+        if key in self._resident or left <= 0:
             return
         self.view_cache_misses += 1
-        r = ResidentView(pend.plan, self._scatter_plan if self._scatter_levels is not None else None,
-                         self._view_flags if self.touched is not None else None, pend.plan.active)
+        try:
+            r = ResidentView(pend.plan, self._scatter_plan if self._scatter_levels is not None else None,
+                             self._view_flags if self.touched is not None else None, pend.plan.active, max_bytes=left)
+        except MemoryError:
+            return             # (would overshoot the budget: recomputed at its next visit)
         self._resident[key] = r
         self._resident_bytes += r.nbytes
 

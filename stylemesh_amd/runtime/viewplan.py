@@ -87,7 +87,9 @@ class ResidentView:
     (data/abstract_dataset.py:498-512). A revisit copies the state back into the slot's fixed-address buffers (a few
     device-to-device copies) instead of recomputing it (69 / 96 kernels, 0.65 / 2.2 ms of GPU work for one / four levels)."""
 
-    def __init__(self, plan, scatter_plan, view_flags, active):
+    def __init__(self, plan, scatter_plan, view_flags, active, max_bytes=None):
+        """``max_bytes``: what is left of the caller's budget - a view that would not fit raises ``MemoryError`` BEFORE it
+        allocates (the budget used to be checked against what was already kept, and could be overshot by a view)."""
         self.plan_key = plan.cache_key
         self.active = tuple(active)
         # lists: only the live prefix of every list buffer (its length is in the summary)
@@ -106,6 +108,8 @@ class ResidentView:
             src.append(view_flags)
         # ONE allocation per view (a device allocation synchronises: forty of them per new view would cost milliseconds)
         sizes = [(t.numel() * t.element_size() + 255) // 256 * 256 for t in src]
+        if max_bytes is not None and sum(sizes) > max_bytes:
+            raise MemoryError(f"resident view of {sum(sizes)} bytes against {int(max_bytes)} left of the budget")
         self.flat = torch.empty(max(sum(sizes), 256), dtype=torch.uint8, device=src[0].device)
         self.tensors, off = [], 0
         for t, sz in zip(src, sizes):

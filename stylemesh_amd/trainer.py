@@ -139,6 +139,11 @@ class MiniTrainer:
             pass
         model.world_size = self.world_size
         self._model = model
+        # which scene / datamodule the batches come from: the engine's resident views are keyed by it (a module fitted on
+        # another datamodule must not find the first one's views under the same indices)
+        model.scene_identity = (type(datamodule).__name__, id(datamodule), getattr(datamodule, "scene", None))
+        if getattr(model, "_engine", None) is not None:
+            model._engine.set_scene(model.scene_identity)
         if self.device != "cpu":
             from .runtime.hostcpu import limit_host_threads
             limit_host_threads()

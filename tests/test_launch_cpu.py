@@ -114,6 +114,13 @@ def test_gpus_are_counted_from_the_kfd_topology_without_the_runtime(tmp_path):
     assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) == 3
     assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "0,2"}, dri=str(dri)) == 2
     assert launch.kfd_gpu_count(str(topo), env={"ROCR_VISIBLE_DEVICES": ""}, dri=str(dri)) == 0
+    #  an index the container does not have names no device; CUDA_VISIBLE_DEVICES is HIP's alias, read only when
+    # HIP_VISIBLE_DEVICES is unset; ROCR narrows first; a UUID list cannot be judged from sysfs
+    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "5"}, dri=str(dri)) == 0
+    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "0,1", "CUDA_VISIBLE_DEVICES": "0"}, dri=str(dri)) == 2
+    assert launch.kfd_gpu_count(str(topo), env={"CUDA_VISIBLE_DEVICES": "1"}, dri=str(dri)) == 1
+    assert launch.kfd_gpu_count(str(topo), env={"ROCR_VISIBLE_DEVICES": "0,1", "HIP_VISIBLE_DEVICES": "0,1,2"}, dri=str(dri)) == 2
+    assert launch.kfd_gpu_count(str(topo), env={"HIP_VISIBLE_DEVICES": "GPU-abcdef"}, dri=str(dri)) is None
     assert launch.kfd_gpu_count(str(tmp_path / "absent"), env={}, dri=str(dri)) == 0
     (dri / "renderD136").unlink()                     # a container that was given two of the three render nodes
     assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) == 2

@@ -121,12 +121,23 @@ def test_budget_and_configuration_changes(monkeypatch):
     eng.set_view(views[0])
     one = eng._resident_bytes
     assert one > 0
-    eng.view_cache_gb = 1.5 * one / 2 ** 30          # room for one more view, not two
+    eng.view_cache_gb = 2.5 * one / 2 ** 30          # room for one more view of this size, not two
     eng.set_view(views[1])
     eng.set_view(views[2])
-    assert len(eng._resident) == 2 and eng._resident_bytes <= 2 * one * 1.5
+    # (the budget is checked against what a view WOULD take, before it is allocated - never overshot)
+    assert len(eng._resident) == 2 and eng._resident_bytes <= eng.view_cache_gb * 2 ** 30
     eng.set_view(views[2])                           # not kept: computed again, correct
     assert eng.view_tiles is not None
+    # the views of ANOTHER scene under the same indices are not these (keyed by the scene's identity)
+    hits = eng.view_cache_hits
+    eng.set_scene("another scene")
+    assert not eng._resident and eng._resident_bytes == 0
+    eng.view_cache_gb = 4.0
+    eng.set_view(views[0])
+    assert eng.view_cache_hits == hits and len(eng._resident) == 1
+    eng.set_view(views[1])
+    eng.set_view(views[0])
+    assert eng.view_cache_hits == hits + 1
     # a view kept under another configuration is forgotten, not restored
     from stylemesh_amd.runtime import ops
     hits = eng.view_cache_hits
