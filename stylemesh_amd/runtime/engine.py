@@ -641,7 +641,7 @@ class StepEngine:
             plan = self._view_plans[pk] = ViewPlan(self, self._wslot, h, w, level_hw, maps_levels, active)
         if res is not None and res.plan_key != plan.cache_key:     # kept under another configuration: forget it
             self._resident_bytes -= res.nbytes
-            del self._resident[vkey]
+            del self._resident[(self.scene_id, vkey)]
             return self._set_view_fast(batch, reducer, defer, active_override, collective)
         self._mark("stage+plan")
         if res is None:
@@ -704,7 +704,7 @@ class StepEngine:
             return
         if res is not None:     # (kept without / with a scatter plan or flags this engine now wants / does not want)
             self._resident_bytes -= res.nbytes
-            del self._resident[vkey]
+            del self._resident[(self.scene_id, vkey)]
             return self._set_view_fast(batch, reducer, defer, active_override, collective)
         if want_scatter:
             self._scatter_plan.build([lv.grid for lv in act], [lv.pixel_weight for lv in act])

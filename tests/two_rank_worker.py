@@ -81,7 +81,10 @@ def main():
             style_weights=STYLE_WEIGHTS, vgg_gatys_model_path=f.name, use_angle_weight=True, use_depth_scaling=True,
             style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"], angle_threshold=cfgd["thr"], save_texture=False,
             learning_rate=1, decay_gamma=0.1, decay_step_size=1, loss_weights=dict(LOSS_WEIGHTS))
-        model.grad_reducer = D.make_sparse_grad_reducer(comm, world)
+        deferred = os.environ.get("STYLEMESH_DEFERRED_EXCHANGE", "0") == "1"
+        # (dense_above 1: the tiny test texture's union footprint is most of the arena - keep the chunk lists anyway)
+        model.grad_reducer = (D.make_sparse_grad_reducer(comm, world, rank=rank, dense_above=1.0) if deferred
+                              else D.make_sparse_grad_reducer(comm, world))
         dm = SyntheticSceneDataModule(n_views=7, view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW, min_pyramid_depth=0.9,
                                       split=(0.8, 0.2), index_repeat=2, room_size=SMALL_ROOM, rank=rank, world_size=world)
         dm.setup()
@@ -90,7 +93,9 @@ def main():
                          progress=False)
         tr.fit(model, dm)
         torch.cuda.synchronize()
-        torch.save({"layers": [l.data.detach().cpu().clone() for l in model.texture.layers], "steps": tr.global_step},
+        used = bool(deferred and model._engine is not None and model._engine.use_deferred_exchange(model.grad_reducer))
+        torch.save({"layers": [l.data.detach().cpu().clone() for l in model.texture.layers], "steps": tr.global_step,
+                    "deferred": used},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     elif mode == "dense_vs_sparse":
         # a ZERO-initialised texture (sparse ever-touched update) with the plain dense reducer. Each

@@ -8,13 +8,13 @@
 # Usage: profile_round.sh <tag> [workload=c3] [steps of the PMC runs=3]
 set -u
 export TMPDIR=/tmp
-TAG=${1:-r05}; WL=${2:-c3}; PSTEPS=${3:-3}
+TAG=${1:-r06}; WL=${2:-c3}; PSTEPS=${3:-3}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-python bench.py --workload $WL > $OUT/${WL}_bench_full.json 2> $OUT/${WL}_bench_full.err
+python bench.py --workload $WL --schedule-epochs 0 > $OUT/${WL}_bench_full.json 2> $OUT/${WL}_bench_full.err
 tail -c 400 $OUT/${WL}_bench_full.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 > $OUT/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --schedule-epochs 0 --resident-steps 0 > $OUT/prof.log 2>&1
 cd $R
 cp $OUT/prof/run_kernel_stats.csv $OUT/${WL}_kernel_stats.csv
 python3 tools/conv_trace_split.py $OUT/prof/run_kernel_trace.csv $OUT/${WL}_conv_launch_classes.csv > /dev/null
@@ -25,7 +25,7 @@ rm -rf gpurun_out/traffic gpurun_out/pmc_bench
 mkdir -p gpurun_out/traffic gpurun_out/pmc_bench
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/traffic/$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/traffic/$c -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --schedule-epochs 0 --resident-steps 0 --no-conv-timer > $R/gpurun_out/traffic/$c.log 2>&1
   echo "pmc $c rc=$?"
 done
 cd $R
@@ -36,7 +36,7 @@ if [ "$WL" = "c3" ]; then
   cd /tmp
   for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-    timeout 420 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$tag -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --no-conv-timer > $R/gpurun_out/pmc_bench/$tag.log 2>&1
+    timeout 420 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$tag -o run -- python3 $R/bench.py --workload $WL --steps $PSTEPS --warmup 1 --cpu-steps 0 --f32-steps 0 --many-views-steps 0 --late-epoch-views 0 --schedule-epochs 0 --resident-steps 0 --no-conv-timer > $R/gpurun_out/pmc_bench/$tag.log 2>&1
     echo "pmc $tag rc=$?"
   done
   cd $R

@@ -9,7 +9,7 @@ src, wl, tag, out = sys.argv[1:5]
 min_launches = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 rows = list(csv.DictReader(open(src)))
 kern = "conv3x3_split_kernel" if tag in ("split", "split2") else "conv3x3_mfma_kernel"
-np_arg = {"split": ", 3, ", "split2": ", 2, "}.get(tag, "")   # template argument NP (parts per operand), before UNPOOL
+np_arg = ""   # (rounds 2-5 told the bf16x3 / fp16x2 instantiations apart by their NP template argument; one arithmetic since r6)
 def col(r, name):
     for k, v in r.items():
         if k.startswith(name):
@@ -22,7 +22,7 @@ for r in rows:
         fetch += r.get("FETCH_SIZE") and float(r["FETCH_SIZE"]) or 0.0
         write += r.get("WRITE_SIZE") and float(r["WRITE_SIZE"]) or 0.0
         launches += col(r, "launches@FETCH")
-    if "adam_kernel<true>" in r["kernel"]:
+    if "adam_kernel<true>" in r["kernel"] or ("adam_sparse_kernel" in r["kernel"] and adam is None):
         adam = r
 corr = 2.0
 cal = None
