@@ -426,7 +426,7 @@ def parse_args(argv=None):
                     "all-reduced before the update; single-owner chunks are updated by their owner at once and reach the "
                     "other ranks in a background all-reduce (runtime/distributed.py:OwnerAwareGradReducer; "
                     "STYLEMESH_DEFERRED_EXCHANGE=1 selects it for the trainer)")
-    ap.add_argument("--mfma", choices=["split2", "split", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
+    ap.add_argument("--mfma", choices=["split2", "f32"], default=None, help="matrix-core path of the conv and Gram kernels: "
                     "'split2' (default; fp16 MFMA on fp16x2-split operands, 3 partial products, fp32 accumulate) "
                     "or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); same as "
                     "STYLEMESH_CONV_MODE / STYLEMESH_GRAM_MODE")
