@@ -120,6 +120,270 @@ constexpr int conv_split_waves(int BM, int BN) {
 // loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
 constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
 constexpr size_t conv_resident_lds_bytes() { return (size_t)(4 * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
+// ---- the epilogue of a WHOLE tile (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31, row = (r & 3) +
+// 8 * (r >> 2) + 4 * (lane >> 5); column tile j of the wave is in acc[.][j]): scale, bias / ReLU / gate / addend, the pooling
+// or the Gram epilogue, stores. Shared by the ring / resident kernel below and by the pipelined resident kernel
+// (conv_resident_pipe.h). `bias`: the launch's bias vector (any address space); `smem4`: LDS the Gram epilogue may stage its
+// operand in, GPH channels at a time ((2 * GPH / 8 * BN) * 16 + (BM / 8) * BN bytes, free of readers; the sums do not depend
+// on GPH). Returns the lane's max |output|.
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool RES, int GPH = 64>
+__device__ __forceinline__ float conv_split_epilogue(const ConvArgs& a, const ConvProblem& P, const int (&qs_)[BN / 32],
+                                                     const bool (&live_)[BN / 32],
+                                                     f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], const int m0,
+                                                     const float out_scale, const float* bias, f32x4* smem4) {
+    constexpr int MI = BM / WGM / 32, NJ = BN / WGN / 32, SEG = BN / 32;
+    constexpr int NP = SM_SPLIT_NP, SEGP = 34, BNP = SEG * SEGP, SLICE = 2 * NP * BNP;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int wm = (wave / WGN) * (32 * MI);
+    const int wn = (wave % WGN) * (32 * NJ);
+    // (copies: every entry is read here, unconditionally - selecting among the caller's array elements by a computed segment
+    // number becomes an indexed load from a scratch copy of the array otherwise)
+    int qs[SEG];
+    bool live[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        qs[i] = qs_[i];
+        live[i] = live_[i];
+    }
+    const int q_end = (P.H + 1) * P.Wp;
+    // the 32 bias values of this lane's rows, as 8 float4 (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4). (Hoisting these
+    // loads above the main loop - so that they do not queue behind the last, unused prefetches - bought nothing.)
+    f32x4 bias4[MI][4];
+    if (FLAGS & SM_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bias4[mi][g] = *reinterpret_cast<const f32x4*>(bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
+    }
+    float vmax = 0.f;   // max |output| of this lane: the operand scale of the conv that consumes this tensor (NP = 2)
+    if constexpr ((FLAGS & SM_EPI_POOL) != 0) {
+        // Forward conv BELOW a 2x2 max-pool: the tile's segments come in vertical pairs (entries 2k, 2k + 1 of the list:
+        // the same 32 columns of image rows 2Y and 2Y + 1, first column even), so every pooling window lies inside one
+        // wave - rows in two accumulator tiles of the same lane, columns in neighbouring lanes. The epilogue stores the
+        // POOLED map and the pool's argmax codes (the formats of maxpool_fwd_codes_kernel); the full-resolution output,
+        // which only the pool would read, is never written: no pool pass, 1.75 plane sizes of HBM traffic less.
+        static_assert(FLAGS == (SM_EPI_BIAS_RELU | SM_EPI_POOL) && NJ % 2 == 0, "forward epilogue, segment pairs per wave");
+        const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
+#pragma unroll
+        for (int pj = 0; pj < NJ; pj += 2) {
+            int q_seg = qs[0];
+            bool alive = live[0];
+#pragma unroll
+            for (int k = 1; k < SEG; ++k)
+                if (wn / 32 + pj == k) { q_seg = qs[k]; alive = live[k]; }
+            if (!alive) continue;                                  // (wave-uniform: a padding pair)
+            const int q = q_seg + l31;                             // this lane's position in the upper row
+            const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
+            // even lanes own a window; a segment that runs past the end of its row holds nothing there
+            const bool ok = ((l31 | yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
+            const int qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                unsigned codes[4] = {0u, 0u, 0u, 0u};              // one dword per 8-channel group: this lane's 4 nibbles
+                const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * plane_o + qo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = acc[mi][pj][r], b = acc[mi][pj + 1][r];
+                    t *= out_scale;
+                    b *= out_scale;
+                    const float bv = bias4[mi][r >> 2][r & 3];
+                    t = fmaxf(t + bv, 0.f);
+                    b = fmaxf(b + bv, 0.f);
+                    // the window partner (lane ^ 1) through a DPP quad permute [1, 0, 3, 2] (round 5; an LDS permute before: -1 % on the launch)
+                    const float tp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
+                    const float bp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
+                    // first maximum in row-major order (strict '>' scan, as max_pool2d_with_indices); 4: maximum <= 0
+                    float m = t;
+                    unsigned c = 0u;
+                    if (tp > m) { m = tp; c = 1u; }
+                    if (b > m) { m = b; c = 2u; }
+                    if (bp > m) { m = bp; c = 3u; }
+                    if (!(m > 0.f)) c = 4u;
+                    vmax = ok ? fmaxf(vmax, m) : vmax;         // (bound of the POOLED map: what the next conv reads)
+                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] = m;
+                    codes[r >> 2] |= c << (4 * ((r & 3) + 4 * lhi));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned full = codes[g] | (unsigned)__shfl_xor((int)codes[g], 32, 64);   // channels 8g + 0..3 | 4..7
+                    if (ok && lhi == 0) P.pool_code[(size_t)((m0 + wm + mi * 32) / 8 + g) * plane_o + qo] = full;
+                }
+            }
+        }
+        return vmax;
+    }
+    // SM_EPI_GRAM: the output layer is a style layer of C = BM channels (the block's row tile holds all of them) and this
+    // epilogue adds its masked Gram backward, sum_k m_k(q) (D_k F)(q), F = the gate operand - C / 16 sixteen-channel steps
+    // per mask on the matrix cores for each of the wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
+    // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
+    constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
+    float g_fscale = 1.f, g_oscale = 1.f;
+    if constexpr (GRAM) {
+        static_assert(MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
+                      "the Gram term replaces the addend of a data gradient whose row tile holds all C = BM channels");
+        float inv_f, inv_d;
+        g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
+        conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
+        g_oscale = inv_f * inv_d;
+    }
+    // Round 4: the operand F is staged ONCE per block through the (now idle) slice ring - 64 channels at a time, already
+    // scaled and split, in the main loop's unit format [part][k-group][position] - instead of being loaded and converted
+    // by every wave that shares the positions (2 of 4 waves on the 64 x 256 tile, all 4 on the 128 x 128 one) in a
+    // load -> convert -> MFMA chain per 32 channels; the derivative matrices' fragments are fetched once per k-step for the
+    // wave's NJ column tiles, whose NJ accumulators take the MFMAs interleaved. Per column tile the products arrive in the
+    // order they always did (chunk, mask, k-step): the sums keep their bits.
+    f32x16 accg[GRAM ? NJ : 1];
+    if constexpr (GRAM) {
+        static_assert(GPH == 64 || GPH == 32, "staging phases of 64 channels (the whole ring) or 32 (half a resident window)");
+        constexpr int KG = GPH / 8;             // k-groups of a phase: the staged image is [part][k-group][position]
+        constexpr int PH = BM / GPH;            // phases
+        constexpr int CH = GPH / 32;            // 32-channel chunks of a phase
+        constexpr int GU = KG * BN / 256;       // staging units (k-group, position) per thread and phase
+        static_assert(GPH != 64 || (2 * 8 * BN) * 16 + (BM / 8) * BN <= (RES ? conv_resident_lds_bytes() : (size_t)SM_SPLIT_SLOTS * SLICE * 16),
+                      "a phase of the Gram operand + the gate bits of all channels fit the slice ring");
+        f32x4* Gs = smem4;
+        // F is also the ReLU gate of this launch's output: the staging threads - which hold the raw values - leave one bit
+        // per (channel, position), x > 0, behind the operand (byte [channel / 8][position]); the store loop below reads its
+        // gate from there instead of loading the layer a second time (conv1_2's data gradient moved 1.27 GB, a third of it
+        // this second read)
+        unsigned char* Gb = reinterpret_cast<unsigned char*>(smem4 + 2 * KG * BN);
+        float mk[NJ][2];
+        bool anyk[NJ][2], alive_j[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+            int q_seg = qs[0];
+            alive_j[nj] = live[0];
+#pragma unroll
+            for (int k = 1; k < SEG; ++k)
+                if (wn / 32 + nj == k) { q_seg = qs[k]; alive_j[nj] = live[k]; }
+            const int q = q_seg + l31;
+            const bool valid = alive_j[nj] && q < q_end;
+            const int qc = valid ? q : q_seg;                          // (lanes past the plane's end load a valid address)
+            mk[nj][0] = valid ? P.gram_mask0[qc] : 0.f;
+            mk[nj][1] = (valid && P.gram_mask1) ? P.gram_mask1[qc] : 0.f;
+            anyk[nj][0] = __ballot(mk[nj][0] != 0.f) != 0ull;
+            anyk[nj][1] = __ballot(mk[nj][1] != 0.f) != 0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accg[nj][r] = 0.f;
+        }
+        // staging unit u of this thread: position tid % BN of the block, k-group tid / BN + u * (256 / BN)
+        const int g_pos = tid & (BN - 1);
+        int g_q = qs[0];
+#pragma unroll
+        for (int k = 1; k < SEG; ++k)
+            if ((g_pos >> 5) == k) g_q = qs[k];
+        g_q += g_pos & 31;
+        if (g_q >= q_end) g_q -= g_pos & 31;                           // (as above: a valid address, masked to zero later)
+        const f32x4* gp = P.gram_p + lhi * BM + wm + l31;            // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
+        const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph) {
+            __syncthreads();                                           // the ring's (the previous phase's) last readers are through
+            {
+                float rb[GU][8];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int kg = tid / BN + u * (256 / BN);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        rb[u][c] = P.gate[(size_t)(ph * GPH + kg * 8 + c) * P.plane + g_q];
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int kg = tid / BN + u * (256 / BN);
+                    f32x4 vh, vl;
+                    conv_gram_split(rb[u], g_fscale, vh, vl);
+                    Gs[kg * BN + g_pos] = vh;
+                    Gs[(KG + kg) * BN + g_pos] = vl;
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        bits |= (rb[u][c] > 0.f ? 1u : 0u) << c;
+                    Gb[(ph * KG + kg) * BN + g_pos] = (unsigned char)bits;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int chunk = 0; chunk < CH; ++chunk)                   // 32 channels
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int t = (ph * CH + chunk) * 2 + ks;      // k-step of 16 channels
+                        const f32x4* gk = k == 0 ? gp : gp1;
+                        f32x4 fa[2];
+                        fa[0] = gk[(t * 4 + 0) * BM];
+                        fa[1] = gk[(t * 4 + 2) * BM];
+#pragma unroll
+                        for (int nj = 0; nj < NJ; ++nj) {
+                            if (!alive_j[nj] || !anyk[nj][k]) continue;   // (wave-uniform)
+                            const f32x4* gf = Gs + ((chunk * 2 + ks) * 2 + lhi) * BN + wn + nj * 32 + l31;
+                            const bool keep = mk[nj][k] != 0.f;
+                            f32x4 fb[2];
+                            fb[0] = keep ? gf[0] : zero4;
+                            fb[1] = keep ? gf[KG * BN] : zero4;
+                            conv_gram_mfma(accg[nj], fa, fb);
+                        }
+                    }
+        }
+    }
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        int q_seg = qs[0];
+        bool alive = live[0];
+#pragma unroll
+        for (int k = 1; k < SEG; ++k)
+            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
+        const int q = q_seg + l31;
+        if (!alive || q >= q_end) continue;
+        // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
+        // continue on the first columns of the next one, which another run of the quad's next segment covers - a position
+        // stored twice, added twice under SM_EPI_ADD: a lane stays in its segment's row)
+        if (RES && q / P.Wp != q_seg / P.Wp) continue;
+        const bool inside = interior(q, P.H, P.W, P.Wp);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
+            // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
+            float prev[16], gate[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
+                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
+            }
+            if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned b8 = Gs_gate_byte(smem4, (wm / 8 + g) * BN + wn + nj * 32 + l31, 2 * (GPH / 8) * BN);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gate[4 * g + k] = ((b8 >> (4 * lhi + k)) & 1u) ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                float v = acc[mi][nj][r];
+                v *= out_scale;
+                if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
+                if (FLAGS & SM_EPI_ADD) v += prev[r];
+                if constexpr (GRAM) v += accg[nj][r] * g_oscale;
+                if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
+                v = inside ? v : 0.f;
+                P.out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+        }
+    }
+    return vmax;
+}
+
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool UNPOOL = false, bool RES = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(conv_split_waves(BM, BN), conv_split_waves(BM, BN))))
@@ -683,236 +947,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         acc[mi][j][r] * out_scale;   // power of two: exact
         return;
     }
-    const int q_end = (P.H + 1) * P.Wp;
-    // the 32 bias values of this lane's rows, as 8 float4 (rows (r&3) + 8(r>>2) + 4 lhi: groups of 4). (Hoisting these
-    // loads above the main loop - so that they do not queue behind the last, unused prefetches - bought nothing.)
-    f32x4 bias4[MI][4];
-    if (FLAGS & SM_EPI_BIAS_RELU) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bias4[mi][g] = *reinterpret_cast<const f32x4*>(a.bias + m0 + wm + mi * 32 + 4 * lhi + 8 * g);
-    }
-    float vmax = 0.f;   // max |output| of this lane: the operand scale of the conv that consumes this tensor (NP = 2)
-    if constexpr ((FLAGS & SM_EPI_POOL) != 0) {
-        // Forward conv BELOW a 2x2 max-pool: the tile's segments come in vertical pairs (entries 2k, 2k + 1 of the list:
-        // the same 32 columns of image rows 2Y and 2Y + 1, first column even), so every pooling window lies inside one
-        // wave - rows in two accumulator tiles of the same lane, columns in neighbouring lanes. The epilogue stores the
-        // POOLED map and the pool's argmax codes (the formats of maxpool_fwd_codes_kernel); the full-resolution output,
-        // which only the pool would read, is never written: no pool pass, 1.75 plane sizes of HBM traffic less.
-        static_assert(FLAGS == (SM_EPI_BIAS_RELU | SM_EPI_POOL) && NJ % 2 == 0, "forward epilogue, segment pairs per wave");
-        const int Ho = P.H >> 1, Wo = P.W >> 1, Wpo = row_stride(Wo), plane_o = plane_size(Ho, Wo);
-#pragma unroll
-        for (int pj = 0; pj < NJ; pj += 2) {
-            int q_seg = qs[0];
-            bool alive = live[0];
-#pragma unroll
-            for (int k = 1; k < SEG; ++k)
-                if (wn / 32 + pj == k) { q_seg = qs[k]; alive = live[k]; }
-            if (!alive) continue;                                  // (wave-uniform: a padding pair)
-            const int q = q_seg + l31;                             // this lane's position in the upper row
-            const int yy = q / P.Wp - 1, xx = q - (yy + 1) * P.Wp - 1;
-            // even lanes own a window; a segment that runs past the end of its row holds nothing there
-            const bool ok = ((l31 | yy | xx) & 1) == 0 && (unsigned)yy < (unsigned)(2 * Ho) && (unsigned)xx < (unsigned)(2 * Wo);
-            const int qo = ((yy >> 1) + 1) * Wpo + (xx >> 1) + 1;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                unsigned codes[4] = {0u, 0u, 0u, 0u};              // one dword per 8-channel group: this lane's 4 nibbles
-                const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * plane_o + qo;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float t = acc[mi][pj][r], b = acc[mi][pj + 1][r];
-                    t *= out_scale;
-                    b *= out_scale;
-                    const float bv = bias4[mi][r >> 2][r & 3];
-                    t = fmaxf(t + bv, 0.f);
-                    b = fmaxf(b + bv, 0.f);
-                    // the window partner (lane ^ 1) through a DPP quad permute [1, 0, 3, 2] (round 5; an LDS permute before: -1 % on the launch)
-                    const float tp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
-                    const float bp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0xB1, 0xF, 0xF, true));
-                    // first maximum in row-major order (strict '>' scan, as max_pool2d_with_indices); 4: maximum <= 0
-                    float m = t;
-                    unsigned c = 0u;
-                    if (tp > m) { m = tp; c = 1u; }
-                    if (b > m) { m = b; c = 2u; }
-                    if (bp > m) { m = bp; c = 3u; }
-                    if (!(m > 0.f)) c = 4u;
-                    vmax = ok ? fmaxf(vmax, m) : vmax;         // (bound of the POOLED map: what the next conv reads)
-                    if (ok) P.pool_out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane_o] = m;
-                    codes[r >> 2] |= c << (4 * ((r & 3) + 4 * lhi));
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned full = codes[g] | (unsigned)__shfl_xor((int)codes[g], 32, 64);   // channels 8g + 0..3 | 4..7
-                    if (ok && lhi == 0) P.pool_code[(size_t)((m0 + wm + mi * 32) / 8 + g) * plane_o + qo] = full;
-                }
-            }
-        }
-        record_amax(a.amax_out, vmax, amax_seen);
-        return;
-    }
-    // SM_EPI_GRAM: the output layer is a style layer of C = BM channels (the block's row tile holds all of them) and this
-    // epilogue adds its masked Gram backward, sum_k m_k(q) (D_k F)(q), F = the gate operand - C / 16 sixteen-channel steps
-    // per mask on the matrix cores for each of the wave's 32-position column tiles, in gram_backward_body's operand format and product order (the sum has its bits);
-    // the gradient plane is then written once instead of written (Gram backward), read (here) and written again.
-    constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
-    float g_fscale = 1.f, g_oscale = 1.f;
-    if constexpr (GRAM) {
-        static_assert(MI == 1 && (BM == 64 || BM == 128) && (FLAGS & SM_EPI_RELU_MASK) && !(FLAGS & SM_EPI_ADD),
-                      "the Gram term replaces the addend of a data gradient whose row tile holds all C = BM channels");
-        float inv_f, inv_d;
-        g_fscale = conv_gram_pow2_scale(amax_read(P.gram_amax_feat), inv_f);
-        conv_gram_pow2_scale(amax_read(P.gram_amax_d), inv_d);
-        g_oscale = inv_f * inv_d;
-    }
-    // Round 4: the operand F is staged ONCE per block through the (now idle) slice ring - 64 channels at a time, already
-    // scaled and split, in the main loop's unit format [part][k-group][position] - instead of being loaded and converted
-    // by every wave that shares the positions (2 of 4 waves on the 64 x 256 tile, all 4 on the 128 x 128 one) in a
-    // load -> convert -> MFMA chain per 32 channels; the derivative matrices' fragments are fetched once per k-step for the
-    // wave's NJ column tiles, whose NJ accumulators take the MFMAs interleaved. Per column tile the products arrive in the
-    // order they always did (chunk, mask, k-step): the sums keep their bits.
-    f32x16 accg[GRAM ? NJ : 1];
-    if constexpr (GRAM) {
-        constexpr int PH = BM / 64;             // phases of 64 channels (the ring holds 2 parts x 8 k-groups x BN units)
-        constexpr int GU = 8 * BN / 256;        // staging units (k-group, position) per thread and phase
-        static_assert((2 * 8 * BN) * 16 + (BM / 8) * BN <= (RES ? conv_resident_lds_bytes() : (size_t)SM_SPLIT_SLOTS * SLICE * 16),
-                      "a phase of the Gram operand + the gate bits of all channels fit the slice ring");
-        f32x4* Gs = smem4;
-        // F is also the ReLU gate of this launch's output: the staging threads - which hold the raw values - leave one bit
-        // per (channel, position), x > 0, behind the operand (byte [channel / 8][position]); the store loop below reads its
-        // gate from there instead of loading the layer a second time (conv1_2's data gradient moved 1.27 GB, a third of it
-        // this second read)
-        unsigned char* Gb = reinterpret_cast<unsigned char*>(smem4 + 2 * 8 * BN);
-        float mk[NJ][2];
-        bool anyk[NJ][2], alive_j[NJ];
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) {
-            int q_seg = qs[0];
-            alive_j[nj] = live[0];
-#pragma unroll
-            for (int k = 1; k < SEG; ++k)
-                if (wn / 32 + nj == k) { q_seg = qs[k]; alive_j[nj] = live[k]; }
-            const int q = q_seg + l31;
-            const bool valid = alive_j[nj] && q < q_end;
-            const int qc = valid ? q : q_seg;                          // (lanes past the plane's end load a valid address)
-            mk[nj][0] = valid ? P.gram_mask0[qc] : 0.f;
-            mk[nj][1] = (valid && P.gram_mask1) ? P.gram_mask1[qc] : 0.f;
-            anyk[nj][0] = __ballot(mk[nj][0] != 0.f) != 0ull;
-            anyk[nj][1] = __ballot(mk[nj][1] != 0.f) != 0ull;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accg[nj][r] = 0.f;
-        }
-        // staging unit u of this thread: position tid % BN of the block, k-group tid / BN + u * (256 / BN)
-        const int g_pos = tid & (BN - 1);
-        int g_q = qs[0];
-#pragma unroll
-        for (int k = 1; k < SEG; ++k)
-            if ((g_pos >> 5) == k) g_q = qs[k];
-        g_q += g_pos & 31;
-        if (g_q >= q_end) g_q -= g_pos & 31;                           // (as above: a valid address, masked to zero later)
-        const f32x4* gp = P.gram_p + lhi * BM + wm + l31;            // operand unit (k-step t, part p): gp[(t * 4 + p * 2) * BM]
-        const f32x4* gp1 = gp + (size_t)6 * BM * BM / 16;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ph = 0; ph < PH; ++ph) {
-            __syncthreads();                                           // the ring's (the previous phase's) last readers are through
-            {
-                float rb[GU][8];
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int kg = tid / BN + u * (256 / BN);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        rb[u][c] = P.gate[(size_t)(ph * 64 + kg * 8 + c) * P.plane + g_q];
-                }
-#pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int kg = tid / BN + u * (256 / BN);
-                    f32x4 vh, vl;
-                    conv_gram_split(rb[u], g_fscale, vh, vl);
-                    Gs[kg * BN + g_pos] = vh;
-                    Gs[(8 + kg) * BN + g_pos] = vl;
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        bits |= (rb[u][c] > 0.f ? 1u : 0u) << c;
-                    Gb[(ph * 8 + kg) * BN + g_pos] = (unsigned char)bits;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int chunk = 0; chunk < 2; ++chunk)                    // 32 channels
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int t = (ph * 2 + chunk) * 2 + ks;       // k-step of 16 channels
-                        const f32x4* gk = k == 0 ? gp : gp1;
-                        f32x4 fa[2];
-                        fa[0] = gk[(t * 4 + 0) * BM];
-                        fa[1] = gk[(t * 4 + 2) * BM];
-#pragma unroll
-                        for (int nj = 0; nj < NJ; ++nj) {
-                            if (!alive_j[nj] || !anyk[nj][k]) continue;   // (wave-uniform)
-                            const f32x4* gf = Gs + ((chunk * 2 + ks) * 2 + lhi) * BN + wn + nj * 32 + l31;
-                            const bool keep = mk[nj][k] != 0.f;
-                            f32x4 fb[2];
-                            fb[0] = keep ? gf[0] : zero4;
-                            fb[1] = keep ? gf[8 * BN] : zero4;
-                            conv_gram_mfma(accg[nj], fa, fb);
-                        }
-                    }
-        }
-    }
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        int q_seg = qs[0];
-        bool alive = live[0];
-#pragma unroll
-        for (int k = 1; k < SEG; ++k)
-            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
-        const int q = q_seg + l31;
-        if (!alive || q >= q_end) continue;
-        // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
-        // continue on the first columns of the next one, which another run of the quad's next segment covers - a position
-        // stored twice, added twice under SM_EPI_ADD: a lane stays in its segment's row)
-        if (RES && q / P.Wp != q_seg / P.Wp) continue;
-        const bool inside = interior(q, P.H, P.W, P.Wp);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
-            // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
-            float prev[16], gate[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
-                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
-            }
-            if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned b8 = Gs_gate_byte(smem4, (wm / 8 + g) * BN + wn + nj * 32 + l31, 2 * 8 * BN);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) gate[4 * g + k] = ((b8 >> (4 * lhi + k)) & 1u) ? 1.f : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                float v = acc[mi][nj][r];
-                v *= out_scale;
-                if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
-                if (FLAGS & SM_EPI_ADD) v += prev[r];
-                if constexpr (GRAM) v += accg[nj][r] * g_oscale;
-                if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
-                v = inside ? v : 0.f;
-                P.out[o] = v;
-                vmax = fmaxf(vmax, fabsf(v));
-            }
-        }
-    }
+    const float vmax = conv_split_epilogue<BM, BN, WGM, WGN, FLAGS, RES>(a, P, qs, live, acc, m0, out_scale, a.bias, smem4);
     record_amax(a.amax_out, vmax, amax_seen);
 }
 
