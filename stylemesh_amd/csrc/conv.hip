@@ -700,7 +700,10 @@ static int launch_conv_resident(sm::ConvArgs& a, int n_list, size_t ws_floats, h
             a.tile_counter = reinterpret_cast<unsigned*>(ws + ws_floats - sm::SM_PIPE_COUNTER_WORDS);
             hipError_t e = hipMemsetAsync(a.tile_counter, 0, sm::SM_PIPE_COUNTER_WORDS * sizeof(unsigned), s);
             if (e != hipSuccess) return (int)e;
-            const int grid = std::min(sm::SM_PIPE_SLOTS_PER_CU * sm::SM_NUM_CU, n_tiles & ~7);
+            // (SM_RES_PIPE_BLOCKS: tests walk many quads per block on small planes with it)
+            const char* const pb = getenv("SM_RES_PIPE_BLOCKS");
+            const int slots = pb ? std::max(8, atoi(pb) & ~7) : sm::SM_PIPE_SLOTS_PER_CU * sm::SM_NUM_CU;
+            const int grid = std::min(slots, n_tiles & ~7);
             hipLaunchKernelGGL((sm::conv3x3_respipe_kernel<FLAGS, UNPOOL>), dim3(grid), dim3(256), sm::conv_respipe_lds_bytes(), s, a);
             SM_LAUNCH_CHECK();
             return 0;

@@ -35,6 +35,8 @@ SWITCHES = {
     "SM_RES_PIPE_MIN": ("1536", "tuning", "(C library) quad count from which a 64-output-channel launch takes the persistent, cross-tile "
                         "pipelined resident kernel (csrc/conv_resident_pipe.h; same bits); default = two rounds of the chip's 768 "
                         "block slots; 0 = never (the one-quad-per-block resident kernel of round 5)"),
+    "SM_RES_PIPE_BLOCKS": ("768", "diagnostic", "(C library) resident blocks of the pipelined resident kernel (a multiple of 8; default three per "
+                           "CU); tests set 16 so that a block walks many quads of a small plane"),
     "SM_ADAM_DENSE_WALK": ("0", "diagnostic", "(C library) 1 = the flagged update walks every tile of the arena and asks each chunk's flag "
                            "(rounds 2-5) instead of compacting a span's flags first (adam_sparse_kernel, round 6; same bits of p, m, v)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),

@@ -144,10 +144,12 @@ def _pipe(monkeypatch, pipe):
     Returns the workspace of the launches: too small for split-K slabs (the ring kernel runs whole tiles: the same sums),
     large enough for the pipelined kernel's tile counters."""
     monkeypatch.setenv("SM_RES_PIPE_MIN", "8" if pipe else "0")
+    if pipe == "narrow":                         # sixteen blocks: every block walks many quads
+        monkeypatch.setenv("SM_RES_PIPE_BLOCKS", "16")
     return torch.zeros(256, device="cuda")
 
 
-@pytest.mark.parametrize("pipe", [False, True])
+@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws", CASES)
 def test_resident_forward_with_pooling_epilogue(hws, pipe, monkeypatch):
     require_gpu()
@@ -215,7 +217,7 @@ def test_resident_forward_with_pooling_epilogue(hws, pipe, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["fwd", "plain128", "gate_unpool", "gate_add_unpool", "gate_add", "gate"])
-@pytest.mark.parametrize("pipe", [False, True])
+@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws", CASES)
 def test_resident_kernel_matches_ring_kernel(variant, hws, pipe, monkeypatch):
     require_gpu()
@@ -285,7 +287,7 @@ def test_resident_kernel_matches_ring_kernel(variant, hws, pipe, monkeypatch):
     assert float(am.max()) == true_max
 
 
-@pytest.mark.parametrize("pipe", [False, True])
+@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws,two_masks", [([(37, 50)], True), ([(150, 201), (64, 85)], True), ([(40, 53)], False)])
 def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
     """conv1_2's data gradient as the step launches it: un-pooled input, relu1_1's Gram backward in the epilogue, its ReLU
@@ -334,6 +336,8 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
         ops.conv3x3_grouped([(d, r, f, c) for d, r, f, c in zip(dps, ref, feats, codes)], wd, None,
                             hip.EPI_RELU_MASK | hip.EPI_ADD, None, 1.0, wd2, amax_in, ops.new_amax("cuda"))
     monkeypatch.setenv("SM_RES_PIPE_MIN", "8" if pipe else "0")
+    if pipe == "narrow":
+        monkeypatch.setenv("SM_RES_PIPE_BLOCKS", "16")
     needs = _needs(hws, False, 13)
     lst = torch.cat([_quad_cover(ops, hip, nd, g) for g, nd in enumerate(needs)])
     out = [FMap(C, H, W) for (H, W) in hws]
@@ -356,7 +360,8 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
 @pytest.mark.parametrize("env", [{}, {"STYLEMESH_FUSE_POOL_FWD": "0"}, {"STYLEMESH_FUSE_POOL_BWD": "0"},
                                  {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"},
                                  {"SM_RES_PIPE_MIN": "8"}, {"SM_RES_PIPE_MIN": "8", "STYLEMESH_FUSE_GRAM_BWD": "0"},
-                                 {"SM_RES_PIPE_MIN": "8", "STYLEMESH_SIDE_STREAMS": "0"}])
+                                 {"SM_RES_PIPE_MIN": "8", "STYLEMESH_SIDE_STREAMS": "0"},
+                                 {"SM_RES_PIPE_MIN": "8", "SM_RES_PIPE_BLOCKS": "16"}])
 def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
     """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses and
     the same GRADIENT after one forward + backward from the same random texture (tests/stepcmp.py) - up to the operand
