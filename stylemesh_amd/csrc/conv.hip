@@ -704,7 +704,7 @@ static int launch_conv_resident(sm::ConvArgs& a, int n_list, size_t ws_floats, h
             const char* const pb = getenv("SM_RES_PIPE_BLOCKS");
             const int slots = pb ? std::max(8, atoi(pb) & ~7) : sm::SM_PIPE_SLOTS_PER_CU * sm::SM_NUM_CU;
             const int grid = std::min(slots, n_tiles & ~7);
-            hipLaunchKernelGGL((sm::conv3x3_respipe_kernel<FLAGS, UNPOOL>), dim3(grid), dim3(256), sm::conv_respipe_lds_bytes(), s, a);
+            hipLaunchKernelGGL((sm::conv3x3_respipe_kernel<FLAGS, UNPOOL>), dim3(grid), dim3(256), sm::conv_respipe_lds_bytes((FLAGS & SM_EPI_GRAM) != 0), s, a);
             SM_LAUNCH_CHECK();
             return 0;
         }

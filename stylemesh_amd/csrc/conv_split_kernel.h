@@ -61,9 +61,6 @@ __device__ __forceinline__ void conv_gram_split(const float (&x)[8], float sm, f
     vh = __builtin_bit_cast(f32x4, h);
     vl = __builtin_bit_cast(f32x4, l);
 }
-__device__ __forceinline__ unsigned Gs_gate_byte(const f32x4* smem, int index, int unit_offset) {
-    return reinterpret_cast<const unsigned char*>(smem + unit_offset)[index];
-}
 __device__ __forceinline__ void conv_gram_mfma(f32x16& acc, const f32x4 (&fa)[2], const f32x4 (&fb)[2]) {
 #define SM_H(x_) __builtin_bit_cast(cg_f16x8, x_)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(SM_H(fa[1]), SM_H(fb[0]), acc, 0, 0, 0);
@@ -119,7 +116,82 @@ constexpr int conv_split_waves(int BM, int BN) {
 // fragment reads only - a tap shift (ky, kx) is the offset ky * 34 + kx - with no barrier and no conversion inside the
 // loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
 constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
-constexpr size_t conv_resident_lds_bytes() { return (size_t)(4 * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
+#ifndef SM_RES_PHASE
+#define SM_RES_PHASE 64   // channels staged per phase (64, or 32: half the LDS - room for a fourth block per CU, see SM_SPLIT_WAVES64)
+#endif
+constexpr int SM_RES_CC = SM_RES_PHASE / 16;                                    // 16-channel chunks of a phase
+constexpr size_t conv_resident_lds_bytes() { return (size_t)(SM_RES_CC * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
+// ---- the stores of a whole tile: scale, bias / ReLU, addend, the Gram term (accg: already summed), gate, border.
+// gate_bits (Gram epilogue): one byte per (8-channel group, position of the block), bit c = channel 8 g + c of the gate
+// operand > 0. Returns the lane's max |output|.
+template <int BM, int BN, int WGM, int WGN, int FLAGS, bool RES>
+__device__ __forceinline__ float conv_split_store_tile(const ConvProblem& P, const int (&qs)[BN / 32], const bool (&live)[BN / 32],
+                                                       f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], const int m0,
+                                                       const float out_scale, const f32x4 (&bias4)[BM / WGM / 32][4],
+                                                       const f32x16 (&accg)[(FLAGS & SM_EPI_GRAM) ? BN / WGN / 32 : 1],
+                                                       const float g_oscale, const unsigned char* gate_bits) {
+    constexpr int MI = BM / WGM / 32, NJ = BN / WGN / 32, SEG = BN / 32;
+    constexpr bool GRAM = (FLAGS & SM_EPI_GRAM) != 0;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lhi = lane >> 5;
+    const int wm = (wave / WGN) * (32 * MI);
+    const int wn = (wave % WGN) * (32 * NJ);
+    const int q_end = (P.H + 1) * P.Wp;
+    float vmax = 0.f;
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        int q_seg = qs[0];
+        bool alive = live[0];
+#pragma unroll
+        for (int k = 1; k < SEG; ++k)
+            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
+        const int q = q_seg + l31;
+        if (!alive || q >= q_end) continue;
+        // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
+        // continue on the first columns of the next one, which another run of the quad's next segment covers - a position
+        // stored twice, added twice under SM_EPI_ADD: a lane stays in its segment's row)
+        if (RES && q / P.Wp != q_seg / P.Wp) continue;
+        const bool inside = interior(q, P.H, P.W, P.Wp);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
+            // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
+            float prev[16], gate[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
+                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
+            }
+            if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned b8 = gate_bits[(wm / 8 + g) * BN + wn + nj * 32 + l31];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gate[4 * g + k] = ((b8 >> (4 * lhi + k)) & 1u) ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
+                float v = acc[mi][nj][r];
+                v *= out_scale;
+                if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
+                if (FLAGS & SM_EPI_ADD) v += prev[r];
+                if constexpr (GRAM) v += accg[nj][r] * g_oscale;
+                if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
+                v = inside ? v : 0.f;
+                P.out[o] = v;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+        }
+    }
+    return vmax;
+}
+
 // ---- the epilogue of a WHOLE tile (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31, row = (r & 3) +
 // 8 * (r >> 2) + 4 * (lane >> 5); column tile j of the wave is in acc[.][j]): scale, bias / ReLU / gate / addend, the pooling
 // or the Gram epilogue, stores. Shared by the ring / resident kernel below and by the pipelined resident kernel
@@ -333,55 +405,8 @@ __device__ __forceinline__ float conv_split_epilogue(const ConvArgs& a, const Co
                     }
         }
     }
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        int q_seg = qs[0];
-        bool alive = live[0];
-#pragma unroll
-        for (int k = 1; k < SEG; ++k)
-            if (wn / 32 + nj == k) { q_seg = qs[k]; alive = live[k]; }
-        const int q = q_seg + l31;
-        if (!alive || q >= q_end) continue;
-        // (quads: the runs of a row group are disjoint within their rows, but a run that passes the end of its row would
-        // continue on the first columns of the next one, which another run of the quad's next segment covers - a position
-        // stored twice, added twice under SM_EPI_ADD: a lane stays in its segment's row)
-        if (RES && q / P.Wp != q_seg / P.Wp) continue;
-        const bool inside = interior(q, P.H, P.W, P.Wp);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const size_t o0 = (size_t)(m0 + wm + mi * 32 + 4 * lhi) * P.plane + q;
-            // independent loads of all 16 rows first, then the 16 stores (no load -> store -> load chains)
-            float prev[16], gate[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                if (FLAGS & SM_EPI_ADD) prev[r] = P.out[o];
-                if ((FLAGS & SM_EPI_RELU_MASK) && !GRAM) gate[r] = P.gate[o];
-            }
-            if constexpr (GRAM) {   // (MI == 1) the gate bits of this lane's 16 rows: byte g = channels wm + 8 g + 0..7
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned b8 = Gs_gate_byte(smem4, (wm / 8 + g) * BN + wn + nj * 32 + l31, 2 * (GPH / 8) * BN);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) gate[4 * g + k] = ((b8 >> (4 * lhi + k)) & 1u) ? 1.f : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * P.plane;
-                float v = acc[mi][nj][r];
-                v *= out_scale;
-                if (FLAGS & SM_EPI_BIAS_RELU) v = fmaxf(v + bias4[mi][r >> 2][r & 3], 0.f);
-                if (FLAGS & SM_EPI_ADD) v += prev[r];
-                if constexpr (GRAM) v += accg[nj][r] * g_oscale;
-                if (FLAGS & SM_EPI_RELU_MASK) v = (gate[r] > 0.f) ? v : 0.f;
-                v = inside ? v : 0.f;
-                P.out[o] = v;
-                vmax = fmaxf(vmax, fabsf(v));
-            }
-        }
-    }
-    return vmax;
+    return fmaxf(vmax, conv_split_store_tile<BM, BN, WGM, WGN, FLAGS, RES>(P, qs, live, acc, m0, out_scale, bias4, accg, g_oscale,
+                                                                            reinterpret_cast<const unsigned char*>(smem4 + 2 * (GPH / 8) * BN)));
 }
 
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool UNPOOL = false, bool RES = false>
@@ -671,7 +696,7 @@ void conv3x3_split_kernel(ConvArgs a) {
 
     if constexpr (RES) {
         constexpr int RP = SM_RES_RP;
-        constexpr int RGRP = 8;                          // (chunk, k-group) groups of eight channels in a 64-channel phase
+        constexpr int RGRP = SM_RES_PHASE / 8;           // (chunk, k-group) groups of eight channels in a phase
         // Staging tasks: (group of 8 channels, window row r, block of four consecutive positions) - 8 x 6 x 9 = 432 per
         // phase, two per thread. A task loads its four positions of each channel with ONE 16-byte load (un-pooling input:
         // its two pooled elements with one 8-byte load + the codes of both) and builds the four positions' 8-channel units
@@ -688,7 +713,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int k = 0; k < RU; ++k) {
             const int t = tid + 256 * k;
             r_on[k] = t < RT;
-            const int tt = r_on[k] ? t : tid;            // (idle tasks load a valid address and store nothing)
+            const int tt = r_on[k] ? t : t % RT;         // (idle tasks repeat a task's loads and store nothing)
             const int grp = tt / (SM_RES_ROWS * RCB), rem = tt - grp * (SM_RES_ROWS * RCB);
             const int r = rem / RCB, cb = rem - r * RCB;
             if constexpr (UNPOOL) {
@@ -724,7 +749,7 @@ void conv3x3_split_kernel(ConvArgs a) {
         for (int t = 0; t < AD; ++t) SM_LOAD_A(t, 0);
         // n-tile i of the wave = segment wn / 32 + i = window row wn / 32 + i + ky of tap row ky
         const f32x4* b_frag = Rs + lhi * RP + (wn / 32) * SEGP + l31;
-        const int n_phases = a.Cin_pad / 64;
+        const int n_phases = a.Cin_pad / SM_RES_PHASE;
         for (int ph = 0; ph < n_phases; ++ph) {
             if (ph > 0) __syncthreads();                 // the previous phase's last fragment reads
             {
@@ -733,13 +758,13 @@ void conv3x3_split_kernel(ConvArgs a) {
                     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
                     f32x2_ rb[RU][8];
                     u32x2_ rc[RU];
-                    const int sc_ = ph * 64 * up_plane * 4;
+                    const int sc_ = ph * SM_RES_PHASE * up_plane * 4;
 #pragma unroll
                     for (int k = 0; k < RU; ++k) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
                             rb[k][c] = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(gp_rsrc, r_src[k], sc_ + c * up_plane * 4, 0));
-                        rc[k] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(code_rsrc, r_code[k], ph * 8 * up_plane * 4, 0));
+                        rc[k] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(code_rsrc, r_code[k], ph * (SM_RES_PHASE / 8) * up_plane * 4, 0));
                     }
 #pragma unroll
                     for (int k = 0; k < RU; ++k)
@@ -765,7 +790,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         }
                 } else {
                     f32x4 rb[RU][8];
-                    const int so_ = ph * 64 * P.plane * 4;
+                    const int so_ = ph * SM_RES_PHASE * P.plane * 4;
 #pragma unroll
                     for (int k = 0; k < RU; ++k)
 #pragma unroll
@@ -796,11 +821,11 @@ void conv3x3_split_kernel(ConvArgs a) {
             for (int s = 0; s < NP; ++s)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) fb[i][s] = b_frag[s * 2 * RP + i * SEGP];
-            for (int cc = 0; cc < 4; ++cc) {
-                const int ch = ph * 4 + cc;
+            for (int cc = 0; cc < SM_RES_CC; ++cc) {
+                const int ch = ph * SM_RES_CC + cc;
                 const int ch_next = ch + 1 < n_chunks ? ch + 1 : ch;   // (loads stay unconditional: see the ring loop)
                 const f32x4* bc = b_frag + cc * 4 * RP;
-                const f32x4* bn = b_frag + (cc < 3 ? cc + 1 : cc) * 4 * RP;
+                const f32x4* bn = b_frag + (cc < SM_RES_CC - 1 ? cc + 1 : cc) * 4 * RP;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     // the next stage's fragments are read under this stage's MFMAs
@@ -947,7 +972,7 @@ void conv3x3_split_kernel(ConvArgs a) {
                         acc[mi][j][r] * out_scale;   // power of two: exact
         return;
     }
-    const float vmax = conv_split_epilogue<BM, BN, WGM, WGN, FLAGS, RES>(a, P, qs, live, acc, m0, out_scale, a.bias, smem4);
+    const float vmax = conv_split_epilogue<BM, BN, WGM, WGN, FLAGS, RES, (RES && SM_RES_PHASE == 32) ? 32 : 64>(a, P, qs, live, acc, m0, out_scale, a.bias, smem4);
     record_amax(a.amax_out, vmax, amax_seen);
 }
 

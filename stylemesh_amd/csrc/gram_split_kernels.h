@@ -215,83 +215,115 @@ __device__ __forceinline__ void gram_backward_body(const GramBwdProb& G, const i
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
     if (nlive > 0) {
-        const int n_chunks = C / (16 * KS);
-        const int n_stages = n_chunks * nlive;   // even: n_chunks is 2, 4, 8 or 16
+        // Round 6: a stage of the B operand = a 32-channel chunk of F, scaled and split ONCE whatever the number of live
+        // masks; a mask is applied where a wave reads its fragments (a column of the MFMA = a position: the lane's own two
+        // mask values select the fragment or zeros). Rounds 2-5 staged m_k F per (chunk, mask): on a tile both masks touch
+        // - 30 % of relu3_1's, 50-65 % of relu4_1's / relu5_1's - every load, conversion, LDS store and barrier twice.
+        // The operand values, and the order (chunk, mask, k-step) in which their products reach an accumulator, are the
+        // same: the sums keep their bits (the conv epilogues' SM_EPI_GRAM form reproduces them).
+        const int n_chunks = C / (16 * KS);      // 2, 4, 8 or 16
         const int kfix = live0 ? 0 : 1;
         const float* bsrc = feat + (size_t)b_kg * 8 * plane + q0 + b_px;
         const int a_off = lhi * C + m0 + wm + l31;
+        // this lane's mask values at its NJ columns, as two bit sets
+        unsigned keep0 = 0u, keep1 = 0u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = q0 + wn + j * 32 + l31;
+            const bool in = q < q_end;
+            keep0 |= ((in && mask0[in ? q : q0] != 0.f) ? 1u : 0u) << j;
+            keep1 |= ((in && mask1 && mask1[in ? q : q0] != 0.f) ? 1u : 0u) << j;
+        }
         f32x4 ra[2][KS][1][GNP];
-        float rb[2][KS][8];
-        // stage s -> (chunk, mask); beyond the last stage the last one is re-read (unconditional loads keep the
-        // compiler's vmcnt bookkeeping exact, see conv_split_kernel.h)
-#define SM_STAGE_OF(s_, chunk_, k_)                                                         \
-    const int sc_ = min((s_), n_stages - 1);                                                \
-    const int k_ = nlive == 2 ? (sc_ & 1) : kfix;                                           \
-    const int chunk_ = nlive == 2 ? (sc_ >> 1) : sc_;
-#define SM_LOAD_A(set_, s_)                                                                 \
+        float rb[KS][8];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define SM_LOAD_A(set_, chunk_, k_)                                                         \
     {                                                                                       \
-        SM_STAGE_OF(s_, chunk_, k_)                                                         \
-        const f32x4* p_ = (k_ ? P1 : P0) + (size_t)chunk_ * KS * 2 * GNP * C + a_off;        \
+        const f32x4* p_ = ((k_) ? P1 : P0) + (size_t)(chunk_) * KS * 2 * GNP * C + a_off;    \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
             _Pragma("unroll") for (int part = 0; part < GNP; ++part)                         \
                 ra[set_][ks][0][part] = p_[(ks * 2 * GNP + part * 2) * C];                   \
     }
-#define SM_LOAD_B(set_, s_)                                                                 \
+    // (beyond the last chunk the last one is re-read: unconditional loads keep the compiler's vmcnt bookkeeping exact,
+    // see conv_split_kernel.h)
+#define SM_LOAD_B(chunk_)                                                                   \
     {                                                                                       \
-        SM_STAGE_OF(s_, chunk_, k_)                                                         \
-        (void)k_;                                                                           \
-        const float* p_ = bsrc + (size_t)chunk_ * 16 * KS * plane;                          \
+        const float* p_ = bsrc + (size_t)min((chunk_), n_chunks - 1) * 16 * KS * plane;     \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                   \
-            _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[set_][ks][c] = side_load(p_ + (size_t)(ks * 16 + c) * plane); \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) rb[ks][c] = side_load(p_ + (size_t)(ks * 16 + c) * plane); \
     }
-#define SM_STORE_B(set_, s_, buf_)                                                          \
+#define SM_STORE_B(buf_)                                                                    \
     {                                                                                       \
-        SM_STAGE_OF(s_, chunk_, k_)                                                         \
-        (void)chunk_;                                                                       \
-        const float mv_ = k_ ? mv1 : mv0;                                                   \
-        float sm_[8];   /* the operand scale where this position's mask is set, 0 elsewhere */ \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) sm_[c] = (mv_ != 0.f) ? f_scale : 0.f; \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
             f32x4 v_[GNP];                                                                   \
-            masked_parts(rb[set_][ks], sm_, v_);                                \
+            float y_[8];                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 8; ++c) y_[c] = rb[ks][c] * f_scale;      \
+            /* (a stale value of a dead position may leave fp16's range: clamped - the mask drops it anyway) */ \
+            split2x8(y_, v_[0], v_[1]);                                                     \
             f32x4* d_ = &Bs[buf_][ks * 2 * GNP * BN + b_kg * BN + b_px];                     \
             _Pragma("unroll") for (int part = 0; part < GNP; ++part) d_[2 * part * BN] = v_[part]; \
         }                                                                                   \
     }
-#define SM_STAGE(s_, par_)                                                                  \
+    // the MFMAs of (chunk in buffer buf_, mask keep_) with the A fragments of set_
+#define SM_MFMAS(buf_, set_, keep_)                                                         \
     {                                                                                       \
-        SM_STORE_B(1 - (par_), (s_) + 1, 1 - (par_))                                        \
-        SM_LOAD_B(1 - (par_), (s_) + 3)   /* back into the set just stored: two stages of lead */ \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                 \
             f32x4 fa[1][GNP], fb[NJ][GNP];                                                    \
-            const f32x4* bf_ = &Bs[par_][ks * 2 * GNP * BN + lhi * BN + wn + l31];           \
+            const f32x4* bf_ = &Bs[buf_][ks * 2 * GNP * BN + lhi * BN + wn + l31];           \
             _Pragma("unroll") for (int part = 0; part < GNP; ++part) {                       \
-                fa[0][part] = ra[par_][ks][0][part];                                        \
-                _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb[j][part] = bf_[part * 2 * BN + j * 32]; \
+                fa[0][part] = ra[set_][ks][0][part];                                        \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j)                              \
+                    fb[j][part] = ((keep_) >> j) & 1u ? bf_[part * 2 * BN + j * 32] : zero4; \
             }                                                                               \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) mfma_parts(acc[0][j], fa[0], fb[j]); \
         }                                                                                   \
+    }
+        // chunk c lives in buffer c & 1; while its stage(s) run, chunk c + 1 is converted into the other buffer and
+        // chunk c + 2 loaded into the registers just stored
+        auto pipeline = [&](auto two_c) {
+            constexpr bool TWO = decltype(two_c)::value;
+            const unsigned keepA = TWO ? keep0 : (kfix ? keep1 : keep0);
+            const int kA = TWO ? 0 : kfix;
+            SM_LOAD_B(0)
+            SM_LOAD_A(0, 0, kA)
+            if (TWO) {
+                SM_LOAD_A(1, 0, 1)
+            } else {
+                SM_LOAD_A(1, min(1, n_chunks - 1), kA)
+            }
+            SM_STORE_B(0)
+            SM_LOAD_B(1)
+            __syncthreads();
+#define SM_CHUNK(c_, buf_)                                                                  \
+    {                                                                                       \
+        SM_STORE_B(1 - (buf_))                                                              \
+        SM_LOAD_B((c_) + 2)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        SM_LOAD_A(par_, (s_) + 2)                                                           \
+        if (TWO) {                                                                          \
+            SM_MFMAS(buf_, 0, keep0)                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            SM_LOAD_A(0, min((c_) + 1, n_chunks - 1), 0)                                    \
+            SM_MFMAS(buf_, 1, keep1)                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            SM_LOAD_A(1, min((c_) + 1, n_chunks - 1), 1)                                    \
+        } else {                                                                            \
+            SM_MFMAS(buf_, buf_, keepA)                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            SM_LOAD_A(buf_, min((c_) + 2, n_chunks - 1), kA)                                \
+        }                                                                                   \
         __syncthreads();                                                                    \
     }
-        SM_LOAD_B(0, 0)
-        SM_LOAD_B(1, 1)
-        SM_LOAD_A(0, 0)
-        SM_LOAD_A(1, 1)
-        SM_STORE_B(0, 0, 0)
-        SM_LOAD_B(0, 2)
-        __syncthreads();
-        for (int s = 0; s < n_stages; s += 2) {
-            SM_STAGE(s, 0)
-            SM_STAGE(s + 1, 1)
-        }
-#undef SM_STAGE_OF
+            for (int c = 0; c < n_chunks; c += 2) {      // (n_chunks is even)
+                SM_CHUNK(c, 0)
+                SM_CHUNK(c + 1, 1)
+            }
+#undef SM_CHUNK
+        };
+        if (nlive == 2) pipeline(std::true_type{}); else pipeline(std::false_type{});
 #undef SM_LOAD_A
 #undef SM_LOAD_B
 #undef SM_STORE_B
-#undef SM_STAGE
+#undef SM_MFMAS
     }
     // epilogue: 32x32 C/D layout, column (position) = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float vmax = 0.f;
