@@ -18,7 +18,6 @@
 #include "conv_common.h"
 #include "conv_tail.h"
 #include "conv_split_kernel.h"
-#include "conv_resident_pipe.h"
 
 #ifndef SM_SPLIT2_BN256
 #define SM_SPLIT2_BN256 1   // fp16x2, Cout % 128 != 0: 64 x 256 tiles instead of 64 x 128
@@ -678,55 +677,27 @@ int sm_abi_version(void) { return 11; }
 }  // extern "C"
 // SM_LIST_QUADS: the list holds vertical quads of segments and the launch has 64 output channels - the resident-input
 // kernel (conv_split_kernel.h, RES). fp32 planes only.
-// Launches of at least SM_RES_PIPE_MIN quads (default: two rounds of the chip's 768 block slots; 0 = never) take the
-// persistent, cross-tile pipelined form of the kernel (conv_resident_pipe.h) - same bits -, whose tile counters are the
-// last SM_PIPE_COUNTER_WORDS words of the caller's workspace, zeroed on the stream before the launch.
 template <int FLAGS, bool UNPOOL>
-static int launch_conv_resident(sm::ConvArgs& a, int n_list, size_t ws_floats, hipStream_t s) {
-    const char* const pm = getenv("SM_RES_PIPE_MIN");   // (read per launch: tests switch it inside one process)
-    const int pipe_min = pm ? atoi(pm) : 2 * sm::SM_PIPE_SLOTS_PER_CU * sm::SM_NUM_CU;
-    float* const ws = a.ws;
+static int launch_conv_resident(sm::ConvArgs& a, int n_list, hipStream_t s) {
     a.ws = nullptr;
-    {
-        const int n_tiles = n_list / 4;
-        if (pipe_min > 0 && n_tiles >= pipe_min && n_tiles >= 8 && ws != nullptr && ws_floats >= (size_t)sm::SM_PIPE_COUNTER_WORDS &&
-            n_list % 4 == 0 && a.Cin_pad % 64 == 0) {
-            a.m_tiles = 1;
-            a.n_tiles = n_tiles;
-            a.list_segments = 1;
-            a.n_whole = n_tiles;
-            a.splits = 1;
-            a.chunks_per_split = a.Cin_pad / 16;
-            a.tile_counter = reinterpret_cast<unsigned*>(ws + ws_floats - sm::SM_PIPE_COUNTER_WORDS);
-            hipError_t e = hipMemsetAsync(a.tile_counter, 0, sm::SM_PIPE_COUNTER_WORDS * sizeof(unsigned), s);
-            if (e != hipSuccess) return (int)e;
-            // (SM_RES_PIPE_BLOCKS: tests walk many quads per block on small planes with it)
-            const char* const pb = getenv("SM_RES_PIPE_BLOCKS");
-            const int slots = pb ? std::max(8, atoi(pb) & ~7) : sm::SM_PIPE_SLOTS_PER_CU * sm::SM_NUM_CU;
-            const int grid = std::min(slots, n_tiles & ~7);
-            hipLaunchKernelGGL((sm::conv3x3_respipe_kernel<FLAGS, UNPOOL>), dim3(grid), dim3(256), sm::conv_respipe_lds_bytes((FLAGS & SM_EPI_GRAM) != 0), s, a);
-            SM_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     return sm::launch_conv<64, 128, 16, 2, 2, FLAGS, true, UNPOOL, true>(a, n_list, 0, s);
 }
-static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
+static int conv_dispatch_resident(sm::ConvArgs& a, int n_list, int flags, bool unpool, hipStream_t s) {
     if (a.Cout != 64 || a.Cin_pad % 64 != 0 || a.tile_list == nullptr) return (int)hipErrorInvalidValue;
     if (unpool) {
         switch (flags) {
-            case SM_EPI_RELU_MASK | SM_EPI_GRAM: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_GRAM, true>(a, n_list, ws_floats, s);
-            case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, true>(a, n_list, ws_floats, s);
-            case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, ws_floats, s);
+            case SM_EPI_RELU_MASK | SM_EPI_GRAM: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_GRAM, true>(a, n_list, s);
+            case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, true>(a, n_list, s);
+            case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, true>(a, n_list, s);
             default: return (int)hipErrorInvalidValue;
         }
     }
     switch (flags) {
-        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return launch_conv_resident<SM_EPI_BIAS_RELU | SM_EPI_POOL, false>(a, n_list, ws_floats, s);
-        case SM_EPI_BIAS_RELU: return launch_conv_resident<SM_EPI_BIAS_RELU, false>(a, n_list, ws_floats, s);
-        case 0: return launch_conv_resident<0, false>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, false>(a, n_list, ws_floats, s);
-        case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, false>(a, n_list, ws_floats, s);
+        case SM_EPI_BIAS_RELU | SM_EPI_POOL: return launch_conv_resident<SM_EPI_BIAS_RELU | SM_EPI_POOL, false>(a, n_list, s);
+        case SM_EPI_BIAS_RELU: return launch_conv_resident<SM_EPI_BIAS_RELU, false>(a, n_list, s);
+        case 0: return launch_conv_resident<0, false>(a, n_list, s);
+        case SM_EPI_RELU_MASK: return launch_conv_resident<SM_EPI_RELU_MASK, false>(a, n_list, s);
+        case SM_EPI_RELU_MASK | SM_EPI_ADD: return launch_conv_resident<SM_EPI_RELU_MASK | SM_EPI_ADD, false>(a, n_list, s);
         default: return (int)hipErrorInvalidValue;
     }
 }
@@ -758,7 +729,7 @@ static int conv_dispatch_flags_split2_t(sm::ConvArgs& a, int n_list, int flags, 
 }
 extern "C" {
 static int conv_dispatch_flags_split2(sm::ConvArgs& a, int n_list, int flags, size_t ws_floats, bool unpool, hipStream_t s) {
-    if (flags & SM_LIST_QUADS) return conv_dispatch_resident(a, n_list, flags & ~SM_LIST_QUADS, ws_floats, unpool, s);
+    if (flags & SM_LIST_QUADS) return conv_dispatch_resident(a, n_list, flags & ~SM_LIST_QUADS, unpool, s);
     return conv_dispatch_flags_split2_t(a, n_list, flags, ws_floats, unpool, s);
 }
 

@@ -61,9 +61,6 @@ struct ConvArgs {
     const float* amax_in;
     float* amax_out;
     float w_scale_inv;
-    // pipelined resident kernel (conv_resident_pipe.h): the XCDs' tile counters, SM_PIPE_COUNTER_WORDS words zeroed on the
-    // launch's stream before the launch (the tail of the caller's split-K workspace)
-    unsigned* tile_counter;
 };
 
 constexpr int SM_NUM_CU = 256;

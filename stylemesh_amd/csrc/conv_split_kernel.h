@@ -34,7 +34,7 @@
 #define SM_SPLIT_PREFETCH_B 1  // read the next stage's activation fragments under this stage's MFMAs
 #endif
 #ifndef SM_SPLIT_WAVES64
-#define SM_SPLIT_WAVES64 3
+#define SM_SPLIT_WAVES64 4     // resident waves per SIMD of the 64 x 128 (resident-input) variant: 118 VGPRs with 32-channel phases
 #endif
 
 namespace sm {
@@ -95,7 +95,6 @@ __device__ __forceinline__ float pow2_scale_for(float amax, float& inv) {
     return __builtin_bit_cast(float, (unsigned)(268 - ex) << 23);    // 2^(141 - ex)
 }
 
-// the 64-row variant needs 129 VGPRs: three of its waves fit a SIMD (SM_SPLIT_WAVES64)
 #ifndef SM_SPLIT2_AD
 #define SM_SPLIT2_AD 3
 #endif
@@ -111,13 +110,19 @@ constexpr int conv_split_waves(int BM, int BN) {
 // 3 x 34 / 32 = 3.2 staged positions per output position and 16 channels - and spends twice the staging per MFMA of the
 // 128-row tile. Here a tile is a QUAD: four vertically adjacent 32-position segments (list entries q, q + Wp, q + 2 Wp,
 // q + 3 Wp; sm_cover_segments quad modes), and the block stages the (4 + 2) rows x 34 positions it needs of 64 input
-// channels ONCE, already scaled and split: 6 x 34 x 64 channels x 2 parts x 2 B = 51 KB (three blocks per CU), 1.59 staged
+// channels ONCE, already scaled and split: 6 x 34 x 64 channels x 2 parts x 2 B = 51 KB (in phases, see below), 1.59 staged
 // positions per output position. The 36 stages of a 64-channel phase then are MFMAs, weight-fragment loads and LDS
 // fragment reads only - a tap shift (ky, kx) is the offset ky * 34 + kx - with no barrier and no conversion inside the
 // loop; Cin = 128 takes two phases. Same chunk / tap / product order as the ring kernel: the sums have its bits.
 constexpr int SM_RES_ROWS = 6, SM_RES_RP = SM_RES_ROWS * 34;                    // staged rows / positions of a quad
+// Round 6: a PHASE stages 32 channels (26 KB, one staging task per thread: 118 VGPRs) instead of 64 (51 KB, 149 VGPRs) - FOUR
+// blocks per CU instead of three; the launches -4.5 % (profiles/r06/resident_phase32.txt), c3 +0.5 %. (What these launches wait
+// for is neither the matrix pipe nor one latency chain: a persistent, cross-tile pipelined form - list entry, loads, weight
+// ring and claim of the next quad under the current quad's loop - was built, is bit-identical and changes nothing; with every
+// MFMA removed the launches get SLOWER, weight-fragment loads are worth 11-19 %, staging 16-28 %, the epilogue 12-51 %:
+// profiles/r06/respipe_ablation.txt, LABNOTES 10.6.)
 #ifndef SM_RES_PHASE
-#define SM_RES_PHASE 64   // channels staged per phase (64, or 32: half the LDS - room for a fourth block per CU, see SM_SPLIT_WAVES64)
+#define SM_RES_PHASE 32   // channels staged per phase (32 or 64)
 #endif
 constexpr int SM_RES_CC = SM_RES_PHASE / 16;                                    // 16-channel chunks of a phase
 constexpr size_t conv_resident_lds_bytes() { return (size_t)(SM_RES_CC * 2 * 2 * SM_RES_RP) * 16; }   // [chunk][part][k-group][RP] units
@@ -194,8 +199,7 @@ __device__ __forceinline__ float conv_split_store_tile(const ConvProblem& P, con
 
 // ---- the epilogue of a WHOLE tile (same 32x32 C/D layout as conv3x3_mfma_kernel: column = lane & 31, row = (r & 3) +
 // 8 * (r >> 2) + 4 * (lane >> 5); column tile j of the wave is in acc[.][j]): scale, bias / ReLU / gate / addend, the pooling
-// or the Gram epilogue, stores. Shared by the ring / resident kernel below and by the pipelined resident kernel
-// (conv_resident_pipe.h). `bias`: the launch's bias vector (any address space); `smem4`: LDS the Gram epilogue may stage its
+// or the Gram epilogue, stores. `bias`: the launch's bias vector; `smem4`: LDS the Gram epilogue may stage its
 // operand in, GPH channels at a time ((2 * GPH / 8 * BN) * 16 + (BM / 8) * BN bytes, free of readers; the sums do not depend
 // on GPH). Returns the lane's max |output|.
 template <int BM, int BN, int WGM, int WGN, int FLAGS, bool RES, int GPH = 64>

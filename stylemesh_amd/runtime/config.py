@@ -32,11 +32,6 @@ SWITCHES = {
                                 "neutral on the reference's index_repeat-20 schedules (profiles/r05/resident_views.txt): opt-in"),
     "SM_CONV_SPLIT_PENALTY": ("3", "tuning", "(C library) cost of a K-split tail's second pass in tile-chunks, in the split-count "
                               "model (c2 +0.6 % at 2-4, -5 % at 8: profiles/r04/split_penalty_ab.txt)"),
-    "SM_RES_PIPE_MIN": ("1536", "tuning", "(C library) quad count from which a 64-output-channel launch takes the persistent, cross-tile "
-                        "pipelined resident kernel (csrc/conv_resident_pipe.h; same bits); default = two rounds of the chip's 768 "
-                        "block slots; 0 = never (the one-quad-per-block resident kernel of round 5)"),
-    "SM_RES_PIPE_BLOCKS": ("768", "diagnostic", "(C library) resident blocks of the pipelined resident kernel (a multiple of 8; default three per "
-                           "CU); tests set 16 so that a block walks many quads of a small plane"),
     "SM_ADAM_DENSE_WALK": ("0", "diagnostic", "(C library) 1 = the flagged update walks every tile of the arena and asks each chunk's flag "
                            "(rounds 2-5) instead of compacting a span's flags first (adam_sparse_kernel, round 6; same bits of p, m, v)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),

@@ -139,19 +139,8 @@ def _needs(hws, pooled, seed):
 CASES = [[(37, 50)], [(150, 201), (64, 85)], [(256, 341)], [(6, 5), (40, 53)]]
 
 
-def _pipe(monkeypatch, pipe):
-    """The one-tile-per-block resident kernel, or its persistent pipelined form (csrc/conv_resident_pipe.h) from 8 quads on.
-    Returns the workspace of the launches: too small for split-K slabs (the ring kernel runs whole tiles: the same sums),
-    large enough for the pipelined kernel's tile counters."""
-    monkeypatch.setenv("SM_RES_PIPE_MIN", "8" if pipe else "0")
-    if pipe == "narrow":                         # sixteen blocks: every block walks many quads
-        monkeypatch.setenv("SM_RES_PIPE_BLOCKS", "16")
-    return torch.zeros(256, device="cuda")
-
-
-@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws", CASES)
-def test_resident_forward_with_pooling_epilogue(hws, pipe, monkeypatch):
+def test_resident_forward_with_pooling_epilogue(hws, monkeypatch):
     require_gpu()
     import torch.nn.functional as F
     from stylemesh_amd.runtime import hip, ops
@@ -167,7 +156,7 @@ def test_resident_forward_with_pooling_epilogue(hws, pipe, monkeypatch):
         x[:, : x.shape[1] // 3] = 0              # closed windows (code 4) and ties
     ins = [FMap(64, H, W).from_dense(x.cuda()) for x, (H, W) in zip(xs, hws)]
     amax_in = ops.new_amax("cuda", max(float(x.abs().max()) for x in xs))
-    tiny = _pipe(monkeypatch, pipe)
+    tiny = torch.zeros(4, device="cuda")
     monkeypatch.setattr(ops, "splitk_workspace", lambda device: tiny)      # the ring kernel on whole tiles: same sums
 
     def run(lst, quads):
@@ -217,9 +206,8 @@ def test_resident_forward_with_pooling_epilogue(hws, pipe, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["fwd", "plain128", "gate_unpool", "gate_add_unpool", "gate_add", "gate"])
-@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws", CASES)
-def test_resident_kernel_matches_ring_kernel(variant, hws, pipe, monkeypatch):
+def test_resident_kernel_matches_ring_kernel(variant, hws, monkeypatch):
     require_gpu()
     import torch.nn.functional as F
     from stylemesh_amd.runtime import hip, ops
@@ -252,7 +240,7 @@ def test_resident_kernel_matches_ring_kernel(variant, hws, pipe, monkeypatch):
         gates.append(FMap(64, H, W).from_dense(F.relu(torch.randn(64, H, W)).cuda()) if flags & hip.EPI_RELU_MASK else None)
         addends.append(torch.randn(64, H, W).cuda() if flags & hip.EPI_ADD else None)
     amax_in = ops.new_amax("cuda", max(float(i.planes.abs().max()) for i in ins))
-    tiny = _pipe(monkeypatch, pipe)
+    tiny = torch.zeros(4, device="cuda")
     monkeypatch.setattr(ops, "splitk_workspace", lambda device: tiny)
 
     def run(lst, quads):
@@ -287,9 +275,8 @@ def test_resident_kernel_matches_ring_kernel(variant, hws, pipe, monkeypatch):
     assert float(am.max()) == true_max
 
 
-@pytest.mark.parametrize("pipe", [False, True, "narrow"])
 @pytest.mark.parametrize("hws,two_masks", [([(37, 50)], True), ([(150, 201), (64, 85)], True), ([(40, 53)], False)])
-def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
+def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
     """conv1_2's data gradient as the step launches it: un-pooled input, relu1_1's Gram backward in the epilogue, its ReLU
     gate from the staged operand - against the two-launch form on the ring kernel (Gram backward, then EPI_ADD)."""
     require_gpu()
@@ -335,9 +322,6 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
         mp.setattr(ops, "splitk_workspace", lambda device: tiny)
         ops.conv3x3_grouped([(d, r, f, c) for d, r, f, c in zip(dps, ref, feats, codes)], wd, None,
                             hip.EPI_RELU_MASK | hip.EPI_ADD, None, 1.0, wd2, amax_in, ops.new_amax("cuda"))
-    monkeypatch.setenv("SM_RES_PIPE_MIN", "8" if pipe else "0")
-    if pipe == "narrow":
-        monkeypatch.setenv("SM_RES_PIPE_BLOCKS", "16")
     needs = _needs(hws, False, 13)
     lst = torch.cat([_quad_cover(ops, hip, nd, g) for g, nd in enumerate(needs)])
     out = [FMap(C, H, W) for (H, W) in hws]
@@ -358,10 +342,7 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, pipe, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"STYLEMESH_FUSE_POOL_FWD": "0"}, {"STYLEMESH_FUSE_POOL_BWD": "0"},
-                                 {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"},
-                                 {"SM_RES_PIPE_MIN": "8"}, {"SM_RES_PIPE_MIN": "8", "STYLEMESH_FUSE_GRAM_BWD": "0"},
-                                 {"SM_RES_PIPE_MIN": "8", "STYLEMESH_SIDE_STREAMS": "0"},
-                                 {"SM_RES_PIPE_MIN": "8", "SM_RES_PIPE_BLOCKS": "16"}])
+                                 {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"}])
 def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
     """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses and
     the same GRADIENT after one forward + backward from the same random texture (tests/stepcmp.py) - up to the operand
