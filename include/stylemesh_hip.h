@@ -52,7 +52,8 @@ extern "C" {
                             * entries really are q, q + Wp, q + 2 Wp, q + 3 Wp of ONE problem (or padding behind a live
                             * first entry); the quad's first row is image row 4 Y; with unpool_code the first column is
                             * even. The kernel reads window rows of 36 floats with 16-byte loads: behind the last channel's
-                            * plane it relies on the SM_FMAP_GUARD floats every feature-map buffer must have. */
+                            * plane it relies on the SM_FMAP_GUARD floats every feature-map buffer must have. (The Python host checks a list
+                            * against these on request: ops.check_quad_list, STYLEMESH_VALIDATE_LISTS=1.) */
 
 /* ---- layout helpers (host, pure functions) -------------------------------------------------------- */
 int sm_fmap_row_stride(int W);        /* Wp */

@@ -32,6 +32,8 @@ SWITCHES = {
                                 "neutral on the reference's index_repeat-20 schedules (profiles/r05/resident_views.txt): opt-in"),
     "SM_CONV_SPLIT_PENALTY": ("3", "tuning", "(C library) cost of a K-split tail's second pass in tile-chunks, in the split-count "
                               "model (c2 +0.6 % at 2-4, -5 % at 8: profiles/r04/split_penalty_ab.txt)"),
+    "STYLEMESH_VALIDATE_LISTS": ("0", "diagnostic", "1 = every quad list is copied to the host and checked against the preconditions of "
+                                 "SM_LIST_QUADS before its launch (ops.check_quad_list: a sync per launch, debugging only)"),
     "SM_ADAM_DENSE_WALK": ("0", "diagnostic", "(C library) 1 = the flagged update walks every tile of the arena and asks each chunk's flag "
                            "(rounds 2-5) instead of compacting a span's flags first (adam_sparse_kernel, round 6; same bits of p, m, v)"),
     "SM_GRAM_TARGET_BLOCKS": ("(library default)", "experiment", "(C library) position-range count of the grouped Gram forward"),

@@ -5,6 +5,7 @@ import os
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import hip
@@ -443,6 +444,8 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
 
     use_split2 = wt2 is not None and amax_in is not None and CONV_MODE == "split2"
     assert not quads or (use_split2 and tile_list is not None and cout == 64), "quad lists: fp16x2 kernel, 64 output channels"
+    if quads and os.environ.get("STYLEMESH_VALIDATE_LISTS", "0") == "1":
+        check_quad_list(tile_list, [(p[1].H, p[1].W) for p in problems], unpool=len(problems[0]) > 3 and problems[0][3] is not None)
 
     def run():
         ws = splitk_workspace(wt.device)
@@ -462,6 +465,38 @@ def conv3x3_grouped(problems, wt: torch.Tensor, bias, flags: int, tile_list=None
         wbytes = wt2[0].numel() * 2 if use_split2 else wt.numel() * 4
         CONV_TIMER.launch(run, flops * active_fraction, tag, nbytes * active_fraction + wbytes,
                           f"{cin_pad:3d}->{cout:3d} flags {flags} levels {len(problems)} active {active_fraction:.2f}")
+
+
+def check_quad_list(tile_list, hws, unpool=False):
+    """The preconditions of ``SM_LIST_QUADS`` (include/stylemesh_hip.h), checked on the HOST (a device-to-host copy and a
+    sync: debugging only, ``STYLEMESH_VALIDATE_LISTS=1``): four entries per quad, one problem per quad, the first entry a
+    live segment inside the plane's interior rows, entry i either padding or the first one + i rows; un-pooling launches:
+    first column even, first row a multiple of four. Raises ``ValueError`` - the library itself does not look at the
+    entries and would compute wrong outputs for a list that is not made of quads."""
+    e = tile_list.detach().cpu().numpy().astype("int64")
+    if e.size % 4:
+        raise ValueError(f"quad list of {e.size} entries: not a multiple of four")
+    e = e.reshape(-1, 4)
+    prob, seg = e >> 24, e & 0xFFFFFF
+    if (prob < 0).any() or (prob >= len(hws)).any() or (prob != prob[:, :1]).any():
+        raise ValueError("quad list: a quad's entries name several problems or a problem the launch does not have")
+    pad = seg == 0xFFFFFF
+    if pad[:, 0].any():
+        raise ValueError("quad list: a quad's first entry is padding")
+    for g, (H, W) in enumerate(hws):
+        s = seg[prob[:, 0] == g]
+        if s.size == 0:
+            continue
+        Wp = hip.row_stride(W)
+        live = s != 0xFFFFFF
+        rows = s[:, :1] // Wp - 1
+        if (rows < 0).any() or (rows >= H).any() or (s[:, :1] % Wp < 1).any():
+            raise ValueError(f"quad list, problem {g}: a first segment outside the image rows / left of column 0")
+        want = s[:, :1] + Wp * np.arange(4)[None, :]
+        if ((s != want) & live).any():
+            raise ValueError(f"quad list, problem {g}: a quad's entries are not vertically adjacent segments")
+        if unpool and (((s[:, 0] % Wp - 1) % 2 != 0).any() or (rows[:, 0] % 4 != 0).any()):
+            raise ValueError(f"quad list, problem {g}: un-pooling quads start on even columns of rows 4 Y")
 
 
 def conv3x3_dgrad_c3(dz: FMap, wd: torch.Tensor, out: FMap):

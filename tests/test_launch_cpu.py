@@ -131,3 +131,35 @@ def test_gpus_are_counted_from_the_kfd_topology_without_the_runtime(tmp_path):
     (topo / "5").mkdir()
     (topo / "5" / "properties").write_text("simd_count not-a-number\n")
     assert launch.kfd_gpu_count(str(topo), env={}, dri=str(dri)) is None
+
+
+def test_quad_list_checker_accepts_quads_and_rejects_other_lists():
+    """ops.check_quad_list = the documented preconditions of SM_LIST_QUADS, host side."""
+    import numpy as np
+    import pytest
+    import torch
+    from stylemesh_amd.runtime import hip, ops
+    H, W = 10, 70
+    Wp = hip.row_stride(W)
+    PAD = 0xFFFFFF
+
+    def quad(g, y, x, live=4):
+        q = (y + 1) * Wp + x + 1
+        return [(g << 24) | (q + i * Wp if i < live else PAD) for i in range(4)]
+    good = torch.tensor(quad(0, 0, 0) + quad(0, 4, 32) + quad(0, 8, 2, live=2) + quad(1, 0, 6), dtype=torch.int32)
+    ops.check_quad_list(good, [(H, W), (H, W)])
+    ops.check_quad_list(good, [(H, W), (H, W)], unpool=True)
+    with pytest.raises(ValueError, match="multiple of four"):
+        ops.check_quad_list(good[:-1], [(H, W), (H, W)])
+    with pytest.raises(ValueError, match="several problems"):
+        bad = good.clone(); bad[1] = (1 << 24) | (int(bad[1]) & PAD); ops.check_quad_list(bad, [(H, W), (H, W)])
+    with pytest.raises(ValueError, match="first entry is padding"):
+        bad = good.clone(); bad[0] = PAD; ops.check_quad_list(bad, [(H, W), (H, W)])
+    with pytest.raises(ValueError, match="vertically adjacent"):
+        bad = good.clone(); bad[2] = int(bad[2]) + 4; ops.check_quad_list(bad, [(H, W), (H, W)])
+    with pytest.raises(ValueError, match="even columns"):
+        ops.check_quad_list(torch.tensor(quad(0, 4, 3), dtype=torch.int32), [(H, W)], unpool=True)
+    with pytest.raises(ValueError, match="even columns"):
+        ops.check_quad_list(torch.tensor(quad(0, 2, 4), dtype=torch.int32), [(H, W)], unpool=True)
+    with pytest.raises(ValueError, match="outside the image rows"):
+        ops.check_quad_list(torch.tensor(quad(0, H, 0), dtype=torch.int32), [(H, W)])

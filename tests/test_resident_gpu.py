@@ -342,7 +342,8 @@ def test_resident_kernel_with_gram_epilogue(hws, two_masks, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"STYLEMESH_FUSE_POOL_FWD": "0"}, {"STYLEMESH_FUSE_POOL_BWD": "0"},
-                                 {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"}])
+                                 {"STYLEMESH_FUSE_GRAM_BWD": "0"}, {"STYLEMESH_SIDE_STREAMS": "0"},
+                                 {"STYLEMESH_VALIDATE_LISTS": "1"}])   # (the engine's own quad lists pass ops.check_quad_list)
 def test_engine_step_with_and_without_quad_lists(env, monkeypatch):
     """A multi-level step with the quad lists (resident-input kernel) and with the ring kernel's lists: the same losses and
     the same GRADIENT after one forward + backward from the same random texture (tests/stepcmp.py) - up to the operand
