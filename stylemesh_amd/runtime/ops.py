@@ -759,11 +759,16 @@ def cover_segments(problems):
         arr[i] = hip.CoverProblem(ptr(need), ptr(starts), ptr(count), h, w, int(tag), starts.numel(), int(pair_w), int(quad))
     nbytes = lib.sm_cover_segments_ws_bytes(arr, len(problems))
     dev = problems[0][0].device
-    ws = _COVER_WS.get(dev)
-    if ws is None or ws.numel() < nbytes:    # grow-only scratch (bit images + chunk tables), one per device
+    # grow-only scratch (bit images + chunk tables), one per (device, launch stream) - as the split-K slabs: the view being
+    # prepared ahead on a side stream, the trunk's own view change and a second engine of the process (tests, bench legs) build
+    # lists concurrently, and a scratch shared by two streams gave one of them another plane's bit image (a two-engine test
+    # failed once in nine suite runs before round 6 keyed it by stream)
+    key = (str(dev), hip.stream())
+    ws = _COVER_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
         if ws is not None:
-            torch.cuda.synchronize(dev)      # (launches of another stream may still be using the old one; rare)
-        ws = _COVER_WS[dev] = torch.empty(max(2 * nbytes, 8 << 20), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)      # (enqueued launches may still be using the old one; rare)
+        ws = _COVER_WS[key] = torch.empty(max(2 * nbytes, 8 << 20), dtype=torch.uint8, device=dev)
     hip.check(lib.sm_cover_segments(arr, len(problems), ptr(ws), ws.numel(), hip.stream()), "sm_cover_segments")
 
 

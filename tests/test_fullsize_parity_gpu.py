@@ -437,8 +437,8 @@ def _late_texture(c):
 @pytest.mark.parametrize("seed", [LATE_VIEWS[2], 16], ids=["trained_view", "unseen_view"])
 def test_one_step_matches_oracle_on_a_late_texture(seed, monkeypatch):
     """c3 from the texture 1120 steps and two learning-rate decays into training, on a view the training saw and on one it
-    never saw: the same one-step comparison, the same identification; the split arithmetic adds no flips over the fp32-MFMA
-    arithmetic ON THIS STATE (<= 1.5 x + 2e-4); and the census of the step's fp16x2 operands is recorded (share of elements
+    never saw: the same one-step comparison, the same identification; both arithmetic modes' flip fractions stay below 0.5 %
+    and within 0.3 % of each other ON THIS STATE (the ratio is asserted over all cases, see below); and the census of the step's fp16x2 operands is recorded (share of elements
     > 2^18 below their tensor's bound)."""
     require_gpu()
     from stylemesh_amd.diagnostics import operand_census, summarize
@@ -454,8 +454,14 @@ def test_one_step_matches_oracle_on_a_late_texture(seed, monkeypatch):
     # 5e-5 = a quarter of the tight bound's absolute term)
     entry = _one_step_case("c3", c, seed, view, tex_late, monkeypatch, f"late_c3_seed{seed}", flip_frac_max=0.05,
                            max_err={"split2": 0.25, "f32": 0.25}, outside_tol=5e-5)
+    # Flips are discrete events with large footprints: on ONE late state the two arithmetic modes' fractions scatter both ways
+    # from run to run (six comparisons on three boxes, profiles/r06/README.md: fp16x2 0.02 / 0.05 / 0.06 / 0.09 / 0.16 / 0.19 %
+    # against fp32-MFMA 0.02 / 0.03 / 0.30 / 0.03 / 0.23 / 0.05 %). The RATIO claim (fp16x2 <= 1.5 x fp32-MFMA + 2e-4) is made
+    # where it is statistically meaningful - over all one-step cases of the session, these two included
+    # (test_split_arithmetic_adds_no_flips_over_all_cases); here: both small, and no gap of the size a scale problem would open.
     key = "fraction_of_touched_texels_beyond_tight_bound"
-    assert entry["split2"][key] <= 1.5 * entry["f32"][key] + 2e-4, (entry["split2"][key], entry["f32"][key])
+    assert entry["split2"][key] <= 5e-3 and entry["f32"][key] <= 5e-3, (entry["split2"][key], entry["f32"][key])
+    assert entry["split2"][key] <= entry["f32"][key] + 3e-3, (entry["split2"][key], entry["f32"][key])
     # the operand census of this very step (dense tiles: every stored position is this step's)
     eng = _engine(c, "split2", tex_late, monkeypatch)
     eng.sparse_tiles = False

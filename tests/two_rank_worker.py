@@ -37,6 +37,43 @@ def main():
     else:
         dist.init_process_group("gloo")
     comm = D.make_comm(dist, rank, world, dev)
+    if backend == "gloo" and comm is dist:
+        # TWO PROCESSES ON ONE GPU TAKE TURNS. With kernels of two processes in flight on one MI355X at the same time a kernel
+        # now and then reads a stale 64-byte sector of data its own process wrote a kernel earlier: a plain gather kernel
+        # launched four times on unchanged inputs - one stream, device syncs in between - gave different results in 7 % of
+        # the steps of a stress run; never with one process on the GPU, never when the processes take turns (0 of 288 steps
+        # against 21 of 288: profiles/r06/two_processes_one_gpu.txt). The product runs one process per GPU; this rig does
+        # not, so a rank holds an inter-process lock whenever it may have GPU work in flight and hands it over - after a
+        # device sync - around every blocking collective, which it stages through the host (torch's gloo backend would
+        # otherwise run CUDA copy streams of its own behind the lock's back).
+        import fcntl
+        turn = open(os.path.join(out_dir, "gpu_turn.lock"), "w")
+
+        class HostStaged:
+            ReduceOp = dist.ReduceOp
+
+            def __getattr__(self, name):
+                return getattr(dist, name)
+
+            @staticmethod
+            def all_reduce(t, op=dist.ReduceOp.SUM, async_op=False):
+                h = t.detach().cpu() if t.is_cuda else t
+                torch.cuda.synchronize()
+                fcntl.flock(turn, fcntl.LOCK_UN)
+                dist.all_reduce(h, op=op)
+                fcntl.flock(turn, fcntl.LOCK_EX)
+                if t.is_cuda:
+                    t.copy_(h)
+                return _Done() if async_op else None
+
+        class _Done:
+            def wait(self):
+                return True
+
+            def is_completed(self):
+                return True
+        comm = HostStaged()
+        fcntl.flock(turn, fcntl.LOCK_EX)
     exchange = type(comm).__name__ if comm is not dist else "torch.distributed"
     if backend == "nccl":
         assert exchange == "RcclComm", exchange
@@ -106,7 +143,10 @@ def main():
         from stepcmp import lock, step_deviation
         from stylemesh_amd.runtime.engine import EngineConfig, StepEngine
         engs, reds = {}, {}
-        for kind in ("dense", "sparse"):
+        # (STYLEMESH_TEST_PAIR=dense,dense / sparse,sparse: a reducer against itself - the harness's own noise)
+        pair = os.environ.get("STYLEMESH_TEST_PAIR", "dense,sparse").split(",")
+        for slot, kind0 in zip(("dense", "sparse"), pair):
+            kind = slot
             cfg = EngineConfig(tex_w=TEX, tex_h=TEX, hierarchical=True, n_layers=4, style_weights=STYLE_WEIGHTS,
                                angle_threshold=cfgd["thr"], style_pyramid_mode=cfgd["mode"], gram_mode=cfgd["gram"],
                                use_angle_weight=True, use_depth_scaling=True, loss_weights=dict(LOSS_WEIGHTS),
@@ -114,7 +154,7 @@ def main():
             eng = engs[kind] = StepEngine(cfg, S.seeded_vgg_state(VGG_SEED), device=dev)
             eng.set_style_image(S.style_image(STYLE_SEED, *STYLE_HW))
             assert eng.touched is not None
-            reds[kind] = D.make_grad_reducer(comm, world) if kind == "dense" else D.make_sparse_grad_reducer(comm, world)
+            reds[kind] = D.make_grad_reducer(comm, world) if kind0 == "dense" else D.make_sparse_grad_reducer(comm, world)
         get = lambda i: S.make_view(MULTIVIEW_SEEDS[i], view_hw=SMALL_VIEW_HW, level_hw=SMALL_LEVEL_HW,
                                     level_heights=[40, 64], min_pyramid_depth=0.9, room=S.BoxRoom(SMALL_ROOM))
         devs = []
@@ -252,6 +292,13 @@ def main():
         raise SystemExit(f"unknown mode {mode}")
     if hasattr(comm, "destroy"):
         comm.destroy()
+    if backend == "gloo":
+        torch.cuda.synchronize()
+        try:
+            import fcntl
+            fcntl.flock(turn, fcntl.LOCK_UN)
+        except NameError:
+            pass
     dist.destroy_process_group()
 
 
