@@ -1,4 +1,4 @@
-"""Condense the FETCH_SIZE / WRITE_SIZE PMC summary (tools/pmc_traffic.sh) into profiles/rNN/conv_traffic_<wl>_<tag>.json.
+"""Condense the FETCH_SIZE / WRITE_SIZE PMC summary (tools/profile_round.sh) into profiles/rNN/conv_traffic_<wl>_<tag>.json.
 Usage: traffic_json.py <summary.csv> <workload> <tag: split2|split|f32> <out.json> [min_launches]
 min_launches: only rows (kernel variant x grid size) launched at least that often are counted - with the number of steps
 of the PMC run this selects the STEP's launches and leaves out the one-off launches of set_style_image / set_view.
@@ -33,6 +33,6 @@ if adam is not None:
 json.dump({"workload": wl, "kernel": kern, "launches": launches, "rows_with_at_least_launches": min_launches, "fetch_size_kb_raw": fetch, "write_size_kb": write,
            "fetch_correction": corr, "calibration": cal,
            "hbm_bytes_per_launch": (fetch * corr + write) * 1024 / max(launches, 1),
-           "source": "tools/pmc_traffic.sh (two rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE) + tools/traffic_json.py"},
+           "source": "tools/profile_round.sh (two rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE) + tools/traffic_json.py"},
           open(out, "w"), indent=1)
 print(open(out).read())
