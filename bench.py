@@ -696,7 +696,7 @@ def _run(args):
                               "max) split into 2 fp16 parts = 22 significand bits (3 partial products, fp32 accumulate) - an "
                               "emulation of the fp32 multiply, NOT native fp32: the strict-fp32 number of this run is f32_mode"}
                .get(ops.CONV_MODE, "fp32 throughout (v_mfma_f32_32x32x2_f32 convolutions)")
-               + ("; error vs an fp64 convolution <= the fp32-MFMA kernel's (tests/test_kernels_gpu.py, tools/bench_conv_split.py); "
+               + ("; error vs an fp64 convolution <= the fp32-MFMA kernel's (tests/test_kernels_gpu.py, tools/bench_conv.py); "
                   "STYLEMESH_CONV_MODE=f32 selects the fp32-MFMA kernel (the f32_mode leg)" if ops.CONV_MODE != "f32" else ""),
                "data": "synthetic",
                "config": {"workload": f"{args.workload}: {wl['desc']}",
