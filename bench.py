@@ -744,7 +744,18 @@ def _run(args):
             # (last: the engine's legs are done; the child gets the GPU to itself apart from this process's idle buffers)
             del eng
             torch.cuda.empty_cache()
-            out["scene_schedule"].update(live_schedule_leg(args, wl))
+            live = live_schedule_leg(args, wl)
+            ss = out["scene_schedule"]
+            if live.get("live_schedule_s") is not None:
+                # the whole fixed schedule ran in THIS run: it is the measured figure; the committed record of an earlier
+                # round keeps a key of its own
+                ss["committed_record"] = {k: ss.pop(k) for k in ("measured_schedule_s", "mean_views_per_s", "per_epoch_views_per_s", "source")
+                                          if k in ss}
+                ss["measured_schedule_s"] = live["live_schedule_s"]
+                ss["mean_views_per_s"] = live["live_mean_views_per_s"]
+                ss["per_epoch_views_per_s"] = live["live_epoch_views_per_s"]
+                ss["source"] = live["live_source"]
+            ss.update(live)
         line = json.dumps(out)
     if world > 1:
         if comm is not None and hasattr(comm, "destroy"):
