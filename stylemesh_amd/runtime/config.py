@@ -12,8 +12,8 @@ bench.py or the C sources must be listed here, and every name listed here must s
 
 SWITCHES = {
     # ---- arithmetic / kernels
-    "STYLEMESH_CONV_MODE": ("split2", "mode", "conv arithmetic: split2 = fp16 x 2 operands, 3 products (default); split = bf16 x 3, "
-                            "6 products; f32 = v_mfma_f32_32x32x2_f32 everywhere (bench.py's f32_mode leg, the parity tests' twin)"),
+    "STYLEMESH_CONV_MODE": ("split2", "mode", "conv arithmetic: split2 = fp16 x 2 operands, 3 products (default); "
+                            "f32 = v_mfma_f32_32x32x2_f32 everywhere (bench.py's f32_mode leg, the parity tests' twin)"),
     "STYLEMESH_GRAM_MODE": ("(follows CONV_MODE)", "mode", "the same choice for the Gram forward / backward kernels"),
     "STYLEMESH_FUSE_POOL_BWD": ("1", "tuning", "max-pool backward taken by the data-gradient conv below the pool from argmax codes "
                                 "(+4.5 % on c3, round 2); 0 = pool-backward kernels"),

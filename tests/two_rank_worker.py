@@ -4,9 +4,12 @@
     two_rank_worker.py trainer <out_dir>   MiniTrainer epoch over 5 train views (odd) with index_repeat 2
     two_rank_worker.py dense_vs_sparse <out_dir>   zero-initialised texture, 6 steps, dense and sparse reducer
     two_rank_worker.py pipelined <out_dir>  pipelined exchange + update against exchange-then-update, same state
+    two_rank_worker.py deferred <out_dir>   owner-aware (critical / deferred) exchange against exchange-then-update
 
 STYLEMESH_TEST_BACKEND=nccl: one GPU per rank, exchange over the product's own RCCL communicator;
-gloo: both ranks on cuda:0, exchange through torch.distributed's gloo backend (1-GPU boxes)."""
+gloo: both ranks on cuda:0, collectives staged through the host over torch.distributed's gloo backend (1-GPU boxes) - the
+ranks TAKE TURNS on the GPU (see ``main``: two processes with kernels in flight on one GPU are not a configuration of the
+product, and not a deterministic one)."""
 import os
 import sys
 import tempfile
