@@ -494,19 +494,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
     const float* a_src = P.feat + (size_t)(tm * TS + u_ch) * plane + u_kg * 8;
     const float* b_src = P.feat + (size_t)(tn * TS + u_ch) * plane + u_kg * 8;
     const int u_dst = (u_kg >> 1) * KSS + (u_kg & 1) * KG + u_ch;
-// (ablation builds, timing only: -DSM_ABL_GRAM_NOMFMA / _NOLOAD / _NOSTORE drop one ingredient of the loop)
-#ifdef SM_ABL_GRAM_NOMFMA
-#define SM_GRAM_MFMA(acc_, fa_, fb_) asm volatile("" :: "v"(fa_[0]), "v"(fb_[0]), "v"(fa_[1]), "v"(fb_[1]))
-#else
 #define SM_GRAM_MFMA(acc_, fa_, fb_) mfma_parts(acc_, fa_, fb_)
-#endif
-#ifdef SM_ABL_GRAM_NOLOAD
-#define SM_ABL_LOAD_COND(i_) if ((i_) < 2)
-#else
-#define SM_ABL_LOAD_COND(i_)
-#endif
 #define SM_LOAD(set_, i_)                                                                               \
-    SM_ABL_LOAD_COND(i_)                                                                                \
     {                                                                                                   \
         const int q_ = qs + live_list[min((i_), n_live - 1)] * SP;                                      \
         const f32x4 m0_ = *reinterpret_cast<const f32x4*>(mask + q_ + u_kg * 8), m1_ = *reinterpret_cast<const f32x4*>(mask + q_ + u_kg * 8 + 4); \
@@ -526,13 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
             }                                                                                           \
         }                                                                                               \
     }
-#ifdef SM_ABL_GRAM_NOSTORE
-#define SM_ABL_STORE_COND if (n_live < 0)
-#else
-#define SM_ABL_STORE_COND
-#endif
 #define SM_STORE(set_, buf_)                                                                            \
-    SM_ABL_STORE_COND                                                                                   \
     {                                                                                                   \
         _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                 \
             f32x4 v_[GNP];                                                                               \
@@ -587,8 +570,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
 #undef SM_STORE
 #undef SM_STAGE
 #undef SM_GRAM_MFMA
-#undef SM_ABL_LOAD_COND
-#undef SM_ABL_STORE_COND
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -597,11 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI == 1 ? S
             for (int r = 0; r < 16; ++r) {
                 const int row = tm * TS + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int col = tn * TS + wn + nj * 32 + l31;
-#ifdef SM_ABL_GRAM_NOATOMIC   // (ablation build, timing only)
-                if (acc[mi][nj][r] == 12345.f) S[(size_t)row * C + col] = 1.f;
-#else
                 atomicAdd(&S[(size_t)row * C + col], GNP == 2 ? acc[mi][nj][r] * out_scale : acc[mi][nj][r]);
-#endif
             }
 }
 
