@@ -23,15 +23,9 @@ def _snap_sample(layers, grids, outs):
     snap[id(eng)] += (runs[0],)
     same = [all(torch.equal(x, y) for x, y in zip(runs[0], runs[r])) for r in range(1, 4)]
     if not all(same):
-        import torch.nn.functional as F
-        msg = []
-        for li, (o, g) in enumerate(zip(outs, grids)):
-            ref = sum(F.grid_sample(l.detach()[None], g.reshape(1, o.H, o.W, 2), mode="bilinear", padding_mode="border", align_corners=False)[0] for l in layers)
-            for r in range(4):
-                got = runs[r][li][:3, :(o.H + 2) * o.Wp].view(3, o.H + 2, o.Wp)[:, 1:o.H + 1, 1:o.W + 1]
-                err = (got - ref).abs()
-                msg.append(f"L{li} run{r}: max|err| per channel {[round(float(err[c].max()), 4) for c in range(3)]} bad px {int((err.max(0).values > 1e-3).sum())}")
-        print(f"   [{'a' if eng is a else 'b'}] 4 launches, equal to the first: {same}; against torch grid_sample of the same p: " + "; ".join(msg))
+        ne = [(x != y) for x, y in zip(runs[0], runs[[i for i, e in enumerate(same) if not e][0] + 1])]
+        print(f"   [{'a' if eng is a else 'b'}] 4 launches of the sampler on unchanged inputs, equal to the first: {same}; differing elements per level "
+              f"{[int(d.sum()) for d in ne]}, per output plane {[[int(d[c].sum()) for c in range(3)] for d in ne]}")
 if os.environ.get('DIAG', '0') == '1':
     _ops.tex_sample_fwd_grouped = _snap_sample
 views = [_small_view(s) for s in MULTIVIEW_SEEDS]
